@@ -1,0 +1,155 @@
+"""ctypes loader for libfuelmi.so (the HIP/gfx950 implementation behind include/fuelmi.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Build it with `python -c "import __graft_entry__ as g; g.build()"` (hipcc, in-tree).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfuelmi.so")
+_LIB = None
+
+K_INFLATE, K_ESDF_ZY, K_ESDF_X, K_FRONTIER, K_BSPLINE, K_INSERT, K_COUNT = range(7)
+
+
+class FuelmiError(RuntimeError):
+    pass
+
+
+class MapCfg(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_double),
+        ("map_size", C.c_double * 3),
+        ("ground_height", C.c_double),
+        ("obstacles_inflation", C.c_double),
+        ("local_bound_inflate", C.c_double),
+        ("default_dist", C.c_double),
+        ("optimistic", C.c_int),
+        ("signed_dist", C.c_int),
+        ("p_hit", C.c_double),
+        ("p_miss", C.c_double),
+        ("p_min", C.c_double),
+        ("p_max", C.c_double),
+        ("p_occ", C.c_double),
+        ("max_ray_length", C.c_double),
+        ("virtual_ceil_height", C.c_double),
+        ("box_min", C.c_double * 3),
+        ("box_max", C.c_double * 3),
+        ("device", C.c_int),
+    ]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [
+        ("voxel_num", C.c_int * 3),
+        ("origin", C.c_double * 3),
+        ("min_boundary", C.c_double * 3),
+        ("max_boundary", C.c_double * 3),
+        ("resolution_inv", C.c_double),
+        ("box_min", C.c_int * 3),
+        ("box_max", C.c_int * 3),
+        ("prob_hit_log", C.c_double),
+        ("prob_miss_log", C.c_double),
+        ("clamp_min_log", C.c_double),
+        ("clamp_max_log", C.c_double),
+        ("min_occupancy_log", C.c_double),
+        ("inflate_step", C.c_int),
+    ]
+
+
+class FrontierCfg(C.Structure):
+    _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double)]
+
+
+class BsplineCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("ld_smooth", "ld_dist", "ld_feasi", "ld_start", "ld_end", "ld_guide", "ld_waypt",
+                 "ld_view", "ld_time", "dist0", "max_vel", "max_acc", "wnl", "dlmin")] + \
+               [("bspline_degree", C.c_int)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class BsplineBatch(C.Structure):
+    _fields_ = [
+        ("cost_function", C.c_int), ("dim", C.c_int), ("point_num", C.c_int), ("n_traj", C.c_int),
+        ("x", _dp), ("pt_dist", _dp), ("knot_span", _dp), ("time_lb", _dp),
+        ("start_state", _dp), ("end_state", _dp), ("end_n", C.c_int),
+        ("guide_pts", _dp), ("waypoints", _dp), ("waypt_idx", _ip), ("n_waypt", C.c_int),
+        ("view_pt", _dp), ("view_dir", _dp), ("view_idx", _ip),
+    ]
+
+
+# every symbol include/fuelmi.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "fuelmi_last_error": (C.c_char_p, []),
+    "fuelmi_version": (C.c_char_p, []),
+    "fuelmi_device_count": (C.c_int, []),
+    "fuelmi_map_create": (C.c_int, [C.POINTER(MapCfg), _PP]),
+    "fuelmi_map_destroy": (None, [_P]),
+    "fuelmi_map_get_info": (C.c_int, [_P, C.POINTER(MapInfo)]),
+    "fuelmi_map_input_points": (C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, _dp]),
+    "fuelmi_map_inflate_local": (C.c_int, [_P]),
+    "fuelmi_map_update_esdf": (C.c_int, [_P]),
+    "fuelmi_map_reset_buffer_all": (C.c_int, [_P]),
+    "fuelmi_map_reset_buffer": (C.c_int, [_P, _dp, _dp]),
+    "fuelmi_map_set_occupied": (C.c_int, [_P, _dp, C.c_int, C.c_int]),
+    "fuelmi_map_get_local_bound": (C.c_int, [_P, _ip, _ip]),
+    "fuelmi_map_set_local_bound": (C.c_int, [_P, _ip, _ip]),
+    "fuelmi_map_get_updated_box": (C.c_int, [_P, _dp, _dp, C.c_int]),
+    "fuelmi_map_set_updated_box": (C.c_int, [_P, _dp, _dp]),
+    "fuelmi_map_upload_occupancy": (C.c_int, [_P, _dp]),
+    "fuelmi_map_sync_host": (C.c_int, [_P, _ip, _ip, _dp, C.c_void_p, _dp]),
+    "fuelmi_map_dist_grad": (C.c_int, [_P, _dp, C.c_int, _dp, _dp]),
+    "fuelmi_map_coarse_dist": (C.c_int, [_P, _dp, C.c_int, _dp]),
+    "fuelmi_map_query_state": (C.c_int, [_P, _ip, C.c_int, _ip, _ip]),
+    "fuelmi_map_synchronize": (C.c_int, [_P]),
+    "fuelmi_frontier_create": (C.c_int, [_P, C.POINTER(FrontierCfg), _PP]),
+    "fuelmi_frontier_destroy": (None, [_P]),
+    "fuelmi_frontier_search": (C.c_int, [_P, _ip]),
+    "fuelmi_frontier_commit": (C.c_int, [_P, C.c_int]),
+    "fuelmi_frontier_count": (C.c_int, [_P, C.c_int]),
+    "fuelmi_frontier_cluster_size": (C.c_int, [_P, C.c_int, C.c_int]),
+    "fuelmi_frontier_cluster_cells": (C.c_int, [_P, C.c_int, C.c_int, _ip]),
+    "fuelmi_frontier_cluster_info": (C.c_int, [_P, C.c_int, C.c_int, _dp]),
+    "fuelmi_frontier_removed_count": (C.c_int, [_P]),
+    "fuelmi_frontier_removed_ids": (C.c_int, [_P, _ip]),
+    "fuelmi_frontier_get_flags": (C.c_int, [_P, C.c_void_p]),
+    "fuelmi_bspline_cost_grad": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), _dp, _dp]),
+    "fuelmi_bspline_dev_create": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), _PP]),
+    "fuelmi_bspline_dev_eval": (C.c_int, [_P]),
+    "fuelmi_bspline_dev_download": (C.c_int, [_P, _dp, _dp]),
+    "fuelmi_bspline_dev_destroy": (None, [_P]),
+    "fuelmi_timer_begin": (C.c_int, [_P]),
+    "fuelmi_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "fuelmi_profile_enable": (C.c_int, [_P, C.c_uint]),
+    "fuelmi_profile_get": (C.c_int, [_P, C.c_int, _ip, _dp]),
+}
+
+
+def lib():
+    """Load libfuelmi.so; raises FuelmiError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FuelmiError(
+                "%s not found: build the HIP extension first (__graft_entry__.build()); "
+                "fuel_amd has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().fuelmi_last_error()
+        raise FuelmiError("libfuelmi error %d: %s" % (rc, msg.decode() if msg else "?"))

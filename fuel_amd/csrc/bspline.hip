@@ -1,0 +1,413 @@
+// bspline.hip -- batched B-spline cost + gradient (BsplineOptimizer::combineCost,
+// bspline_opt/src/bspline_optimizer.cpp:518-691, and the calc*Cost terms :255-516).
+//
+// One 64-lane wavefront per candidate trajectory; lane i owns control points i, i+64, ...
+// Control points are staged in LDS; every gradient is evaluated in GATHER form (each point sums
+// the stencils it belongs to) so no atomics are needed; cost and the knot-span gradient are
+// wave-reduced with DPP shuffles.  All arithmetic is f64 like the reference; the ESDF is read
+// as 8 f32 gathers per control point (trilinear, SDFMap::getDistWithGrad sdf_map.cpp:497-536).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "fuelmi_internal.h"
+
+struct BsplineArgs {
+  fuelmi_bspline_cfg cfg;
+  int cost_function, dim, N, C, end_n, n_waypt, nvar, order, n_guide;
+  const double* x;
+  const double* pt_dist;
+  const double* knot_span;
+  const double* time_lb;
+  const double* start_state;
+  const double* end_state;
+  const double* guide_pts;
+  const double* waypoints;
+  const int* waypt_idx;
+  const double* view_pt;
+  const double* view_dir;
+  const int* view_idx;
+  double* cost;
+  double* grad;
+};
+
+struct fuelmi_bspline_dev {
+  fuelmi_map* map;
+  BsplineArgs a;
+  std::vector<void*> allocs;
+  size_t lds;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+__global__ void __launch_bounds__(64)
+k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = A.N, dim = A.dim;
+  double* q = reinterpret_cast<double*>(smem_raw);  // [N][3]
+  double* tj = q + 3 * N;                            // [N][3] 2*jerk/pt_dist      (j <= N-4)
+  double* tv = tj + 3 * N;                           // [N][3] vel hinge factor    (j <= N-2)
+  double* ta = tv + 3 * N;                           // [N][3] acc hinge factor    (j <= N-3)
+  double* gw = ta + 3 * N;                           // [N][3] waypoint gradient scratch
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* x = A.x + (size_t)c * A.nvar;
+  const bool opt_time = (A.cost_function & FUELMI_COST_MINTIME) != 0;
+  const double dt = opt_time ? x[A.nvar - 1] : A.knot_span[c];
+  const double pt_dist = A.pt_dist[c];
+  const fuelmi_bspline_cfg& P = A.cfg;
+
+  for (int i = lane; i < N; i += 64)
+    for (int j = 0; j < 3; ++j) q[3 * i + j] = (j < dim) ? x[dim * i + j] : 0.0;
+  __syncthreads();
+
+  double cost = 0.0, gt = 0.0;  // lane-partial weighted cost and knot-span gradient
+  const double dt_inv = 1 / dt, dt_inv2 = dt_inv * dt_inv;
+
+  // ---- pass 1: per-stencil quantities ----
+  for (int i = lane; i < N; i += 64) {
+    for (int k = 0; k < 3; ++k) {
+      tj[3 * i + k] = 0.0;
+      tv[3 * i + k] = 0.0;
+      ta[3 * i + k] = 0.0;
+      gw[3 * i + k] = 0.0;
+    }
+    if ((A.cost_function & FUELMI_COST_SMOOTHNESS) && i + 3 < N) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        double ji = (q[3 * (i + 3) + k] - 3 * q[3 * (i + 2) + k] + 3 * q[3 * (i + 1) + k] - q[3 * i + k]) / pt_dist;
+        s += ji * ji;
+        tj[3 * i + k] = 2 * ji / pt_dist;
+      }
+      cost += P.ld_smooth * s;
+    }
+    if (A.cost_function & FUELMI_COST_FEASIBILITY) {
+      if (i + 1 < N) {
+        for (int k = 0; k < 3; ++k) {
+          double vi = (q[3 * (i + 1) + k] - q[3 * i + k]) * dt_inv;
+          double vd = fabs(vi) - P.max_vel;
+          if (vd > 0.0) {
+            cost += P.ld_feasi * (vd * vd);
+            double sign = vi > 0 ? 1.0 : -1.0;
+            double tmp = 2 * vd * sign * dt_inv;
+            tv[3 * i + k] = tmp;
+            if (opt_time) gt += P.ld_feasi * (tmp * (-vi));
+          }
+        }
+      }
+      if (i + 2 < N) {
+        for (int k = 0; k < 3; ++k) {
+          double ai = (q[3 * (i + 2) + k] - 2 * q[3 * (i + 1) + k] + q[3 * i + k]) * dt_inv2;
+          double ad = fabs(ai) - P.max_acc;
+          if (ad > 0.0) {
+            cost += P.ld_feasi * (ad * ad);
+            double sign = ai > 0 ? 1.0 : -1.0;
+            double tmp = 2 * ad * sign * dt_inv2;
+            ta[3 * i + k] = tmp;
+            if (opt_time) gt += P.ld_feasi * (tmp * ai * (-2) * dt);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if ((A.cost_function & FUELMI_COST_WAYPOINTS) && lane == 0) {
+    double s = 0.0;
+    for (int w = 0; w < A.n_waypt; ++w) {
+      const double* wp = A.waypoints + ((size_t)c * A.n_waypt + w) * 3;
+      int idx = A.waypt_idx[(size_t)c * A.n_waypt + w];
+      for (int k = 0; k < 3; ++k) {
+        double dq = 1 / 6.0 * (q[3 * idx + k] + 4 * q[3 * (idx + 1) + k] + q[3 * (idx + 2) + k]) - wp[k];
+        s += dq * dq;
+        gw[3 * idx + k] += dq * (2.0 / 6.0);
+        gw[3 * (idx + 1) + k] += dq * (8.0 / 6.0);
+        gw[3 * (idx + 2) + k] += dq * (2.0 / 6.0);
+      }
+    }
+    cost += P.ld_waypt * s;
+  }
+  __syncthreads();
+
+  // ---- pass 2: per-point gradient (gather) ----
+  double* grad = A.grad + (size_t)c * A.nvar;
+  for (int i = lane; i < N; i += 64) {
+    double gq[3] = {0.0, 0.0, 0.0};
+    if (A.cost_function & FUELMI_COST_SMOOTHNESS) {
+      // point i sits at offset s of stencil j = i - s; weights (-1, 3, -3, 1)
+      const double wgt[4] = {-1.0, 3.0, -3.0, 1.0};
+      for (int s = 0; s < 4; ++s) {
+        int j = i - s;
+        if (j >= 0 && j + 3 < N)
+          for (int k = 0; k < 3; ++k) gq[k] += P.ld_smooth * wgt[s] * tj[3 * j + k];
+      }
+    }
+    if (A.cost_function & FUELMI_COST_DISTANCE) {
+      double dg[3];
+      double d = dist_with_grad_dev(g, dist, &q[3 * i], dg);
+      double nrm = sqrt(dot3(dg, dg));
+      if (nrm > 1e-4)
+        for (int k = 0; k < 3; ++k) dg[k] /= nrm;
+      if (d < P.dist0) {
+        cost += P.ld_dist * ((d - P.dist0) * (d - P.dist0));
+        for (int k = 0; k < 3; ++k) gq[k] += P.ld_dist * (2.0 * (d - P.dist0) * dg[k]);
+      }
+    }
+    if (A.cost_function & FUELMI_COST_FEASIBILITY) {
+      for (int k = 0; k < 3; ++k) {
+        double s = 0.0;
+        if (i + 1 < N) s += -tv[3 * i + k];
+        if (i >= 1) s += tv[3 * (i - 1) + k];
+        if (i + 2 < N) s += ta[3 * i + k];
+        if (i >= 1 && i + 1 < N) s += -2 * ta[3 * (i - 1) + k];
+        if (i >= 2) s += ta[3 * (i - 2) + k];
+        gq[k] += P.ld_feasi * s;
+      }
+    }
+    if ((A.cost_function & FUELMI_COST_START) && i < 3) {
+      const double* ss = A.start_state + (size_t)c * 9;
+      const double w_pos = 10.0;
+      double c_start = 0.0, gt_start = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        double q1 = q[k], q2 = q[3 + k], q3 = q[6 + k];
+        double dq = 1 / 6.0 * (q1 + 4 * q2 + q3) - ss[k];
+        c_start += w_pos * dq * dq;
+        double gk = w_pos * 2 * dq * ((i == 1) ? (4 / 6.0) : (1 / 6.0));
+        dq = 1 / (2 * dt) * (q3 - q1) - ss[3 + k];
+        c_start += dq * dq;
+        if (i == 0) gk += 2 * dq * (-1.0) / (2 * dt);
+        if (i == 2) gk += 2 * dq * 1.0 / (2 * dt);
+        gt_start += dq * (q3 - q1) / (-dt * dt);
+        dq = 1 / (dt * dt) * (q1 - 2 * q2 + q3) - ss[6 + k];
+        c_start += dq * dq;
+        gk += 2 * dq * ((i == 1) ? -2.0 : 1.0) / (dt * dt);
+        gt_start += dq * (q1 - 2 * q2 + q3) / (-dt * dt * dt);
+        gq[k] += P.ld_start * gk;
+      }
+      if (i == 0) {
+        cost += P.ld_start * c_start;
+        if (opt_time) gt += P.ld_start * gt_start;
+      }
+    }
+    if ((A.cost_function & FUELMI_COST_END) && i >= N - 3) {
+      const double* es = A.end_state + (size_t)c * 9;
+      const int r = i - (N - 3);  // 0: q_3, 1: q_2, 2: q_1
+      double c_end = 0.0, gt_end = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        double q_3 = q[3 * (N - 3) + k], q_2 = q[3 * (N - 2) + k], q_1 = q[3 * (N - 1) + k];
+        double dq = 1 / 6.0 * (q_1 + 4 * q_2 + q_3) - es[k];
+        c_end += dq * dq;
+        double gk = 2 * dq * ((r == 1) ? (4 / 6.0) : (1 / 6.0));
+        if (A.end_n >= 2) {
+          dq = 1 / (2 * dt) * (q_1 - q_3) - es[3 + k];
+          c_end += dq * dq;
+          if (r == 2) gk += 2 * dq * 1.0 / (2 * dt);
+          if (r == 0) gk += 2 * dq * (-1.0) / (2 * dt);
+          gt_end += dq * (q_1 - q_3) / (-dt * dt);
+        }
+        if (A.end_n == 3) {
+          dq = 1 / (dt * dt) * (q_1 - 2 * q_2 + q_3) - es[6 + k];
+          c_end += dq * dq;
+          gk += 2 * dq * ((r == 1) ? -2.0 : 1.0) / (dt * dt);
+          gt_end += dq * (q_1 - 2 * q_2 + q_3) / (-dt * dt * dt);
+        }
+        gq[k] += P.ld_end * gk;
+      }
+      if (r == 2) {
+        cost += P.ld_end * c_end;
+        if (opt_time) gt += P.ld_end * gt_end;
+      }
+    }
+    if ((A.cost_function & FUELMI_COST_GUIDE) && i >= A.order && i < N - A.order) {
+      const double* gp = A.guide_pts + ((size_t)c * A.n_guide + (i - A.order)) * 3;
+      for (int k = 0; k < 3; ++k) {
+        double d = q[3 * i + k] - gp[k];
+        cost += P.ld_guide * d * d;
+        gq[k] += P.ld_guide * 2 * d;
+      }
+    }
+    if (A.cost_function & FUELMI_COST_WAYPOINTS)
+      for (int k = 0; k < 3; ++k) gq[k] += P.ld_waypt * gw[3 * i + k];
+    if ((A.cost_function & FUELMI_COST_VIEWCONS) && i == A.view_idx[c]) {
+      const double* p = A.view_pt + (size_t)c * 3;
+      const double* dir = A.view_dir + (size_t)c * 3;
+      double dn_ = sqrt(dot3(dir, dir));
+      double v[3] = {dir[0] / dn_, dir[1] / dn_, dir[2] / dn_};
+      double qp[3] = {q[3 * i] - p[0], q[3 * i + 1] - p[1], q[3 * i + 2] - p[2]};
+      double pr = dot3(qp, v);
+      double dn[3], dl[3];
+      for (int k = 0; k < 3; ++k) {
+        dn[k] = qp[k] - pr * v[k];
+        dl[k] = pr * v[k];
+      }
+      double c_view = dot3(dn, dn);
+      double vdn = dot3(v, dn);
+      for (int k = 0; k < 3; ++k) gq[k] += P.ld_view * 2 * (dn[k] - vdn * v[k]);
+      double norm_dl = sqrt(dot3(dl, dl));
+      if (norm_dl < dn_) {
+        c_view += P.wnl * (norm_dl - dn_) * (norm_dl - dn_);
+        double vdl = dot3(v, dl);
+        for (int k = 0; k < 3; ++k) gq[k] += P.ld_view * (P.wnl * 2 * (norm_dl - dn_) * (vdl * v[k]) / norm_dl);
+      }
+      cost += P.ld_view * c_view;
+    }
+    for (int j = 0; j < dim; ++j) grad[dim * i + j] = gq[j];
+  }
+
+  if ((A.cost_function & FUELMI_COST_MINTIME) && lane == 0) {
+    // calcTimeCost (:504-516)
+    double duration = (N - A.order) * dt;
+    double cst = duration, g_t = double(N - A.order);
+    double lb = A.time_lb ? A.time_lb[c] : -1.0;
+    if (lb > 0 && duration < lb) {
+      const double w_lb = 10;
+      cst += w_lb * (duration - lb) * (duration - lb);
+      g_t += w_lb * 2 * (duration - lb) * (N - A.order);
+    }
+    cost += P.ld_time * cst;
+    gt += P.ld_time * g_t;
+  }
+  cost = wave_sum(cost);
+  gt = wave_sum(gt);
+  if (lane == 0) {
+    A.cost[c] = cost;
+    if (opt_time) grad[A.nvar - 1] = gt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int upload(fuelmi_bspline_dev* b, const void* src, size_t bytes, const void** dst) {
+  *dst = nullptr;
+  if (!src || bytes == 0) return FUELMI_OK;
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, bytes));
+  b->allocs.push_back(d);
+  HIPCHK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, b->map->stream));
+  *dst = d;
+  return FUELMI_OK;
+}
+
+extern "C" void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->map->device);
+  (void)hipStreamSynchronize(b->map->stream);
+  for (void* p : b->allocs) (void)hipFree(p);
+  delete b;
+}
+
+extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
+                                         const fuelmi_bspline_batch* in, fuelmi_bspline_dev** out) {
+  ARGCHK(m && cfg && in && out);
+  *out = nullptr;
+  ARGCHK(in->dim >= 1 && in->dim <= 3 && in->point_num >= 4 && in->n_traj >= 1);
+  ARGCHK(in->x && in->pt_dist);
+  const int cf = in->cost_function;
+  const bool opt_time = (cf & FUELMI_COST_MINTIME) != 0;
+  ARGCHK(opt_time || in->knot_span);
+  ARGCHK(!(cf & FUELMI_COST_START) || in->start_state);
+  ARGCHK(!(cf & FUELMI_COST_END) || (in->end_state && in->end_n >= 1 && in->end_n <= 3));
+  ARGCHK(!(cf & FUELMI_COST_GUIDE) || in->guide_pts);
+  ARGCHK(!(cf & FUELMI_COST_WAYPOINTS) || (in->n_waypt >= 0 && (in->n_waypt == 0 || (in->waypoints && in->waypt_idx))));
+  ARGCHK(!(cf & FUELMI_COST_VIEWCONS) || (in->view_pt && in->view_dir && in->view_idx));
+  HIPCHK(hipSetDevice(m->device));
+  fuelmi_bspline_dev* b = new fuelmi_bspline_dev;
+  b->map = m;
+  BsplineArgs& A = b->a;
+  memset(&A, 0, sizeof(A));
+  A.cfg = *cfg;
+  A.cost_function = cf;
+  A.dim = in->dim;
+  A.N = in->point_num;
+  A.C = in->n_traj;
+  A.end_n = in->end_n;
+  A.n_waypt = (cf & FUELMI_COST_WAYPOINTS) ? in->n_waypt : 0;
+  A.nvar = opt_time ? A.dim * A.N + 1 : A.dim * A.N;
+  A.order = (A.dim == 1) ? 3 : cfg->bspline_degree;  // optimize() :123-127
+  A.n_guide = A.N - 2 * A.order;
+  b->lds = (size_t)A.N * 3 * 5 * sizeof(double);
+  if (b->lds > 160 * 1024) {
+    fuelmi_set_error("%d control points exceed the LDS budget", A.N);
+    delete b;
+    return FUELMI_ELIMIT;
+  }
+  const size_t C = (size_t)A.C;
+  int rc = FUELMI_OK;
+  auto up = [&](const void* src, size_t bytes, const void** dst) {
+    if (rc == FUELMI_OK) rc = upload(b, src, bytes, dst);
+  };
+  up(in->x, C * A.nvar * sizeof(double), (const void**)&A.x);
+  up(in->pt_dist, C * sizeof(double), (const void**)&A.pt_dist);
+  up(in->knot_span, C * sizeof(double), (const void**)&A.knot_span);
+  up(in->time_lb, C * sizeof(double), (const void**)&A.time_lb);
+  if (cf & FUELMI_COST_START) up(in->start_state, C * 9 * sizeof(double), (const void**)&A.start_state);
+  if (cf & FUELMI_COST_END) up(in->end_state, C * 9 * sizeof(double), (const void**)&A.end_state);
+  if ((cf & FUELMI_COST_GUIDE) && A.n_guide > 0)
+    up(in->guide_pts, C * A.n_guide * 3 * sizeof(double), (const void**)&A.guide_pts);
+  if (A.n_waypt > 0) {
+    up(in->waypoints, C * A.n_waypt * 3 * sizeof(double), (const void**)&A.waypoints);
+    up(in->waypt_idx, C * A.n_waypt * sizeof(int), (const void**)&A.waypt_idx);
+  }
+  if (cf & FUELMI_COST_VIEWCONS) {
+    up(in->view_pt, C * 3 * sizeof(double), (const void**)&A.view_pt);
+    up(in->view_dir, C * 3 * sizeof(double), (const void**)&A.view_dir);
+    up(in->view_idx, C * sizeof(int), (const void**)&A.view_idx);
+  }
+  if (rc == FUELMI_OK) {
+    void* d = nullptr;
+    if (hipMalloc(&d, C * sizeof(double)) == hipSuccess) {
+      b->allocs.push_back(d);
+      A.cost = (double*)d;
+    } else
+      rc = FUELMI_ENOMEM;
+    if (rc == FUELMI_OK && hipMalloc(&d, C * A.nvar * sizeof(double)) == hipSuccess) {
+      b->allocs.push_back(d);
+      A.grad = (double*)d;
+    } else
+      rc = FUELMI_ENOMEM;
+  }
+  if (rc != FUELMI_OK) {
+    fuelmi_bspline_dev_destroy(b);
+    return rc;
+  }
+  if (b->lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_cost_grad),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds));
+  *out = b;
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b) {
+  ARGCHK(b);
+  HIPCHK(hipSetDevice(b->map->device));
+  StageScope sc(b->map, FUELMI_K_BSPLINE);
+  k_bspline_cost_grad<<<b->a.C, 64, b->lds, b->map->stream>>>(b->map->g, b->map->dist, b->a);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, double* grad) {
+  ARGCHK(b && cost && grad);
+  HIPCHK(hipSetDevice(b->map->device));
+  HIPCHK(hipMemcpyAsync(cost, b->a.cost, (size_t)b->a.C * sizeof(double), hipMemcpyDeviceToHost, b->map->stream));
+  HIPCHK(hipMemcpyAsync(grad, b->a.grad, (size_t)b->a.C * b->a.nvar * sizeof(double), hipMemcpyDeviceToHost,
+                        b->map->stream));
+  HIPCHK(hipStreamSynchronize(b->map->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_bspline_cost_grad(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
+                                        const fuelmi_bspline_batch* batch, double* cost, double* grad) {
+  fuelmi_bspline_dev* b = nullptr;
+  int rc = fuelmi_bspline_dev_create(m, cfg, batch, &b);
+  if (rc) return rc;
+  rc = fuelmi_bspline_dev_eval(b);
+  if (rc == FUELMI_OK) rc = fuelmi_bspline_dev_download(b, cost, grad);
+  fuelmi_bspline_dev_destroy(b);
+  return rc;
+}

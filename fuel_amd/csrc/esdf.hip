@@ -1,0 +1,262 @@
+// esdf.hip -- box-local exact Euclidean distance transform (SDFMap::updateESDF3d,
+// plan_env/src/sdf_map.cpp:152-241; 1-D pass = fillESDF :116-150).
+//
+// The reference computes, inside [local_bound_min_, local_bound_max_], three 1-D lower-envelope
+// passes (z, y, x) over exact-integer squared distances held in doubles, then res*sqrt().  The
+// passes compute D(q) = min_p f(p) + (q-p)^2 exactly (all integers < 2^24), so any exact
+// evaluation of that min-plus gives bit-identical squared distances.  On the GPU:
+//   * z pass  : sources come from bit-planes; the distance to the nearest set bit of a z-line is
+//               two ctz/clz scans -- no sequential envelope.  Fused into the y-pass kernel: the
+//               WG fills an LDS tile f[y][z-chunk] = dz^2 (u16) straight from the planes.
+//   * y, x    : every output voxel is a lane; it scans outward r = 1,2,.. over the LDS-staged
+//               line while r^2 < best ("pruned brute force").  Work is O(distance) per voxel,
+//               fully parallel, no per-line sequential stack.  Source voxels cost nothing.
+// HBM traffic per box voxel: planes 2 x 1/8 B read, y-pass result u32 written + read, f32
+// distance written = 12.25 B.
+#include <cmath>
+
+#include "fuelmi_internal.h"
+
+// MODE 0: sources = inflated | unknown (optimistic_ == false, sdf_map.cpp:169-182)
+// MODE 1: sources = inflated            (optimistic_ == true,  :156-167)
+// MODE 2: sources = !inflated           (signed_dist_ negative pass, :203-215)
+template <int MODE>
+__device__ __forceinline__ u64 src_word(const u64* __restrict__ infl, const u64* __restrict__ unk, long w) {
+  if (MODE == 0) return infl[w] | unk[w];
+  if (MODE == 1) return infl[w];
+  return ~infl[w];
+}
+
+// distance (in voxels) from z to the nearest source of the line inside [zlo, zhi]; -1 if none
+template <int MODE>
+__device__ __forceinline__ int nearest_src(const u64* __restrict__ infl, const u64* __restrict__ unk,
+                                           long linebit, int zlo, int zhi, int z) {
+  int best = -1;
+  {
+    long pos = linebit + z, end = linebit + zhi;
+    long w = pos >> 6;
+    u64 word = src_word<MODE>(infl, unk, w) & (~0ull << (pos & 63));
+    while (true) {
+      if (word) {
+        long c = (w << 6) + __builtin_ctzll(word);
+        if (c <= end) best = (int)(c - pos);
+        break;
+      }
+      ++w;
+      if ((w << 6) > end) break;
+      word = src_word<MODE>(infl, unk, w);
+    }
+  }
+  if (best != 0) {
+    long pos = linebit + z - 1, beg = linebit + zlo;
+    if (pos >= beg) {
+      long w = pos >> 6;
+      u64 word = src_word<MODE>(infl, unk, w) & (~0ull >> (63 - (int)(pos & 63)));
+      while (true) {
+        if (word) {
+          long c = (w << 6) + 63 - __builtin_clzll(word);
+          if (c >= beg) {
+            int d = (int)(linebit + z - c);
+            if (best < 0 || d < best) best = d;
+          }
+          break;
+        }
+        --w;
+        if ((w << 6) + 63 < beg) break;
+        word = src_word<MODE>(infl, unk, w);
+      }
+    }
+  }
+  return best;
+}
+
+// fused z + y pass.  grid.x = (#x in box) * nzc ; block handles one x and one z-chunk of ZC.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_esdf_zy(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp,
+          int ZC, int nzc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* tile = reinterpret_cast<unsigned short*>(smem_raw);  // [ylen][ZC] dz^2 or INF16
+  const int x = b.lo[0] + blockIdx.x / nzc;
+  const int zc = blockIdx.x % nzc;
+  const int z0 = b.lo[2] + zc * ZC;
+  const int zcnt = min(ZC, b.hi[2] - z0 + 1);
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int total = ylen * ZC;
+  const int T = blockDim.x;
+  const int dy = T / ZC, dz = T - dy * ZC;  // incremental (yi, zi) stepping, no division in loops
+
+  {
+    int yi = threadIdx.x / ZC, zi = threadIdx.x - yi * ZC;
+    for (int o = threadIdx.x; o < total; o += T) {
+      unsigned short v = INF16;
+      if (zi < zcnt) {
+        long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
+        int d = nearest_src<MODE>(infl, unk, linebit, b.lo[2], b.hi[2], z0 + zi);
+        if (d >= 0) v = (unsigned short)(d * d);
+      }
+      tile[o] = v;
+      yi += dy;
+      zi += dz;
+      if (zi >= ZC) {
+        zi -= ZC;
+        ++yi;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    int yi = threadIdx.x / ZC, zi = threadIdx.x - yi * ZC;
+    for (int o = threadIdx.x; o < total; o += T) {
+      if (zi < zcnt) {
+        unsigned short v0 = tile[o];
+        u32 best = (v0 == INF16) ? INF32 : (u32)v0;
+        if (best != 0u) {
+          const int rmax = max(yi, ylen - 1 - yi);
+          for (int r = 1; r <= rmax && (u32)(r * r) < best; ++r) {
+            const u32 rr = (u32)(r * r);
+            if (yi - r >= 0) {
+              unsigned short v = tile[o - r * ZC];
+              if (v != INF16) best = min(best, (u32)v + rr);
+            }
+            if (yi + r < ylen) {
+              unsigned short v = tile[o + r * ZC];
+              if (v != INF16) best = min(best, (u32)v + rr);
+            }
+          }
+        }
+        tmp[(long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz + z0 + zi] = best;
+      }
+      yi += dy;
+      zi += dz;
+      if (zi >= ZC) {
+        zi -= ZC;
+        ++yi;
+      }
+    }
+  }
+}
+
+// x pass.  The (y,z) columns of the box are enumerated j = yy*zlen + zz; a block stages S
+// consecutive columns for every x of the box in LDS (rows of S*4 B are contiguous in memory
+// whenever the box spans full z-lines) and every lane scans its own column.
+// OUT 0: distance_buffer_ = res*sqrt(D)                      (sdf_map.cpp:191-199)
+// OUT 1: negative pass merged in place                       (sdf_map.cpp:216-240):
+//        dneg = res*sqrt(D); if (dneg > 0) distance_buffer_ += -dneg + res
+template <int S, int OUT>
+__global__ void __launch_bounds__(256)
+k_esdf_x(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32* tile = reinterpret_cast<u32*>(smem_raw);  // [xlen][S]
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int zlen = b.hi[2] - b.lo[2] + 1;
+  const int ncol = ylen * zlen;
+  const int c = threadIdx.x % S;
+  const int col = blockIdx.x * S + c;
+  const bool valid = col < ncol;
+  const int yy = valid ? col / zlen : 0;
+  const int zz = valid ? col - yy * zlen : 0;
+  const long coloff = (long)(b.lo[1] + yy) * g.nz + b.lo[2] + zz;
+  const int rows = blockDim.x / S;
+  for (int xi = threadIdx.x / S; xi < xlen; xi += rows)
+    tile[xi * S + c] = valid ? tmp[(long)(b.lo[0] + xi) * g.nyz + coloff] : INF32;
+  __syncthreads();
+  if (!valid) return;
+  for (int xi = threadIdx.x / S; xi < xlen; xi += rows) {
+    u32 best = tile[xi * S + c];
+    if (best != 0u) {
+      const int rmax = max(xi, xlen - 1 - xi);
+      for (int r = 1; r <= rmax && (u32)(r * r) < best; ++r) {
+        const u32 rr = (u32)(r * r);
+        if (xi - r >= 0) best = min(best, tile[(xi - r) * S + c] + rr);
+        if (xi + r < xlen) best = min(best, tile[(xi + r) * S + c] + rr);
+      }
+    }
+    const long a = (long)(b.lo[0] + xi) * g.nyz + coloff;
+    if (OUT == 0) {
+      dist[a] = (best >= INF32) ? INFINITY : (float)(g.res * sqrt((double)best));
+    } else {
+      if (best >= INF32) {
+        dist[a] = -INFINITY;  // reference: += -(res*sqrt(DBL_MAX)) + res
+      } else if (best > 0u) {
+        double dneg = g.res * sqrt((double)best);
+        dist[a] = (float)((double)dist[a] - dneg + g.res);
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int launch_zy(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
+  // z-chunk: LDS tile <= 16 KiB so several WGs share a CU, chunks balanced over the z extent
+  int zc_max = std::max(1, (16 * 1024) / (2 * ylen));
+  if (zc_max > zlen) zc_max = zlen;
+  if (zc_max > 256) zc_max = 256;
+  int nzc = (zlen + zc_max - 1) / zc_max;
+  int ZC = (zlen + nzc - 1) / nzc;
+  size_t lds = (size_t)ylen * ZC * sizeof(unsigned short);
+  if (lds > 160 * 1024) {
+    fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
+    return FUELMI_ELIMIT;
+  }
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy<MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_esdf_zy<MODE><<<xlen * nzc, 256, lds, m->stream>>>(g, b, m->infl_bits.p, m->unk_bits.p, m->esdf_tmp, ZC,
+                                                       nzc);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+template <int S, int OUT>
+static int launch_x_s(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
+  size_t lds = (size_t)xlen * S * sizeof(u32);
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x<S, OUT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int ncol = ylen * zlen;
+  k_esdf_x<S, OUT><<<(ncol + S - 1) / S, 256, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+template <int OUT>
+static int launch_x(fuelmi_map* m, const Box3& b) {
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const size_t budget = 64 * 1024;
+  if ((size_t)xlen * 32 * 4 <= budget) return launch_x_s<32, OUT>(m, b);
+  if ((size_t)xlen * 16 * 4 <= 128 * 1024) return launch_x_s<16, OUT>(m, b);
+  if ((size_t)xlen * 8 * 4 <= 128 * 1024) return launch_x_s<8, OUT>(m, b);
+  fuelmi_set_error("ESDF x-line of %d voxels does not fit the LDS tile", xlen);
+  return FUELMI_ELIMIT;
+}
+
+int esdf_update(fuelmi_map* m) {
+  const Box3& b = m->local_bound;
+  int rc;
+  {
+    StageScope sc(m, FUELMI_K_ESDF_ZY);
+    rc = m->cfg.optimistic ? launch_zy<1>(m, b) : launch_zy<0>(m, b);
+  }
+  if (rc) return rc;
+  {
+    StageScope sc(m, FUELMI_K_ESDF_X);
+    rc = launch_x<0>(m, b);
+  }
+  if (rc) return rc;
+  if (m->cfg.signed_dist) {
+    {
+      StageScope sc(m, FUELMI_K_ESDF_ZY);
+      rc = launch_zy<2>(m, b);
+    }
+    if (rc) return rc;
+    StageScope sc(m, FUELMI_K_ESDF_X);
+    rc = launch_x<1>(m, b);
+  }
+  return rc;
+}

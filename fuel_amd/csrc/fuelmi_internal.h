@@ -1,0 +1,212 @@
+// fuelmi_internal.h -- shared host/device declarations of libfuelmi (gfx950 only).
+#ifndef FUELMI_INTERNAL_H_
+#define FUELMI_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/fuelmi.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- error plumbing -------------------------------------------------------------------------
+void fuelmi_set_error(const char* fmt, ...);
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      fuelmi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,    \
+                       __LINE__);                                                           \
+      return FUELMI_EHIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+#define ARGCHK(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      fuelmi_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+      return FUELMI_EINVAL;                                                 \
+    }                                                                       \
+  } while (0)
+
+// ---- grid geometry passed to kernels by value -------------------------------------------------
+struct Geo {
+  int nx, ny, nz;
+  int nyz;    // ny*nz
+  int N;      // nx*ny*nz  (< 2^31)
+  int W;      // number of 64-bit words covering N bits
+  double res, res_inv;
+  double org[3];
+  double minb[3], maxb[3];
+};
+
+struct Box3 {  // inclusive voxel index box
+  int lo[3], hi[3];
+};
+
+// A bit-plane over the linear voxel address space: bit (adr & 63) of word (adr >> 6).
+// Allocated with `margin` zero words on both sides so shifted window loads need no bounds tests.
+struct Plane {
+  u64* base = nullptr;  // allocation
+  u64* p = nullptr;     // word 0
+};
+
+#define INF32 0x3FFFFFFFu
+#define INF16 0xFFFFu
+
+// ---- the map object ---------------------------------------------------------------------------
+struct ProfileSlot {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+};
+
+struct fuelmi_map {
+  fuelmi_map_cfg cfg;
+  fuelmi_map_info info;
+  Geo g;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int margin_words = 0;
+
+  // device state
+  double* occ = nullptr;        // log-odds, exact reference values            8 B/voxel
+  Plane occ_bits;               // occ > min_occupancy_log
+  Plane unk_bits;               // occ < clamp_min_log - 1e-3
+  Plane infl_bits;              // occupancy_buffer_inflate_ == 1
+  Plane tmp_bits;               // scratch plane (occ & box)
+  float* dist = nullptr;        // distance_buffer_ as f32                     4 B/voxel
+  u32* esdf_tmp = nullptr;      // y-pass result (squared voxel units)         4 B/voxel
+  unsigned char* flag_rayend = nullptr;  // flag_rayend_                      1 B/voxel
+  u32* ray_owner = nullptr;     // per-frame end-voxel owner (point index)     4 B/voxel
+  Plane hit_bits, miss_bits;    // per-frame touched voxels
+  signed char raycast_num = 0;
+
+  // host-side bookkeeping the reference keeps in MapData
+  Box3 local_bound;
+  double upd_min[3], upd_max[3];
+  bool reset_updated_box = true;
+
+  // staging
+  void* d_stage = nullptr;
+  size_t d_stage_bytes = 0;
+  void* h_stage = nullptr;  // pinned
+  size_t h_stage_bytes = 0;
+
+  // measurement
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  unsigned profile_mask = 0;
+  ProfileSlot prof[FUELMI_K_COUNT];
+};
+
+int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
+
+// stage profiling helpers: bracket a launch sequence belonging to `stage`
+struct StageScope {
+  fuelmi_map* m;
+  int stage;
+  hipEvent_t e1 = nullptr;
+  StageScope(fuelmi_map* m_, int stage_);
+  ~StageScope();
+};
+
+// ---- device helpers ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ u64 plane_window(const u64* __restrict__ p, long bit) {
+  // 64 bits of the plane starting at (signed) bit index `bit`
+  long wi = bit >> 6;
+  int sh = (int)(bit & 63);
+  u64 lo = p[wi];
+  if (sh == 0) return lo;
+  u64 hi = p[wi + 1];
+  return (lo >> sh) | (hi << (64 - sh));
+}
+
+__device__ __forceinline__ u64 bit_range(int first, int count) {
+  // `count` ones starting at bit `first` (0 <= first, first+count <= 64)
+  if (count <= 0) return 0ull;
+  u64 ones = (count >= 64) ? ~0ull : ((1ull << count) - 1ull);
+  return ones << first;
+}
+
+// mask of the bits of word w whose voxel lies inside the inclusive index box
+__device__ __forceinline__ u64 box_mask_word(const Geo& g, int w, const Box3& b) {
+  long a0 = 64L * w;
+  if (a0 >= g.N) return 0ull;
+  int line = (int)(a0 / g.nz);
+  int z = (int)(a0 - (long)line * g.nz);
+  int x = line / g.ny;
+  int y = line - x * g.ny;
+  u64 mask = 0ull;
+  int bpos = 0;
+  while (bpos < 64 && x < g.nx) {
+    int len = min(g.nz - z, 64 - bpos);
+    if (x >= b.lo[0] && x <= b.hi[0] && y >= b.lo[1] && y <= b.hi[1]) {
+      int zlo = max(z, b.lo[2]);
+      int zhi = min(z + len - 1, b.hi[2]);
+      if (zlo <= zhi) mask |= bit_range(bpos + (zlo - z), zhi - zlo + 1);
+    }
+    bpos += len;
+    z = 0;
+    if (++y == g.ny) {
+      y = 0;
+      ++x;
+    }
+  }
+  return mask;
+}
+__device__ __forceinline__ double dist_to_f64(float d, double res) {
+  // "no source in the box": the reference stores res*sqrt(DBL_MAX) (sdf_map.cpp:196 with
+  // fillESDF's DBL_MAX sentinel); the device keeps +inf in f32
+  return isinf(d) ? res * sqrt(1.7976931348623157e308) : (double)d;
+}
+// SDFMap::getDistWithGrad (sdf_map.cpp:497-536), one thread per query, f64 like the reference
+__device__ __forceinline__ double get_distance_idx(const Geo& g, const float* dist, int x, int y, int z) {
+  if (x < 0 || y < 0 || z < 0 || x > g.nx - 1 || y > g.ny - 1 || z > g.nz - 1) return -1.0;
+  return dist_to_f64(dist[(long)x * g.nyz + (long)y * g.nz + z], g.res);
+}
+__device__ __forceinline__ double dist_with_grad_dev(const Geo& g, const float* __restrict__ dist, const double pos[3],
+                                     double grad[3]) {
+  for (int k = 0; k < 3; ++k)
+    if (pos[k] < g.minb[k] + 1e-4 || pos[k] > g.maxb[k] - 1e-4) {
+      grad[0] = grad[1] = grad[2] = 0.0;
+      return 0.0;
+    }
+  int idx[3];
+  double diff[3];
+  for (int k = 0; k < 3; ++k) {
+    double pm = pos[k] - 0.5 * g.res * 1.0;
+    idx[k] = (int)floor((pm - g.org[k]) * g.res_inv);
+    double ip = (idx[k] + 0.5) * g.res + g.org[k];
+    diff[k] = (pos[k] - ip) * g.res_inv;
+  }
+  double v[2][2][2];
+  for (int x = 0; x < 2; x++)
+    for (int y = 0; y < 2; y++)
+      for (int z = 0; z < 2; z++) v[x][y][z] = get_distance_idx(g, dist, idx[0] + x, idx[1] + y, idx[2] + z);
+  double v00 = (1 - diff[0]) * v[0][0][0] + diff[0] * v[1][0][0];
+  double v01 = (1 - diff[0]) * v[0][0][1] + diff[0] * v[1][0][1];
+  double v10 = (1 - diff[0]) * v[0][1][0] + diff[0] * v[1][1][0];
+  double v11 = (1 - diff[0]) * v[0][1][1] + diff[0] * v[1][1][1];
+  double v0 = (1 - diff[1]) * v00 + diff[1] * v10;
+  double v1 = (1 - diff[1]) * v01 + diff[1] * v11;
+  double d = (1 - diff[2]) * v0 + diff[2] * v1;
+  grad[2] = (v1 - v0) * g.res_inv;
+  grad[1] = ((1 - diff[2]) * (v10 - v00) + diff[2] * (v11 - v01)) * g.res_inv;
+  double g0 = (1 - diff[2]) * (1 - diff[1]) * (v[1][0][0] - v[0][0][0]);
+  g0 += (1 - diff[2]) * diff[1] * (v[1][1][0] - v[0][1][0]);
+  g0 += diff[2] * (1 - diff[1]) * (v[1][0][1] - v[0][0][1]);
+  g0 += diff[2] * diff[1] * (v[1][1][1] - v[0][1][1]);
+  grad[0] = g0 * g.res_inv;
+  return d;
+}
+#endif  // __HIPCC__
+
+// ---- kernels' host launchers (defined in the .hip files) ---------------------------------------
+int esdf_update(fuelmi_map* m);
+int insert_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n, const double cam[3]);
+
+#endif

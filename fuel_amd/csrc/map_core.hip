@@ -1,0 +1,663 @@
+// map_core.hip -- map object, occupancy state planes, inflation, queries, host mirrors.
+//
+// Device layout: the voxel grid is addressed linearly (z fastest) exactly
+// like the reference (plan_env/include/plan_env/sdf_map.h:145-147).  Per-voxel predicates that
+// the per-cycle kernels consume are kept as BIT-PLANES over that linear address space
+// (1 bit/voxel): `occupied` (occ > min_occupancy_log), `unknown` (occ < clamp_min_log-1e-3) and
+// `inflated`.  Morphology (inflation, the 6-neighbour frontier test) then becomes shifts of the
+// linear bit string, which reproduces the reference's "only 0 <= adr < N is checked" wrap quirk
+// (sdf_map.cpp:453-458) for free.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+#include "fuelmi_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void fuelmi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* fuelmi_last_error(void) { return g_err; }
+extern "C" const char* fuelmi_version(void) { return "fuelmi 0.1 (gfx950)"; }
+extern "C" int fuelmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static std::mutex g_query_mutex;  // serialises host-staged queries (staging buffers are shared)
+
+// ---------------------------------------------------------------------------------------------
+// profiling scopes
+// ---------------------------------------------------------------------------------------------
+StageScope::StageScope(fuelmi_map* m_, int stage_) : m(m_), stage(stage_) {
+  if (!(m->profile_mask & (1u << stage))) return;
+  ProfileSlot& s = m->prof[stage];
+  if (s.used + 2 > s.ev.size()) {
+    size_t old = s.ev.size();
+    s.ev.resize(old + 64);
+    for (size_t i = old; i < s.ev.size(); ++i) (void)hipEventCreate(&s.ev[i]);
+  }
+  (void)hipEventRecord(s.ev[s.used], m->stream);
+  e1 = s.ev[s.used + 1];
+  s.used += 2;
+}
+StageScope::~StageScope() {
+  if (e1) (void)hipEventRecord(e1, m->stream);
+}
+
+int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes) {
+  if (dev_bytes > m->d_stage_bytes) {
+    if (m->d_stage) HIPCHK(hipFree(m->d_stage));
+    m->d_stage = nullptr;
+    m->d_stage_bytes = 0;
+    size_t want = dev_bytes + dev_bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&m->d_stage, want));
+    m->d_stage_bytes = want;
+  }
+  if (host_bytes > m->h_stage_bytes) {
+    if (m->h_stage) HIPCHK(hipHostFree(m->h_stage));
+    m->h_stage = nullptr;
+    m->h_stage_bytes = 0;
+    size_t want = host_bytes + host_bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&m->h_stage, want, hipHostMallocDefault));
+    m->h_stage_bytes = want;
+  }
+  return FUELMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// occupancy log-odds -> (occupied, unknown) bit-planes; one lane per voxel, one ballot per word.
+// thresholds exactly as SDFMap::getOccupancy (sdf_map.h:196-203) in f64.
+__global__ void __launch_bounds__(256)
+k_state_planes(Geo g, const double* __restrict__ occ, u64* __restrict__ occ_bits,
+               u64* __restrict__ unk_bits, double thr_occ, double thr_unk, int w_lo, int w_hi) {
+  long a = 64L * w_lo + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long aend = 64L * (w_hi + 1);
+  for (; a < aend; a += (long)gridDim.x * blockDim.x) {
+    bool in = a < g.N;
+    double o = in ? occ[a] : 0.0;
+    u64 mo = __ballot(in && o > thr_occ);
+    u64 mu = __ballot(in && o < thr_unk);
+    if ((threadIdx.x & 63) == 0) {
+      occ_bits[a >> 6] = mo;
+      unk_bits[a >> 6] = mu;
+    }
+  }
+}
+
+__global__ void k_fill_f64(double* p, double v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill_f32(float* p, float v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// S[w] = occupied[w] & box(w) for w in [w_lo, w_hi] (may extend into the zero margins)
+__global__ void __launch_bounds__(256)
+k_box_and(Geo g, Box3 b, const u64* __restrict__ src, u64* __restrict__ dst, int w_lo, int w_hi) {
+  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > w_hi) return;
+  u64 v = 0ull;
+  if (w >= 0 && w < g.W) v = src[w] & box_mask_word(g, w, b);
+  dst[w] = v;
+}
+
+// SDFMap::clearAndInflateLocalMap (sdf_map.cpp:434-462) on bit-planes:
+//   infl = (infl & ~box) | OR_{dx,dy,dz in [-s,s]} shift(S, dx*ny*nz + dy*nz + dz), clipped to [0,N)
+// One thread per output word; the dz loop is a funnel-shifted OR over a 128-bit window.
+__global__ void __launch_bounds__(256)
+k_inflate(Geo g, Box3 b, int step, const u64* __restrict__ S, u64* __restrict__ infl, int w_lo,
+          int w_hi) {
+  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > w_hi) return;
+  u64 acc = 0ull;
+  for (int dx = -step; dx <= step; ++dx)
+    for (int dy = -step; dy <= step; ++dy) {
+      long off = (long)dx * g.nyz + (long)dy * g.nz;
+      long start = 64L * w - off - step;
+      u64 lo = plane_window(S, start);
+      u64 hi = plane_window(S, start + 64);
+      if ((lo | hi) == 0ull) continue;
+      u64 r = lo;
+      for (int k = 1; k <= 2 * step; ++k) r |= (lo >> k) | (hi << (64 - k));
+      acc |= r;
+    }
+  long a0 = 64L * w;
+  if (a0 + 64 > g.N) acc &= bit_range(0, (int)(g.N - a0));
+  infl[w] = (infl[w] & ~box_mask_word(g, w, b)) | acc;
+}
+
+// virtual ceiling (sdf_map.cpp:464-471): occupancy_buffer_[x,y,ceil_id] = clamp_max_log
+__global__ void k_virtual_ceil(Geo g, Box3 b, int ceil_id, double lmax, double* occ, u64* occ_bits,
+                               u64* unk_bits, double thr_occ, double thr_unk) {
+  int nxb = b.hi[0] - b.lo[0] + 1, nyb = b.hi[1] - b.lo[1] + 1;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nxb * nyb) return;
+  int x = b.lo[0] + i / nyb, y = b.lo[1] + i % nyb;
+  long a = (long)x * g.nyz + (long)y * g.nz + ceil_id;
+  occ[a] = lmax;
+  u64 bit = 1ull << (a & 63);
+  if (lmax > thr_occ) atomicOr(&occ_bits[a >> 6], bit);
+  else atomicAnd(&occ_bits[a >> 6], ~bit);
+  if (lmax < thr_unk) atomicOr(&unk_bits[a >> 6], bit);
+  else atomicAnd(&unk_bits[a >> 6], ~bit);
+}
+
+// SDFMap::setOccupied (sdf_map.h:210-215)
+__global__ void k_set_occupied(Geo g, const double* __restrict__ pos, int n, int occv, u64* infl) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  for (int k = 0; k < 3; ++k)
+    if (p[k] < g.minb[k] + 1e-4 || p[k] > g.maxb[k] - 1e-4) return;
+  int id[3];
+  for (int k = 0; k < 3; ++k) id[k] = (int)floor((p[k] - g.org[k]) * g.res_inv);
+  long a = (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2];
+  if (a < 0 || a >= g.N) return;
+  u64 bit = 1ull << (a & 63);
+  if (occv)
+    atomicOr(&infl[a >> 6], bit);
+  else
+    atomicAnd(&infl[a >> 6], ~bit);
+}
+
+// SDFMap::resetBuffer(min,max) (sdf_map.cpp:101-114): inflate = 0, distance = default in the box
+__global__ void k_reset_bits(Geo g, Box3 b, u64* infl, int w_lo, int w_hi) {
+  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > w_hi) return;
+  infl[w] &= ~box_mask_word(g, w, b);
+}
+__global__ void k_reset_dist(Geo g, Box3 b, float* dist, float v) {
+  // grid: x = z-line chunks; one thread per voxel of the box
+  int zl = b.hi[2] - b.lo[2] + 1, yl = b.hi[1] - b.lo[1] + 1, xl = b.hi[0] - b.lo[0] + 1;
+  long n = (long)xl * yl * zl;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) {
+    int z = (int)(i % zl);
+    long r = i / zl;
+    int y = (int)(r % yl), x = (int)(r / yl);
+    dist[(long)(b.lo[0] + x) * g.nyz + (long)(b.lo[1] + y) * g.nz + b.lo[2] + z] = v;
+  }
+}
+
+// bits -> bytes / f32 -> f64 expansion for the host mirrors (contiguous address range)
+__global__ void k_expand_bits(const u64* __restrict__ bits, long a0, long n, char* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) {
+    long a = a0 + i;
+    out[i] = (char)((bits[a >> 6] >> (a & 63)) & 1ull);
+  }
+}
+__global__ void k_expand_dist(const float* __restrict__ dist, long a0, long n, double res,
+                              double* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) out[i] = dist_to_f64(dist[a0 + i], res);
+}
+
+__global__ void k_dist_grad(Geo g, const float* __restrict__ dist, const double* __restrict__ pos, int n,
+                            double* __restrict__ out_d, double* __restrict__ out_g) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}, gr[3];
+  out_d[i] = dist_with_grad_dev(g, dist, p, gr);
+  out_g[3 * i] = gr[0];
+  out_g[3 * i + 1] = gr[1];
+  out_g[3 * i + 2] = gr[2];
+}
+__global__ void k_coarse_dist(Geo g, const float* __restrict__ dist, const double* __restrict__ pos, int n,
+                              double* __restrict__ out_d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int id[3];
+  for (int k = 0; k < 3; ++k) id[k] = (int)floor((pos[3 * i + k] - g.org[k]) * g.res_inv);
+  out_d[i] = get_distance_idx(g, dist, id[0], id[1], id[2]);
+}
+__global__ void k_query_state(Geo g, const u64* __restrict__ occ_bits, const u64* __restrict__ unk_bits,
+                              const u64* __restrict__ infl_bits, const int* __restrict__ idx, int n,
+                              int* __restrict__ o_occ, int* __restrict__ o_infl) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int x = idx[3 * i], y = idx[3 * i + 1], z = idx[3 * i + 2];
+  if (x < 0 || y < 0 || z < 0 || x > g.nx - 1 || y > g.ny - 1 || z > g.nz - 1) {
+    o_occ[i] = -1;
+    o_infl[i] = -1;
+    return;
+  }
+  long a = (long)x * g.nyz + (long)y * g.nz + z;
+  u64 bit = 1ull << (a & 63);
+  int st = (unk_bits[a >> 6] & bit) ? 0 : ((occ_bits[a >> 6] & bit) ? 2 : 1);
+  o_occ[i] = st;
+  o_infl[i] = (infl_bits[a >> 6] & bit) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API
+// ---------------------------------------------------------------------------------------------
+static int alloc_plane(fuelmi_map* m, Plane& pl) {
+  size_t words = (size_t)m->g.W + 2 * (size_t)m->margin_words + 2;
+  HIPCHK(hipMalloc(&pl.base, words * sizeof(u64)));
+  HIPCHK(hipMemsetAsync(pl.base, 0, words * sizeof(u64), m->stream));
+  pl.p = pl.base + m->margin_words;
+  return FUELMI_OK;
+}
+
+static inline void pos_to_index(const fuelmi_map* m, const double p[3], int id[3]) {
+  for (int i = 0; i < 3; ++i) id[i] = (int)std::floor((p[i] - m->g.org[i]) * m->g.res_inv);
+}
+static inline void bound_index(const fuelmi_map* m, int id[3]) {
+  const int nv[3] = {m->g.nx, m->g.ny, m->g.nz};
+  for (int i = 0; i < 3; ++i) id[i] = std::max(std::min(id[i], nv[i] - 1), 0);
+}
+static inline long adr_of(const Geo& g, const int id[3]) {
+  return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2];
+}
+static inline int blocks_for(long n, int threads, int cap = 1 << 20) {
+  long b = (n + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
+  ARGCHK(c && out);
+  ARGCHK(c->resolution > 0 && c->map_size[0] > 0 && c->map_size[1] > 0 && c->map_size[2] > 0);
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fuelmi_set_error("no HIP device available: libfuelmi has no CPU fallback");
+    return FUELMI_ENODEV;
+  }
+  ARGCHK(c->device >= 0 && c->device < ndev);
+  HIPCHK(hipSetDevice(c->device));
+  fuelmi_map* m = new fuelmi_map;
+  m->cfg = *c;
+  m->device = c->device;
+  // --- derived constants exactly as SDFMap::initMap (sdf_map.cpp:30-56,78-84) ---
+  fuelmi_map_info& I = m->info;
+  Geo& g = m->g;
+  g.res = c->resolution;
+  g.res_inv = 1 / c->resolution;
+  I.resolution_inv = g.res_inv;
+  g.org[0] = -c->map_size[0] / 2.0;
+  g.org[1] = -c->map_size[1] / 2.0;
+  g.org[2] = c->ground_height;
+  int nv[3];
+  for (int i = 0; i < 3; ++i) {
+    nv[i] = (int)std::ceil(c->map_size[i] / c->resolution);
+    I.voxel_num[i] = nv[i];
+    I.origin[i] = g.org[i];
+    g.minb[i] = I.min_boundary[i] = g.org[i];
+    g.maxb[i] = I.max_boundary[i] = g.org[i] + c->map_size[i];
+  }
+  long N = (long)nv[0] * nv[1] * nv[2];
+  if (N <= 0 || N >= (1L << 31) - 64) {
+    fuelmi_set_error("grid of %ld voxels exceeds the 2^31 address limit", N);
+    delete m;
+    return FUELMI_ELIMIT;
+  }
+  if (nv[2] > 255) {
+    fuelmi_set_error("nz=%d > 255 unsupported (ESDF z-pass tile holds dz^2 in 16 bits)", nv[2]);
+    delete m;
+    return FUELMI_ELIMIT;
+  }
+  g.nx = nv[0], g.ny = nv[1], g.nz = nv[2];
+  g.nyz = nv[1] * nv[2];
+  g.N = (int)N;
+  g.W = (int)((N + 63) / 64);
+  auto logit = [](double x) { return std::log(x / (1 - x)); };
+  I.prob_hit_log = logit(c->p_hit);
+  I.prob_miss_log = logit(c->p_miss);
+  I.clamp_min_log = logit(c->p_min);
+  I.clamp_max_log = logit(c->p_max);
+  I.min_occupancy_log = logit(c->p_occ);
+  I.inflate_step = (int)std::ceil(c->obstacles_inflation / c->resolution);
+  pos_to_index(m, c->box_min, I.box_min);
+  pos_to_index(m, c->box_max, I.box_max);
+  for (int i = 0; i < 3; ++i) m->local_bound.lo[i] = m->local_bound.hi[i] = 0;
+  for (int i = 0; i < 3; ++i) m->upd_min[i] = m->upd_max[i] = 0.0;
+  m->reset_updated_box = true;
+  int step = std::max(I.inflate_step, 1);
+  m->margin_words = (int)(((long)step * ((long)g.nyz + g.nz + 1) + 64) / 64 + 4);
+
+  int rc = FUELMI_OK;
+  auto fail = [&](int code) {
+    fuelmi_map_destroy(m);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    fuelmi_set_error("hipStreamCreate failed");
+    return fail(FUELMI_EHIP);
+  }
+  if ((rc = alloc_plane(m, m->occ_bits)) || (rc = alloc_plane(m, m->unk_bits)) ||
+      (rc = alloc_plane(m, m->infl_bits)) || (rc = alloc_plane(m, m->tmp_bits)) ||
+      (rc = alloc_plane(m, m->hit_bits)) || (rc = alloc_plane(m, m->miss_bits)))
+    return fail(rc);
+  size_t Npad = (size_t)g.W * 64;
+  if (hipMalloc(&m->occ, Npad * sizeof(double)) != hipSuccess ||
+      hipMalloc(&m->dist, Npad * sizeof(float)) != hipSuccess ||
+      hipMalloc(&m->esdf_tmp, Npad * sizeof(u32)) != hipSuccess ||
+      hipMalloc(&m->flag_rayend, Npad) != hipSuccess ||
+      hipMalloc(&m->ray_owner, Npad * sizeof(u32)) != hipSuccess) {
+    fuelmi_set_error("hipMalloc of %zu-voxel grid failed", Npad);
+    return fail(FUELMI_ENOMEM);
+  }
+  // initial state (sdf_map.cpp:61-72): all unknown, inflate 0, distance default, flag_rayend -1
+  k_fill_f64<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(m->occ, I.clamp_min_log - 0.01, (long)Npad);
+  k_fill_f32<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(m->dist, (float)c->default_dist, (long)Npad);
+  (void)hipMemsetAsync(m->esdf_tmp, 0, Npad * sizeof(u32), m->stream);
+  (void)hipMemsetAsync(m->flag_rayend, 0xFF, Npad, m->stream);
+  (void)hipMemsetAsync(m->ray_owner, 0xFF, Npad * sizeof(u32), m->stream);
+  k_state_planes<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(
+      g, m->occ, m->occ_bits.p, m->unk_bits.p, I.min_occupancy_log, I.clamp_min_log - 1e-3, 0, g.W - 1);
+  if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess ||
+      hipStreamSynchronize(m->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+    fuelmi_set_error("device initialisation failed (is this a gfx950 device?)");
+    return fail(FUELMI_EHIP);
+  }
+  *out = m;
+  return FUELMI_OK;
+}
+
+extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  Plane* planes[] = {&m->occ_bits, &m->unk_bits, &m->infl_bits, &m->tmp_bits, &m->hit_bits, &m->miss_bits};
+  for (Plane* p : planes)
+    if (p->base) (void)hipFree(p->base);
+  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (m->h_stage) (void)hipHostFree(m->h_stage);
+  for (auto& s : m->prof)
+    for (auto e : s.ev) (void)hipEventDestroy(e);
+  if (m->t0) (void)hipEventDestroy(m->t0);
+  if (m->t1) (void)hipEventDestroy(m->t1);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int fuelmi_map_get_info(const fuelmi_map* m, fuelmi_map_info* info) {
+  ARGCHK(m && info);
+  *info = m->info;
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ) {
+  ARGCHK(m && occ);
+  HIPCHK(hipSetDevice(m->device));
+  const Geo& g = m->g;
+  HIPCHK(hipMemcpyAsync(m->occ, occ, (size_t)g.N * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  k_state_planes<<<blocks_for((long)g.W * 64, 256, 65536), 256, 0, m->stream>>>(
+      g, m->occ, m->occ_bits.p, m->unk_bits.p, m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3, 0,
+      g.W - 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  const Geo& g = m->g;
+  const Box3& b = m->local_bound;
+  const int step = m->info.inflate_step;
+  long reach = (long)step * ((long)g.nyz + g.nz + 1);
+  long a_lo = adr_of(g, b.lo) - reach, a_hi = adr_of(g, b.hi) + reach;
+  int out_lo = (int)std::max(0L, a_lo >> 6), out_hi = (int)std::min((long)g.W - 1, a_hi >> 6);
+  // S must be valid wherever k_inflate reads: output range +- (reach + step + 64) bits
+  int rd = (int)((reach + step + 127) / 64) + 1;
+  int s_lo = std::max(out_lo - rd, -m->margin_words), s_hi = std::min(out_hi + rd, g.W - 1 + m->margin_words);
+  {
+    StageScope sc(m, FUELMI_K_INFLATE);
+    k_box_and<<<blocks_for(s_hi - s_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->occ_bits.p, m->tmp_bits.p,
+                                                                        s_lo, s_hi);
+    k_inflate<<<blocks_for(out_hi - out_lo + 1, 256), 256, 0, m->stream>>>(g, b, step, m->tmp_bits.p,
+                                                                           m->infl_bits.p, out_lo, out_hi);
+  }
+  if (m->cfg.virtual_ceil_height > -0.5) {
+    int ceil_id = (int)std::floor((m->cfg.virtual_ceil_height - g.org[2]) * g.res_inv);
+    if (ceil_id >= 0 && ceil_id < g.nz) {
+      int n = (b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1);
+      k_virtual_ceil<<<blocks_for(n, 256), 256, 0, m->stream>>>(
+          g, b, ceil_id, m->info.clamp_max_log, m->occ, m->occ_bits.p, m->unk_bits.p,
+          m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  return esdf_update(m);
+}
+
+extern "C" int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]) {
+  ARGCHK(m && min_pos && max_pos);
+  HIPCHK(hipSetDevice(m->device));
+  const Geo& g = m->g;
+  Box3 b;
+  pos_to_index(m, min_pos, b.lo);
+  pos_to_index(m, max_pos, b.hi);
+  bound_index(m, b.lo);
+  bound_index(m, b.hi);
+  for (int i = 0; i < 3; ++i)
+    if (b.lo[i] > b.hi[i]) return FUELMI_OK;
+  int w_lo = (int)(adr_of(g, b.lo) >> 6), w_hi = (int)(adr_of(g, b.hi) >> 6);
+  k_reset_bits<<<blocks_for(w_hi - w_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->infl_bits.p, w_lo, w_hi);
+  long n = (long)(b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1);
+  k_reset_dist<<<blocks_for(n, 256, 65536), 256, 0, m->stream>>>(g, b, m->dist, (float)m->cfg.default_dist);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_reset_buffer_all(fuelmi_map* m) {
+  ARGCHK(m);
+  int rc = fuelmi_map_reset_buffer(m, m->info.min_boundary, m->info.max_boundary);
+  if (rc) return rc;
+  for (int i = 0; i < 3; ++i) m->local_bound.lo[i] = 0;
+  m->local_bound.hi[0] = m->g.nx - 1;
+  m->local_bound.hi[1] = m->g.ny - 1;
+  m->local_bound.hi[2] = m->g.nz - 1;
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_set_occupied(fuelmi_map* m, const double* pos, int n, int occ) {
+  ARGCHK(m && (pos || n == 0) && n >= 0);
+  if (occ != 0 && occ != 1) {
+    fuelmi_set_error("setOccupied: only occ in {0,1} is representable (inflate buffer is a bit-plane)");
+    return FUELMI_ELIMIT;
+  }
+  if (n == 0) return FUELMI_OK;
+  HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(g_query_mutex);
+  size_t bytes = (size_t)n * 3 * sizeof(double);
+  int rc = map_ensure_stage(m, bytes, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(m->d_stage, pos, bytes, hipMemcpyHostToDevice, m->stream));
+  k_set_occupied<<<blocks_for(n, 256), 256, 0, m->stream>>>(m->g, (const double*)m->d_stage, n, occ,
+                                                            m->infl_bits.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_get_local_bound(const fuelmi_map* m, int bmin[3], int bmax[3]) {
+  ARGCHK(m && bmin && bmax);
+  for (int i = 0; i < 3; ++i) bmin[i] = m->local_bound.lo[i], bmax[i] = m->local_bound.hi[i];
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_map_set_local_bound(fuelmi_map* m, const int bmin[3], const int bmax[3]) {
+  ARGCHK(m && bmin && bmax);
+  const int nv[3] = {m->g.nx, m->g.ny, m->g.nz};
+  for (int i = 0; i < 3; ++i) ARGCHK(bmin[i] >= 0 && bmax[i] < nv[i] && bmin[i] <= bmax[i]);
+  for (int i = 0; i < 3; ++i) m->local_bound.lo[i] = bmin[i], m->local_bound.hi[i] = bmax[i];
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_map_get_updated_box(fuelmi_map* m, double bmin[3], double bmax[3], int reset) {
+  ARGCHK(m && bmin && bmax);
+  for (int i = 0; i < 3; ++i) bmin[i] = m->upd_min[i], bmax[i] = m->upd_max[i];
+  if (reset) m->reset_updated_box = true;
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_map_set_updated_box(fuelmi_map* m, const double bmin[3], const double bmax[3]) {
+  ARGCHK(m && bmin && bmax);
+  for (int i = 0; i < 3; ++i) m->upd_min[i] = bmin[i], m->upd_max[i] = bmax[i];
+  m->reset_updated_box = false;
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_sync_host(fuelmi_map* m, const int bmin[3], const int bmax[3], double* occupancy,
+                                    char* inflate, double* distance) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  const Geo& g = m->g;
+  int x0 = 0, x1 = g.nx - 1;
+  if (bmin && bmax) {
+    ARGCHK(bmin[0] >= 0 && bmax[0] < g.nx && bmin[0] <= bmax[0]);
+    x0 = bmin[0], x1 = bmax[0];
+  }
+  long a0 = (long)x0 * g.nyz, n = (long)(x1 - x0 + 1) * g.nyz;
+  std::lock_guard<std::mutex> lk(g_query_mutex);
+  if (occupancy)
+    HIPCHK(hipMemcpyAsync(occupancy + a0, m->occ + a0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
+                          m->stream));
+  if (inflate || distance) {
+    int rc = map_ensure_stage(m, (size_t)n * sizeof(double), 0);
+    if (rc) return rc;
+  }
+  if (inflate) {
+    k_expand_bits<<<blocks_for(n, 256, 65536), 256, 0, m->stream>>>(m->infl_bits.p, a0, n, (char*)m->d_stage);
+    HIPCHK(hipMemcpyAsync(inflate + a0, m->d_stage, (size_t)n, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+  }
+  if (distance) {
+    k_expand_dist<<<blocks_for(n, 256, 65536), 256, 0, m->stream>>>(m->dist, a0, n, g.res, (double*)m->d_stage);
+    HIPCHK(hipMemcpyAsync(distance + a0, m->d_stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
+                          m->stream));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_dist_grad(fuelmi_map* m, const double* pos, int n, double* dist, double* grad) {
+  ARGCHK(m && n >= 0 && (n == 0 || (pos && dist && grad)));
+  if (n == 0) return FUELMI_OK;
+  HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(g_query_mutex);
+  size_t in_b = (size_t)n * 3 * sizeof(double), out_b = (size_t)n * 4 * sizeof(double);
+  int rc = map_ensure_stage(m, in_b + out_b, 0);
+  if (rc) return rc;
+  double* d_pos = (double*)m->d_stage;
+  double* d_d = d_pos + (size_t)n * 3;
+  double* d_g = d_d + n;
+  HIPCHK(hipMemcpyAsync(d_pos, pos, in_b, hipMemcpyHostToDevice, m->stream));
+  k_dist_grad<<<blocks_for(n, 128), 128, 0, m->stream>>>(m->g, m->dist, d_pos, n, d_d, d_g);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(grad, d_g, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_coarse_dist(fuelmi_map* m, const double* pos, int n, double* dist) {
+  ARGCHK(m && n >= 0 && (n == 0 || (pos && dist)));
+  if (n == 0) return FUELMI_OK;
+  HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(g_query_mutex);
+  size_t in_b = (size_t)n * 3 * sizeof(double);
+  int rc = map_ensure_stage(m, in_b + (size_t)n * sizeof(double), 0);
+  if (rc) return rc;
+  double* d_pos = (double*)m->d_stage;
+  double* d_d = d_pos + (size_t)n * 3;
+  HIPCHK(hipMemcpyAsync(d_pos, pos, in_b, hipMemcpyHostToDevice, m->stream));
+  k_coarse_dist<<<blocks_for(n, 128), 128, 0, m->stream>>>(m->g, m->dist, d_pos, n, d_d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_query_state(fuelmi_map* m, const int* idx, int n, int* occupancy, int* inflate) {
+  ARGCHK(m && n >= 0 && (n == 0 || (idx && occupancy && inflate)));
+  if (n == 0) return FUELMI_OK;
+  HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(g_query_mutex);
+  size_t in_b = (size_t)n * 3 * sizeof(int);
+  int rc = map_ensure_stage(m, in_b + (size_t)n * 2 * sizeof(int), 0);
+  if (rc) return rc;
+  int* d_idx = (int*)m->d_stage;
+  int* d_o = d_idx + (size_t)n * 3;
+  int* d_i = d_o + n;
+  HIPCHK(hipMemcpyAsync(d_idx, idx, in_b, hipMemcpyHostToDevice, m->stream));
+  k_query_state<<<blocks_for(n, 128), 128, 0, m->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, m->infl_bits.p,
+                                                           d_idx, n, d_o, d_i);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(occupancy, d_o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(inflate, d_i, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_synchronize(fuelmi_map* m) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement hooks
+// ---------------------------------------------------------------------------------------------
+extern "C" int fuelmi_timer_begin(fuelmi_map* m) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipEventRecord(m->t0, m->stream));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_timer_end(fuelmi_map* m, float* ms) {
+  ARGCHK(m && ms);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipEventRecord(m->t1, m->stream));
+  HIPCHK(hipEventSynchronize(m->t1));
+  HIPCHK(hipEventElapsedTime(ms, m->t0, m->t1));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_profile_enable(fuelmi_map* m, unsigned mask) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  m->profile_mask = mask;
+  for (auto& s : m->prof) s.used = 0;
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, double* total_ms) {
+  ARGCHK(m && stage >= 0 && stage < FUELMI_K_COUNT && launches && total_ms);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  ProfileSlot& s = m->prof[stage];
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < s.used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+    tot += ms;
+  }
+  *launches = (int)(s.used / 2);
+  *total_ms = tot;
+  return FUELMI_OK;
+}

@@ -1,0 +1,381 @@
+"""Python host mirror of the reference's C++ class interfaces over the libfuelmi C-ABI.
+
+The production host layer is the C++ facade in fuel_amd/facade/ (same class names and
+signatures as the reference).  These thin classes exist so tests and bench.py read like calls
+into the reference: SDFMap (plan_env/include/plan_env/sdf_map.h:27-84), EDTEnvironment
+(plan_env/include/plan_env/edt_environment.h:38-43), FrontierFinder
+(active_perception/include/active_perception/frontier_finder.h:53-80) and BsplineOptimizer
+(bspline_opt/include/bspline_opt/bspline_optimizer.h:36-59).  Everything computes on the GPU;
+numpy arrays are only the host-side views the reference exposes (occupancy_buffer_ etc.).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BsplineBatch, BsplineCfg, FrontierCfg, MapCfg, MapInfo, check, lib)
+
+# exploration.launch / algorithm.xml defaults (exploration_manager/launch/algorithm.xml:33-59,170-181)
+DEFAULT_MAP = dict(resolution=0.1, ground_height=-1.0, obstacles_inflation=0.199,
+                   local_bound_inflate=0.5, default_dist=0.0, optimistic=0, signed_dist=0,
+                   p_hit=0.65, p_miss=0.35, p_min=0.12, p_max=0.90, p_occ=0.80,
+                   max_ray_length=4.5, virtual_ceil_height=-10.0)
+DEFAULT_BSPLINE = dict(ld_smooth=20.0, ld_dist=10.0, ld_feasi=2.0, ld_start=100.0, ld_end=0.5,
+                       ld_guide=1.5, ld_waypt=0.3, ld_view=0.0, ld_time=1.0, dist0=0.7,
+                       max_vel=2.0, max_acc=2.0, wnl=1.0, dlmin=0.0, bspline_degree=3)
+
+SMOOTHNESS, DISTANCE, FEASIBILITY, START, END, GUIDE, WAYPOINTS, VIEWCONS, MINTIME = \
+    (1 << k for k in range(9))
+GUIDE_PHASE = SMOOTHNESS | GUIDE | START | END
+NORMAL_PHASE = SMOOTHNESS | DISTANCE | FEASIBILITY | START | END
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+class SDFMap:
+    """fast_planner::SDFMap with the grid resident in HBM."""
+    UNKNOWN, FREE, OCCUPIED = 0, 1, 2
+
+    def __init__(self, map_size, box_min=None, box_max=None, device=0, **params):
+        self.L = lib()
+        p = dict(DEFAULT_MAP)
+        p.update(params)
+        c = MapCfg()
+        for k, v in p.items():
+            setattr(c, k, v)
+        org = (-map_size[0] / 2.0, -map_size[1] / 2.0, p["ground_height"])
+        bmin = box_min if box_min is not None else org
+        bmax = box_max if box_max is not None else tuple(org[i] + map_size[i] for i in range(3))
+        for i in range(3):
+            c.map_size[i] = float(map_size[i])
+            c.box_min[i] = float(bmin[i])
+            c.box_max[i] = float(bmax[i])
+        c.device = device
+        self.cfg = c
+        h = C.c_void_p()
+        check(self.L.fuelmi_map_create(C.byref(c), C.byref(h)))
+        self.h = h
+        info = MapInfo()
+        check(self.L.fuelmi_map_get_info(self.h, C.byref(info)))
+        self.info = info
+        self.nvox = tuple(info.voxel_num)
+        self.N = self.nvox[0] * self.nvox[1] * self.nvox[2]
+        self.origin = np.array(info.origin)
+        self.res = c.resolution
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fuelmi_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- reference API ---
+    def inputPointCloud(self, points, camera_pos):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        check(self.L.fuelmi_map_input_points(self.h, pts.ctypes.data, 12, len(pts), _d3(camera_pos)))
+
+    def clearAndInflateLocalMap(self):
+        check(self.L.fuelmi_map_inflate_local(self.h))
+
+    def updateESDF3d(self):
+        check(self.L.fuelmi_map_update_esdf(self.h))
+
+    def resetBuffer(self, lo=None, hi=None):
+        if lo is None:
+            check(self.L.fuelmi_map_reset_buffer_all(self.h))
+        else:
+            check(self.L.fuelmi_map_reset_buffer(self.h, _d3(lo), _d3(hi)))
+
+    def setOccupied(self, pos, occ=1):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        check(self.L.fuelmi_map_set_occupied(self.h, _dp(pos), len(pos), occ))
+
+    def getDistWithGrad(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        d = np.empty(len(pos))
+        g = np.empty((len(pos), 3))
+        check(self.L.fuelmi_map_dist_grad(self.h, _dp(pos), len(pos), _dp(d), _dp(g)))
+        return d, g
+
+    def getDistance(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        d = np.empty(len(pos))
+        check(self.L.fuelmi_map_coarse_dist(self.h, _dp(pos), len(pos), _dp(d)))
+        return d
+
+    def getOccupancy(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, 3)
+        o = np.empty(len(idx), dtype=np.int32)
+        i = np.empty(len(idx), dtype=np.int32)
+        check(self.L.fuelmi_map_query_state(self.h, _ip(idx), len(idx), _ip(o), _ip(i)))
+        return o, i
+
+    def getUpdatedBox(self, reset=False):
+        a, b = (C.c_double * 3)(), (C.c_double * 3)()
+        check(self.L.fuelmi_map_get_updated_box(self.h, a, b, int(reset)))
+        return np.array(a), np.array(b)
+
+    def setUpdatedBox(self, lo, hi):
+        check(self.L.fuelmi_map_set_updated_box(self.h, _d3(lo), _d3(hi)))
+
+    def getLocalBound(self):
+        a, b = (C.c_int * 3)(), (C.c_int * 3)()
+        check(self.L.fuelmi_map_get_local_bound(self.h, a, b))
+        return tuple(a), tuple(b)
+
+    def setLocalBound(self, lo, hi):
+        check(self.L.fuelmi_map_set_local_bound(self.h, _i3(lo), _i3(hi)))
+
+    def getBoxIndex(self):
+        return tuple(self.info.box_min), tuple(self.info.box_max)
+
+    # --- device <-> host ---
+    def uploadOccupancy(self, occ):
+        occ = np.ascontiguousarray(occ, dtype=np.float64).reshape(-1)
+        assert occ.size == self.N
+        check(self.L.fuelmi_map_upload_occupancy(self.h, _dp(occ)))
+
+    def syncHost(self, occupancy=False, inflate=False, distance=False, box=None):
+        """Refresh host mirrors (occupancy_buffer_, occupancy_buffer_inflate_, distance_buffer_)."""
+        out = {}
+        o = np.zeros(self.N) if occupancy else None
+        i = np.zeros(self.N, dtype=np.int8) if inflate else None
+        d = np.zeros(self.N) if distance else None
+        bmin = _i3(box[0]) if box else None
+        bmax = _i3(box[1]) if box else None
+        check(self.L.fuelmi_map_sync_host(self.h, bmin, bmax, _dp(o),
+                                          None if i is None else i.ctypes.data, _dp(d)))
+        if occupancy:
+            out["occupancy"] = o
+        if inflate:
+            out["inflate"] = i
+        if distance:
+            out["distance"] = d
+        return out
+
+    def synchronize(self):
+        check(self.L.fuelmi_map_synchronize(self.h))
+
+    # --- measurement ---
+    def timerBegin(self):
+        check(self.L.fuelmi_timer_begin(self.h))
+
+    def timerEnd(self):
+        ms = C.c_float()
+        check(self.L.fuelmi_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def profileEnable(self, mask):
+        check(self.L.fuelmi_profile_enable(self.h, mask))
+
+    def profileGet(self, stage):
+        n = C.c_int()
+        t = C.c_double()
+        check(self.L.fuelmi_profile_get(self.h, stage, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+
+class EDTEnvironment:
+    """fast_planner::EDTEnvironment: distance/gradient query facade over SDFMap."""
+
+    def __init__(self):
+        self.sdf_map_ = None
+
+    def setMap(self, sdf_map):
+        self.sdf_map_ = sdf_map
+
+    def evaluateEDTWithGrad(self, pos, time=-1.0):
+        return self.sdf_map_.getDistWithGrad(pos)
+
+    def evaluateCoarseEDT(self, pos, time=-1.0):
+        return self.sdf_map_.getDistance(pos)
+
+
+class FrontierFinder:
+    """Grid part of fast_planner::FrontierFinder (searchFrontiers / expandFrontier)."""
+
+    def __init__(self, edt_or_map, cluster_min=100, min_z=0.4):
+        self.L = lib()
+        self.map = edt_or_map.sdf_map_ if isinstance(edt_or_map, EDTEnvironment) else edt_or_map
+        cfg = FrontierCfg(cluster_min, min_z)
+        h = C.c_void_p()
+        check(self.L.fuelmi_frontier_create(self.map.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fuelmi_frontier_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def searchFrontiers(self):
+        n = C.c_int()
+        check(self.L.fuelmi_frontier_search(self.h, C.byref(n)))
+        return n.value
+
+    def commit(self, dormant=False):
+        check(self.L.fuelmi_frontier_commit(self.h, int(dormant)))
+
+    def clusters(self, which=0):
+        out = []
+        cnt = self.L.fuelmi_frontier_count(self.h, which)
+        if cnt < 0:
+            check(cnt)
+        for k in range(cnt):
+            n = self.L.fuelmi_frontier_cluster_size(self.h, which, k)
+            a = np.empty(n, dtype=np.int32)
+            check(self.L.fuelmi_frontier_cluster_cells(self.h, which, k, _ip(a)))
+            out.append(a)
+        return out
+
+    def getFrontiers(self):
+        """clusters of frontiers_ as voxel-centre positions (reference: getFrontiers)."""
+        nv = self.map.nvox
+        res = []
+        for a in self.clusters(1):
+            idx = np.stack(np.unravel_index(a, nv), axis=1)
+            res.append((idx + 0.5) * self.map.res + self.map.origin)
+        return res
+
+    def clusterInfo(self, which, k):
+        o = np.empty(9)
+        check(self.L.fuelmi_frontier_cluster_info(self.h, which, k, _dp(o)))
+        return o[:3], o[3:6], o[6:9]
+
+    def removedIds(self):
+        n = self.L.fuelmi_frontier_removed_count(self.h)
+        a = np.empty(max(n, 0), dtype=np.int32)
+        if n > 0:
+            check(self.L.fuelmi_frontier_removed_ids(self.h, _ip(a)))
+        return a
+
+    def flags(self):
+        f = np.zeros(self.map.N, dtype=np.int8)
+        check(self.L.fuelmi_frontier_get_flags(self.h, f.ctypes.data))
+        return f
+
+
+class BsplineBatchProblem:
+    """Keeps the numpy arrays of one batch alive and exposes the C struct."""
+
+    def __init__(self, x, point_num, cost_function, pt_dist, start_state=None, end_state=None, end_n=3,
+                 dim=3, knot_span=None, time_lb=None, guide_pts=None, waypoints=None, waypt_idx=None,
+                 view_pt=None, view_dir=None, view_idx=None):
+        f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        self.x = f64(x)
+        self.C = self.x.shape[0]
+        self.nvar = self.x.shape[1]
+        self.pt_dist = f64(np.broadcast_to(pt_dist, (self.C,)))
+        self.knot_span = f64(np.broadcast_to(knot_span if knot_span is not None else 0.0, (self.C,)))
+        self.time_lb = None if time_lb is None else f64(np.broadcast_to(time_lb, (self.C,)))
+        self.start_state = f64(start_state)
+        self.end_state = f64(end_state)
+        self.guide_pts = f64(guide_pts)
+        self.waypoints = f64(waypoints)
+        self.waypt_idx = i32(waypt_idx)
+        self.view_pt = f64(view_pt)
+        self.view_dir = f64(view_dir)
+        self.view_idx = i32(view_idx)
+        b = BsplineBatch()
+        b.cost_function = cost_function
+        b.dim = dim
+        b.point_num = point_num
+        b.n_traj = self.C
+        b.x = _dp(self.x)
+        b.pt_dist = _dp(self.pt_dist)
+        b.knot_span = _dp(self.knot_span)
+        b.time_lb = _dp(self.time_lb)
+        b.start_state = _dp(self.start_state)
+        b.end_state = _dp(self.end_state)
+        b.end_n = end_n
+        b.guide_pts = _dp(self.guide_pts)
+        b.waypoints = _dp(self.waypoints)
+        b.waypt_idx = _ip(self.waypt_idx)
+        b.n_waypt = 0 if self.waypoints is None else self.waypoints.shape[1]
+        b.view_pt = _dp(self.view_pt)
+        b.view_dir = _dp(self.view_dir)
+        b.view_idx = _ip(self.view_idx)
+        self.c = b
+
+
+class BsplineOptimizer:
+    """Cost/gradient side of fast_planner::BsplineOptimizer, batched over candidates."""
+
+    def __init__(self, **params):
+        p = dict(DEFAULT_BSPLINE)
+        p.update(params)
+        self.cfg = BsplineCfg(**p)
+        self.L = lib()
+        self.env = None
+
+    def setEnvironment(self, env):
+        self.env = env
+
+    def _map(self):
+        return self.env.sdf_map_ if isinstance(self.env, EDTEnvironment) else self.env
+
+    def combineCost(self, problem):
+        """Evaluate C trajectories; returns (cost[C], grad[C, nvar])."""
+        cost = np.empty(problem.C)
+        grad = np.empty((problem.C, problem.nvar))
+        check(self.L.fuelmi_bspline_cost_grad(self._map().h, C.byref(self.cfg), C.byref(problem.c),
+                                              _dp(cost), _dp(grad)))
+        return cost, grad
+
+    def deviceProblem(self, problem):
+        return BsplineDeviceProblem(self, problem)
+
+
+class BsplineDeviceProblem:
+    def __init__(self, opt, problem):
+        self.L = opt.L
+        self.problem = problem
+        self.map = opt._map()
+        h = C.c_void_p()
+        check(self.L.fuelmi_bspline_dev_create(self.map.h, C.byref(opt.cfg), C.byref(problem.c), C.byref(h)))
+        self.h = h
+
+    def eval(self):
+        check(self.L.fuelmi_bspline_dev_eval(self.h))
+
+    def download(self):
+        cost = np.empty(self.problem.C)
+        grad = np.empty((self.problem.C, self.problem.nvar))
+        check(self.L.fuelmi_bspline_dev_download(self.h, _dp(cost), _dp(grad)))
+        return cost, grad
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fuelmi_bspline_dev_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,244 @@
+/*
+ * fuelmi.h -- C-ABI of libfuelmi.so: the MI355X (gfx950) implementation of FUEL's per-cycle
+ * mapping-and-planning hot path.  Plain C types only (no torch / Eigen / ROS in any signature).
+ *
+ * The reference has no FFI layer: the path sits behind three C++ class APIs
+ * (fast_planner::SDFMap / EDTEnvironment, FrontierFinder, BsplineOptimizer).  The C++ facade in
+ * fuel_amd/facade/ re-declares those classes over this C-ABI.  Every entry
+ * point below names the reference interface it replaces; paths are relative to
+ * /root/reference/fuel_planner/.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FUELMI_E* code on failure, and never
+ *     throws or aborts; fuelmi_last_error() returns a thread-local message for the last failure.
+ *   - voxel linear address: adr = x*ny*nz + y*nz + z  (plan_env/include/plan_env/sdf_map.h:145-147)
+ *   - one HIP stream per map; mutators of one map must be called from one thread at a time
+ *     (the reference runs them on the single ros::spin thread); different maps are independent.
+ *   - all work is done by HIP kernels; there is no CPU fallback.  If no gfx950 device is
+ *     usable fuelmi_map_create fails with FUELMI_ENODEV.
+ */
+#ifndef FUELMI_H_
+#define FUELMI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FUELMI_OK 0
+#define FUELMI_EINVAL (-1)  /* bad argument */
+#define FUELMI_ENODEV (-2)  /* no usable HIP device */
+#define FUELMI_EHIP (-3)    /* HIP runtime error (message in fuelmi_last_error) */
+#define FUELMI_ENOMEM (-4)
+#define FUELMI_ELIMIT (-5)  /* problem exceeds a documented limit */
+
+const char* fuelmi_last_error(void);
+const char* fuelmi_version(void);
+/* number of visible HIP devices (0 if none / runtime unusable) */
+int fuelmi_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Map: replaces fast_planner::SDFMap  (plan_env/include/plan_env/sdf_map.h:27-84)
+ * ---------------------------------------------------------------------------------------- */
+
+/* the ROS parameters SDFMap::initMap reads (plan_env/src/sdf_map.cpp:19-47,78-82) */
+typedef struct {
+  double resolution;          /* sdf_map/resolution */
+  double map_size[3];         /* sdf_map/map_size_{x,y,z} */
+  double ground_height;       /* sdf_map/ground_height */
+  double obstacles_inflation; /* sdf_map/obstacles_inflation */
+  double local_bound_inflate; /* sdf_map/local_bound_inflate */
+  double default_dist;        /* sdf_map/default_dist */
+  int optimistic;             /* sdf_map/optimistic */
+  int signed_dist;            /* sdf_map/signed_dist */
+  double p_hit, p_miss, p_min, p_max, p_occ;
+  double max_ray_length;      /* sdf_map/max_ray_length */
+  double virtual_ceil_height; /* sdf_map/virtual_ceil_height */
+  double box_min[3], box_max[3]; /* sdf_map/box_{min,max}_{x,y,z} (exploration box) */
+  int device;                 /* HIP device ordinal this map lives on */
+} fuelmi_map_cfg;
+
+/* derived constants, as initMap computes them (sdf_map.cpp:30-56,78-84) */
+typedef struct {
+  int voxel_num[3];
+  double origin[3];
+  double min_boundary[3], max_boundary[3];
+  double resolution_inv;
+  int box_min[3], box_max[3];           /* posToIndex of the exploration box */
+  double prob_hit_log, prob_miss_log, clamp_min_log, clamp_max_log, min_occupancy_log;
+  int inflate_step;                     /* ceil(obstacles_inflation / resolution) */
+} fuelmi_map_info;
+
+typedef struct fuelmi_map fuelmi_map;
+
+/* SDFMap::initMap (sdf_map.cpp:12-93): allocates the device grid, all voxels unknown */
+int fuelmi_map_create(const fuelmi_map_cfg* cfg, fuelmi_map** out);
+void fuelmi_map_destroy(fuelmi_map* m);
+int fuelmi_map_get_info(const fuelmi_map* m, fuelmi_map_info* info);
+
+/* SDFMap::inputPointCloud (sdf_map.cpp:259-345).  xyz: n points, float x,y,z at the start of
+ * each stride_bytes record (12 for packed, 16 for pcl::PointXYZ); host memory. */
+int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,
+                            const double camera_pos[3]);
+/* SDFMap::clearAndInflateLocalMap (sdf_map.cpp:434-471) over the current local bound */
+int fuelmi_map_inflate_local(fuelmi_map* m);
+/* SDFMap::updateESDF3d (sdf_map.cpp:152-241) over the current local bound */
+int fuelmi_map_update_esdf(fuelmi_map* m);
+/* SDFMap::resetBuffer() (sdf_map.cpp:95-99) and resetBuffer(min,max) (:101-114) */
+int fuelmi_map_reset_buffer_all(fuelmi_map* m);
+int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]);
+/* SDFMap::setOccupied (sdf_map.h:210-215) for n positions; occ must be 0 or 1 */
+int fuelmi_map_set_occupied(fuelmi_map* m, const double* pos_xyz, int n, int occ);
+/* md_->local_bound_min_/max_ (inclusive voxel indices).  The reference sets them inside
+ * inputPointCloud / resetBuffer(); the setter lets a caller run "full-box" updates. */
+int fuelmi_map_get_local_bound(const fuelmi_map* m, int bmin[3], int bmax[3]);
+int fuelmi_map_set_local_bound(fuelmi_map* m, const int bmin[3], const int bmax[3]);
+/* SDFMap::getUpdatedBox (sdf_map.cpp:491-495); setter for callers that fuse elsewhere */
+int fuelmi_map_get_updated_box(fuelmi_map* m, double bmin[3], double bmax[3], int reset);
+int fuelmi_map_set_updated_box(fuelmi_map* m, const double bmin[3], const double bmax[3]);
+
+/* Bulk load of occupancy_buffer_ (log-odds, double[N], host) -- replaces nothing in the
+ * reference (its buffers are host vectors); used to restore a map / build benchmarks. */
+int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ);
+
+/* Host mirrors for the reference's inline getters (sdf_map.h:196-237 read host vectors
+ * directly).  Each non-NULL pointer is a full-size host buffer laid out like the reference's
+ * (occupancy_buffer_ double[N], occupancy_buffer_inflate_ char[N], distance_buffer_ double[N]);
+ * the voxels inside [bmin,bmax] (inclusive indices; NULL = whole map) are refreshed from the
+ * device.  Bytes outside the box may also be refreshed (contiguous slab copies). */
+int fuelmi_map_sync_host(fuelmi_map* m, const int bmin[3], const int bmax[3], double* occupancy,
+                         char* inflate, double* distance);
+
+/* SDFMap::getDistWithGrad (sdf_map.cpp:497-536) == EDTEnvironment::evaluateEDTWithGrad
+ * (plan_env/src/edt_environment.cpp:78-87) for n host positions; re-entrant w.r.t. queries */
+int fuelmi_map_dist_grad(fuelmi_map* m, const double* pos_xyz, int n, double* dist, double* grad_xyz);
+/* SDFMap::getDistance(pos) == EDTEnvironment::evaluateCoarseEDT(pos,-1) (edt_environment.cpp:89-97) */
+int fuelmi_map_coarse_dist(fuelmi_map* m, const double* pos_xyz, int n, double* dist);
+/* SDFMap::getOccupancy / getInflateOccupancy for n voxel indices (-1 outside the map) */
+int fuelmi_map_query_state(fuelmi_map* m, const int* idx_xyz, int n, int* occupancy, int* inflate);
+
+int fuelmi_map_synchronize(fuelmi_map* m);
+
+/* ------------------------------------------------------------------------------------------
+ * Frontier scan + clustering: replaces the grid part of active_perception::FrontierFinder
+ * (active_perception/src/frontier_finder.cpp:54-164 searchFrontiers/expandFrontier,
+ *  :353-390 haveOverlap/isFrontierChanged/computeFrontierInfo, :811-881 neighbour helpers)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int cluster_min; /* frontier/cluster_min */
+  double min_z;    /* the literal 0.4 at frontier_finder.cpp:151 */
+} fuelmi_frontier_cfg;
+
+typedef struct fuelmi_frontier fuelmi_frontier;
+
+int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* cfg, fuelmi_frontier** out);
+void fuelmi_frontier_destroy(fuelmi_frontier* f);
+/* searchFrontiers up to (not including) splitLargeFrontiers: consumes the map's updated box
+ * (getUpdatedBox(reset=true)), drops changed clusters, scans, clusters.  *n_new = number of new
+ * clusters (tmp_frontiers_.size()). */
+int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new);
+/* move tmp_frontiers_ into frontiers_ (dormant=0) or dormant_frontiers_ (dormant=1) */
+int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant);
+/* which: 0 tmp_frontiers_, 1 frontiers_, 2 dormant_frontiers_ */
+int fuelmi_frontier_count(const fuelmi_frontier* f, int which);
+int fuelmi_frontier_cluster_size(const fuelmi_frontier* f, int which, int k);
+/* cells of cluster k as linear voxel addresses, ascending (the reference keeps BFS order;
+ * the SET is identical) */
+int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which, int k, int* adr);
+/* average_[3], box_min_[3], box_max_[3] (computeFrontierInfo) */
+int fuelmi_frontier_cluster_info(const fuelmi_frontier* f, int which, int k, double out9[9]);
+int fuelmi_frontier_removed_count(const fuelmi_frontier* f);
+int fuelmi_frontier_removed_ids(const fuelmi_frontier* f, int* ids);
+/* frontier_flag_ expanded to one byte per voxel (char[N], host) -- for tests/debug */
+int fuelmi_frontier_get_flags(fuelmi_frontier* f, char* flags);
+
+/* ------------------------------------------------------------------------------------------
+ * B-spline cost + gradient: replaces BsplineOptimizer::combineCost and the calc*Cost terms
+ * (bspline_opt/src/bspline_optimizer.cpp:255-516, 518-691), batched over C trajectories.
+ * ---------------------------------------------------------------------------------------- */
+#define FUELMI_COST_SMOOTHNESS (1 << 0)
+#define FUELMI_COST_DISTANCE (1 << 1)
+#define FUELMI_COST_FEASIBILITY (1 << 2)
+#define FUELMI_COST_START (1 << 3)
+#define FUELMI_COST_END (1 << 4)
+#define FUELMI_COST_GUIDE (1 << 5)
+#define FUELMI_COST_WAYPOINTS (1 << 6)
+#define FUELMI_COST_VIEWCONS (1 << 7)
+#define FUELMI_COST_MINTIME (1 << 8)
+
+/* BsplineOptimizer::setParam (bspline_optimizer.cpp:25-53) */
+typedef struct {
+  double ld_smooth, ld_dist, ld_feasi, ld_start, ld_end, ld_guide, ld_waypt, ld_view, ld_time;
+  double dist0, max_vel, max_acc, wnl, dlmin;
+  int bspline_degree;
+} fuelmi_bspline_cfg;
+
+/* One batch of C independent combineCost evaluations, all with the same cost_function,
+ * dimension and point count (host arrays, row-major, candidate-major):
+ *   x          [C][nvar]   nvar = dim*N (+1 trailing knot span if MINTIME)     NLopt layout
+ *   pt_dist    [C]         optimize()'s pt_dist_ from the INITIAL control points (:136-140)
+ *   knot_span  [C]         used when MINTIME is clear
+ *   time_lb    [C] or NULL (treated as -1)
+ *   start_state[C][3][3]   pos, vel, acc (START)
+ *   end_state  [C][3][3]   END; end_n = end_state_.size() in {1,2,3}
+ *   guide_pts  [C][N-2*order][3]   (GUIDE)
+ *   waypoints  [C][n_waypt][3], waypt_idx [C][n_waypt]   (WAYPOINTS)
+ *   view_pt/view_dir [C][3], view_idx [C]                (VIEWCONS)
+ * outputs: cost [C], grad [C][nvar]. */
+typedef struct {
+  int cost_function;
+  int dim;
+  int point_num;
+  int n_traj;
+  const double* x;
+  const double* pt_dist;
+  const double* knot_span;
+  const double* time_lb;
+  const double* start_state;
+  const double* end_state;
+  int end_n;
+  const double* guide_pts;
+  const double* waypoints;
+  const int* waypt_idx;
+  int n_waypt;
+  const double* view_pt;
+  const double* view_dir;
+  const int* view_idx;
+} fuelmi_bspline_batch;
+
+int fuelmi_bspline_cost_grad(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
+                             const fuelmi_bspline_batch* batch, double* cost, double* grad);
+
+/* Device-resident variant for benchmarking / optimiser loops: upload once, evaluate many times
+ * without host copies.  Handles are owned by the map. */
+typedef struct fuelmi_bspline_dev fuelmi_bspline_dev;
+int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
+                              const fuelmi_bspline_batch* batch, fuelmi_bspline_dev** out);
+int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b);             /* async on the map's stream */
+int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, double* grad);
+void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): HIP events recorded on the map's own stream.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+  FUELMI_K_INFLATE = 0,
+  FUELMI_K_ESDF_ZY = 1,
+  FUELMI_K_ESDF_X = 2,
+  FUELMI_K_FRONTIER = 3,
+  FUELMI_K_BSPLINE = 4,
+  FUELMI_K_INSERT = 5,
+  FUELMI_K_COUNT = 6
+};
+int fuelmi_timer_begin(fuelmi_map* m);
+int fuelmi_timer_end(fuelmi_map* m, float* elapsed_ms); /* synchronises the stream */
+/* bracket every launch of the stages selected by stage_mask (bit k = FUELMI_K_*) with events */
+int fuelmi_profile_enable(fuelmi_map* m, unsigned stage_mask);
+/* synchronises, then returns launches and summed device milliseconds of a stage since enable */
+int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUELMI_H_ */

@@ -1,0 +1,1026 @@
+// fuel_oracle.cpp -- CPU ORACLE (test infrastructure only; see fuel_oracle.h).
+// Dependency-free restatement of the FUEL hot path in double precision, single thread.
+// Every function cites the reference lines it follows (paths relative to
+// /root/reference/fuel_planner/).  Quirks of the reference are reproduced on purpose.
+#include "fuel_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <list>
+#include <vector>
+
+namespace {
+
+struct V3d {
+  double v[3];
+  double& operator[](int i) { return v[i]; }
+  const double& operator[](int i) const { return v[i]; }
+};
+struct V3i {
+  int v[3];
+  int& operator[](int i) { return v[i]; }
+  const int& operator[](int i) const { return v[i]; }
+};
+inline V3d mk(double a, double b, double c) { return V3d{{a, b, c}}; }
+inline V3d operator+(const V3d& a, const V3d& b) { return mk(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+inline V3d operator-(const V3d& a, const V3d& b) { return mk(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline V3d operator*(const V3d& a, double s) { return mk(a[0] * s, a[1] * s, a[2] * s); }
+inline V3d operator*(double s, const V3d& a) { return mk(a[0] * s, a[1] * s, a[2] * s); }
+inline V3d operator/(const V3d& a, double s) { return mk(a[0] / s, a[1] / s, a[2] / s); }
+inline double dot(const V3d& a, const V3d& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double sqnorm(const V3d& a) { return dot(a, a); }
+inline double norm(const V3d& a) { return std::sqrt(sqnorm(a)); }
+
+// ---------------------------------------------------------------------------------------------
+// RayCaster -- plan_env/src/raycast.cpp:6-23 (helpers), :323-327 setParams, :329-372 input,
+// :374-407 nextId.  Works in coordinates scaled by 1/resolution (NOT origin shifted).
+// ---------------------------------------------------------------------------------------------
+inline int signum_i(int x) { return x == 0 ? 0 : (x < 0 ? -1 : 1); }
+inline double mod_pos(double value, double modulus) {
+  return std::fmod(std::fmod(value, modulus) + modulus, modulus);
+}
+double intbound(double s, double ds) {
+  // smallest positive t with s + t*ds integer (raycast.cpp:14-23)
+  if (ds < 0) return intbound(-s, -ds);
+  s = mod_pos(s, 1);
+  return (1 - s) / ds;
+}
+
+struct RayWalk {
+  double res;
+  V3d offset;  // 0.5 - origin/res
+  int x, y, z, ex, ey, ez;
+  int sx, sy, sz;
+  double tmx, tmy, tmz, tdx, tdy, tdz;
+
+  void setParams(double resolution, const V3d& origin) {
+    res = resolution;
+    offset = mk(0.5, 0.5, 0.5) - origin / resolution;
+  }
+  bool input(const V3d& start, const V3d& end) {
+    V3d s = start / res, e = end / res;
+    x = (int)std::floor(s[0]);
+    y = (int)std::floor(s[1]);
+    z = (int)std::floor(s[2]);
+    ex = (int)std::floor(e[0]);
+    ey = (int)std::floor(e[1]);
+    ez = (int)std::floor(e[2]);
+    // the reference stores the INTEGER cell differences in doubles and uses them as direction
+    double dx = ex - x, dy = ey - y, dz = ez - z;
+    sx = signum_i((int)dx);
+    sy = signum_i((int)dy);
+    sz = signum_i((int)dz);
+    tmx = intbound(s[0], dx);
+    tmy = intbound(s[1], dy);
+    tmz = intbound(s[2], dz);
+    tdx = ((double)sx) / dx;
+    tdy = ((double)sy) / dy;
+    tdz = ((double)sz) / dz;
+    return !(sx == 0 && sy == 0 && sz == 0);
+  }
+  // writes the CURRENT cell (map index), then steps; false when current == end cell
+  bool nextId(V3i& idx) {
+    idx[0] = (int)((double)x + offset[0]);  // Eigen cast<int>: truncation
+    idx[1] = (int)((double)y + offset[1]);
+    idx[2] = (int)((double)z + offset[2]);
+    if (x == ex && y == ey && z == ez) return false;
+    if (tmx < tmy) {
+      if (tmx < tmz) {
+        x += sx;
+        tmx += tdx;
+      } else {
+        z += sz;
+        tmz += tdz;
+      }
+    } else {
+      if (tmy < tmz) {
+        y += sy;
+        tmy += tdy;
+      } else {
+        z += sz;
+        tmz += tdz;
+      }
+    }
+    return true;
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// SDFMap state -- plan_env/include/plan_env/sdf_map.h:86-125
+// ---------------------------------------------------------------------------------------------
+struct fo_map {
+  // MapParam
+  V3d origin, size, min_bound, max_bound;
+  V3i nvox;
+  double res, res_inv, obstacles_inflation, virtual_ceil_height, ground_height;
+  V3i box_min, box_max;
+  V3d box_mind, box_maxd;
+  double default_dist;
+  bool optimistic, signed_dist;
+  double p_hit, p_miss, p_min, p_max, p_occ;
+  double l_hit, l_miss, l_min, l_max, l_occ;
+  double max_ray_length, local_bound_inflate, unknown_flag;
+  // MapData
+  std::vector<double> occ, dist_neg, dist, tmp1, tmp2;
+  std::vector<char> infl;
+  std::vector<short> cnt_hit, cnt_miss;
+  std::vector<char> flag_rayend;
+  char raycast_num;
+  std::deque<int> cache;
+  V3i lb_min, lb_max;
+  V3d upd_min, upd_max;
+  bool reset_updated_box;
+  bool local_updated;
+  RayWalk caster;
+
+  // sdf_map.h:127-147
+  void posToIndex(const V3d& p, V3i& id) const {
+    for (int i = 0; i < 3; ++i) id[i] = (int)std::floor((p[i] - origin[i]) * res_inv);
+  }
+  void indexToPos(const V3i& id, V3d& p) const {
+    for (int i = 0; i < 3; ++i) p[i] = (id[i] + 0.5) * res + origin[i];
+  }
+  void boundIndex(V3i& id) const {
+    for (int i = 0; i < 3; ++i) id[i] = std::max(std::min(id[i], nvox[i] - 1), 0);
+  }
+  int adr(int x, int y, int z) const { return x * nvox[1] * nvox[2] + y * nvox[2] + z; }
+  int adr(const V3i& id) const { return adr(id[0], id[1], id[2]); }
+  int total() const { return nvox[0] * nvox[1] * nvox[2]; }
+  // sdf_map.h:149-166
+  bool isInMap(const V3d& p) const {
+    for (int i = 0; i < 3; ++i)
+      if (p[i] < min_bound[i] + 1e-4) return false;
+    for (int i = 0; i < 3; ++i)
+      if (p[i] > max_bound[i] - 1e-4) return false;
+    return true;
+  }
+  bool isInMap(const V3i& id) const {
+    for (int i = 0; i < 3; ++i)
+      if (id[i] < 0 || id[i] > nvox[i] - 1) return false;
+    return true;
+  }
+  // sdf_map.h:168-175 (index version: min <= id < max)
+  bool isInBox(const V3i& id) const {
+    for (int i = 0; i < 3; ++i)
+      if (id[i] < box_min[i] || id[i] >= box_max[i]) return false;
+    return true;
+  }
+  // sdf_map.h:196-203
+  int getOccupancy(const V3i& id) const {
+    if (!isInMap(id)) return -1;
+    double o = occ[adr(id)];
+    if (o < l_min - 1e-3) return 0;  // UNKNOWN
+    if (o > l_occ) return 2;         // OCCUPIED
+    return 1;                        // FREE
+  }
+  double getDistance(const V3i& id) const {
+    if (!isInMap(id)) return -1;
+    return dist[adr(id)];
+  }
+};
+
+extern "C" {
+
+// plan_env/src/sdf_map.cpp:12-93 (initMap) minus ROS
+fo_map* fo_map_create(const fo_map_cfg* c) {
+  fo_map* m = new fo_map;
+  m->res = c->resolution;
+  m->obstacles_inflation = c->obstacles_inflation;
+  m->local_bound_inflate = std::max(m->res, c->local_bound_inflate);
+  m->ground_height = c->ground_height;
+  m->default_dist = c->default_dist;
+  m->optimistic = c->optimistic != 0;
+  m->signed_dist = c->signed_dist != 0;
+  m->res_inv = 1 / m->res;
+  m->origin = mk(-c->map_size[0] / 2.0, -c->map_size[1] / 2.0, c->ground_height);
+  m->size = mk(c->map_size[0], c->map_size[1], c->map_size[2]);
+  for (int i = 0; i < 3; ++i) m->nvox[i] = (int)std::ceil(m->size[i] / m->res);
+  m->min_bound = m->origin;
+  m->max_bound = m->origin + m->size;
+  m->p_hit = c->p_hit;
+  m->p_miss = c->p_miss;
+  m->p_min = c->p_min;
+  m->p_max = c->p_max;
+  m->p_occ = c->p_occ;
+  m->max_ray_length = c->max_ray_length;
+  m->virtual_ceil_height = c->virtual_ceil_height;
+  auto logit = [](double x) { return std::log(x / (1 - x)); };
+  m->l_hit = logit(m->p_hit);
+  m->l_miss = logit(m->p_miss);
+  m->l_min = logit(m->p_min);
+  m->l_max = logit(m->p_max);
+  m->l_occ = logit(m->p_occ);
+  m->unknown_flag = 0.01;
+  size_t n = (size_t)m->total();
+  m->occ.assign(n, m->l_min - m->unknown_flag);
+  m->infl.assign(n, 0);
+  m->dist_neg.assign(n, m->default_dist);
+  m->dist.assign(n, m->default_dist);
+  m->cnt_hit.assign(n, 0);
+  m->cnt_miss.assign(n, 0);
+  m->flag_rayend.assign(n, -1);
+  m->tmp1.assign(n, 0);
+  m->tmp2.assign(n, 0);
+  m->raycast_num = 0;
+  m->reset_updated_box = true;
+  m->upd_min = m->upd_max = mk(0, 0, 0);
+  for (int i = 0; i < 3; ++i) {
+    m->box_mind[i] = c->box_min[i];
+    m->box_maxd[i] = c->box_max[i];
+  }
+  m->posToIndex(m->box_mind, m->box_min);
+  m->posToIndex(m->box_maxd, m->box_max);
+  m->lb_min = V3i{{0, 0, 0}};
+  m->lb_max = V3i{{0, 0, 0}};
+  m->local_updated = false;
+  m->caster.setParams(m->res, m->origin);
+  return m;
+}
+void fo_map_destroy(fo_map* m) { delete m; }
+
+void fo_map_voxel_num(const fo_map* m, int out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = m->nvox[i];
+}
+void fo_map_origin(const fo_map* m, double out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = m->origin[i];
+}
+void fo_map_box_index(const fo_map* m, int bmin[3], int bmax[3]) {
+  for (int i = 0; i < 3; ++i) bmin[i] = m->box_min[i], bmax[i] = m->box_max[i];
+}
+void fo_map_logodds(const fo_map* m, double out[5]) {
+  out[0] = m->l_hit, out[1] = m->l_miss, out[2] = m->l_min, out[3] = m->l_max, out[4] = m->l_occ;
+}
+double* fo_map_occupancy(fo_map* m) { return m->occ.data(); }
+char* fo_map_inflate(fo_map* m) { return m->infl.data(); }
+double* fo_map_distance(fo_map* m) { return m->dist.data(); }
+double* fo_map_distance_neg(fo_map* m) { return m->dist_neg.data(); }
+char* fo_map_flag_rayend(fo_map* m) { return m->flag_rayend.data(); }
+
+// plan_env/src/sdf_map.cpp:95-114
+void fo_map_reset_buffer(fo_map* m, const double min_pos[3], const double max_pos[3]) {
+  V3i a, b;
+  m->posToIndex(mk(min_pos[0], min_pos[1], min_pos[2]), a);
+  m->posToIndex(mk(max_pos[0], max_pos[1], max_pos[2]), b);
+  m->boundIndex(a);
+  m->boundIndex(b);
+  for (int x = a[0]; x <= b[0]; ++x)
+    for (int y = a[1]; y <= b[1]; ++y)
+      for (int z = a[2]; z <= b[2]; ++z) {
+        m->infl[m->adr(x, y, z)] = 0;
+        m->dist[m->adr(x, y, z)] = m->default_dist;
+      }
+}
+void fo_map_reset_buffer_all(fo_map* m) {
+  fo_map_reset_buffer(m, m->min_bound.v, m->max_bound.v);
+  m->lb_min = V3i{{0, 0, 0}};
+  m->lb_max = V3i{{m->nvox[0] - 1, m->nvox[1] - 1, m->nvox[2] - 1}};
+}
+
+// sdf_map.h:210-215
+void fo_map_set_occupied(fo_map* m, const double pos[3], int occ) {
+  V3d p = mk(pos[0], pos[1], pos[2]);
+  if (!m->isInMap(p)) return;
+  V3i id;
+  m->posToIndex(p, id);
+  m->infl[m->adr(id)] = (char)occ;
+}
+
+void fo_map_get_local_bound(const fo_map* m, int bmin[3], int bmax[3]) {
+  for (int i = 0; i < 3; ++i) bmin[i] = m->lb_min[i], bmax[i] = m->lb_max[i];
+}
+void fo_map_set_local_bound(fo_map* m, const int bmin[3], const int bmax[3]) {
+  for (int i = 0; i < 3; ++i) m->lb_min[i] = bmin[i], m->lb_max[i] = bmax[i];
+}
+// plan_env/src/sdf_map.cpp:491-495
+void fo_map_get_updated_box(fo_map* m, double bmin[3], double bmax[3], int reset) {
+  for (int i = 0; i < 3; ++i) bmin[i] = m->upd_min[i], bmax[i] = m->upd_max[i];
+  if (reset) m->reset_updated_box = true;
+}
+void fo_map_set_updated_box(fo_map* m, const double bmin[3], const double bmax[3]) {
+  for (int i = 0; i < 3; ++i) m->upd_min[i] = bmin[i], m->upd_max[i] = bmax[i];
+  m->reset_updated_box = false;
+}
+
+int fo_map_get_occupancy_idx(const fo_map* m, const int id[3]) {
+  return m->getOccupancy(V3i{{id[0], id[1], id[2]}});
+}
+int fo_map_get_occupancy_pos(const fo_map* m, const double pos[3]) {
+  V3i id;
+  m->posToIndex(mk(pos[0], pos[1], pos[2]), id);
+  return m->getOccupancy(id);
+}
+int fo_map_get_inflate_idx(const fo_map* m, const int id[3]) {
+  V3i i3{{id[0], id[1], id[2]}};
+  if (!m->isInMap(i3)) return -1;
+  return (int)m->infl[m->adr(i3)];
+}
+double fo_map_get_distance_idx(const fo_map* m, const int id[3]) {
+  return m->getDistance(V3i{{id[0], id[1], id[2]}});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fusion -- plan_env/src/sdf_map.cpp:243-257 (setCacheOccupancy), :259-345 (inputPointCloud),
+// :347-362 (closetPointInMap)
+// ---------------------------------------------------------------------------------------------
+static void set_cache_occupancy(fo_map* m, int a, int occ) {
+  if (m->cnt_hit[a] == 0 && m->cnt_miss[a] == 0) m->cache.push_back(a);
+  if (occ == 0)
+    m->cnt_miss[a] = 1;  // NOT incremented in the reference
+  else if (occ == 1)
+    m->cnt_hit[a] += 1;
+}
+
+static V3d closest_point_in_map(const fo_map* m, const V3d& pt, const V3d& cam) {
+  V3d diff = pt - cam;
+  V3d max_tc = m->max_bound - cam;
+  V3d min_tc = m->min_bound - cam;
+  double min_t = 1000000;
+  for (int i = 0; i < 3; ++i) {
+    if (std::fabs(diff[i]) > 0) {
+      double t1 = max_tc[i] / diff[i];
+      if (t1 > 0 && t1 < min_t) min_t = t1;
+      double t2 = min_tc[i] / diff[i];
+      if (t2 > 0 && t2 < min_t) min_t = t2;
+    }
+  }
+  return cam + (min_t - 1e-3) * diff;
+}
+
+void fo_map_input_points(fo_map* m, const float* xyz, int stride_bytes, int n, const double camv[3]) {
+  if (n == 0) return;
+  m->raycast_num += 1;  // char: wraps like the reference (sdf_map.h:118)
+  V3d cam = mk(camv[0], camv[1], camv[2]);
+  V3d umin = cam, umax = cam;
+  if (m->reset_updated_box) {
+    m->upd_min = cam;
+    m->upd_max = cam;
+    m->reset_updated_box = false;
+  }
+  V3i idx;
+  for (int i = 0; i < n; ++i) {
+    const float* p = (const float*)((const char*)xyz + (size_t)i * stride_bytes);
+    V3d pt = mk(p[0], p[1], p[2]);
+    int flag;
+    double length;
+    if (!m->isInMap(pt)) {
+      pt = closest_point_in_map(m, pt, cam);
+      length = norm(pt - cam);
+      if (length > m->max_ray_length) pt = (pt - cam) / length * m->max_ray_length + cam;
+      if (pt[2] < 0.2) continue;
+      flag = 0;
+    } else {
+      length = norm(pt - cam);
+      if (length > m->max_ray_length) {
+        pt = (pt - cam) / length * m->max_ray_length + cam;
+        if (pt[2] < 0.2) continue;
+        flag = 0;
+      } else
+        flag = 1;
+    }
+    m->posToIndex(pt, idx);
+    int a = m->adr(idx);
+    set_cache_occupancy(m, a, flag);
+    for (int k = 0; k < 3; ++k) {
+      umin[k] = std::min(umin[k], pt[k]);
+      umax[k] = std::max(umax[k], pt[k]);
+    }
+    // only the FIRST point landing in an end voxel this frame casts a ray
+    if (m->flag_rayend[a] == m->raycast_num) continue;
+    m->flag_rayend[a] = m->raycast_num;
+
+    m->caster.input(pt, cam);
+    m->caster.nextId(idx);  // end voxel itself discarded
+    // safety cap (the reference has none): a correct walk takes exactly |dx|+|dy|+|dz| steps
+    int cap = std::abs(m->caster.ex - m->caster.x) + std::abs(m->caster.ey - m->caster.y) +
+        std::abs(m->caster.ez - m->caster.z) + 4;
+    while (m->caster.nextId(idx)) {
+      set_cache_occupancy(m, m->adr(idx), 0);
+      if (--cap < 0) break;
+    }
+  }
+  V3d inf = mk(m->local_bound_inflate, m->local_bound_inflate, 0);
+  m->posToIndex(umax + inf, m->lb_max);
+  m->posToIndex(umin - inf, m->lb_min);
+  m->boundIndex(m->lb_min);
+  m->boundIndex(m->lb_max);
+  m->local_updated = true;
+  for (int k = 0; k < 3; ++k) {
+    m->upd_min[k] = std::min(umin[k], m->upd_min[k]);
+    m->upd_max[k] = std::max(umax[k], m->upd_max[k]);
+  }
+  while (!m->cache.empty()) {
+    int a = m->cache.front();
+    m->cache.pop_front();
+    double upd = m->cnt_hit[a] >= m->cnt_miss[a] ? m->l_hit : m->l_miss;
+    m->cnt_hit[a] = m->cnt_miss[a] = 0;
+    if (m->occ[a] < m->l_min - 1e-3) m->occ[a] = m->l_occ;
+    m->occ[a] = std::min(std::max(m->occ[a] + upd, m->l_min), m->l_max);
+  }
+}
+
+int fo_raycast_cells(const fo_map* m, const double start[3], const double end[3], int* out, int cap) {
+  RayWalk w;
+  w.setParams(m->res, m->origin);
+  w.input(mk(start[0], start[1], start[2]), mk(end[0], end[1], end[2]));
+  V3i idx;
+  w.nextId(idx);
+  int n = 0;
+  int guard = std::abs(w.ex - w.x) + std::abs(w.ey - w.y) + std::abs(w.ez - w.z) + 4;
+  while (w.nextId(idx)) {
+    if (n < cap) {
+      out[3 * n + 0] = idx[0];
+      out[3 * n + 1] = idx[1];
+      out[3 * n + 2] = idx[2];
+    }
+    ++n;
+    if (--guard < 0) break;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inflation -- plan_env/src/sdf_map.cpp:434-471, sdf_map.h:239-266 (all-inflate cube).
+// Quirk kept: the only bounds test is 0 <= linear address < N, so stamps wrap across rows.
+// ---------------------------------------------------------------------------------------------
+void fo_map_inflate_local(fo_map* m) {
+  int step = (int)std::ceil(m->obstacles_inflation / m->res);
+  const int N = m->total();
+  for (int x = m->lb_min[0]; x <= m->lb_max[0]; ++x)
+    for (int y = m->lb_min[1]; y <= m->lb_max[1]; ++y)
+      for (int z = m->lb_min[2]; z <= m->lb_max[2]; ++z) m->infl[m->adr(x, y, z)] = 0;
+  for (int x = m->lb_min[0]; x <= m->lb_max[0]; ++x)
+    for (int y = m->lb_min[1]; y <= m->lb_max[1]; ++y)
+      for (int z = m->lb_min[2]; z <= m->lb_max[2]; ++z) {
+        if (m->occ[m->adr(x, y, z)] > m->l_occ) {
+          for (int dx = -step; dx <= step; ++dx)
+            for (int dy = -step; dy <= step; ++dy)
+              for (int dz = -step; dz <= step; ++dz) {
+                int a = m->adr(x + dx, y + dy, z + dz);
+                if (a >= 0 && a < N) m->infl[a] = 1;
+              }
+        }
+      }
+  if (m->virtual_ceil_height > -0.5) {
+    int ceil_id = (int)std::floor((m->virtual_ceil_height - m->origin[2]) * m->res_inv);
+    for (int x = m->lb_min[0]; x <= m->lb_max[0]; ++x)
+      for (int y = m->lb_min[1]; y <= m->lb_max[1]; ++y) m->occ[m->adr(x, y, ceil_id)] = m->l_max;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ESDF -- plan_env/src/sdf_map.cpp:116-150 (fillESDF: 1-D lower envelope of parabolas),
+// :152-241 (updateESDF3d: z, y, x passes restricted to the local box; optional signed pass).
+// "Infinity" is DBL_MAX exactly as in the reference.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+template <typename FG, typename FS>
+static void fill_esdf(FG get, FS set, int start, int end, int dimlen) {
+  std::vector<int> v(dimlen);
+  std::vector<double> z(dimlen + 1);
+  const double DMAX = std::numeric_limits<double>::max();
+  int k = start;
+  v[start] = start;
+  z[start] = -DMAX;
+  z[start + 1] = DMAX;
+  for (int q = start + 1; q <= end; q++) {
+    k++;
+    double s;
+    do {
+      k--;
+      s = ((get(q) + q * q) - (get(v[k]) + v[k] * v[k])) / (2 * q - 2 * v[k]);
+    } while (s <= z[k]);
+    k++;
+    v[k] = q;
+    z[k] = s;
+    z[k + 1] = DMAX;
+  }
+  k = start;
+  for (int q = start; q <= end; q++) {
+    while (z[k + 1] < q) k++;
+    double val = (q - v[k]) * (q - v[k]) + get(v[k]);
+    set(q, val);
+  }
+}
+
+extern "C" {
+void fo_map_update_esdf(fo_map* m) {
+  const V3i lo = m->lb_min, hi = m->lb_max;
+  const double DMAX = std::numeric_limits<double>::max();
+  auto three_pass = [&](auto is_source, std::vector<double>& out) {
+    for (int x = lo[0]; x <= hi[0]; x++)
+      for (int y = lo[1]; y <= hi[1]; y++)
+        fill_esdf([&](int z) { return is_source(m->adr(x, y, z)) ? 0.0 : DMAX; },
+                  [&](int z, double val) { m->tmp1[m->adr(x, y, z)] = val; }, lo[2], hi[2], m->nvox[2]);
+    for (int x = lo[0]; x <= hi[0]; x++)
+      for (int z = lo[2]; z <= hi[2]; z++)
+        fill_esdf([&](int y) { return m->tmp1[m->adr(x, y, z)]; },
+                  [&](int y, double val) { m->tmp2[m->adr(x, y, z)] = val; }, lo[1], hi[1], m->nvox[1]);
+    for (int y = lo[1]; y <= hi[1]; y++)
+      for (int z = lo[2]; z <= hi[2]; z++)
+        fill_esdf([&](int x) { return m->tmp2[m->adr(x, y, z)]; },
+                  [&](int x, double val) { out[m->adr(x, y, z)] = m->res * std::sqrt(val); }, lo[0], hi[0],
+                  m->nvox[0]);
+  };
+  if (m->optimistic)
+    three_pass([&](int a) { return m->infl[a] == 1; }, m->dist);
+  else
+    three_pass([&](int a) { return m->infl[a] == 1 || m->occ[a] < m->l_min - 1e-3; }, m->dist);
+  if (m->signed_dist) {
+    three_pass([&](int a) { return m->infl[a] == 0; }, m->dist_neg);
+    for (int x = lo[0]; x <= hi[0]; ++x)
+      for (int y = lo[1]; y <= hi[1]; ++y)
+        for (int z = lo[2]; z <= hi[2]; ++z) {
+          int a = m->adr(x, y, z);
+          if (m->dist_neg[a] > 0.0) m->dist[a] += (-m->dist_neg[a] + m->res);
+        }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trilinear distance + gradient -- plan_env/src/sdf_map.cpp:497-536
+// (EDTEnvironment::evaluateEDTWithGrad forwards here: edt_environment.cpp:78-87)
+// ---------------------------------------------------------------------------------------------
+static double dist_with_grad(const fo_map* m, const V3d& pos, V3d& grad) {
+  if (!m->isInMap(pos)) {
+    grad = mk(0, 0, 0);
+    return 0;
+  }
+  V3d pos_m = pos - 0.5 * m->res * mk(1, 1, 1);
+  V3i idx;
+  m->posToIndex(pos_m, idx);
+  V3d idx_pos, diff;
+  m->indexToPos(idx, idx_pos);
+  diff = (pos - idx_pos) * m->res_inv;
+  double val[2][2][2];
+  for (int x = 0; x < 2; x++)
+    for (int y = 0; y < 2; y++)
+      for (int z = 0; z < 2; z++) val[x][y][z] = m->getDistance(V3i{{idx[0] + x, idx[1] + y, idx[2] + z}});
+  double v00 = (1 - diff[0]) * val[0][0][0] + diff[0] * val[1][0][0];
+  double v01 = (1 - diff[0]) * val[0][0][1] + diff[0] * val[1][0][1];
+  double v10 = (1 - diff[0]) * val[0][1][0] + diff[0] * val[1][1][0];
+  double v11 = (1 - diff[0]) * val[0][1][1] + diff[0] * val[1][1][1];
+  double v0 = (1 - diff[1]) * v00 + diff[1] * v10;
+  double v1 = (1 - diff[1]) * v01 + diff[1] * v11;
+  double d = (1 - diff[2]) * v0 + diff[2] * v1;
+  grad[2] = (v1 - v0) * m->res_inv;
+  grad[1] = ((1 - diff[2]) * (v10 - v00) + diff[2] * (v11 - v01)) * m->res_inv;
+  grad[0] = (1 - diff[2]) * (1 - diff[1]) * (val[1][0][0] - val[0][0][0]);
+  grad[0] += (1 - diff[2]) * diff[1] * (val[1][1][0] - val[0][1][0]);
+  grad[0] += diff[2] * (1 - diff[1]) * (val[1][0][1] - val[0][0][1]);
+  grad[0] += diff[2] * diff[1] * (val[1][1][1] - val[0][1][1]);
+  grad[0] *= m->res_inv;
+  return d;
+}
+
+void fo_map_dist_grad(const fo_map* m, const double* pos, int n, double* dist, double* grad) {
+  for (int i = 0; i < n; ++i) {
+    V3d g;
+    dist[i] = dist_with_grad(m, mk(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), g);
+    grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+  }
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// FrontierFinder -- active_perception/src/frontier_finder.cpp
+//   :54-121 searchFrontiers, :123-164 expandFrontier, :353-363 haveOverlap,
+//   :365-372 isFrontierChanged, :374-390 computeFrontierInfo (minus PCL downsample),
+//   :811-829 sixNeighbors, :848-860 allNeighbors, :862-877 isNeighborUnknown/knownfree
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Cluster {
+  std::vector<V3d> cells;  // voxel centres, BFS order
+  V3d average, bmin, bmax;
+};
+}  // namespace
+
+struct fo_frontier {
+  fo_map* map;
+  int cluster_min;
+  double min_z;
+  std::vector<char> flag;
+  std::list<Cluster> frontiers, dormant, tmp;
+  std::vector<int> removed_ids;
+
+  bool knownfree(const V3i& id) const { return map->getOccupancy(id) == 1; }
+  bool isNeighborUnknown(const V3i& v) const {
+    static const int d[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    for (auto& o : d)
+      if (map->getOccupancy(V3i{{v[0] + o[0], v[1] + o[1], v[2] + o[2]}}) == 0) return true;
+    return false;
+  }
+  bool isFrontier(const V3i& id) const { return knownfree(id) && isNeighborUnknown(id); }
+
+  static bool haveOverlap(const V3d& min1, const V3d& max1, const V3d& min2, const V3d& max2) {
+    for (int i = 0; i < 3; ++i) {
+      double bmin = std::max(min1[i], min2[i]);
+      double bmax = std::min(max1[i], max2[i]);
+      if (bmin > bmax + 1e-3) return false;
+    }
+    return true;
+  }
+  bool isFrontierChanged(const Cluster& c) const {
+    for (auto& cell : c.cells) {
+      V3i idx;
+      map->posToIndex(cell, idx);
+      if (!isFrontier(idx)) return true;
+    }
+    return false;
+  }
+  static void computeInfo(Cluster& c) {
+    c.average = mk(0, 0, 0);
+    c.bmax = c.cells.front();
+    c.bmin = c.cells.front();
+    for (auto& cell : c.cells) {
+      c.average = c.average + cell;
+      for (int i = 0; i < 3; ++i) {
+        c.bmin[i] = std::min(c.bmin[i], cell[i]);
+        c.bmax[i] = std::max(c.bmax[i], cell[i]);
+      }
+    }
+    c.average = c.average / double(c.cells.size());
+  }
+
+  void expand(const V3i& first) {
+    std::deque<V3i> queue;
+    std::vector<V3d> expanded;
+    V3d pos;
+    map->indexToPos(first, pos);
+    expanded.push_back(pos);
+    queue.push_back(first);
+    flag[map->adr(first)] = 1;
+    while (!queue.empty()) {
+      V3i cur = queue.front();
+      queue.pop_front();
+      for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dz = -1; dz <= 1; ++dz) {
+            if (dx == 0 && dy == 0 && dz == 0) continue;
+            V3i nbr{{cur[0] + dx, cur[1] + dy, cur[2] + dz}};
+            // The reference reads frontier_flag_[toadr(nbr)] BEFORE the box test (UB when nbr is
+            // outside the map).  Outside the map isInBox() is false (box is inside the map), so
+            // the outcome is "continue" either way; test the box first to stay defined.
+            if (!map->isInMap(nbr) || !map->isInBox(nbr)) continue;
+            int a = map->adr(nbr);
+            if (flag[a] == 1 || !isFrontier(nbr)) continue;
+            map->indexToPos(nbr, pos);
+            if (pos[2] < min_z) continue;
+            expanded.push_back(pos);
+            queue.push_back(nbr);
+            flag[a] = 1;
+          }
+    }
+    if ((int)expanded.size() > cluster_min) {
+      Cluster c;
+      c.cells = expanded;
+      computeInfo(c);
+      tmp.push_back(c);
+    }
+    // rejected small clusters keep flag == 1 forever (reference quirk)
+  }
+
+  int search() {
+    tmp.clear();
+    V3d umin, umax;
+    fo_map_get_updated_box(map, umin.v, umax.v, 1);
+    auto resetFlag = [&](std::list<Cluster>::iterator& it, std::list<Cluster>& L) {
+      V3i idx;
+      for (auto& cell : it->cells) {
+        map->posToIndex(cell, idx);
+        flag[map->adr(idx)] = 0;
+      }
+      it = L.erase(it);
+    };
+    removed_ids.clear();
+    int rmv_idx = 0;
+    for (auto it = frontiers.begin(); it != frontiers.end();) {
+      if (haveOverlap(it->bmin, it->bmax, umin, umax) && isFrontierChanged(*it)) {
+        resetFlag(it, frontiers);
+        removed_ids.push_back(rmv_idx);
+      } else {
+        ++rmv_idx;
+        ++it;
+      }
+    }
+    for (auto it = dormant.begin(); it != dormant.end();) {
+      if (haveOverlap(it->bmin, it->bmax, umin, umax) && isFrontierChanged(*it))
+        resetFlag(it, dormant);
+      else
+        ++it;
+    }
+    V3d smin = umin - mk(1, 1, 0.5), smax = umax + mk(1, 1, 0.5);
+    for (int k = 0; k < 3; ++k) {
+      smin[k] = std::max(smin[k], map->box_mind[k]);
+      smax[k] = std::min(smax[k], map->box_maxd[k]);
+    }
+    V3i lo, hi;
+    map->posToIndex(smin, lo);
+    map->posToIndex(smax, hi);
+    // The reference loops lo..hi inclusive without a map test; hi can equal nvox when the
+    // exploration box touches the map face (UB there).  Clamp to the map to stay defined.
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::max(lo[k], 0);
+      hi[k] = std::min(hi[k], map->nvox[k] - 1);
+    }
+    for (int x = lo[0]; x <= hi[0]; ++x)
+      for (int y = lo[1]; y <= hi[1]; ++y)
+        for (int z = lo[2]; z <= hi[2]; ++z) {
+          V3i cur{{x, y, z}};
+          if (flag[map->adr(cur)] == 0 && isFrontier(cur)) expand(cur);
+        }
+    return (int)tmp.size();
+  }
+};
+
+extern "C" {
+
+fo_frontier* fo_frontier_create(fo_map* m, const fo_frontier_cfg* cfg) {
+  fo_frontier* f = new fo_frontier;
+  f->map = m;
+  f->cluster_min = cfg->cluster_min;
+  f->min_z = cfg->min_z;
+  f->flag.assign((size_t)m->total(), 0);
+  return f;
+}
+void fo_frontier_destroy(fo_frontier* f) { delete f; }
+char* fo_frontier_flags(fo_frontier* f) { return f->flag.data(); }
+int fo_frontier_search(fo_frontier* f) { return f->search(); }
+void fo_frontier_commit(fo_frontier* f, int dormant) {
+  auto& dst = dormant ? f->dormant : f->frontiers;
+  dst.insert(dst.end(), f->tmp.begin(), f->tmp.end());
+  f->tmp.clear();
+}
+static const std::list<Cluster>& pick(const fo_frontier* f, int which) {
+  return which == 0 ? f->tmp : (which == 1 ? f->frontiers : f->dormant);
+}
+static const Cluster& nth(const std::list<Cluster>& L, int k) {
+  auto it = L.begin();
+  std::advance(it, k);
+  return *it;
+}
+int fo_frontier_count(const fo_frontier* f, int which) { return (int)pick(f, which).size(); }
+int fo_frontier_cluster_size(const fo_frontier* f, int which, int k) {
+  return (int)nth(pick(f, which), k).cells.size();
+}
+void fo_frontier_cluster_cells(const fo_frontier* f, int which, int k, int* adr) {
+  const Cluster& c = nth(pick(f, which), k);
+  V3i idx;
+  for (size_t i = 0; i < c.cells.size(); ++i) {
+    f->map->posToIndex(c.cells[i], idx);
+    adr[i] = f->map->adr(idx);
+  }
+}
+void fo_frontier_cluster_info(const fo_frontier* f, int which, int k, double* out9) {
+  const Cluster& c = nth(pick(f, which), k);
+  for (int i = 0; i < 3; ++i) out9[i] = c.average[i], out9[3 + i] = c.bmin[i], out9[6 + i] = c.bmax[i];
+}
+int fo_frontier_removed_count(const fo_frontier* f) { return (int)f->removed_ids.size(); }
+void fo_frontier_removed_ids(const fo_frontier* f, int* ids) {
+  for (size_t i = 0; i < f->removed_ids.size(); ++i) ids[i] = f->removed_ids[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// BsplineOptimizer cost terms -- bspline_opt/src/bspline_optimizer.cpp
+//   :136-140 pt_dist_, :255-282 smoothness, :284-306 distance, :308-353 feasibility,
+//   :355-391 start, :393-431 end, :433-457 waypoints, :462-475 guide, :477-502 view,
+//   :504-516 time, :518-691 combineCost
+// ---------------------------------------------------------------------------------------------
+double fo_bspline_pt_dist(const double* ctrl, int n, int dim) {
+  double d = 0.0;
+  for (int i = 0; i < n - 1; ++i) {
+    double s = 0;
+    for (int j = 0; j < dim; ++j) {
+      double e = ctrl[dim * (i + 1) + j] - ctrl[dim * i + j];
+      s += e * e;
+    }
+    d += std::sqrt(s);
+  }
+  return d / double(n);
+}
+
+void fo_bspline_cost_grad(const fo_map* m, const fo_bspline_cfg* cfg, const fo_bspline_problem* pb,
+                          const double* x, double* cost_out, double* grad) {
+  const int N = pb->point_num, dim = pb->dim;
+  const int MINTIME = 1 << 8;
+  const bool opt_time = (pb->cost_function & MINTIME) != 0;
+  const int nvar = opt_time ? dim * N + 1 : dim * N;
+  const int order = (dim == 1) ? 3 : cfg->bspline_degree;
+  std::vector<V3d> q(N), g(N);
+  for (int i = 0; i < N; ++i) {
+    for (int j = 0; j < dim; ++j) q[i][j] = x[dim * i + j];
+    for (int j = dim; j < 3; ++j) q[i][j] = 0.0;
+  }
+  const double dt = opt_time ? x[nvar - 1] : pb->knot_span;
+  double f = 0.0;
+  for (int i = 0; i < nvar; ++i) grad[i] = 0.0;
+  auto zero_g = [&]() {
+    for (auto& e : g) e = mk(0, 0, 0);
+  };
+  auto add_all = [&](double ld) {
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < dim; j++) grad[dim * i + j] += ld * g[i][j];
+  };
+
+  if (pb->cost_function & (1 << 0)) {  // SMOOTHNESS
+    double c = 0.0;
+    zero_g();
+    for (int i = 0; i < N - 3; i++) {
+      V3d ji = (q[i + 3] - 3 * q[i + 2] + 3 * q[i + 1] - q[i]) / pb->pt_dist;
+      c += sqnorm(ji);
+      V3d tj = 2 * ji / pb->pt_dist;
+      g[i + 0] = g[i + 0] + (-1.0) * tj;
+      g[i + 1] = g[i + 1] + 3.0 * tj;
+      g[i + 2] = g[i + 2] + (-3.0) * tj;
+      g[i + 3] = g[i + 3] + tj;
+    }
+    f += cfg->ld_smooth * c;
+    add_all(cfg->ld_smooth);
+    // gt_smoothness stays 0 in the reference
+  }
+  if (pb->cost_function & (1 << 1)) {  // DISTANCE (static environment branch)
+    double c = 0.0;
+    zero_g();
+    for (int i = 0; i < N; i++) {
+      V3d dg;
+      double d = dist_with_grad(m, q[i], dg);
+      double nrm = norm(dg);
+      if (nrm > 1e-4) dg = dg / nrm;  // Eigen normalize(): v /= v.norm()
+      if (d < cfg->dist0) {
+        c += std::pow(d - cfg->dist0, 2);
+        g[i] = g[i] + 2.0 * (d - cfg->dist0) * dg;
+      }
+    }
+    f += cfg->ld_dist * c;
+    add_all(cfg->ld_dist);
+  }
+  if (pb->cost_function & (1 << 2)) {  // FEASIBILITY
+    double c = 0.0, gt = 0.0;
+    zero_g();
+    const double dt_inv = 1 / dt, dt_inv2 = dt_inv * dt_inv;
+    for (int i = 0; i < N - 1; ++i) {
+      V3d vi = (q[i + 1] - q[i]) * dt_inv;
+      for (int k = 0; k < 3; ++k) {
+        double vd = std::fabs(vi[k]) - cfg->max_vel;
+        if (vd > 0.0) {
+          c += std::pow(vd, 2);
+          double sign = vi[k] > 0 ? 1.0 : -1.0;
+          double tmp = 2 * vd * sign * dt_inv;
+          g[i][k] += -tmp;
+          g[i + 1][k] += tmp;
+          if (opt_time) gt += tmp * (-vi[k]);
+        }
+      }
+    }
+    for (int i = 0; i < N - 2; ++i) {
+      V3d ai = (q[i + 2] - 2 * q[i + 1] + q[i]) * dt_inv2;
+      for (int k = 0; k < 3; ++k) {
+        double ad = std::fabs(ai[k]) - cfg->max_acc;
+        if (ad > 0.0) {
+          c += std::pow(ad, 2);
+          double sign = ai[k] > 0 ? 1.0 : -1.0;
+          double tmp = 2 * ad * sign * dt_inv2;
+          g[i][k] += tmp;
+          g[i + 1][k] += -2 * tmp;
+          g[i + 2][k] += tmp;
+          if (opt_time) gt += tmp * ai[k] * (-2) * dt;
+        }
+      }
+    }
+    f += cfg->ld_feasi * c;
+    add_all(cfg->ld_feasi);
+    if (opt_time) grad[nvar - 1] += cfg->ld_feasi * gt;
+  }
+  if (pb->cost_function & (1 << 3)) {  // START
+    double c = 0.0, gt = 0.0;
+    V3d gs[3] = {mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0)};
+    const double* ss = pb->start_state;
+    V3d s0 = mk(ss[0], ss[1], ss[2]), s1 = mk(ss[3], ss[4], ss[5]), s2 = mk(ss[6], ss[7], ss[8]);
+    V3d q1 = q[0], q2 = q[1], q3 = q[2], dq;
+    static const double w_pos = 10.0;
+    dq = 1 / 6.0 * (q1 + 4 * q2 + q3) - s0;
+    c += w_pos * sqnorm(dq);
+    gs[0] = gs[0] + w_pos * 2 * dq * (1 / 6.0);
+    gs[1] = gs[1] + w_pos * 2 * dq * (4 / 6.0);
+    gs[2] = gs[2] + w_pos * 2 * dq * (1 / 6.0);
+    dq = 1 / (2 * dt) * (q3 - q1) - s1;
+    c += sqnorm(dq);
+    gs[0] = gs[0] + 2 * dq * (-1.0) / (2 * dt);
+    gs[2] = gs[2] + 2 * dq * 1.0 / (2 * dt);
+    if (opt_time) gt += dot(dq, q3 - q1) / (-dt * dt);
+    dq = 1 / (dt * dt) * (q1 - 2 * q2 + q3) - s2;
+    c += sqnorm(dq);
+    gs[0] = gs[0] + 2 * dq * 1.0 / (dt * dt);
+    gs[1] = gs[1] + 2 * dq * (-2.0) / (dt * dt);
+    gs[2] = gs[2] + 2 * dq * 1.0 / (dt * dt);
+    if (opt_time) gt += dot(dq, q1 - 2 * q2 + q3) / (-dt * dt * dt);
+    f += cfg->ld_start * c;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < dim; j++) grad[dim * i + j] += cfg->ld_start * gs[i][j];
+    if (opt_time) grad[nvar - 1] += cfg->ld_start * gt;
+  }
+  if (pb->cost_function & (1 << 4)) {  // END
+    double c = 0.0, gt = 0.0;
+    V3d ge[3] = {mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0)};  // for points N-3, N-2, N-1
+    const double* es = pb->end_state;
+    V3d q_3 = q[N - 3], q_2 = q[N - 2], q_1 = q[N - 1], dq;
+    dq = 1 / 6.0 * (q_1 + 4 * q_2 + q_3) - mk(es[0], es[1], es[2]);
+    c += sqnorm(dq);
+    ge[2] = ge[2] + 2 * dq * (1 / 6.0);
+    ge[1] = ge[1] + 2 * dq * (4 / 6.0);
+    ge[0] = ge[0] + 2 * dq * (1 / 6.0);
+    if (pb->end_n >= 2) {
+      dq = 1 / (2 * dt) * (q_1 - q_3) - mk(es[3], es[4], es[5]);
+      c += sqnorm(dq);
+      ge[2] = ge[2] + 2 * dq * 1.0 / (2 * dt);
+      ge[0] = ge[0] + 2 * dq * (-1.0) / (2 * dt);
+      if (opt_time) gt += dot(dq, q_1 - q_3) / (-dt * dt);
+    }
+    if (pb->end_n == 3) {
+      dq = 1 / (dt * dt) * (q_1 - 2 * q_2 + q_3) - mk(es[6], es[7], es[8]);
+      c += sqnorm(dq);
+      ge[2] = ge[2] + 2 * dq * 1.0 / (dt * dt);
+      ge[1] = ge[1] + 2 * dq * (-2.0) / (dt * dt);
+      ge[0] = ge[0] + 2 * dq * 1.0 / (dt * dt);
+      if (opt_time) gt += dot(dq, q_1 - 2 * q_2 + q_3) / (-dt * dt * dt);
+    }
+    f += cfg->ld_end * c;
+    for (int i = N - 3; i < N; i++)
+      for (int j = 0; j < dim; j++) grad[dim * i + j] += cfg->ld_end * ge[i - (N - 3)][j];
+    if (opt_time) grad[nvar - 1] += cfg->ld_end * gt;
+  }
+  if (pb->cost_function & (1 << 5)) {  // GUIDE
+    double c = 0.0;
+    zero_g();
+    int end_idx = N - order;
+    for (int i = order; i < end_idx; i++) {
+      const double* gp = pb->guide_pts + 3 * (i - order);
+      V3d d = q[i] - mk(gp[0], gp[1], gp[2]);
+      c += sqnorm(d);
+      g[i] = g[i] + 2 * d;
+    }
+    f += cfg->ld_guide * c;
+    add_all(cfg->ld_guide);
+  }
+  if (pb->cost_function & (1 << 6)) {  // WAYPOINTS
+    double c = 0.0;
+    zero_g();
+    for (int i = 0; i < pb->n_waypt; ++i) {
+      const double* wp = pb->waypoints + 3 * i;
+      int idx = pb->waypt_idx[i];
+      V3d dq = 1 / 6.0 * (q[idx] + 4 * q[idx + 1] + q[idx + 2]) - mk(wp[0], wp[1], wp[2]);
+      c += sqnorm(dq);
+      g[idx] = g[idx] + dq * (2.0 / 6.0);
+      g[idx + 1] = g[idx + 1] + dq * (8.0 / 6.0);
+      g[idx + 2] = g[idx + 2] + dq * (2.0 / 6.0);
+    }
+    f += cfg->ld_waypt * c;
+    add_all(cfg->ld_waypt);
+  }
+  if (pb->cost_function & (1 << 7)) {  // VIEWCONS
+    double c = 0.0;
+    zero_g();
+    V3d p = mk(pb->view_pt[0], pb->view_pt[1], pb->view_pt[2]);
+    V3d dir = mk(pb->view_dir[0], pb->view_dir[1], pb->view_dir[2]);
+    V3d v = dir / norm(dir);
+    int i = pb->view_idx;
+    V3d qp = q[i] - p;
+    V3d dn = qp - dot(qp, v) * v;
+    c += sqnorm(dn);
+    // (I - v v^T) dn
+    V3d t = dn - dot(v, dn) * v;
+    g[i] = g[i] + 2 * t;
+    V3d dl = dot(qp, v) * v;
+    double norm_dl = norm(dl);
+    double safe = norm(dir);
+    if (norm_dl < safe) {
+      c += cfg->wnl * std::pow(norm_dl - safe, 2);
+      V3d vvT_dl = dot(v, dl) * v;
+      g[i] = g[i] + cfg->wnl * 2 * (norm_dl - safe) * vvT_dl / norm_dl;
+    }
+    f += cfg->ld_view * c;
+    add_all(cfg->ld_view);
+  }
+  if (pb->cost_function & MINTIME) {
+    double duration = (N - order) * dt;
+    double c = duration;
+    double gt = double(N - order);
+    if (pb->time_lb > 0 && duration < pb->time_lb) {
+      static const double w_lb = 10;
+      c += w_lb * std::pow(duration - pb->time_lb, 2);
+      gt += w_lb * 2 * (duration - pb->time_lb) * (N - order);
+    }
+    f += cfg->ld_time * c;
+    grad[nvar - 1] += cfg->ld_time * gt;
+  }
+  *cost_out = f;
+}
+
+}  // extern "C"
