@@ -103,6 +103,7 @@ struct fuelmi_map {
 };
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
+int plane_alloc(fuelmi_map* m, Plane& pl);  // zeroed, with margins
 
 // stage profiling helpers: bracket a launch sequence belonging to `stage`
 struct StageScope {

@@ -1,0 +1,328 @@
+// insert.hip -- depth-point fusion (SDFMap::inputPointCloud, plan_env/src/sdf_map.cpp:259-345;
+// setCacheOccupancy :243-257; closetPointInMap :347-362; RayCaster plan_env/src/raycast.cpp:323-407).
+//
+// The reference is sequential: per point classify/clip, count hit|miss at the end voxel, and the
+// FIRST point that lands in an end voxel this frame casts a ray back to the camera marking misses;
+// afterwards every touched voxel gets one clamped log-odds update (hit wins iff any hit, because
+// count_miss_ is set to 1, not incremented).  Order only matters for "first point per end voxel",
+// which is the lowest point index -> atomicMin.  Everything else is a set union:
+//   A  per point : classify, atomicOr hit/miss bit of the end voxel, atomicMin owner, bbox
+//   B  per point : if owner and flag_rayend_ != raycast_num_: walk the ray, atomicOr miss bits
+//   C  per word  : touched = hit|miss -> log-odds update in f64 (bit-exact), refresh state planes
+// All geometry is f64 with the reference's exact expressions (compiled with -ffp-contract=off).
+#include <cfloat>
+#include <cstring>
+#include <cmath>
+
+#include "fuelmi_internal.h"
+
+struct InsertArgs {
+  const unsigned char* pts;  // device copy of the records
+  int stride, n;
+  double cam[3];
+  double max_ray;
+  signed char num;  // raycast_num_ after increment
+  u64* hit;
+  u64* miss;
+  u32* owner;
+  unsigned char* flag_rayend;
+  u64* bbox;  // [6] sortable-encoded min xyz, max xyz
+};
+
+__device__ __forceinline__ u64 enc_f64(double d) {
+  u64 u = (u64)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+static inline double dec_f64(u64 e) {
+  u64 u = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+  double d;
+  memcpy(&d, &u, sizeof(d));
+  return d;
+}
+static inline u64 enc_f64_host(double d) {
+  u64 u;
+  memcpy(&u, &d, sizeof(u));
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ bool in_map_pos(const Geo& g, const double p[3]) {
+  for (int i = 0; i < 3; ++i)
+    if (p[i] < g.minb[i] + 1e-4) return false;
+  for (int i = 0; i < 3; ++i)
+    if (p[i] > g.maxb[i] - 1e-4) return false;
+  return true;
+}
+
+// classify one point exactly like sdf_map.cpp:276-303; returns false if the point is dropped
+__device__ __forceinline__ bool classify(const Geo& g, const InsertArgs& A, int i, double pt[3], int& flag) {
+  const float* p = reinterpret_cast<const float*>(A.pts + (size_t)i * A.stride);
+  pt[0] = p[0];
+  pt[1] = p[1];
+  pt[2] = p[2];
+  double length;
+  if (!in_map_pos(g, pt)) {
+    // closetPointInMap (:347-362)
+    double diff[3], min_t = 1000000;
+    for (int k = 0; k < 3; ++k) diff[k] = pt[k] - A.cam[k];
+    for (int k = 0; k < 3; ++k) {
+      if (fabs(diff[k]) > 0) {
+        double t1 = (g.maxb[k] - A.cam[k]) / diff[k];
+        if (t1 > 0 && t1 < min_t) min_t = t1;
+        double t2 = (g.minb[k] - A.cam[k]) / diff[k];
+        if (t2 > 0 && t2 < min_t) min_t = t2;
+      }
+    }
+    for (int k = 0; k < 3; ++k) pt[k] = A.cam[k] + (min_t - 1e-3) * diff[k];
+    double d0 = pt[0] - A.cam[0], d1 = pt[1] - A.cam[1], d2 = pt[2] - A.cam[2];
+    length = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    if (length > A.max_ray) {
+      pt[0] = d0 / length * A.max_ray + A.cam[0];
+      pt[1] = d1 / length * A.max_ray + A.cam[1];
+      pt[2] = d2 / length * A.max_ray + A.cam[2];
+    }
+    if (pt[2] < 0.2) return false;
+    flag = 0;
+  } else {
+    double d0 = pt[0] - A.cam[0], d1 = pt[1] - A.cam[1], d2 = pt[2] - A.cam[2];
+    length = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    if (length > A.max_ray) {
+      pt[0] = d0 / length * A.max_ray + A.cam[0];
+      pt[1] = d1 / length * A.max_ray + A.cam[1];
+      pt[2] = d2 / length * A.max_ray + A.cam[2];
+      if (pt[2] < 0.2) return false;
+      flag = 0;
+    } else
+      flag = 1;
+  }
+  return true;
+}
+
+__device__ __forceinline__ long pos_adr(const Geo& g, const double p[3]) {
+  int id[3];
+  for (int k = 0; k < 3; ++k) id[k] = (int)floor((p[k] - g.org[k]) * g.res_inv);
+  return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2];
+}
+
+__global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double pt[3];
+  int flag = 0;
+  bool ok = (i < A.n) && classify(g, A, i, pt, flag);
+  if (ok) {
+    long a = pos_adr(g, pt);
+    if (a >= 0 && a < g.N) {
+      u64 bit = 1ull << (a & 63);
+      if (flag)
+        atomicOr(&A.hit[a >> 6], bit);
+      else
+        atomicOr(&A.miss[a >> 6], bit);
+      atomicMin(&A.owner[a], (u32)i);
+    } else
+      ok = false;
+  }
+  // bounding box of the kept end points (update_min/max, :303-306): wave reduce, then atomics
+  u64 lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = ok ? enc_f64(pt[k]) : ~0ull;
+    hi[k] = ok ? enc_f64(pt[k]) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+      u64 t = __shfl_down(lo[k], off, 64);
+      lo[k] = min(lo[k], t);
+      t = __shfl_down(hi[k], off, 64);
+      hi[k] = max(hi[k], t);
+    }
+  }
+  if ((threadIdx.x & 63) == 0 && lo[0] != ~0ull)
+    for (int k = 0; k < 3; ++k) {
+      atomicMin(&A.bbox[k], lo[k]);
+      atomicMax(&A.bbox[3 + k], hi[k]);
+    }
+}
+
+// RayCaster helpers (raycast.cpp:6-23)
+__device__ __forceinline__ double rc_mod(double value, double modulus) {
+  return fmod(fmod(value, modulus) + modulus, modulus);
+}
+__device__ __forceinline__ double rc_intbound(double s, double ds) {
+  if (ds < 0) {
+    s = -s;
+    ds = -ds;
+  }
+  s = rc_mod(s, 1);
+  return (1 - s) / ds;
+}
+
+__global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  double pt[3];
+  int flag = 0;
+  if (!classify(g, A, i, pt, flag)) return;
+  long a = pos_adr(g, pt);
+  if (a < 0 || a >= g.N) return;
+  if (A.owner[a] != (u32)i) return;  // not the first point of this end voxel
+  A.owner[a] = 0xFFFFFFFFu;          // leave the owner table clean for the next frame
+  if ((signed char)A.flag_rayend[a] == A.num) return;
+  A.flag_rayend[a] = (unsigned char)A.num;
+
+  // RayCaster::input(pt_w, camera_pos) (raycast.cpp:329-372)
+  double s[3], e[3];
+  for (int k = 0; k < 3; ++k) {
+    s[k] = pt[k] / g.res;
+    e[k] = A.cam[k] / g.res;
+  }
+  int c[3], ec[3], st[3];
+  double tmax[3], tdel[3];
+  for (int k = 0; k < 3; ++k) {
+    c[k] = (int)floor(s[k]);
+    ec[k] = (int)floor(e[k]);
+    double d = ec[k] - c[k];
+    int di = (int)d;
+    st[k] = di == 0 ? 0 : (di < 0 ? -1 : 1);
+    tmax[k] = rc_intbound(s[k], d);
+    tdel[k] = ((double)st[k]) / d;
+  }
+  const double off[3] = {0.5 - g.org[0] / g.res, 0.5 - g.org[1] / g.res, 0.5 - g.org[2] / g.res};
+  int guard = abs(ec[0] - c[0]) + abs(ec[1] - c[1]) + abs(ec[2] - c[2]) + 4;
+  bool first = true;
+  while (true) {
+    // nextId (:374-407): report current cell, stop at the end cell, else step
+    int ix = (int)((double)c[0] + off[0]), iy = (int)((double)c[1] + off[1]), iz = (int)((double)c[2] + off[2]);
+    if (c[0] == ec[0] && c[1] == ec[1] && c[2] == ec[2]) break;
+    if (!first) {  // the first reported cell (the end voxel itself) is discarded (:314)
+      long av = (long)ix * g.nyz + (long)iy * g.nz + iz;
+      if (av >= 0 && av < g.N) atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
+    }
+    first = false;
+    if (tmax[0] < tmax[1]) {
+      if (tmax[0] < tmax[2]) {
+        c[0] += st[0];
+        tmax[0] += tdel[0];
+      } else {
+        c[2] += st[2];
+        tmax[2] += tdel[2];
+      }
+    } else {
+      if (tmax[1] < tmax[2]) {
+        c[1] += st[1];
+        tmax[1] += tdel[1];
+      } else {
+        c[2] += st[2];
+        tmax[2] += tdel[2];
+      }
+    }
+    if (--guard < 0) break;
+  }
+}
+
+// log-odds update of every touched voxel (:332-344) + refresh of the state planes
+__global__ void __launch_bounds__(256)
+k_insert_update(Geo g, u64* __restrict__ hit, u64* __restrict__ miss, double* __restrict__ occ,
+                u64* __restrict__ occ_bits, u64* __restrict__ unk_bits, int w_lo, int w_hi, double l_hit,
+                double l_miss, double l_min, double l_max, double l_occ) {
+  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > w_hi) return;
+  u64 h = hit[w], ms = miss[w];
+  u64 t = h | ms;
+  if (t == 0ull) return;
+  hit[w] = 0ull;
+  miss[w] = 0ull;
+  u64 ob = occ_bits[w], ub = unk_bits[w];
+  const double thr_unk = l_min - 1e-3;
+  while (t) {
+    int b = __builtin_ctzll(t);
+    t &= t - 1;
+    long a = 64L * w + b;
+    double upd = ((h >> b) & 1ull) ? l_hit : l_miss;
+    double o = occ[a];
+    if (o < thr_unk) o = l_occ;
+    o = fmin(fmax(o + upd, l_min), l_max);
+    occ[a] = o;
+    u64 bit = 1ull << b;
+    ob = (o > l_occ) ? (ob | bit) : (ob & ~bit);
+    ub = (o < thr_unk) ? (ub | bit) : (ub & ~bit);
+  }
+  occ_bits[w] = ob;
+  unk_bits[w] = ub;
+}
+
+int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const double cam[3]) {
+  const Geo& g = m->g;
+  const fuelmi_map_info& I = m->info;
+  m->raycast_num = (signed char)(m->raycast_num + 1);  // char wrap like the reference
+  if (m->reset_updated_box) {
+    for (int k = 0; k < 3; ++k) m->upd_min[k] = m->upd_max[k] = cam[k];
+    m->reset_updated_box = false;
+  }
+  size_t pbytes = (size_t)n * stride;
+  int rc = map_ensure_stage(m, pbytes + 64, 0);
+  if (rc) return rc;
+  u64* d_bbox = reinterpret_cast<u64*>(m->d_stage);
+  unsigned char* d_pts = reinterpret_cast<unsigned char*>(m->d_stage) + 64;
+  u64 h_bbox[6];
+  for (int k = 0; k < 3; ++k) {
+    h_bbox[k] = enc_f64_host(cam[k]);  // update_min = update_max = camera_pos (:265-266)
+    h_bbox[3 + k] = h_bbox[k];
+  }
+  StageScope sc(m, FUELMI_K_INSERT);
+  HIPCHK(hipMemcpyAsync(d_bbox, h_bbox, sizeof(h_bbox), hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d_pts, xyz, pbytes, hipMemcpyHostToDevice, m->stream));
+  InsertArgs A;
+  A.pts = d_pts;
+  A.stride = stride;
+  A.n = n;
+  for (int k = 0; k < 3; ++k) A.cam[k] = cam[k];
+  A.max_ray = m->cfg.max_ray_length;
+  A.num = m->raycast_num;
+  A.hit = m->hit_bits.p;
+  A.miss = m->miss_bits.p;
+  A.owner = m->ray_owner;
+  A.flag_rayend = m->flag_rayend;
+  A.bbox = d_bbox;
+  int nb = (n + 255) / 256;
+  k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
+  k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  double umin[3], umax[3];
+  for (int k = 0; k < 3; ++k) {
+    umin[k] = dec_f64(h_bbox[k]);
+    umax[k] = dec_f64(h_bbox[3 + k]);
+  }
+  // local bound (:319-324) and accumulated update box (:326-330)
+  const int nv[3] = {g.nx, g.ny, g.nz};
+  const double linf = std::max(m->cfg.resolution, m->cfg.local_bound_inflate);
+  for (int k = 0; k < 3; ++k) {
+    double inf = (k < 2) ? linf : 0.0;
+    int hi = (int)std::floor((umax[k] + inf - g.org[k]) * g.res_inv);
+    int lo = (int)std::floor((umin[k] - inf - g.org[k]) * g.res_inv);
+    m->local_bound.lo[k] = std::max(std::min(lo, nv[k] - 1), 0);
+    m->local_bound.hi[k] = std::max(std::min(hi, nv[k] - 1), 0);
+    m->upd_min[k] = std::min(umin[k], m->upd_min[k]);
+    m->upd_max[k] = std::max(umax[k], m->upd_max[k]);
+  }
+  // touched voxels lie in the index bbox of camera and end points (+1 voxel: the ray walker
+  // and posToIndex floor differently at cell faces)
+  int lo3[3], hi3[3];
+  for (int k = 0; k < 3; ++k) {
+    lo3[k] = std::max((int)std::floor((umin[k] - g.org[k]) * g.res_inv) - 1, 0);
+    hi3[k] = std::min((int)std::floor((umax[k] - g.org[k]) * g.res_inv) + 1, nv[k] - 1);
+  }
+  long a_lo = (long)lo3[0] * g.nyz + (long)lo3[1] * g.nz + lo3[2];
+  long a_hi = (long)hi3[0] * g.nyz + (long)hi3[1] * g.nz + hi3[2];
+  int w_lo = (int)(a_lo >> 6), w_hi = (int)(a_hi >> 6);
+  k_insert_update<<<(w_hi - w_lo + 256) / 256, 256, 0, m->stream>>>(
+      g, m->hit_bits.p, m->miss_bits.p, m->occ, m->occ_bits.p, m->unk_bits.p, w_lo, w_hi, I.prob_hit_log,
+      I.prob_miss_log, I.clamp_min_log, I.clamp_max_log, I.min_occupancy_log);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,
+                                       const double camera_pos[3]) {
+  ARGCHK(m && camera_pos && n >= 0 && stride_bytes >= 12 && (n == 0 || xyz));
+  if (n == 0) return FUELMI_OK;  // reference: if (point_num == 0) return;
+  HIPCHK(hipSetDevice(m->device));
+  return insert_points(m, xyz, stride_bytes, n, camera_pos);
+}

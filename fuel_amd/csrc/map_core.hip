@@ -245,7 +245,7 @@ __global__ void k_query_state(Geo g, const u64* __restrict__ occ_bits, const u64
 // ---------------------------------------------------------------------------------------------
 // host API
 // ---------------------------------------------------------------------------------------------
-static int alloc_plane(fuelmi_map* m, Plane& pl) {
+int plane_alloc(fuelmi_map* m, Plane& pl) {
   size_t words = (size_t)m->g.W + 2 * (size_t)m->margin_words + 2;
   HIPCHK(hipMalloc(&pl.base, words * sizeof(u64)));
   HIPCHK(hipMemsetAsync(pl.base, 0, words * sizeof(u64), m->stream));
@@ -340,9 +340,9 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
     fuelmi_set_error("hipStreamCreate failed");
     return fail(FUELMI_EHIP);
   }
-  if ((rc = alloc_plane(m, m->occ_bits)) || (rc = alloc_plane(m, m->unk_bits)) ||
-      (rc = alloc_plane(m, m->infl_bits)) || (rc = alloc_plane(m, m->tmp_bits)) ||
-      (rc = alloc_plane(m, m->hit_bits)) || (rc = alloc_plane(m, m->miss_bits)))
+  if ((rc = plane_alloc(m, m->occ_bits)) || (rc = plane_alloc(m, m->unk_bits)) ||
+      (rc = plane_alloc(m, m->infl_bits)) || (rc = plane_alloc(m, m->tmp_bits)) ||
+      (rc = plane_alloc(m, m->hit_bits)) || (rc = plane_alloc(m, m->miss_bits)))
     return fail(rc);
   size_t Npad = (size_t)g.W * 64;
   if (hipMalloc(&m->occ, Npad * sizeof(double)) != hipSuccess ||
