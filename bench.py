@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- plan cycles/s of the MI355X hot path (BASELINE.json metric).
+
+One "step" = one full plan cycle on one 400x400x100 @ 0.1 m map (BASELINE configs[1], with the
+64-candidate B-spline batch the metric is quoted on), inputs already resident in HBM:
+    clearAndInflateLocalMap (full box)  ->  updateESDF3d (full box)
+    -> FrontierFinder::searchFrontiers over the whole exploration box (fresh flags)
+    -> 64 x combineCost (NORMAL_PHASE|MINTIME, 32 control points each)
+Every rank owns an independent map on its own GPU (RACER-style fleet; the path has no exchange
+step, so there is NO data-path collective -- "weak" scaling by construction).  torch is used only
+for the process group (barrier / max-reduce of the timing) and device selection.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (map_size m, n_obstacles, n_known_spheres)
+    "G400": ((40.0, 40.0, 10.0), 400, 120),
+    "G800": ((80.0, 80.0, 20.0), 3200, 960),
+    "G100": ((10.0, 10.0, 5.0), 25, 8),  # smoke-sized
+}
+
+
+def exploration_box(map_size):
+    org = (-map_size[0] / 2.0, -map_size[1] / 2.0, -1.0)
+    lo = (org[0] + 1.0, org[1] + 1.0, 0.0)
+    hi = (-org[0] - 1.0, -org[1] - 1.0, max(0.8 * map_size[2] - 1.0, 1.0))
+    return lo, hi
+
+
+def make_trajectories(rng, n_traj, n_pts, lo, hi, seg_len=6.0, noise=0.3):
+    ctrl = np.empty((n_traj, n_pts, 3))
+    lo = np.asarray(lo, dtype=float)
+    hi = np.asarray(hi, dtype=float)
+    for c in range(n_traj):
+        a = lo + (hi - lo) * rng.random(3)
+        d = rng.normal(size=3)
+        d[2] *= 0.2
+        d /= np.linalg.norm(d)
+        b = np.clip(a + seg_len * d, lo, hi)
+        t = np.linspace(0, 1, n_pts)[:, None]
+        ctrl[c] = a + (b - a) * t + rng.normal(scale=noise, size=(n_pts, 3))
+    return ctrl
+
+
+def bspline_problem(ctrl, dt):
+    """NLopt-layout variables + boundary states (host arrays) for a batch of candidates."""
+    C, N, _ = ctrl.shape
+    x = np.concatenate([ctrl.reshape(C, N * 3), np.full((C, 1), dt)], axis=1)
+    seg = np.linalg.norm(np.diff(ctrl, axis=1), axis=2).sum(axis=1)
+    pt_dist = seg / float(N)  # optimize(): sum |dq| / point_num (bspline_optimizer.cpp:136-140)
+    start = np.zeros((C, 3, 3))
+    end = np.zeros((C, 3, 3))
+    start[:, 0] = (ctrl[:, 0] + 4 * ctrl[:, 1] + ctrl[:, 2]) / 6.0
+    start[:, 1] = (ctrl[:, 2] - ctrl[:, 0]) / (2 * dt)
+    end[:, 0] = (ctrl[:, -1] + 4 * ctrl[:, -2] + ctrl[:, -3]) / 6.0
+    return np.ascontiguousarray(x), pt_dist, start, end
+
+
+def build_inputs(workload, seed):
+    """Synthetic map state (host) for one agent: occupancy log-odds + candidate trajectories."""
+    from fuel_amd import synth
+    map_size, n_obs, n_sph = WORKLOADS[workload]
+    w = synth.World.for_map_size(map_size)
+    truth = w.world(seed, n_obs)
+    occ, n_known = w.known_state(truth, seed, n_sph)
+    lo, hi = exploration_box(map_size)
+    rng = np.random.default_rng(1000 + seed)
+    ctrl = make_trajectories(rng, 64, 32, np.array(lo) + 0.5, np.array(hi) - 0.5)
+    return map_size, (lo, hi), occ, ctrl, n_known
+
+
+class GpuCycle:
+    """The hot path on one GPU through the C-ABI (fuel_amd.host mirrors the reference classes)."""
+
+    def __init__(self, map_size, box, occ, ctrl, device, dt=0.175):
+        import fuel_amd
+        self.fa = fuel_amd
+        self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device)
+        self.map.uploadOccupancy(occ)
+        nv = self.map.nvox
+        self.map.setLocalBound((0, 0, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1))
+        self.box = box
+        self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100)
+        self.opt = fuel_amd.BsplineOptimizer()
+        self.opt.setEnvironment(self.map)
+        x, ptd, st, en = bspline_problem(ctrl, dt)
+        cf = fuel_amd.NORMAL_PHASE | fuel_amd.MINTIME
+        self.problem = fuel_amd.BsplineBatchProblem(x, ctrl.shape[1], cf, ptd, st, en, 3, 3, dt)
+        self.dev_problem = self.opt.deviceProblem(self.problem)
+        self.n_clusters = 0
+
+    def step(self):
+        m = self.map
+        m.clearAndInflateLocalMap()
+        m.updateESDF3d()
+        self.ff.reset()
+        m.setUpdatedBox(self.box[0], self.box[1])
+        self.n_clusters = self.ff.searchFrontiers()
+        self.dev_problem.eval()
+
+    def finish(self):
+        self.map.synchronize()
+
+
+def cpu_baseline(map_size, box, occ, ctrl, budget_s=12.0, dt=0.175):
+    """The CPU oracle (restatement of the reference, 1 thread) on the same cycle, bounded sample."""
+    from oracle import fuel_oracle as fo
+    om = fo.OracleMap(map_size, box[0], box[1])
+    om.occ[:] = occ
+    nv = om.nvox
+    om.set_local_bound((0, 0, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1))
+    x, ptd, st, en = bspline_problem(ctrl, dt)
+    cf = fo.COST["NORMAL_PHASE"] | fo.COST["MINTIME"]
+    times = []
+    stage = np.zeros(4)
+    t_all = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        om.inflate_local()
+        t1 = time.perf_counter()
+        om.update_esdf()
+        t2 = time.perf_counter()
+        of = fo.OracleFrontier(om, 100)
+        om.set_updated_box(box[0], box[1])
+        of.search()
+        t3 = time.perf_counter()
+        for c in range(ctrl.shape[0]):
+            fo.bspline_cost_grad(om, x[c], ctrl.shape[1], cf, ptd[c], st[c], en[c], 3, 3, dt)
+        t4 = time.perf_counter()
+        times.append(t4 - t0)
+        stage += (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+        del of
+        if len(times) >= 2 and time.perf_counter() - t_all > budget_s:
+            break
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "cycles/s", "cores": 1, "kind": "port",
+            "sample": "%d full plan cycles of the same G-map (median), 1 thread, g++ -O3; "
+                      "stage ms inflate/esdf/frontier/bspline = %s" %
+                      (len(times), "/".join("%.1f" % (1e3 * s / len(times)) for s in stage))}
+
+
+def timed_fleet_run(step, finish, steps, dist=None, device_sync=None, device="cuda"):
+    """Time exactly `steps` steps, bracketed by barrier + device sync on both sides; returns the MAX
+    elapsed seconds over ranks.  No data-path collective: ranks are independent maps."""
+    import torch
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        finish()
+        if device_sync is not None:
+            device_sync()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def fleet_value(n_ranks, steps, elapsed_max):
+    """Whole-job throughput: units all ranks processed / max-over-ranks time."""
+    return n_ranks * steps / elapsed_max
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="G400", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    import fuel_amd
+    from fuel_amd import _lib
+    map_size, box, occ, ctrl, n_known = build_inputs(args.workload, seed=42 + rank)
+    cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank)
+
+    # W untimed warmup steps, then a short untimed pass with every stage bracketed by HIP events
+    # (on the map's own stream) to find the dominant kernel
+    stages = {"inflate": _lib.K_INFLATE, "esdf_zy": _lib.K_ESDF_ZY, "esdf_x": _lib.K_ESDF_X,
+              "frontier": _lib.K_FRONTIER, "bspline": _lib.K_BSPLINE}
+    for _ in range(args.warmup):
+        cyc.step()
+    cyc.finish()
+    cyc.map.profileEnable(sum(1 << v for v in stages.values()))
+    for _ in range(3):
+        cyc.step()
+    cyc.finish()
+    stage_ms = {}
+    for name, sid in stages.items():
+        n, tot = cyc.map.profileGet(sid)
+        stage_ms[name] = tot / max(n, 1)
+    kernel_stages = {k: v for k, v in stage_ms.items() if k != "frontier"}  # frontier = many kernels + host
+    dominant = max(kernel_stages, key=kernel_stages.get)
+    # timed region: only the dominant kernel stays bracketed (two event records per step)
+    cyc.map.profileEnable(1 << stages[dominant])
+    elapsed = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
+    n_launch, dom_total_ms = cyc.map.profileGet(stages[dominant])
+    dom_ms = dom_total_ms / max(n_launch, 1)
+
+    if rank == 0:
+        nv = cyc.map.nvox
+        nvox = nv[0] * nv[1] * nv[2]
+        # algorithmic HBM bytes per launch of each stage, full box = nvox
+        alg_bytes = {
+            "inflate": nvox * (3 / 8.0),          # occupied plane in, scratch plane out+in, inflated plane out
+            "esdf_zy": nvox * (2 / 8.0 + 4.0),    # inflated+unknown planes in, u32 y-pass result out
+            "esdf_x": nvox * (4.0 + 4.0),         # u32 in, f32 distance out
+            "bspline": ctrl.shape[0] * ctrl.shape[1] * 56.0,
+        }
+        achieved = alg_bytes[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "plan_cycles_per_sec",
+            "value": fleet_value(n_gpus, args.steps, elapsed),
+            "unit": "cycles/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 bit-planes / u32 squared distances / f32 ESDF / f64 log-odds and B-spline",
+            "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d @0.1m map per GPU, full-box inflate+ESDF, full "
+                                   "exploration-box frontier search, 64 B-spline candidates x 32 ctrl pts"
+                                   % (args.workload, nv[0], nv[1], nv[2]),
+                       "known_voxels": int(n_known), "frontier_clusters": int(cyc.n_clusters),
+                       "parallelism": "independent map per GPU (no collective)"},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes[dominant]},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(map_size, box, occ, ctrl, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

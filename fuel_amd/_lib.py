@@ -111,6 +111,7 @@ SYMBOLS = {
     "fuelmi_map_synchronize": (C.c_int, [_P]),
     "fuelmi_frontier_create": (C.c_int, [_P, C.POINTER(FrontierCfg), _PP]),
     "fuelmi_frontier_destroy": (None, [_P]),
+    "fuelmi_frontier_reset": (C.c_int, [_P]),
     "fuelmi_frontier_search": (C.c_int, [_P, _ip]),
     "fuelmi_frontier_commit": (C.c_int, [_P, C.c_int]),
     "fuelmi_frontier_count": (C.c_int, [_P, C.c_int]),

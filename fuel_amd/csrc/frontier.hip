@@ -732,6 +732,18 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   return FUELMI_OK;
 }
 
+extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
+  ARGCHK(f);
+  fuelmi_map* m = f->map;
+  HIPCHK(hipSetDevice(m->device));
+  f->frontiers.clear();
+  f->dormant.clear();
+  f->tmp.clear();
+  f->removed_ids.clear();
+  HIPCHK(hipMemsetAsync(f->flag.p, 0, (size_t)m->g.W * sizeof(u64), m->stream));
+  return FUELMI_OK;
+}
+
 extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
   ARGCHK(f);
   auto& dst = dormant ? f->dormant : f->frontiers;

@@ -240,6 +240,9 @@ class FrontierFinder:
     def commit(self, dormant=False):
         check(self.L.fuelmi_frontier_commit(self.h, int(dormant)))
 
+    def reset(self):
+        check(self.L.fuelmi_frontier_reset(self.h))
+
     def clusters(self, which=0):
         out = []
         cnt = self.L.fuelmi_frontier_count(self.h, which)

@@ -1,19 +1,28 @@
-// fixture.cpp -- deterministic synthetic worlds and depth frames (TEST INFRASTRUCTURE ONLY).
+// synth.cpp -- deterministic synthetic worlds, knowledge states and depth frames.
 //
-// Not a restatement of reference code: the reference gets its worlds from .pcd files
-// (uav_simulator/map_generator/src/map_publisher.cpp:20-52) and its depth frames from a
-// simulator (uav_simulator/local_sensing/src/depth_render_node.cpp:112-168); office.pcd is a
-// missing blob in the snapshot.  This generator follows SURVEY.md section 8(d): splitmix64-seeded
-// pillars/walls on a floor slab, pinhole frames (intrinsics exploration.launch:38-41) rendered by
-// exact voxel traversal of the ground-truth grid, then projected to world points the way
-// MapROS::proessDepthImage does (plan_env/src/map_ros.cpp:176-212: depth beyond
-// depth_filter_maxdist -> maxdist, pt = R*[(u-cx)d/fx,(v-cy)d/fy,d]+t, stored as float).
+// Host-side input generator for bench.py and the tests (there is no network for datasets and
+// office.pcd is a missing blob in the reference snapshot).  It is independent of both the oracle
+// and libfuelmi: plain grid parameters in, plain arrays out.  Recipe: SURVEY.md section 8(d) --
+// splitmix64-seeded pillars/walls on a floor slab (the reference gets worlds from .pcd files,
+// uav_simulator/map_generator/src/map_publisher.cpp:20-52), pinhole frames (intrinsics
+// exploration_manager/launch/exploration.launch:38-41) rendered by exact voxel traversal of the
+// ground truth, projected to world points the way MapROS::proessDepthImage does
+// (plan_env/src/map_ros.cpp:176-212: depth beyond depth_filter_maxdist -> maxdist,
+// pt = R*[(u-cx)d/fx,(v-cy)d/fy,d]+t, stored as float).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
-#include "fuel_oracle.h"
+extern "C" {
+typedef struct {
+  int nv[3];
+  double origin[3];
+  double res;
+  double logodds[5]; /* prob_hit_log, prob_miss_log, clamp_min_log, clamp_max_log, min_occupancy_log */
+} synth_grid;
+}
 
 namespace {
 struct Rng {
@@ -32,20 +41,14 @@ struct Rng {
 extern "C" {
 
 // Ground-truth occupancy (1 = solid) on the map's voxel grid.  Returns number of solid voxels.
-long fo_fixture_world(const fo_map* m, uint64_t seed, int n_obstacles, unsigned char* truth) {
-  int nv[3];
-  double org[3];
-  fo_map_voxel_num(m, nv);
-  fo_map_origin(m, org);
-  const double res = 0.1;  // generator works in voxel units below; res only sets the slab index
-  (void)res;
+long synth_world(const synth_grid* G, uint64_t seed, int n_obstacles, unsigned char* truth) {
+  const int* nv = G->nv;
+  const double* org = G->origin;
   const long N = (long)nv[0] * nv[1] * nv[2];
   std::memset(truth, 0, (size_t)N);
   auto adr = [&](int x, int y, int z) { return ((long)x * nv[1] + y) * nv[2] + z; };
-  // voxel size from map extent: identical in all axes by construction
   // floor slab: the voxel layer whose top face is z = 0  (z in [-res, 0))
-  // index = floor((-0.5*res - org_z)/res); recover res from origin.x and nv[0] (map is centred)
-  const double vres = (-2.0 * org[0]) / nv[0];
+  const double vres = G->res;
   int zf = (int)std::floor((-0.5 * vres - org[2]) / vres);
   if (zf < 0) zf = 0;
   for (int x = 0; x < nv[0]; ++x)
@@ -75,15 +78,75 @@ long fo_fixture_world(const fo_map* m, uint64_t seed, int n_obstacles, unsigned 
   return cnt;
 }
 
+// "As-if-explored" knowledge state for the large benchmark maps (ray-fusing enough frames to know
+// ~45 % of a 16 M-voxel map would take minutes on the CPU).  Known region K = union of seeded
+// spheres; inside K free-truth voxels become FREE, solid-truth voxels with a free 6-neighbour
+// inside K become OCCUPIED (visible surfaces), everything else stays UNKNOWN.  Log-odds values
+// are ones the fusion rule reaches: clamp_min / one-miss for free, clamp_max / one-hit for
+// occupied (sdf_map.cpp:332-344).  Writes occ[N]; returns the number of known voxels.
+long synth_known_state(const synth_grid* G, const unsigned char* truth, uint64_t seed, int n_spheres,
+                       double rmin, double rmax, double* occ) {
+  const int* nv = G->nv;
+  const double* org = G->origin;
+  const double* lo = G->logodds;
+  const double l_hit = lo[0], l_miss = lo[1], l_min = lo[2], l_max = lo[3], l_occ = lo[4];
+  const double vres = G->res;
+  const long N = (long)nv[0] * nv[1] * nv[2];
+  std::vector<unsigned char> known((size_t)N, 0);
+  Rng r{seed ^ 0x5EEDull};
+  for (int s = 0; s < n_spheres; ++s) {
+    double cx = r.uni(org[0] + 1.0, -org[0] - 1.0), cy = r.uni(org[1] + 1.0, -org[1] - 1.0);
+    double cz = r.uni(0.8, 2.5), rad = r.uni(rmin, rmax);
+    int x0 = std::max(0, (int)std::floor((cx - rad - org[0]) / vres)), x1 = std::min(nv[0] - 1, (int)std::floor((cx + rad - org[0]) / vres));
+    int y0 = std::max(0, (int)std::floor((cy - rad - org[1]) / vres)), y1 = std::min(nv[1] - 1, (int)std::floor((cy + rad - org[1]) / vres));
+    int z0 = std::max(0, (int)std::floor((cz - rad - org[2]) / vres)), z1 = std::min(nv[2] - 1, (int)std::floor((cz + rad - org[2]) / vres));
+    for (int x = x0; x <= x1; ++x)
+      for (int y = y0; y <= y1; ++y)
+        for (int z = z0; z <= z1; ++z) {
+          double dx = (x + 0.5) * vres + org[0] - cx, dy = (y + 0.5) * vres + org[1] - cy, dz = (z + 0.5) * vres + org[2] - cz;
+          if (dx * dx + dy * dy + dz * dz <= rad * rad) known[((long)x * nv[1] + y) * nv[2] + z] = 1;
+        }
+  }
+  long cnt = 0;
+  const double unknown = l_min - 0.01;
+  for (int x = 0; x < nv[0]; ++x)
+    for (int y = 0; y < nv[1]; ++y)
+      for (int z = 0; z < nv[2]; ++z) {
+        long a = ((long)x * nv[1] + y) * nv[2] + z;
+        double v = unknown;
+        if (known[a]) {
+          uint64_t h = (uint64_t)a * 0x9E3779B97F4A7C15ull;
+          h ^= h >> 29;
+          if (!truth[a]) {
+            v = (h & 3) ? l_min : std::min(std::max(l_occ + l_miss, l_min), l_max);
+            ++cnt;
+          } else {
+            bool surf = false;
+            const int d[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+            for (auto& o : d) {
+              int xx = x + o[0], yy = y + o[1], zz = z + o[2];
+              if (xx < 0 || yy < 0 || zz < 0 || xx >= nv[0] || yy >= nv[1] || zz >= nv[2]) continue;
+              long b = ((long)xx * nv[1] + yy) * nv[2] + zz;
+              if (known[b] && !truth[b]) surf = true;
+            }
+            if (surf) {
+              v = (h & 3) ? l_max : std::min(std::max(l_occ + l_hit, l_min), l_max);
+              ++cnt;
+            }
+          }
+        }
+        occ[a] = v;
+      }
+  return cnt;
+}
+
 // k-th camera pose of the seeded tour: a Lissajous path at flight height with sweeping yaw,
 // nudged out of solid voxels.  pose = {x,y,z,yaw,pitch}
-void fo_fixture_camera(const fo_map* m, const unsigned char* truth, uint64_t seed, int k, int n_total,
-                       double extent_frac, double pose[5]) {
-  int nv[3];
-  double org[3];
-  fo_map_voxel_num(m, nv);
-  fo_map_origin(m, org);
-  const double vres = (-2.0 * org[0]) / nv[0];
+void synth_camera(const synth_grid* G, const unsigned char* truth, uint64_t seed, int k, int n_total,
+                  double extent_frac, double pose[5]) {
+  const int* nv = G->nv;
+  const double* org = G->origin;
+  const double vres = G->res;
   Rng r{seed ^ 0xC0FFEEull};
   double ph1 = r.uni(0, 6.28318), ph2 = r.uni(0, 6.28318);
   double t = (n_total > 1) ? (double)k / (double)n_total : 0.0;
@@ -111,14 +174,12 @@ void fo_fixture_camera(const fo_map* m, const unsigned char* truth, uint64_t see
 
 // Render one depth frame against the truth grid and project to world points (float xyz, 12-byte
 // stride).  Returns number of points written (<= cap).
-int fo_fixture_render(const fo_map* m, const unsigned char* truth, const double pose[5], int width,
-                      int height, int skip, int margin, double fx, double fy, double cx, double cy,
-                      double maxdist, double mindist, float* out, int cap) {
-  int nv[3];
-  double org[3];
-  fo_map_voxel_num(m, nv);
-  fo_map_origin(m, org);
-  const double vres = (-2.0 * org[0]) / nv[0];
+int synth_render(const synth_grid* G, const unsigned char* truth, const double pose[5], int width, int height,
+                 int skip, int margin, double fx, double fy, double cx, double cy, double maxdist,
+                 double mindist, float* out, int cap) {
+  const int* nv = G->nv;
+  const double* org = G->origin;
+  const double vres = G->res;
   const double yaw = pose[3], pitch = pose[4];
   // camera axes in world: z_c forward, x_c right, y_c down
   double cyw = std::cos(yaw), syw = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);

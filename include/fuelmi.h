@@ -134,6 +134,9 @@ typedef struct fuelmi_frontier fuelmi_frontier;
 
 int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* cfg, fuelmi_frontier** out);
 void fuelmi_frontier_destroy(fuelmi_frontier* f);
+/* forget all clusters and clear frontier_flag_ (== constructing a fresh FrontierFinder,
+ * frontier_finder.cpp:23-27) */
+int fuelmi_frontier_reset(fuelmi_frontier* f);
 /* searchFrontiers up to (not including) splitLargeFrontiers: consumes the map's updated box
  * (getUpdatedBox(reset=true)), drops changed clusters, scans, clusters.  *n_new = number of new
  * clusters (tmp_frontiers_.size()). */

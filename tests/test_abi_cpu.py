@@ -1,0 +1,93 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/fuelmi.h declares, the ctypes mirrors match the C struct layouts, and without a GPU the
+product fails loudly (there is no CPU fallback).  No compute calls are made here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fuelmi.h")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    import fuel_amd
+    return fuel_amd
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fuelmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_functions_are_all_exported(built):
+    names = declared_functions()
+    assert len(names) >= 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (fuelmi_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, "declared in include/fuelmi.h but not exported: %s" % missing
+
+
+def test_python_binding_covers_header(built):
+    from fuel_amd import _lib
+    assert sorted(_lib.SYMBOLS) == declared_functions()
+    L = built.lib()
+    assert L.fuelmi_version().startswith(b"fuelmi")
+
+
+def test_ctypes_struct_layouts_match_c(built, tmp_path):
+    from fuel_amd import _lib
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fuelmi.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fuelmi_map_cfg), '
+                    'sizeof(fuelmi_map_info), sizeof(fuelmi_frontier_cfg), sizeof(fuelmi_bspline_cfg), '
+                    'sizeof(fuelmi_bspline_batch), offsetof(fuelmi_map_cfg, device), '
+                    'offsetof(fuelmi_bspline_batch, view_idx));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_lib.MapCfg), C.sizeof(_lib.MapInfo), C.sizeof(_lib.FrontierCfg), C.sizeof(_lib.BsplineCfg),
+            C.sizeof(_lib.BsplineBatch), _lib.MapCfg.device.offset, _lib.BsplineBatch.view_idx.offset]
+    assert got == want
+
+
+def test_header_is_plain_c(tmp_path):
+    prog = tmp_path / "c.c"
+    prog.write_text('#include "fuelmi.h"\nint main(void){return FUELMI_OK;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(prog), "-o", str(tmp_path / "c.o")])
+
+
+def test_no_gpu_means_loud_failure(built):
+    L = built.lib()
+    if L.fuelmi_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(built.FuelmiError) as e:
+        built.SDFMap((4.0, 4.0, 2.0))
+    assert "no CPU fallback" in str(e.value) or "-2" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under fuel_amd/ or include/ may import, include or link the oracle."""
+    bad = []
+    for base in ("fuel_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle|fuel_oracle|libfuel_oracle|oracle/", txt):
+                        # comments that merely mention the oracle are fine in docs, not in code
+                        for line in txt.splitlines():
+                            s = line.strip()
+                            if re.search(r"(from|import)\s+oracle|#include.*oracle|libfuel_oracle", s) and \
+                                    not s.startswith(("#", "//", "*", '"""')):
+                                bad.append((f, s))
+    assert not bad, bad

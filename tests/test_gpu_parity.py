@@ -1,0 +1,406 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (fuel_amd.host is a thin ctypes
+mirror of the reference classes), against the CPU oracle on the same seeded inputs, against the
+committed golden fixture, and -- at BASELINE.json's full 400x400x100 size -- against the oracle
+plus size-independent properties.  Bars: bit-exact for occupancy log-odds, inflation, occupancy
+state and frontier voxel indices; <= 1e-4 for ESDF values and B-spline gradients; cost rel 1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import fuel_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+ESDF_TOL = 1e-4
+GRAD_TOL = 1e-4
+BIG = 1e6  # "no source" sentinel clamp (reference: res*sqrt(DBL_MAX); device: +inf)
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import fuel_amd
+    assert fuel_amd.lib().fuelmi_device_count() > 0, "no GPU visible: the HIP path cannot run"
+    return fuel_amd
+
+
+def gpu_twin(fa, om, box, **kw):
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1], **kw)
+    gm.uploadOccupancy(om.occ)
+    return gm
+
+
+def assert_map_equal(om, gm, box_idx=None, esdf=True):
+    h = gm.syncHost(occupancy=True, inflate=True, distance=esdf)
+    assert np.array_equal(h["occupancy"], om.occ), "occupancy log-odds not bit-exact"
+    assert np.array_equal(h["inflate"], om.infl), "inflated occupancy not bit-exact"
+    if esdf:
+        d_o = np.minimum(om.dist, BIG).reshape(om.nvox)
+        d_g = np.minimum(h["distance"], BIG).reshape(om.nvox)
+        if box_idx is not None:
+            sl = tuple(slice(box_idx[0][i], box_idx[1][i] + 1) for i in range(3))
+            d_o, d_g = d_o[sl], d_g[sl]
+        assert np.abs(d_o - d_g).max() <= ESDF_TOL
+    return h
+
+
+def sorted_clusters(cl):
+    return [np.sort(c) for c in cl]
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("optimistic,signed", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_inflate_and_esdf_full_and_sub_box(fa, optimistic, signed):
+    om, _, _, box = helpers.explored_oracle_map((8.0, 6.0, 4.0), 12, 20, optimistic=optimistic,
+                                                signed_dist=signed)
+    gm = gpu_twin(fa, om, box, optimistic=optimistic, signed_dist=signed)
+    for lo, hi in [helpers.full_box(om.nvox), ((10, 5, 3), (60, 40, 30)), ((0, 0, 0), (79, 0, 39)),
+                   ((33, 17, 9), (33, 17, 9)), ((70, 50, 30), (79, 59, 39))]:
+        om.set_local_bound(lo, hi)
+        gm.setLocalBound(lo, hi)
+        om.inflate_local()
+        om.update_esdf()
+        gm.clearAndInflateLocalMap()
+        gm.updateESDF3d()
+        assert_map_equal(om, gm, (lo, hi))
+    gm.close()
+
+
+def test_inflate_wrap_quirk_at_map_faces(fa):
+    """Occupied voxels ON the map faces: stamps wrap across rows exactly like the reference's
+    linear-address bounds check (sdf_map.cpp:453-458)."""
+    om = fo.OracleMap((4.0, 3.0, 2.0))
+    nv = om.nvox
+    occ = om.occ.reshape(nv)
+    for id3 in [(0, 0, 0), (0, 0, nv[2] - 1), (0, nv[1] - 1, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1),
+                (5, 0, 7), (5, nv[1] - 1, 7), (9, 11, 0), (9, 11, nv[2] - 1), (nv[0] - 1, 3, 3), (0, 20, 10)]:
+        occ[id3] = om.l_max
+    gm = gpu_twin(fa, om, ((-2, -1.5, -1), (2, 1.5, 1)))
+    for lo, hi in [helpers.full_box(nv), ((0, 0, 0), (6, nv[1] - 1, nv[2] - 1))]:
+        om.infl[:] = 0
+        gm.resetBuffer()
+        om.set_local_bound(lo, hi)
+        gm.setLocalBound(lo, hi)
+        om.inflate_local()
+        gm.clearAndInflateLocalMap()
+        om.update_esdf()
+        gm.updateESDF3d()
+        assert_map_equal(om, gm, (lo, hi))
+    gm.close()
+
+
+def test_esdf_no_sources_and_all_sources(fa):
+    om = fo.OracleMap((3.0, 3.0, 2.0), optimistic=1)
+    gm = fa.SDFMap((3.0, 3.0, 2.0), optimistic=1)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.update_esdf()
+    gm.updateESDF3d()
+    d = gm.syncHost(distance=True)["distance"]
+    assert np.all(d == 0.1 * np.sqrt(np.finfo(np.float64).max)) and np.array_equal(d, om.dist)
+    gm.close()
+    om = fo.OracleMap((3.0, 3.0, 2.0), optimistic=0)  # every voxel unknown -> every voxel a source
+    gm = fa.SDFMap((3.0, 3.0, 2.0), optimistic=0)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.update_esdf()
+    gm.updateESDF3d()
+    assert np.all(gm.syncHost(distance=True)["distance"] == 0.0) and np.all(om.dist == 0.0)
+    gm.close()
+
+
+def test_reset_set_occupied_update_recipe(fa):
+    """The only standalone usage pattern in the reference: resetBuffer -> setOccupied(each pt) ->
+    updateESDF3d (plan_manage/test/compare_topo.cpp:121-133)."""
+    om = fo.OracleMap((6.0, 6.0, 3.0), optimistic=1)
+    gm = fa.SDFMap((6.0, 6.0, 3.0), optimistic=1)
+    rng = np.random.default_rng(2)
+    pts = om.origin + np.array([6.0, 6.0, 3.0]) * rng.random((300, 3))
+    pts = np.vstack([pts, [[50.0, 0, 0], [0, 0, -1.0]]])  # outside the map: ignored
+    om.reset_buffer()
+    gm.resetBuffer()
+    for p in pts:
+        om.set_occupied(p)
+    gm.setOccupied(pts)
+    om.update_esdf()
+    gm.updateESDF3d()
+    assert_map_equal(om, gm, helpers.full_box(om.nvox))
+    lo, hi = (-1.0, -1.0, 0.0), (1.0, 1.5, 1.0)
+    om.reset_buffer(lo, hi)
+    gm.resetBuffer(lo, hi)
+    assert_map_equal(om, gm, None, esdf=False)
+    h = gm.syncHost(distance=True)
+    assert np.abs(np.minimum(h["distance"], BIG) - np.minimum(om.dist, BIG)).max() <= ESDF_TOL
+    gm.close()
+
+
+def test_dist_grad_coarse_dist_and_state_queries(fa):
+    om, _, _, box = helpers.explored_oracle_map((8.0, 6.0, 4.0), 12, 20)
+    gm = gpu_twin(fa, om, box)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    rng = np.random.default_rng(0)
+    pos = om.origin - 0.3 + (np.array([8.0, 6.0, 4.0]) + 0.6) * rng.random((5000, 3))
+    d0, g0 = om.dist_grad(pos)
+    d1, g1 = gm.getDistWithGrad(pos)
+    assert np.abs(d0 - d1).max() <= ESDF_TOL and np.abs(g0 - g1).max() <= GRAD_TOL
+    idx = rng.integers(-2, 85, size=(3000, 3)).astype(np.int32)
+    o_g, i_g = gm.getOccupancy(idx)
+    for k in range(0, 3000, 7):
+        i3 = (fo.C.c_int * 3)(*idx[k])
+        assert o_g[k] == om.L.fo_map_get_occupancy_idx(om.h, i3)
+        assert i_g[k] == om.L.fo_map_get_inflate_idx(om.h, i3)
+    dc = gm.getDistance(pos[:500])
+    for k in range(0, 500, 5):
+        i3 = (fo.C.c_int * 3)(*np.floor((pos[k] - om.origin) * 10).astype(int))
+        assert abs(dc[k] - om.L.fo_map_get_distance_idx(om.h, i3)) <= ESDF_TOL
+    gm.close()
+
+
+def test_depth_insert_bit_exact_over_many_frames(fa):
+    """inputPointCloud parity, including points outside the map, beyond max range, below z=0.2
+    after clipping, duplicates in one end voxel, pcl-style 16-byte stride and an empty cloud."""
+    map_size = (10.0, 8.0, 4.0)
+    box = ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    truth = om.fixture_world(3, 14)
+    rng = np.random.default_rng(9)
+    for k in range(30):
+        pose = om.fixture_camera(truth, 5, k, 30, 0.9)
+        pts = om.fixture_render(truth, pose, 160, 120, 2, 2, maxdist=9.0 if k % 3 == 0 else 5.0)
+        extra = pose[:3] + rng.normal(scale=6.0, size=(40, 3))  # some far outside the map
+        pts = np.vstack([pts, extra.astype(np.float32), pts[:50]])
+        om.input_points(pts, pose[:3])
+        if k % 2:
+            rec = np.zeros((len(pts), 4), dtype=np.float32)
+            rec[:, :3] = pts
+            from fuel_amd._lib import check
+            check(gm.L.fuelmi_map_input_points(gm.h, rec.ctypes.data, 16, len(rec),
+                                               (fo.C.c_double * 3)(*pose[:3])))
+        else:
+            gm.inputPointCloud(pts, pose[:3])
+        assert om.get_local_bound() == gm.getLocalBound()
+        assert np.array_equal(np.concatenate(om.get_updated_box()), np.concatenate(gm.getUpdatedBox()))
+    gm.inputPointCloud(np.zeros((0, 3), np.float32), (0, 0, 0))  # reference: returns immediately
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    assert_map_equal(om, gm, om.get_local_bound())
+    gm.close()
+
+
+def test_frontier_incremental_rounds(fa):
+    map_size = (20.0, 20.0, 5.0)
+    org = (-10.0, -10.0, -1.0)
+    box = ((org[0] + 1, org[1] + 1, 0.0), (9.0, 9.0, 3.0))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    truth = om.fixture_world(42, 60)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    k = 0
+    for r in range(5):
+        for _ in range(12):
+            pose = om.fixture_camera(truth, 7, k, 60, 0.7)
+            k += 1
+            pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+            om.input_points(pts, pose[:3])
+            gm.inputPointCloud(pts, pose[:3])
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g
+        for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+            assert np.array_equal(a, b)  # frontier voxel indices bit-exact, cluster by cluster
+        assert np.array_equal(of.flags, gf.flags())
+        assert np.array_equal(of.removed_ids(), gf.removedIds())
+        for c in range(n_o):
+            for u, v in zip(of.cluster_info(0, c), gf.clusterInfo(0, c)):
+                assert np.abs(u - v).max() < 1e-9
+        of.commit(r == 2)
+        gf.commit(r == 2)
+        for which in (1, 2):
+            for a, b in zip(sorted_clusters(of.clusters(which)), gf.clusters(which)):
+                assert np.array_equal(a, b)
+    gm.close()
+
+
+def test_frontier_low_z_seeds_and_box_faces(fa):
+    """Exploration box whose faces cut through frontier surfaces and a known region reaching below
+    z = 0.4: exercises the non-qualified seeds (never added by BFS, but they start clusters)."""
+    map_size = (8.0, 6.0, 4.0)
+    box = ((-2.0, -1.5, -0.5), (1.0, 2.0, 1.0))
+    om = fo.OracleMap(map_size, *box)
+    truth = om.fixture_world(5, 6)
+    om.fixture_known_state(truth, 5, 6, 1.0, 2.2)
+    gm = gpu_twin(fa, om, box)
+    for cmin in (0, 5, 60):
+        of = fo.OracleFrontier(om, cmin)
+        gf = fa.FrontierFinder(gm, cluster_min=cmin)
+        om.set_updated_box((-1.0, -1.0, 0.2), (0.5, 1.0, 0.8))
+        gm.setUpdatedBox((-1.0, -1.0, 0.2), (0.5, 1.0, 0.8))
+        assert of.search() == gf.searchFrontiers()
+        for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+            assert np.array_equal(a, b)
+        assert np.array_equal(of.flags, gf.flags())
+        gf.close()
+    gm.close()
+
+
+@pytest.mark.parametrize("cf_name", ["NORMAL|MINTIME", "NORMAL", "GUIDE_PHASE", "SMOOTH|WAYPT", "ALL"])
+def test_bspline_cost_and_gradient(fa, cf_name):
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    gm = gpu_twin(fa, om, box)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    cf = {"NORMAL|MINTIME": fa.NORMAL_PHASE | fa.MINTIME, "NORMAL": fa.NORMAL_PHASE, "GUIDE_PHASE": fa.GUIDE_PHASE,
+          "SMOOTH|WAYPT": fa.SMOOTHNESS | fa.WAYPOINTS, "ALL": 0x1FF}[cf_name]
+    rng = np.random.default_rng(4)
+    for Cn, N in [(64, 32), (3, 70), (5, 6)]:
+        ctrl = helpers.make_trajectories(rng, Cn, N, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
+        mint = bool(cf & fa.MINTIME)
+        x, ptd, st, en = helpers.bspline_inputs(ctrl, 0.175, mint)
+        guide = ctrl[:, 3:N - 3, :] + 0.1 if N > 6 else np.zeros((Cn, 0, 3))
+        widx = np.array([1, N // 2, N - 3], dtype=np.int32)
+        wp = ctrl[:, widx + 1, :] + 0.2
+        wi = np.tile(widx, (Cn, 1))
+        vpt = ctrl[:, N // 2, :] + 0.5
+        vdir = np.tile(np.array([0.5, 1.0, 0.2]), (Cn, 1))
+        vidx = np.full(Cn, N // 2 + 1, dtype=np.int32)
+        opt = fa.BsplineOptimizer(ld_view=0.7)
+        opt.setEnvironment(gm)
+        pb = fa.BsplineBatchProblem(x, N, cf, ptd, st, en, 3, 3, 0.175, 1.0 if mint else None, guide, wp, wi,
+                                    vpt, vdir, vidx)
+        cg, gg = opt.combineCost(pb)
+        for c in range(Cn):
+            co, go = fo.bspline_cost_grad(om, x[c], N, cf, ptd[c], st[c], en[c], 3, 3, 0.175,
+                                          1.0 if mint else -1.0, guide[c], wp[c], wi[c], (vpt[c], vdir[c], vidx[c]),
+                                          ld_view=0.7)
+            assert abs(cg[c] - co) <= 1e-6 * max(1.0, abs(co))
+            assert np.abs(gg[c] - go).max() <= GRAD_TOL
+    gm.close()
+
+
+def test_bspline_one_dimensional_yaw_case(fa):
+    """dim = 1 (yaw B-spline, planner_manager.cpp:774-865): order is forced to 3."""
+    om = fo.OracleMap((4.0, 4.0, 2.0))
+    gm = fa.SDFMap((4.0, 4.0, 2.0))
+    rng = np.random.default_rng(8)
+    N, Cn = 12, 4
+    x = rng.normal(size=(Cn, N))
+    cf = fa.SMOOTHNESS | fa.WAYPOINTS | fa.START | fa.END
+    st = np.zeros((Cn, 3, 3))
+    en = np.zeros((Cn, 3, 3))
+    st[:, :, 0] = rng.normal(size=(Cn, 3))
+    en[:, :, 0] = rng.normal(size=(Cn, 3))
+    wp = np.zeros((Cn, 2, 3))
+    wp[:, :, 0] = rng.normal(size=(Cn, 2))
+    wi = np.tile(np.array([2, 6], np.int32), (Cn, 1))
+    ptd = np.array([fo.bspline_pt_dist(x[c].reshape(N, 1)) for c in range(Cn)])
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    cg, gg = opt.combineCost(fa.BsplineBatchProblem(x, N, cf, ptd, st, en, 3, 1, 0.3, None, None, wp, wi))
+    for c in range(Cn):
+        co, go = fo.bspline_cost_grad(om, x[c], N, cf, ptd[c], st[c], en[c], 3, 1, 0.3, -1.0, None, wp[c], wi[c])
+        assert abs(cg[c] - co) <= 1e-9 * max(1.0, abs(co)) and np.abs(gg[c] - go).max() <= 1e-8 * max(1, np.abs(go).max())
+    gm.close()
+
+
+def test_golden_fixture_replay(fa):
+    """Replays the committed inputs of tests/golden/small_cycle.npz through the HIP path."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_cycle.npz"))
+    gm = fa.SDFMap(mg.MAP_SIZE, *mg.BOX)
+    for k in range(mg.N_FRAMES):
+        gm.inputPointCloud(z["pts%d" % k], z["cam%d" % k])
+    lo, hi = gm.getLocalBound()
+    assert np.array_equal(np.array([lo, hi]), z["local_bound"])
+    assert np.array_equal(np.concatenate(gm.getUpdatedBox()), z["updated_box"])
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    h = gm.syncHost(occupancy=True, inflate=True, distance=True)
+    assert np.array_equal(h["occupancy"], z["occupancy"]) and np.array_equal(h["inflate"], z["inflate"])
+    sl = tuple(slice(lo[i], hi[i] + 1) for i in range(3))
+    assert np.abs(h["distance"].reshape(gm.nvox)[sl] - z["distance_box"]).max() <= ESDF_TOL
+    gf = fa.FrontierFinder(gm, cluster_min=mg.CLUSTER_MIN)
+    n = gf.searchFrontiers()
+    off = z["cluster_offsets"]
+    assert n == len(off) - 1
+    for k, c in enumerate(gf.clusters(0)):
+        assert np.array_equal(c, z["cluster_cells"][off[k]:off[k + 1]])
+    assert np.array_equal(gf.flags(), z["frontier_flags"])
+    ctrl, st, en = z["ctrl"], z["start"], z["end"]
+    x = np.concatenate([ctrl.reshape(len(ctrl), -1), np.full((len(ctrl), 1), 0.2)], axis=1)
+    ptd = np.array([fo.bspline_pt_dist(c) for c in ctrl])
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    cost, grad = opt.combineCost(fa.BsplineBatchProblem(x, ctrl.shape[1], fa.NORMAL_PHASE | fa.MINTIME, ptd, st,
+                                                        en, 3, 3, 0.2))
+    assert np.abs(cost - z["bspline_cost"]).max() <= 1e-6 * np.abs(z["bspline_cost"]).max()
+    assert np.abs(grad - z["bspline_grad"]).max() <= GRAD_TOL
+    d, g = gm.getDistWithGrad(z["query_pos"])
+    assert np.abs(d - z["query_dist"]).max() <= ESDF_TOL and np.abs(g - z["query_grad"]).max() <= GRAD_TOL
+    gm.close()
+
+
+def test_full_size_g400_cycle_against_oracle_and_properties(fa):
+    """BASELINE.json configs[1]/[2]: 400x400x100 @ 0.1 m, full-box cycle, 256 candidates."""
+    import bench
+    map_size, box, occ, ctrl64, _ = bench.build_inputs("G400", seed=42)
+    om = fo.OracleMap(map_size, *box)
+    om.occ[:] = occ
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(occ)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    h = assert_map_equal(om, gm, (lo, hi))
+    # size-independent properties of an exact box-local EDT
+    D = h["distance"].reshape(om.nvox)
+    src = (h["inflate"].reshape(om.nvox) == 1) | (occ.reshape(om.nvox) < om.l_min - 1e-3)
+    assert np.array_equal(D == 0.0, src)                      # zero exactly on the sources
+    for ax in range(3):                                        # 1-Lipschitz along every axis
+        assert np.abs(np.diff(D, axis=ax)).max() <= 0.1 + 1e-6
+    q = np.round((D / 0.1) ** 2)                               # squared voxel distances are integers
+    assert np.abs((D / 0.1) ** 2 - q).max() < 1e-3
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    om.set_updated_box(*box)
+    gm.setUpdatedBox(*box)
+    assert of.search() == gf.searchFrontiers()
+    for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(of.flags, gf.flags())
+    # idempotence: nothing changed -> nothing new, nothing removed
+    gf.commit()
+    gm.setUpdatedBox(*box)
+    assert gf.searchFrontiers() == 0 and len(gf.removedIds()) == 0
+    rng = np.random.default_rng(77)
+    ctrl = bench.make_trajectories(rng, 256, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
+    x, ptd, st, en = bench.bspline_problem(ctrl, 0.175)
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    cf = fa.NORMAL_PHASE | fa.MINTIME
+    cg, gg = opt.combineCost(fa.BsplineBatchProblem(x, 32, cf, ptd, st, en, 3, 3, 0.175))
+    for c in range(0, 256, 3):
+        co, go = fo.bspline_cost_grad(om, x[c], 32, cf, ptd[c], st[c], en[c], 3, 3, 0.175)
+        assert abs(cg[c] - co) <= 1e-6 * max(1.0, abs(co)) and np.abs(gg[c] - go).max() <= GRAD_TOL
+    gm.close()
