@@ -162,7 +162,8 @@ __device__ __forceinline__ u64 box_mask_word(const Geo& g, int w, const Box3& b)
 __device__ __forceinline__ double dist_to_f64(float d, double res) {
   // "no source in the box": the reference stores res*sqrt(DBL_MAX) (sdf_map.cpp:196 with
   // fillESDF's DBL_MAX sentinel); the device keeps +inf in f32
-  return isinf(d) ? res * sqrt(1.7976931348623157e308) : (double)d;
+  // (-inf appears only in signed mode: "+= -dist_neg + res" with dist_neg = res*sqrt(DBL_MAX))
+  return isinf(d) ? copysign(res * sqrt(1.7976931348623157e308), (double)d) : (double)d;
 }
 // SDFMap::getDistWithGrad (sdf_map.cpp:497-536), one thread per query, f64 like the reference
 __device__ __forceinline__ double get_distance_idx(const Geo& g, const float* dist, int x, int y, int z) {

@@ -36,8 +36,8 @@ def assert_map_equal(om, gm, box_idx=None, esdf=True):
     assert np.array_equal(h["occupancy"], om.occ), "occupancy log-odds not bit-exact"
     assert np.array_equal(h["inflate"], om.infl), "inflated occupancy not bit-exact"
     if esdf:
-        d_o = np.minimum(om.dist, BIG).reshape(om.nvox)
-        d_g = np.minimum(h["distance"], BIG).reshape(om.nvox)
+        d_o = np.clip(om.dist, -BIG, BIG).reshape(om.nvox)
+        d_g = np.clip(h["distance"], -BIG, BIG).reshape(om.nvox)
         if box_idx is not None:
             sl = tuple(slice(box_idx[0][i], box_idx[1][i] + 1) for i in range(3))
             d_o, d_g = d_o[sl], d_g[sl]
