@@ -107,10 +107,10 @@ class GpuCycle:
         m = self.map
         m.clearAndInflateLocalMap()
         m.updateESDF3d()
+        self.dev_problem.eval()  # async; needs only the ESDF, independent of the frontier search
         self.ff.reset()
         m.setUpdatedBox(self.box[0], self.box[1])
         self.n_clusters = self.ff.searchFrontiers()
-        self.dev_problem.eval()
 
     def finish(self):
         self.map.synchronize()

@@ -314,33 +314,65 @@ __device__ __forceinline__ bool in_box(const Geo& g, const Box3& b, long a) {
   return x >= b.lo[0] && x <= b.hi[0] && y >= b.lo[1] && y <= b.hi[1] && z >= b.lo[2] && z <= b.hi[2];
 }
 
+// one atomicMin per distinct root per wave (a frontier surface is often ONE huge component:
+// per-lane atomics on its root serialise)
+__device__ __forceinline__ void wave_min_claim(u32* claim, bool active, u32 root, u32 a) {
+  u64 todo = __ballot(active);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    int leader = __builtin_ctzll(todo);
+    u32 k = __shfl(root, leader, 64);
+    u64 same = __ballot(active && root == k) & todo;
+    u32 v = ((same >> lane) & 1ull) ? a : 0xFFFFFFFFu;
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (u32)__shfl_xor((int)v, off, 64));
+    if (lane == leader && claim[k] > v) atomicMin(&claim[k], v);
+    todo &= ~same;
+  }
+}
+
 // claims: own cells inside the scan box, then NQ seeds adjacent to a component
 __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
   const u32 nq = F.counts[0], ns = F.counts[1];
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq + ns; i += gridDim.x * blockDim.x) {
+  const u32 nq_r = (nq + 63u) & ~63u, ns_r = (ns + 63u) & ~63u;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq_r; i += gridDim.x * blockDim.x) {
+    bool active = false;
+    u32 a = 0, r = 0;
     if (i < nq) {
-      u32 a = F.cell_adr[i];
+      a = F.cell_adr[i];
       if (in_box(g, F.sbox, a)) {
-        u32 r = F.parent[i];
-        if (F.claim[r] > a) atomicMin(&F.claim[r], a);
+        active = true;
+        r = F.parent[i];
       }
-    } else {
-      long a = F.seed_adr[i - nq];
-      int x = (int)(a / g.nyz);
-      int rr = (int)(a - (long)x * g.nyz);
-      int y = rr / g.nz, z = rr - y * g.nz;
-      for (int k = 0; k < 27; ++k) {
-        if (k == 13) continue;
-        int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
-        int xx = x + dx, yy = y + dy, zz = z + dz;
-        if (xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
+    }
+    wave_min_claim(F.claim, active, r, a);
+  }
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < ns_r; i += gridDim.x * blockDim.x) {
+    const bool live = i < ns;
+    long a = live ? F.seed_adr[i] : 0;
+    int x = (int)(a / g.nyz);
+    int rr = (int)(a - (long)x * g.nyz);
+    int y = rr / g.nz, z = rr - y * g.nz;
+    u32 last = NOCLAIM;
+    for (int k = 0; k < 27; ++k) {
+      if (k == 13) continue;
+      int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+      int xx = x + dx, yy = y + dy, zz = z + dz;
+      bool active = live && !(xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz);
+      u32 r = 0;
+      if (active) {
         long an = a + (long)dx * g.nyz + (long)dy * g.nz + dz;
-        if (!((F.qb[an >> 6] >> (an & 63)) & 1ull)) continue;
-        u32 j = rank_q(F, an);
-        if (j >= F.cap_q) continue;
-        u32 r = F.parent[j];
-        if (F.claim[r] > (u32)a) atomicMin(&F.claim[r], (u32)a);
+        active = (F.qb[an >> 6] >> (an & 63)) & 1ull;
+        if (active) {
+          u32 j = rank_q(F, an);
+          active = j < F.cap_q;
+          if (active) {
+            r = F.parent[j];
+            if (r == last) active = false;  // this seed already claimed that component
+            last = r;
+          }
+        }
       }
+      if (__ballot(active)) wave_min_claim(F.claim, active, r, (u32)a);
     }
   }
 }
@@ -454,8 +486,9 @@ struct fuelmi_frontier {
   std::vector<void*> allocs;
   std::list<HCluster> frontiers, dormant, tmp;
   std::vector<int> removed_ids;
-  std::vector<u32> h_adr, h_seed, h_kept;
-  std::vector<int> h_slot;
+  void* h_pin = nullptr;  // pinned result staging
+  size_t pin_bytes = 0;
+  std::vector<int> slot2rank;
 };
 
 static inline int fblocks(long n, int t, int cap = 1 << 16) {
@@ -510,6 +543,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   (void)hipSetDevice(f->map->device);
   (void)hipStreamSynchronize(f->map->stream);
   for (void* p : f->allocs) (void)hipFree(p);
+  if (f->h_pin) (void)hipHostFree(f->h_pin);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
@@ -684,8 +718,14 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   k_finalize<<<nblocks, 256, 0, m->stream>>>(g, F);
   HIPCHK(hipGetLastError());
 
-  u32 counts[4];
-  HIPCHK(hipMemcpyAsync(counts, F.counts, sizeof(counts), hipMemcpyDeviceToHost, m->stream));
+  // results come back through one pinned staging buffer: [counts | kept | cell_adr | cell_slot]
+  if (!f->h_pin) {
+    f->pin_bytes = 64 + (size_t)F.cap_kept * 12 + (size_t)F.cap_q * 8;
+    HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
+    f->slot2rank.assign((size_t)F.cap_q + F.cap_s, -1);
+  }
+  u32* counts = reinterpret_cast<u32*>(f->h_pin);
+  HIPCHK(hipMemcpyAsync(counts, F.counts, 4 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
@@ -694,38 +734,45 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   }
   const u32 nq = counts[0], nkept = counts[3];
   if (nkept == 0) return FUELMI_OK;
-  f->h_adr.resize(nq);
-  f->h_slot.resize(nq);
-  f->h_kept.resize((size_t)nkept * 3);
-  HIPCHK(hipMemcpyAsync(f->h_kept.data(), F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+  u32* h_kept = counts + 16;
+  u32* h_adr = h_kept + (size_t)F.cap_kept * 3;
+  int* h_slot = reinterpret_cast<int*>(h_adr + F.cap_q);
+  HIPCHK(hipMemcpyAsync(h_kept, F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
   if (nq) {
-    HIPCHK(hipMemcpyAsync(f->h_adr.data(), F.cell_adr, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(f->h_slot.data(), F.cell_slot, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(h_adr, F.cell_adr, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(h_slot, F.cell_slot, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
   }
   HIPCHK(hipStreamSynchronize(m->stream));
 
-  // assemble: clusters in creation order (= ascending claimer address), cells ascending
+  // assemble: clusters in creation order (= ascending claimer address); cells arrive in ascending
+  // address order, so appending keeps every cluster sorted -- only an NQ seed needs inserting
   std::vector<u32> order(nkept);
   for (u32 k = 0; k < nkept; ++k) order[k] = k;
-  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return f->h_kept[3 * a] < f->h_kept[3 * b]; });
-  std::unordered_map<u32, HCluster*> by_slot;
-  by_slot.reserve(nkept * 2);
-  for (u32 k : order) {
+  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return h_kept[3 * a] < h_kept[3 * b]; });
+  std::vector<HCluster*> by_rank(nkept);
+  for (u32 r = 0; r < nkept; ++r) {
+    const u32 k = order[r];
     f->tmp.emplace_back();
     HCluster& c = f->tmp.back();
-    c.cells.reserve(f->h_kept[3 * k + 2]);
-    u32 slot = f->h_kept[3 * k + 1];
-    if (slot >= nq) c.cells.push_back((int)f->h_kept[3 * k]);  // NQ seed belongs to its cluster
-    by_slot[slot] = &c;
+    c.cells.reserve(h_kept[3 * k + 2]);
+    f->slot2rank[h_kept[3 * k + 1]] = (int)r;
+    by_rank[r] = &c;
   }
   for (u32 i = 0; i < nq; ++i) {
-    int s = f->h_slot[i];
+    int s = h_slot[i];
     if (s < 0) continue;
-    auto it = by_slot.find((u32)s);
-    if (it != by_slot.end()) it->second->cells.push_back((int)f->h_adr[i]);
+    int r = f->slot2rank[s];
+    if (r >= 0) by_rank[r]->cells.push_back((int)h_adr[i]);
   }
-  for (auto& c : f->tmp) {
-    std::sort(c.cells.begin(), c.cells.end());  // only the NQ seed can be out of place
+  for (u32 r = 0; r < nkept; ++r) {
+    const u32 k = order[r];
+    const u32 slot = h_kept[3 * k + 1];
+    f->slot2rank[slot] = -1;
+    HCluster& c = *by_rank[r];
+    if (slot >= nq) {  // the NQ seed belongs to its cluster
+      int a = (int)h_kept[3 * k];
+      c.cells.insert(std::lower_bound(c.cells.begin(), c.cells.end(), a), a);
+    }
     cluster_info(m, c);
   }
   *n_new = (int)f->tmp.size();
