@@ -187,8 +187,244 @@ k_esdf_x(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Vectorised variants (nz % 4 == 0): every lane owns 4 z-adjacent voxels, so LDS traffic is
+// ds_read_b64 / ds_read_b128, global traffic is 16 B per lane, and the 4 outward scans of a lane
+// share one loop (z-neighbours have near-equal distances: the field is 1-Lipschitz).
+// The z range is processed on its 4-aligned superset [z0a, z1a]; voxels outside the true box get
+// f = INF and are never written.
+// ------------------------------------------------------------------------------------------------
+// highest / lowest source position of a line inside [zlo, zhi], or -1
+template <int MODE>
+__device__ __forceinline__ int line_src_down(const u64* __restrict__ infl, const u64* __restrict__ unk,
+                                             long linebit, int zlo, int zhi) {
+  if (zhi < zlo) return -1;
+  long pos = linebit + zhi, beg = linebit + zlo;
+  long w = pos >> 6;
+  u64 word = src_word<MODE>(infl, unk, w) & (~0ull >> (63 - (int)(pos & 63)));
+  while (true) {
+    if (word) {
+      long c = (w << 6) + 63 - __builtin_clzll(word);
+      return c >= beg ? (int)(c - linebit) : -1;
+    }
+    --w;
+    if ((w << 6) + 63 < beg) return -1;
+    word = src_word<MODE>(infl, unk, w);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ int line_src_up(const u64* __restrict__ infl, const u64* __restrict__ unk,
+                                           long linebit, int zlo, int zhi) {
+  if (zhi < zlo) return -1;
+  long pos = linebit + zlo, end = linebit + zhi;
+  long w = pos >> 6;
+  u64 word = src_word<MODE>(infl, unk, w) & (~0ull << (pos & 63));
+  while (true) {
+    if (word) {
+      long c = (w << 6) + __builtin_ctzll(word);
+      return c <= end ? (int)(c - linebit) : -1;
+    }
+    ++w;
+    if ((w << 6) > end) return -1;
+    word = src_word<MODE>(infl, unk, w);
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp,
+           int ZC, int nzc, int z0a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* tile = reinterpret_cast<unsigned short*>(smem_raw);  // [ylen][ZC], ZC % 4 == 0, ZC <= 64
+  const int x = b.lo[0] + blockIdx.x / nzc;
+  const int zc0 = z0a + (blockIdx.x % nzc) * ZC;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int T = blockDim.x;
+  // z pass: one lane per row of the chunk; chunk source bits live in one register
+  const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);  // in-box part of the chunk
+  for (int yi = threadIdx.x; yi < ylen; yi += T) {
+    unsigned short* row = tile + yi * ZC;
+    const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
+    u64 bits = 0ull;
+    int below = -1, above = -1;
+    if (zs <= ze) {
+      u64 lo = src_word<MODE>(infl, unk, (linebit + zc0) >> 6), hi = src_word<MODE>(infl, unk, ((linebit + zc0) >> 6) + 1);
+      int sh = (int)((linebit + zc0) & 63);
+      bits = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+      bits &= bit_range(zs - zc0, ze - zs + 1);
+      below = line_src_down<MODE>(infl, unk, linebit, b.lo[2], zs - 1);
+      above = line_src_up<MODE>(infl, unk, linebit, ze + 1, b.hi[2]);
+    }
+    for (int zi = 0; zi < ZC; ++zi) {
+      unsigned short v = INF16;
+      const int z = zc0 + zi;
+      if (z >= zs && z <= ze) {
+        u64 lowm = bits & (~0ull >> (63 - zi));
+        int pb = lowm ? (63 - __builtin_clzll(lowm)) + zc0 : below;
+        u64 him = bits >> zi;
+        int pa = him ? zi + __builtin_ctzll(him) + zc0 : above;
+        int d = 0x7FFF;
+        if (pb >= 0) d = z - pb;
+        if (pa >= 0) d = min(d, pa - z);
+        if (d != 0x7FFF) v = (unsigned short)(d * d);
+      }
+      row[zi] = v;
+    }
+  }
+  __syncthreads();
+  // y pass: one lane per 4 z-adjacent outputs
+  const int G = ZC >> 2;
+  const int total = ylen * G;
+  const int dyi = T / G, dgi = T - dyi * G;
+  int yi = threadIdx.x / G, gi = threadIdx.x - yi * G;
+  for (int o = threadIdx.x; o < total; o += T) {
+    const ushort4 v0 = *reinterpret_cast<const ushort4*>(tile + yi * ZC + 4 * gi);
+    u32 b0 = v0.x == INF16 ? INF32 : v0.x, b1 = v0.y == INF16 ? INF32 : v0.y;
+    u32 b2 = v0.z == INF16 ? INF32 : v0.z, b3 = v0.w == INF16 ? INF32 : v0.w;
+    u32 mx = max(max(b0, b1), max(b2, b3));
+    const int rmax = max(yi, ylen - 1 - yi);
+    for (int r = 1; r <= rmax && (u32)(r * r) < mx; ++r) {
+      const u32 rr = (u32)(r * r);
+      const ushort4 va = *reinterpret_cast<const ushort4*>(tile + max(yi - r, 0) * ZC + 4 * gi);
+      const ushort4 vb = *reinterpret_cast<const ushort4*>(tile + min(yi + r, ylen - 1) * ZC + 4 * gi);
+      // a clamped row repeats a candidate already seen with a smaller r: harmless
+      b0 = min(b0, min(va.x == INF16 ? INF32 : va.x + rr, vb.x == INF16 ? INF32 : vb.x + rr));
+      b1 = min(b1, min(va.y == INF16 ? INF32 : va.y + rr, vb.y == INF16 ? INF32 : vb.y + rr));
+      b2 = min(b2, min(va.z == INF16 ? INF32 : va.z + rr, vb.z == INF16 ? INF32 : vb.z + rr));
+      b3 = min(b3, min(va.w == INF16 ? INF32 : va.w + rr, vb.w == INF16 ? INF32 : vb.w + rr));
+      mx = max(max(b0, b1), max(b2, b3));
+    }
+    const int z = zc0 + 4 * gi;
+    u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz + z;
+    if (z >= b.lo[2] && z + 3 <= b.hi[2]) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
+    } else {
+      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = b0;
+      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = b1;
+      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = b2;
+      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = b3;
+    }
+    yi += dyi;
+    gi += dgi;
+    if (gi >= G) {
+      gi -= G;
+      ++yi;
+    }
+  }
+}
+
+__device__ __forceinline__ float esdf_out(u32 best, double res) {
+  return (best >= INF32) ? INFINITY : (float)(res * sqrt((double)best));
+}
+__device__ __forceinline__ float esdf_merge_neg(float cur, u32 best, double res) {
+  if (best >= INF32) return -INFINITY;
+  if (best == 0u) return cur;
+  return (float)((double)cur - res * sqrt((double)best) + res);
+}
+
+// x pass, 32 columns (8 lanes x 4) per tile row; a wave covers 8 x-rows x 32 columns
+template <int OUT>
+__global__ void __launch_bounds__(256)
+k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][8] of uint4
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int ncol = ylen * zlen_a;
+  const int seg = threadIdx.x & 7;
+  const int row0 = threadIdx.x >> 3;  // 0..31
+  const int col = blockIdx.x * 32 + seg * 4;
+  const bool valid = col < ncol;
+  const int yy = valid ? col / zlen_a : 0;
+  const int z = z0a + (valid ? col - yy * zlen_a : 0);
+  const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
+  const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
+#pragma unroll 4
+  for (int xi = row0; xi < xlen; xi += 32)
+    tile[xi * 8 + seg] = valid ? *reinterpret_cast<const uint4*>(tmp + (long)(b.lo[0] + xi) * g.nyz + coloff) : inf4;
+  __syncthreads();
+  if (!valid) return;
+  const bool full = z >= b.lo[2] && z + 3 <= b.hi[2];
+  for (int xi = row0; xi < xlen; xi += 32) {
+    uint4 bb = tile[xi * 8 + seg];
+    u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
+    const int rmax = max(xi, xlen - 1 - xi);
+    for (int r = 1; r <= rmax && (u32)(r * r) < mx; ++r) {
+      const u32 rr = (u32)(r * r);
+      const uint4 va = tile[max(xi - r, 0) * 8 + seg];
+      const uint4 vb = tile[min(xi + r, xlen - 1) * 8 + seg];
+      bb.x = min(bb.x, min(va.x, vb.x) + rr);
+      bb.y = min(bb.y, min(va.y, vb.y) + rr);
+      bb.z = min(bb.z, min(va.z, vb.z) + rr);
+      bb.w = min(bb.w, min(va.w, vb.w) + rr);
+      mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
+    }
+    float* dst = dist + (long)(b.lo[0] + xi) * g.nyz + coloff;
+    if (OUT == 0) {
+      if (full) {
+        *reinterpret_cast<float4*>(dst) =
+            make_float4(esdf_out(bb.x, g.res), esdf_out(bb.y, g.res), esdf_out(bb.z, g.res), esdf_out(bb.w, g.res));
+      } else {
+        if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_out(bb.x, g.res);
+        if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_out(bb.y, g.res);
+        if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_out(bb.z, g.res);
+        if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_out(bb.w, g.res);
+      }
+    } else {
+      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_merge_neg(dst[0], bb.x, g.res);
+      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_merge_neg(dst[1], bb.y, g.res);
+      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_merge_neg(dst[2], bb.z, g.res);
+      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_merge_neg(dst[3], bb.w, g.res);
+    }
+  }
+}
+
+static inline bool use_vec4(const Geo& g, int xlen) { return (g.nz % 4) == 0 && (size_t)xlen * 128 <= 160 * 1024; }
+
+template <int MODE>
+static int launch_zy4(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
+  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
+  const int zlen_a = z1a - z0a + 1;
+  int zc_max = std::max(4, ((16 * 1024) / (2 * ylen)) & ~3);
+  zc_max = std::min(zc_max, std::min(zlen_a, 64));
+  int nzc = (zlen_a + zc_max - 1) / zc_max;
+  int ZC = (((zlen_a + nzc - 1) / nzc) + 3) & ~3;
+  nzc = (zlen_a + ZC - 1) / ZC;
+  size_t lds = (size_t)ylen * ZC * sizeof(unsigned short);
+  if (lds > 160 * 1024) {
+    fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
+    return FUELMI_ELIMIT;
+  }
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_esdf_zy4<MODE><<<xlen * nzc, 256, lds, m->stream>>>(g, b, m->infl_bits.p, m->unk_bits.p, m->esdf_tmp, ZC, nzc,
+                                                        z0a);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+template <int OUT>
+static int launch_x4(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
+  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
+  const int zlen_a = z1a - z0a + 1;
+  size_t lds = (size_t)xlen * 32 * sizeof(u32);
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int ncol = ylen * zlen_a;
+  k_esdf_x4<OUT><<<(ncol + 31) / 32, 256, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a, zlen_a);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
 template <int MODE>
 static int launch_zy(fuelmi_map* m, const Box3& b) {
+  if (use_vec4(m->g, b.hi[0] - b.lo[0] + 1)) return launch_zy4<MODE>(m, b);
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
   // z-chunk: LDS tile <= 16 KiB so several WGs share a CU, chunks balanced over the z extent
@@ -228,6 +464,7 @@ static int launch_x_s(fuelmi_map* m, const Box3& b) {
 template <int OUT>
 static int launch_x(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
+  if (use_vec4(m->g, xlen)) return launch_x4<OUT>(m, b);
   const size_t budget = 64 * 1024;
   if ((size_t)xlen * 32 * 4 <= budget) return launch_x_s<32, OUT>(m, b);
   if ((size_t)xlen * 16 * 4 <= 128 * 1024) return launch_x_s<16, OUT>(m, b);

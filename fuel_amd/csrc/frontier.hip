@@ -53,7 +53,20 @@ struct FArgs {
   u32* csize;      // [cap_q + cap_s] cluster sizes by slot
   u32* kept;       // [.. x 3] (claimer address, slot, size)
   u32 cap_kept;
+  // grouping of the kept cells by cluster rank (stable 8-bit radix multisplit)
+  int* slot2rank;    // [cap_q + cap_s] valid only at kept slots
+  u32* kept_slots;   // [cap_kept] slot of rank r (uploaded after the host sorted the kept list)
+  u32* ms_key[2];    // [cap_q]
+  u32* ms_val[2];    // [cap_q]
+  u32* ms_hist;      // [256][ms_nb_max]
+  u32 ms_nb_max;
+  unsigned long long* info_sum;  // [cap_kept][3] sum of voxel indices
+  u32* info_box;                 // [cap_kept][6] min xyz, max xyz
+  u32* info_part;                // [cap_q / SZ_CH + 1][10] per-chunk records (key, sums, min, max)
 };
+
+#define MS_CH 2048  // cells per multisplit block (256 threads x 8)
+#define NOKEY 0xFFFFFFFFu
 
 // ---- per-word masks ---------------------------------------------------------------------------
 __device__ __forceinline__ void word_masks(const Geo& g, int w, const Box3& qb, const Box3& sb, u64& z0,
@@ -257,11 +270,18 @@ __global__ void __launch_bounds__(256) k_compact(Geo g, FArgs F) {
   }
 }
 
-__device__ __forceinline__ u32 uf_find(const u32* parent, u32 i) {
+// find with path halving.  The shortcut is written with a (non-returning) device-scope atomicMin,
+// NOT a plain store: plain stores stay dirty in this XCD's write-back L2 and their later line
+// write-back would clobber links other XCDs made on neighbouring entries with memory-side atomics
+// (observed as lost unions).  Every write to parent[] inside k_union is therefore an atomic; plain
+// reads may be stale, but a stale parent is still an ancestor (parents only decrease).
+__device__ __forceinline__ u32 uf_find(u32* parent, u32 i) {
   u32 p = parent[i];
   while (p != i) {
+    u32 gp = parent[p];
+    if (gp != p) (void)__hip_atomic_fetch_min(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     i = p;
-    p = parent[i];
+    p = gp;
   }
   return i;
 }
@@ -289,14 +309,34 @@ __global__ void __launch_bounds__(256) k_union(Geo g, FArgs F) {
     int x = (int)(a / g.nyz);
     int r = (int)(a - (long)x * g.nyz);
     int y = r / g.nz, z = r - y * g.nz;
-    for (int k = 0; k < 13; ++k) {
-      int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;  // k=0..12: lexicographically < 0
-      int xx = x + dx, yy = y + dy, zz = z + dz;
-      if (xx < 0 || yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
-      long an = a + (long)dx * g.nyz + (long)dy * g.nz + dz;
-      if (!((F.qb[an >> 6] >> (an & 63)) & 1ull)) continue;
-      u32 j = rank_q(F, an);
-      if (j < F.cap_q) uf_union(F.parent, i, j);
+    const bool zlo = z > 0, zhi = z < g.nz - 1;
+    // (0,0,-1): the compact predecessor
+    if (zlo && ((F.qb[(a - 1) >> 6] >> ((a - 1) & 63)) & 1ull)) uf_union(F.parent, i, i - 1);
+    // the four lower z-lines (dx,dy) = (-1,-1) (-1,0) (-1,1) (0,-1): one 3-bit window each (dz -1,0,+1),
+    // all four fetched before any dependent work
+    const int ldx[4] = {-1, -1, -1, 0}, ldy[4] = {-1, 0, 1, -1};
+    u32 pat[4];
+    long nb0[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int xx = x + ldx[l], yy = y + ldy[l];
+      const bool ok = xx >= 0 && yy >= 0 && yy < g.ny;
+      nb0[l] = a + (long)ldx[l] * g.nyz + (long)ldy[l] * g.nz - 1;
+      u32 p = ok ? (u32)(plane_window(F.qb, nb0[l]) & 7ull) : 0u;
+      if (!zlo) p &= ~1u;
+      if (!zhi) p &= ~4u;
+      pat[l] = p;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (pat[l] == 0u) continue;
+      // z-adjacent neighbours of one line are joined by their own (0,0,-1) unions: link once per
+      // run; only the pattern 101 holds two separate runs
+      const u32 j = rank_q(F, nb0[l] + __builtin_ctz(pat[l]));
+      if (j < F.cap_q) {
+        uf_union(F.parent, i, j);
+        if (pat[l] == 5u && j + 1 < F.cap_q) uf_union(F.parent, i, j + 1);
+      }
     }
   }
 }
@@ -377,33 +417,67 @@ __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
   }
 }
 
+// one atomicAdd per distinct key per wave
+__device__ __forceinline__ void wave_agg_add(u32* base, bool active, u32 key) {
+  u64 todo = __ballot(active);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    int leader = __builtin_ctzll(todo);
+    u32 k = __shfl(key, leader, 64);
+    u64 same = __ballot(active && key == k) & todo;
+    if (lane == leader) atomicAdd(&base[k], (u32)__popcll(same));
+    todo &= ~same;
+  }
+}
+
 // cluster sizes by slot: own claimer -> its compact index; NQ seed claimer -> nq + seed rank.
-// lanes of a wave that hit the same slot are merged into one atomic.
+// A frontier surface is typically ONE huge cluster, so per-lane (even per-wave) atomics on its
+// counter serialise: every 1024-cell chunk is reduced in the block for its leading slot (key0) and
+// only cells of other slots take the wave-aggregated atomic path.
+#define SZ_CH 1024
 __global__ void __launch_bounds__(256) k_sizes(Geo g, FArgs F) {
+  __shared__ u32 s_key0;
+  __shared__ u32 s_part[4];
   const u32 nq = F.counts[0];
-  const u32 total = (nq + 63u) & ~63u;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    bool active = false;
-    u32 slot = 0;
-    if (i < nq) {
-      u32 cl = F.claim[F.parent[i]];
-      if (cl != NOCLAIM) {
-        active = true;
-        bool own = (F.qb[cl >> 6] >> (cl & 63)) & 1ull;
-        slot = own ? rank_q(F, cl) : nq + rank_s(F, cl);
-        F.cell_slot[i] = (int)slot;
-      } else
-        F.cell_slot[i] = -1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 base = blockIdx.x * SZ_CH; base < nq; base += gridDim.x * SZ_CH) {
+    u32 slots[SZ_CH / 256];
+    bool act[SZ_CH / 256];
+#pragma unroll
+    for (int k = 0; k < SZ_CH / 256; ++k) {
+      const u32 i = base + k * 256 + threadIdx.x;
+      act[k] = false;
+      slots[k] = 0;
+      if (i < nq) {
+        u32 cl = F.claim[F.parent[i]];
+        if (cl != NOCLAIM) {
+          act[k] = true;
+          bool own = (F.qb[cl >> 6] >> (cl & 63)) & 1ull;
+          slots[k] = own ? rank_q(F, cl) : nq + rank_s(F, cl);
+          F.cell_slot[i] = (int)slots[k];
+        } else
+          F.cell_slot[i] = -1;
+      }
     }
-    u64 todo = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-      int leader = __builtin_ctzll(todo);
-      u32 k = __shfl(slot, leader, 64);
-      u64 same = __ballot(active && slot == k) & todo;
-      if (lane == leader) atomicAdd(&F.csize[k], (u32)__popcll(same));
-      todo &= ~same;
+    if (wave == 0) {
+      u64 m = __ballot(act[0]);
+      u32 k0 = m ? (u32)__shfl((int)slots[0], __builtin_ctzll(m), 64) : NOCLAIM;
+      if (lane == 0) s_key0 = k0;
     }
+    __syncthreads();
+    const u32 key0 = s_key0;
+    u32 local = 0;
+#pragma unroll
+    for (int k = 0; k < SZ_CH / 256; ++k) {
+      const bool fast = act[k] && slots[k] == key0;
+      local += fast ? 1u : 0u;
+      wave_agg_add(F.csize, act[k] && !fast, slots[k]);
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor((int)local, off, 64);
+    if (lane == 0) s_part[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0 && key0 != NOCLAIM) atomicAdd(&F.csize[key0], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+    __syncthreads();
   }
 }
 
@@ -463,6 +537,201 @@ __global__ void __launch_bounds__(256) k_finalize(Geo g, FArgs F) {
   F.flag[w] |= newflag;
 }
 
+// ---- grouping of kept cells by cluster: stable radix multisplit ---------------------------------
+__global__ void k_ms_set_ranks(FArgs F, int nkept) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nkept) F.slot2rank[F.kept_slots[r]] = r;
+}
+__global__ void __launch_bounds__(256) k_ms_keys(FArgs F, u32 nq, int nkept) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (u32)(3 * nkept)) {
+    // reset the per-cluster accumulators (sum = 0, min = max-int, max = 0)
+    if (i < (u32)nkept) {
+      F.info_sum[3 * i] = F.info_sum[3 * i + 1] = F.info_sum[3 * i + 2] = 0ull;
+      for (int k = 0; k < 3; ++k) {
+        F.info_box[6 * i + k] = 0xFFFFFFFFu;
+        F.info_box[6 * i + 3 + k] = 0u;
+      }
+    }
+  }
+  for (; i < nq; i += gridDim.x * blockDim.x) {
+    int s = F.cell_slot[i];
+    F.ms_key[0][i] = s >= 0 ? (u32)F.slot2rank[s] : NOKEY;
+    F.ms_val[0][i] = F.cell_adr[i];
+  }
+}
+// histogram of the current 8-bit digit per block, digit-major: hist[d * nb + block]
+__global__ void __launch_bounds__(256)
+k_ms_hist(const u32* __restrict__ key, u32 n, int shift, u32* __restrict__ hist, int nb, int ndig) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 base = blockIdx.x * MS_CH;
+  for (int k = 0; k < MS_CH / 256; ++k) {
+    u32 i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      u32 kk = key[i];
+      if (kk != NOKEY) atomicAdd(&h[(kk >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ndig) hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+// in-place exclusive scan of `cnt` u32 values by one block; total -> *total_out
+__global__ void __launch_bounds__(256) k_ms_scan(u32* v, int cnt, u32* total_out) {
+  __shared__ u32 part[256];
+  const int per = (cnt + 255) / 256;
+  const int b0 = threadIdx.x * per, b1 = min(cnt, b0 + per);
+  u32 s = 0;
+  for (int b = b0; b < b1; ++b) s += v[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (int t = 0; t < 256; ++t) {
+      u32 x = part[t];
+      part[t] = run;
+      run += x;
+    }
+    *total_out = run;
+  }
+  __syncthreads();
+  u32 run = part[threadIdx.x];
+  for (int b = b0; b < b1; ++b) {
+    u32 x = v[b];
+    v[b] = run;
+    run += x;
+  }
+}
+// stable scatter: position = scanned[d][block] + (# earlier elements of this block with digit d)
+__global__ void __launch_bounds__(256)
+k_ms_scatter(const u32* __restrict__ key, const u32* __restrict__ val, u32 n, int shift,
+             const u32* __restrict__ scanned, int nb, int ndig, u32* __restrict__ key_out,
+             u32* __restrict__ val_out) {
+  __shared__ u32 running[256];
+  __shared__ u32 wcnt[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  running[threadIdx.x] = (int)threadIdx.x < ndig ? scanned[threadIdx.x * nb + blockIdx.x] : 0u;
+  const u32 base = blockIdx.x * MS_CH;
+  for (int k = 0; k < MS_CH / 256; ++k) {
+    for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const u32 i = base + k * 256 + threadIdx.x;
+    u32 kk = (i < n) ? key[i] : NOKEY;
+    const bool active = kk != NOKEY;
+    const u32 d = (kk >> shift) & 255u;
+    u32 lane_rank = 0;
+    u64 todo = __ballot(active);
+    while (todo) {
+      int leader = __builtin_ctzll(todo);
+      u32 dl = __shfl(d, leader, 64);
+      u64 same = __ballot(active && d == dl) & todo;
+      if (active && d == dl) lane_rank = (u32)__popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wcnt[wave][dl] = (u32)__popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (active) {
+      u32 pos = running[d] + lane_rank;
+      for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
+      key_out[pos] = kk;
+      val_out[pos] = val[i];
+    }
+    __syncthreads();
+    running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+// computeFrontierInfo (:374-390) accumulators per cluster: sum of voxel indices and index AABB.
+// Input is grouped by cluster, so a 1024-cell chunk nearly always holds one key: reduce it in the
+// block and issue 9 atomics per chunk; cells of other keys take per-cell atomics.
+__device__ __forceinline__ void info_atomics(FArgs& F, u32 k, u32 sx, u32 sy, u32 sz, u32 nx_, u32 ny_, u32 nz_,
+                                             u32 mx, u32 my, u32 mz) {
+  atomicAdd(&F.info_sum[3 * k], (unsigned long long)sx);
+  atomicAdd(&F.info_sum[3 * k + 1], (unsigned long long)sy);
+  atomicAdd(&F.info_sum[3 * k + 2], (unsigned long long)sz);
+  atomicMin(&F.info_box[6 * k], nx_);
+  atomicMin(&F.info_box[6 * k + 1], ny_);
+  atomicMin(&F.info_box[6 * k + 2], nz_);
+  atomicMax(&F.info_box[6 * k + 3], mx);
+  atomicMax(&F.info_box[6 * k + 4], my);
+  atomicMax(&F.info_box[6 * k + 5], mz);
+}
+__global__ void __launch_bounds__(256)
+k_ms_info(Geo g, const u32* __restrict__ key, const u32* __restrict__ val, u32 n, FArgs F) {
+  __shared__ u32 s_red[4][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 base = blockIdx.x * SZ_CH; base < n; base += gridDim.x * SZ_CH) {
+    const u32 key0 = key[base];
+    u32 sx = 0, sy = 0, sz = 0, nx_ = 0xFFFFFFFFu, ny_ = 0xFFFFFFFFu, nz_ = 0xFFFFFFFFu, mx = 0, my = 0, mz = 0;
+#pragma unroll
+    for (int k = 0; k < SZ_CH / 256; ++k) {
+      const u32 i = base + k * 256 + threadIdx.x;
+      const bool in = i < n;
+      const u32 kk = in ? key[i] : key0, a = in ? val[i] : 0u;
+      const u32 x = a / (u32)g.nyz, r = a - x * (u32)g.nyz, y = r / (u32)g.nz, z = r - y * (u32)g.nz;
+      if (in && kk == key0) {
+        sx += x, sy += y, sz += z;
+        nx_ = min(nx_, x), ny_ = min(ny_, y), nz_ = min(nz_, z);
+        mx = max(mx, x), my = max(my, y), mz = max(mz, z);
+      }
+      // cells of another cluster (chunk straddles a boundary): one set of atomics per key per wave
+      u64 todo = __ballot(in && kk != key0);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const u32 kl = (u32)__shfl((int)kk, leader, 64);
+        const bool mine = in && kk == kl;
+        const u64 same = __ballot(mine) & todo;
+        u32 tx = mine ? x : 0, ty = mine ? y : 0, tz = mine ? z : 0;
+        u32 ax = mine ? x : 0xFFFFFFFFu, ay = mine ? y : 0xFFFFFFFFu, az = mine ? z : 0xFFFFFFFFu;
+        u32 bx = tx, by = ty, bz = tz;
+        for (int off = 32; off > 0; off >>= 1) {
+          tx += __shfl_xor((int)tx, off, 64);
+          ty += __shfl_xor((int)ty, off, 64);
+          tz += __shfl_xor((int)tz, off, 64);
+          ax = min(ax, (u32)__shfl_xor((int)ax, off, 64));
+          ay = min(ay, (u32)__shfl_xor((int)ay, off, 64));
+          az = min(az, (u32)__shfl_xor((int)az, off, 64));
+          bx = max(bx, (u32)__shfl_xor((int)bx, off, 64));
+          by = max(by, (u32)__shfl_xor((int)by, off, 64));
+          bz = max(bz, (u32)__shfl_xor((int)bz, off, 64));
+        }
+        if (lane == leader) info_atomics(F, kl, tx, ty, tz, ax, ay, az, bx, by, bz);
+        todo &= ~same;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      sx += __shfl_xor((int)sx, off, 64);
+      sy += __shfl_xor((int)sy, off, 64);
+      sz += __shfl_xor((int)sz, off, 64);
+      nx_ = min(nx_, (u32)__shfl_xor((int)nx_, off, 64));
+      ny_ = min(ny_, (u32)__shfl_xor((int)ny_, off, 64));
+      nz_ = min(nz_, (u32)__shfl_xor((int)nz_, off, 64));
+      mx = max(mx, (u32)__shfl_xor((int)mx, off, 64));
+      my = max(my, (u32)__shfl_xor((int)my, off, 64));
+      mz = max(mz, (u32)__shfl_xor((int)mz, off, 64));
+    }
+    if (lane == 0) {
+      u32* q = s_red[wave];
+      q[0] = sx, q[1] = sy, q[2] = sz, q[3] = nx_, q[4] = ny_, q[5] = nz_, q[6] = mx, q[7] = my, q[8] = mz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+        sx += s_red[w][0], sy += s_red[w][1], sz += s_red[w][2];
+        nx_ = min(nx_, s_red[w][3]), ny_ = min(ny_, s_red[w][4]), nz_ = min(nz_, s_red[w][5]);
+        mx = max(mx, s_red[w][6]), my = max(my, s_red[w][7]), mz = max(mz, s_red[w][8]);
+      }
+      // no atomics for the chunk's leading key (same-address device atomics cost ~60 ns each):
+      // the host folds these per-chunk records into the per-cluster totals
+      u32* rec = F.info_part + (size_t)(base / SZ_CH) * 10;
+      rec[0] = key0, rec[1] = sx, rec[2] = sy, rec[3] = sz;
+      rec[4] = nx_, rec[5] = ny_, rec[6] = nz_, rec[7] = mx, rec[8] = my, rec[9] = mz;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* __restrict__ out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (char)((bits[i >> 6] >> (i & 63)) & 1ull);
@@ -496,7 +765,7 @@ static inline int fblocks(long n, int t, int cap = 1 << 16) {
   return (int)std::max(1L, std::min((long)cap, b));
 }
 
-static void cluster_info(const fuelmi_map* m, HCluster& c) {
+[[maybe_unused]] static void cluster_info(const fuelmi_map* m, HCluster& c) {
   // computeFrontierInfo (:374-390): mean and AABB of the voxel centres
   const Geo& g = m->g;
   for (int k = 0; k < 3; ++k) c.avg[k] = 0.0;
@@ -581,14 +850,21 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   F.cap_kept = 1u << 16;
   F.cluster_min = cfg->cluster_min;
   if ((rc = dmalloc(f, &F.pref, nwords)) || (rc = dmalloc(f, &F.blocksum, nwords / 256 + 1)) ||
-      (rc = dmalloc(f, &F.blockscan, nwords / 256 + 1)) || (rc = dmalloc(f, &F.counts, 8)) ||
+      (rc = dmalloc(f, &F.blockscan, nwords / 256 + 1)) ||
+      (rc = dmalloc(f, &F.counts, 16 + (size_t)F.cap_kept * 3)) ||  // counts, then the kept list
       (rc = dmalloc(f, &F.cell_adr, F.cap_q)) || (rc = dmalloc(f, &F.parent, F.cap_q)) ||
       (rc = dmalloc(f, &F.claim, F.cap_q)) || (rc = dmalloc(f, &F.cell_slot, F.cap_q)) ||
       (rc = dmalloc(f, &F.seed_adr, F.cap_s)) || (rc = dmalloc(f, &F.csize, (size_t)F.cap_q + F.cap_s)) ||
-      (rc = dmalloc(f, &F.kept, (size_t)F.cap_kept * 3))) {
+      (rc = dmalloc(f, &F.slot2rank, (size_t)F.cap_q + F.cap_s)) || (rc = dmalloc(f, &F.kept_slots, F.cap_kept)) ||
+      (rc = dmalloc(f, &F.ms_key[0], F.cap_q)) || (rc = dmalloc(f, &F.ms_key[1], F.cap_q)) ||
+      (rc = dmalloc(f, &F.ms_val[0], F.cap_q)) || (rc = dmalloc(f, &F.ms_val[1], F.cap_q)) ||
+      (rc = dmalloc(f, &F.ms_hist, (size_t)256 * (F.cap_q / MS_CH + 2))) ||
+      (rc = dmalloc(f, &F.info_sum, (size_t)F.cap_kept * 3)) || (rc = dmalloc(f, &F.info_box, (size_t)F.cap_kept * 6)) ||
+      (rc = dmalloc(f, &F.info_part, ((size_t)F.cap_q / SZ_CH + 2) * 10))) {
     fuelmi_frontier_destroy(f);
     return rc;
   }
+  F.kept = F.counts + 16;
   F.occ = m->occ_bits.p;
   F.unk = m->unk_bits.p;
   F.flag = f->flag.p;
@@ -714,18 +990,25 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   k_union<<<cgrid, 256, 0, m->stream>>>(g, F);
   k_flatten<<<cgrid, 256, 0, m->stream>>>(g, F);
   k_claim<<<cgrid, 256, 0, m->stream>>>(g, F);
-  k_sizes<<<cgrid, 256, 0, m->stream>>>(g, F);
+  k_sizes<<<cgrid, 256, 0, m->stream>>>(g, F);  // grid-stride over 1024-cell chunks
   k_finalize<<<nblocks, 256, 0, m->stream>>>(g, F);
   HIPCHK(hipGetLastError());
 
-  // results come back through one pinned staging buffer: [counts | kept | cell_adr | cell_slot]
+  // ---- results: one pinned staging buffer [counts | kept | kept_slots | info | cells] ----
   if (!f->h_pin) {
-    f->pin_bytes = 64 + (size_t)F.cap_kept * 12 + (size_t)F.cap_q * 8;
+    f->pin_bytes = 64 + (size_t)F.cap_kept * (12 + 4 + 24 + 24) + (size_t)F.cap_q * 4 +
+        ((size_t)F.cap_q / SZ_CH + 2) * 40;
     HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
-    f->slot2rank.assign((size_t)F.cap_q + F.cap_s, -1);
   }
   u32* counts = reinterpret_cast<u32*>(f->h_pin);
-  HIPCHK(hipMemcpyAsync(counts, F.counts, 4 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+  u32* h_kept = counts + 16;
+  u32* h_slots = h_kept + (size_t)F.cap_kept * 3;
+  unsigned long long* h_sum = reinterpret_cast<unsigned long long*>(h_slots + F.cap_kept);
+  u32* h_box = reinterpret_cast<u32*>(h_sum + (size_t)F.cap_kept * 3);
+  u32* h_cells = h_box + (size_t)F.cap_kept * 6;
+  // counts and the head of the kept list live contiguously on the device: one copy, one sync
+  const u32 head = std::min<u32>(F.cap_kept, 1024u);
+  HIPCHK(hipMemcpyAsync(counts, F.counts, (16 + (size_t)head * 3) * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
@@ -734,46 +1017,93 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   }
   const u32 nq = counts[0], nkept = counts[3];
   if (nkept == 0) return FUELMI_OK;
-  u32* h_kept = counts + 16;
-  u32* h_adr = h_kept + (size_t)F.cap_kept * 3;
-  int* h_slot = reinterpret_cast<int*>(h_adr + F.cap_q);
-  HIPCHK(hipMemcpyAsync(h_kept, F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
-  if (nq) {
-    HIPCHK(hipMemcpyAsync(h_adr, F.cell_adr, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(h_slot, F.cell_slot, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  if (nkept > head) {
+    HIPCHK(hipMemcpyAsync(h_kept, F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
   }
-  HIPCHK(hipStreamSynchronize(m->stream));
-
-  // assemble: clusters in creation order (= ascending claimer address); cells arrive in ascending
-  // address order, so appending keeps every cluster sorted -- only an NQ seed needs inserting
+  // clusters in creation order = ascending claimer address (the reference's scan order)
   std::vector<u32> order(nkept);
   for (u32 k = 0; k < nkept; ++k) order[k] = k;
   std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return h_kept[3 * a] < h_kept[3 * b]; });
-  std::vector<HCluster*> by_rank(nkept);
+  std::vector<u32> off(nkept + 1, 0);
+  for (u32 r = 0; r < nkept; ++r) {
+    const u32 k = order[r];
+    h_slots[r] = h_kept[3 * k + 1];
+    const bool seed = h_kept[3 * k + 1] >= nq;  // an NQ seed is not part of the compact Q0 cells
+    off[r + 1] = off[r] + h_kept[3 * k + 2] - (seed ? 1u : 0u);
+  }
+  const u32 n_out = off[nkept];
+  // group the kept cells by cluster on the device (stable: ascending address inside a cluster)
+  HIPCHK(hipMemcpyAsync(F.kept_slots, h_slots, (size_t)nkept * sizeof(u32), hipMemcpyHostToDevice, m->stream));
+  k_ms_set_ranks<<<(nkept + 255) / 256, 256, 0, m->stream>>>(F, (int)nkept);
+  k_ms_keys<<<std::max(fblocks((long)nq, 256, 2048), (int)(nkept + 255) / 256), 256, 0, m->stream>>>(F, nq, (int)nkept);
+  const int nb = (int)((nq + MS_CH - 1) / MS_CH);
+  int cur = 0;
+  const int passes = nkept <= 256 ? 1 : 2;
+  for (int p = 0; p < passes && nq > 0; ++p) {
+    const u32 n_in = (p == 0) ? nq : n_out;
+    const int nbp = (int)((n_in + MS_CH - 1) / MS_CH);
+    // digits in use: low pass sees min(nkept,256) values, high pass (nkept-1)>>8 + 1
+    const int ndig = (p == 0) ? (int)std::min<u32>(nkept, 256u) : (int)((nkept - 1) >> 8) + 1;
+    k_ms_hist<<<nbp, 256, 0, m->stream>>>(F.ms_key[cur], n_in, 8 * p, F.ms_hist, nbp, ndig);
+    k_ms_scan<<<1, 256, 0, m->stream>>>(F.ms_hist, ndig * nbp, F.counts + 4);
+    k_ms_scatter<<<nbp, 256, 0, m->stream>>>(F.ms_key[cur], F.ms_val[cur], n_in, 8 * p, F.ms_hist, nbp, ndig,
+                                            F.ms_key[1 - cur], F.ms_val[1 - cur]);
+    cur = 1 - cur;
+  }
+  (void)nb;
+  if (n_out) k_ms_info<<<fblocks((long)n_out, SZ_CH, 2048), 256, 0, m->stream>>>(g, F.ms_key[cur], F.ms_val[cur], n_out, F);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h_sum, F.info_sum, (size_t)nkept * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        m->stream));
+  HIPCHK(hipMemcpyAsync(h_box, F.info_box, (size_t)nkept * 6 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+  const u32 nchunk = (n_out + SZ_CH - 1) / SZ_CH;
+  u32* h_part = h_cells + F.cap_q;
+  if (n_out) {
+    HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[cur], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)nchunk * 10 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+  }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
+    const u32* rec = h_part + (size_t)c * 10;
+    const u32 r = rec[0];
+    if (r >= nkept) continue;
+    for (int q = 0; q < 3; ++q) {
+      h_sum[3 * r + q] += rec[1 + q];
+      h_box[6 * r + q] = std::min(h_box[6 * r + q], rec[4 + q]);
+      h_box[6 * r + 3 + q] = std::max(h_box[6 * r + 3 + q], rec[7 + q]);
+    }
+  }
+
+  // host: bulk copies only (+ inserting an NQ seed where a seed started the cluster)
   for (u32 r = 0; r < nkept; ++r) {
     const u32 k = order[r];
     f->tmp.emplace_back();
     HCluster& c = f->tmp.back();
-    c.cells.reserve(h_kept[3 * k + 2]);
-    f->slot2rank[h_kept[3 * k + 1]] = (int)r;
-    by_rank[r] = &c;
-  }
-  for (u32 i = 0; i < nq; ++i) {
-    int s = h_slot[i];
-    if (s < 0) continue;
-    int r = f->slot2rank[s];
-    if (r >= 0) by_rank[r]->cells.push_back((int)h_adr[i]);
-  }
-  for (u32 r = 0; r < nkept; ++r) {
-    const u32 k = order[r];
-    const u32 slot = h_kept[3 * k + 1];
-    f->slot2rank[slot] = -1;
-    HCluster& c = *by_rank[r];
-    if (slot >= nq) {  // the NQ seed belongs to its cluster
-      int a = (int)h_kept[3 * k];
+    const u32 cnt = off[r + 1] - off[r];
+    c.cells.resize(cnt);
+    if (cnt) memcpy(c.cells.data(), h_cells + off[r], (size_t)cnt * sizeof(int));
+    unsigned long long sum[3] = {h_sum[3 * r], h_sum[3 * r + 1], h_sum[3 * r + 2]};
+    u32 lo[3] = {h_box[6 * r], h_box[6 * r + 1], h_box[6 * r + 2]};
+    u32 hi[3] = {h_box[6 * r + 3], h_box[6 * r + 4], h_box[6 * r + 5]};
+    if (h_kept[3 * k + 1] >= nq) {
+      const int a = (int)h_kept[3 * k];
       c.cells.insert(std::lower_bound(c.cells.begin(), c.cells.end(), a), a);
+      const u32 x = (u32)a / (u32)g.nyz, rr = (u32)a - x * (u32)g.nyz, y = rr / (u32)g.nz, z = rr - y * (u32)g.nz;
+      const u32 id[3] = {x, y, z};
+      for (int q = 0; q < 3; ++q) {
+        sum[q] += id[q];
+        lo[q] = cnt ? std::min(lo[q], id[q]) : id[q];
+        hi[q] = cnt ? std::max(hi[q], id[q]) : id[q];
+      }
     }
-    cluster_info(m, c);
+    // computeFrontierInfo (:374-390): mean of voxel centres = centre of the mean index
+    const double nn = (double)c.cells.size();
+    for (int q = 0; q < 3; ++q) {
+      c.avg[q] = ((double)sum[q] / nn + 0.5) * g.res + g.org[q];
+      c.bmin[q] = ((int)lo[q] + 0.5) * g.res + g.org[q];
+      c.bmax[q] = ((int)hi[q] + 0.5) * g.res + g.org[q];
+    }
   }
   *n_new = (int)f->tmp.size();
   return FUELMI_OK;
