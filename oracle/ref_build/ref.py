@@ -1,0 +1,148 @@
+"""ctypes binding of oracle/_ref/libfuel_ref.so: the REAL reference classes (SDFMap,
+EDTEnvironment, RayCaster, BsplineOptimizer) compiled from /root/reference with header stand-ins.
+TEST INFRASTRUCTURE ONLY.  available() is False where the library was never built."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from oracle import fuel_oracle as fo
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(os.path.dirname(_HERE), "_ref", "libfuel_ref.so")
+_LIB = None
+
+
+def available():
+    return os.path.exists(SO)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(SO)
+        P = C.c_void_p
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        L.ref_map_create.restype = P
+        L.ref_map_create.argtypes = [C.POINTER(fo.MapCfg)]
+        L.ref_map_destroy.argtypes = [P]
+        L.ref_map_voxel_num.argtypes = [P, ip]
+        for n in ("ref_map_occupancy", "ref_map_distance"):
+            getattr(L, n).restype = dp
+            getattr(L, n).argtypes = [P]
+        L.ref_map_inflate_buf.restype = C.POINTER(C.c_char)
+        L.ref_map_inflate_buf.argtypes = [P]
+        L.ref_map_input_points.argtypes = [P, C.c_void_p, C.c_int, dp]
+        L.ref_map_inflate_local.argtypes = [P]
+        L.ref_map_update_esdf.argtypes = [P]
+        L.ref_map_get_local_bound.argtypes = [P, ip, ip]
+        L.ref_map_set_local_bound.argtypes = [P, ip, ip]
+        L.ref_map_get_updated_box.argtypes = [P, dp, dp, C.c_int]
+        L.ref_map_reset_buffer_all.argtypes = [P]
+        L.ref_map_set_occupied.argtypes = [P, dp, C.c_int]
+        L.ref_map_get_occupancy_idx.argtypes = [P, ip]
+        L.ref_map_dist_grad.argtypes = [P, dp, C.c_int, dp, dp]
+        L.ref_raycast_cells.argtypes = [P, dp, dp, ip, C.c_int]
+        L.ref_bspline_cost_grad.argtypes = [P, C.POINTER(fo.BsplineCfg), C.POINTER(fo.BsplineProblem), dp, dp, dp]
+        _LIB = L
+    return _LIB
+
+
+class RefMap:
+    """Same surface as fuel_oracle.OracleMap, backed by the reference's own SDFMap."""
+
+    def __init__(self, map_size, box_min=None, box_max=None, **kw):
+        self.L = lib()
+        self.cfg = fo.make_cfg(fo.MapCfg, map_size, box_min, box_max, **kw)
+        self.h = self.L.ref_map_create(C.byref(self.cfg))
+        nv = (C.c_int * 3)()
+        self.L.ref_map_voxel_num(self.h, nv)
+        self.nvox = tuple(nv)
+        self.N = self.nvox[0] * self.nvox[1] * self.nvox[2]
+        self.occ = np.ctypeslib.as_array(self.L.ref_map_occupancy(self.h), shape=(self.N,))
+        self.dist = np.ctypeslib.as_array(self.L.ref_map_distance(self.h), shape=(self.N,))
+        self.infl = np.ctypeslib.as_array(C.cast(self.L.ref_map_inflate_buf(self.h), C.POINTER(C.c_int8)),
+                                          shape=(self.N,))
+
+    def __del__(self):
+        try:
+            self.L.ref_map_destroy(self.h)
+        except Exception:
+            pass
+
+    def input_points(self, pts, cam):
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        self.L.ref_map_input_points(self.h, pts.ctypes.data, len(pts), fo._d3(cam))
+
+    def inflate_local(self):
+        self.L.ref_map_inflate_local(self.h)
+
+    def update_esdf(self):
+        self.L.ref_map_update_esdf(self.h)
+
+    def get_local_bound(self):
+        a, b = (C.c_int * 3)(), (C.c_int * 3)()
+        self.L.ref_map_get_local_bound(self.h, a, b)
+        return tuple(a), tuple(b)
+
+    def set_local_bound(self, lo, hi):
+        self.L.ref_map_set_local_bound(self.h, fo._i3(lo), fo._i3(hi))
+
+    def get_updated_box(self, reset=False):
+        a, b = (C.c_double * 3)(), (C.c_double * 3)()
+        self.L.ref_map_get_updated_box(self.h, a, b, int(reset))
+        return np.array(a), np.array(b)
+
+    def reset_buffer(self):
+        self.L.ref_map_reset_buffer_all(self.h)
+
+    def set_occupied(self, pos, occ=1):
+        self.L.ref_map_set_occupied(self.h, fo._d3(pos), occ)
+
+    def get_occupancy_idx(self, idx):
+        return self.L.ref_map_get_occupancy_idx(self.h, fo._i3(idx))
+
+    def dist_grad(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        d = np.empty(len(pos))
+        g = np.empty((len(pos), 3))
+        self.L.ref_map_dist_grad(self.h, fo._dp(pos), len(pos), fo._dp(d), fo._dp(g))
+        return d, g
+
+    def raycast_cells(self, start, end, cap=4096):
+        out = np.empty((cap, 3), dtype=np.int32)
+        n = self.L.ref_raycast_cells(self.h, fo._d3(start), fo._d3(end), fo._ip(out), cap)
+        return out[:min(n, cap)].copy()
+
+
+def bspline_cost_grad(rmap, x, point_num, cost_function, pt_dist, start_state, end_state, end_n=3, dim=3,
+                      knot_span=0.0, time_lb=-1.0, guide_pts=None, waypoints=None, waypt_idx=None, view=None,
+                      **cfgkw):
+    """BsplineOptimizer::combineCost of the reference; same signature as fuel_oracle.bspline_cost_grad."""
+    L = lib()
+    p = dict(fo.DEFAULT_BSPLINE)
+    p.update(cfgkw)
+    cfg = fo.BsplineCfg(**p)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    keep = []
+
+    def ptr(a, dt=np.float64):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_double if dt == np.float64 else C.c_int))
+    pb = fo.BsplineProblem()
+    pb.cost_function, pb.dim, pb.point_num = cost_function, dim, point_num
+    pb.knot_span, pb.pt_dist, pb.time_lb = knot_span, pt_dist, time_lb
+    pb.start_state, pb.end_state, pb.end_n = ptr(start_state), ptr(end_state), end_n
+    pb.guide_pts, pb.waypoints = ptr(guide_pts), ptr(waypoints)
+    pb.waypt_idx = ptr(waypt_idx, np.int32)
+    pb.n_waypt = 0 if waypoints is None else len(waypoints)
+    if view is not None:
+        pb.view_pt, pb.view_dir, pb.view_idx = ptr(view[0]), ptr(view[1]), int(view[2])
+    cost = C.c_double()
+    grad = np.zeros(len(x))
+    L.ref_bspline_cost_grad(rmap.h, C.byref(cfg), C.byref(pb), fo._dp(x), C.byref(cost), fo._dp(grad))
+    return cost.value, grad

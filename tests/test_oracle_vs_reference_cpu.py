@@ -1,0 +1,147 @@
+"""Pins the oracle against the REAL reference: oracle/_ref/libfuel_ref.so is built from
+/root/reference/fuel_planner/{plan_env/src/sdf_map.cpp, raycast.cpp, edt_environment.cpp,
+bspline_opt/src/bspline_optimizer.cpp} with header stand-ins for Eigen/ROS/PCL/NLopt
+(oracle/ref_build/).  Bars: bit-exact (same IEEE f64 operations in the same order) for fusion,
+inflation, ESDF, ray walking; <= 1e-12 relative for the B-spline cost/gradient (summation order
+of independent terms is the only difference).  Skipped where the library was never built."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import fuel_oracle as fo
+from oracle.ref_build import ref
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def twin(map_size, box, **kw):
+    return fo.OracleMap(map_size, *box, **kw), ref.RefMap(map_size, *box, **kw)
+
+
+def test_constants_and_initial_state():
+    om, rm = twin((50.0, 50.0, 10.0), ((-10, -15, 0), (10, 15, 2)))
+    assert om.nvox == rm.nvox == (500, 500, 100)
+    assert np.array_equal(om.occ, rm.occ) and np.array_equal(om.dist, rm.dist)
+
+
+@pytest.mark.parametrize("optimistic,signed", [(0, 0), (1, 0), (1, 1)])
+def test_fusion_inflation_esdf_bit_exact(optimistic, signed):
+    box = ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    om, rm = twin((10.0, 8.0, 4.0), box, optimistic=optimistic, signed_dist=signed)
+    truth = om.fixture_world(3, 14)
+    rng = np.random.default_rng(9)
+    for k in range(24):
+        pose = om.fixture_camera(truth, 5, k, 24, 0.9)
+        pts = om.fixture_render(truth, pose, 160, 120, 2, 2, maxdist=9.0 if k % 3 == 0 else 5.0)
+        extra = pose[:3] + rng.normal(scale=6.0, size=(40, 3))
+        pts = np.vstack([pts, extra.astype(np.float32), pts[:50]])
+        om.input_points(pts, pose[:3])
+        rm.input_points(pts, pose[:3])
+        assert om.get_local_bound() == rm.get_local_bound()
+        assert np.array_equal(np.concatenate(om.get_updated_box()), np.concatenate(rm.get_updated_box()))
+        if k % 6 == 5:
+            om.inflate_local()
+            rm.inflate_local()
+            om.update_esdf()
+            rm.update_esdf()
+            assert np.array_equal(om.occ, rm.occ)
+            assert np.array_equal(om.infl, rm.infl)
+            assert np.array_equal(om.dist, rm.dist)  # identical doubles, incl. res*sqrt(DBL_MAX)
+    pos = om.origin - 0.3 + (np.array([10.0, 8.0, 4.0]) + 0.6) * rng.random((4000, 3))
+    d0, g0 = om.dist_grad(pos)
+    d1, g1 = rm.dist_grad(pos)
+    assert np.array_equal(d0, d1) and np.array_equal(g0, g1)
+
+
+def test_char_wrap_of_raycast_num():
+    om, rm = twin((4.0, 4.0, 2.0), ((-2, -2, -1), (2, 2, 1)))
+    cam = np.array([0.0, 0.0, 0.0])
+    rng = np.random.default_rng(1)
+    for k in range(300):  # crosses the 127 -> -128 and the == -1 frames
+        pts = (rng.random((30, 3)) * np.array([3.6, 3.6, 1.6]) - np.array([1.8, 1.8, 0.8])).astype(np.float32)
+        om.input_points(pts, cam)
+        rm.input_points(pts, cam)
+        if k in (126, 127, 128, 254, 255, 256, 299):
+            assert np.array_equal(om.occ, rm.occ), k
+
+
+def test_full_box_and_map_face_wrap():
+    om, rm = twin((4.0, 3.0, 2.0), ((-2, -1.5, -1), (2, 1.5, 1)))
+    nv = om.nvox
+    for m in (om, rm):
+        occ = m.occ.reshape(nv)
+        for id3 in [(0, 0, 0), (0, 0, nv[2] - 1), (0, nv[1] - 1, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1),
+                    (5, 0, 7), (5, nv[1] - 1, 7), (9, 11, 0), (9, 11, nv[2] - 1), (nv[0] - 1, 3, 3)]:
+            occ[id3] = 2.0
+        m.set_local_bound(*helpers.full_box(nv))
+        m.inflate_local()
+        m.update_esdf()
+    assert np.array_equal(om.infl, rm.infl) and np.array_equal(om.dist, rm.dist)
+
+
+def test_raycaster_cells_identical():
+    om, rm = twin((8.0, 6.0, 4.0), ((-3, -2, 0), (3, 2, 2)))
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a = om.origin + 0.2 + (np.array([8.0, 6.0, 4.0]) - 0.4) * rng.random(3)
+        b = om.origin + 0.2 + (np.array([8.0, 6.0, 4.0]) - 0.4) * rng.random(3)
+        assert np.array_equal(om.raycast_cells(a, b), rm.raycast_cells(a, b))
+
+
+@pytest.mark.parametrize("cf", [0x11F, 0x01F, 0x039, 0x041, 0x1FF, 0x002, 0x104])
+def test_bspline_combine_cost_matches_reference(cf):
+    om, rm = twin((20.0, 20.0, 5.0), ((-9, -9, 0), (9, 9, 3)))
+    truth = om.fixture_world(42, 60)
+    om.fixture_known_state(truth, 42, 10)
+    rm.occ[:] = om.occ
+    for m in (om, rm):
+        m.set_local_bound(*helpers.full_box(om.nvox))
+        m.inflate_local()
+        m.update_esdf()
+    rng = np.random.default_rng(4)
+    for N in (6, 14, 32):
+        ctrl = helpers.make_trajectories(rng, 6, N, np.array([-8.5, -8.5, 0.5]), np.array([8.5, 8.5, 2.5]))
+        mint = bool(cf & 0x100)
+        x, ptd, st, en = helpers.bspline_inputs(ctrl, 0.175, mint)
+        for c in range(len(ctrl)):
+            guide = ctrl[c, 3:N - 3] + 0.1 if N > 6 else np.zeros((0, 3))
+            widx = np.array([1, N // 2, N - 3], dtype=np.int32)
+            kw = dict(guide_pts=guide, waypoints=ctrl[c, widx + 1] + 0.2, waypt_idx=widx,
+                      view=(ctrl[c, N // 2] + 0.5, np.array([0.5, 1.0, 0.2]), N // 2 + 1), ld_view=0.7)
+            for end_n in (1, 2, 3):
+                f0, g0 = fo.bspline_cost_grad(om, x[c], N, cf, ptd[c], st[c], en[c], end_n, 3, 0.175,
+                                              1.0 if mint else -1.0, **kw)
+                f1, g1 = ref.bspline_cost_grad(rm, x[c], N, cf, ptd[c], st[c], en[c], end_n, 3, 0.175,
+                                               1.0 if mint else -1.0, **kw)
+                assert abs(f0 - f1) <= 1e-12 * max(1.0, abs(f1))
+                assert np.abs(g0 - g1).max() <= 1e-12 * max(1.0, np.abs(g1).max())
+
+
+def test_golden_fixture_agrees_with_reference():
+    """The committed known-answer vectors were produced by the oracle; the reference build must
+    reproduce them from the same stored inputs."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_cycle.npz"))
+    rm = ref.RefMap(mg.MAP_SIZE, *mg.BOX)
+    for k in range(mg.N_FRAMES):
+        rm.input_points(z["pts%d" % k], z["cam%d" % k])
+    assert np.array_equal(rm.occ, z["occupancy"])
+    lo, hi = rm.get_local_bound()
+    assert np.array_equal(np.array([lo, hi]), z["local_bound"])
+    rm.inflate_local()
+    rm.update_esdf()
+    assert np.array_equal(rm.infl, z["inflate"])
+    sl = tuple(slice(lo[i], hi[i] + 1) for i in range(3))
+    assert np.array_equal(rm.dist.reshape(rm.nvox)[sl], z["distance_box"])
+    d, g = rm.dist_grad(z["query_pos"])
+    assert np.array_equal(d, z["query_dist"]) and np.array_equal(g, z["query_grad"])
+    ctrl, st, en = z["ctrl"], z["start"], z["end"]
+    for c in range(len(ctrl)):
+        x = np.concatenate([ctrl[c].reshape(-1), [0.2]])
+        f, gr = ref.bspline_cost_grad(rm, x, ctrl.shape[1], 0x11F, fo.bspline_pt_dist(ctrl[c]), st[c], en[c], 3, 3, 0.2)
+        assert abs(f - z["bspline_cost"][c]) <= 1e-12 * abs(f)
+        assert np.abs(gr - z["bspline_grad"][c]).max() <= 1e-12 * np.abs(gr).max()
