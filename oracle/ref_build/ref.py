@@ -45,8 +45,66 @@ def lib():
         L.ref_map_dist_grad.argtypes = [P, dp, C.c_int, dp, dp]
         L.ref_raycast_cells.argtypes = [P, dp, dp, ip, C.c_int]
         L.ref_bspline_cost_grad.argtypes = [P, C.POINTER(fo.BsplineCfg), C.POINTER(fo.BsplineProblem), dp, dp, dp]
+        L.ref_map_set_updated_box.argtypes = [P, dp, dp]
+        L.ref_frontier_create.restype = P
+        L.ref_frontier_create.argtypes = [P, C.c_int]
+        L.ref_frontier_destroy.argtypes = [P]
+        L.ref_frontier_flags.restype = C.POINTER(C.c_char)
+        L.ref_frontier_flags.argtypes = [P]
+        L.ref_frontier_search.argtypes = [P]
+        L.ref_frontier_commit.argtypes = [P, C.c_int]
+        L.ref_frontier_count.argtypes = [P, C.c_int]
+        L.ref_frontier_cluster_size.argtypes = [P, C.c_int, C.c_int]
+        L.ref_frontier_cluster_cells.argtypes = [P, C.c_int, C.c_int, ip]
+        L.ref_frontier_cluster_info.argtypes = [P, C.c_int, C.c_int, dp]
+        L.ref_frontier_removed_count.argtypes = [P]
+        L.ref_frontier_removed_ids.argtypes = [P, ip]
         _LIB = L
     return _LIB
+
+
+class RefFrontier:
+    """fast_planner::FrontierFinder (the reference's own searchFrontiers / expandFrontier)."""
+
+    def __init__(self, rmap, cluster_min=100):
+        self.L = lib()
+        self.map = rmap
+        self.h = self.L.ref_frontier_create(rmap.h, cluster_min)
+        self.flags = np.ctypeslib.as_array(C.cast(self.L.ref_frontier_flags(self.h), C.POINTER(C.c_int8)),
+                                           shape=(rmap.N,))
+
+    def __del__(self):
+        try:
+            self.L.ref_frontier_destroy(self.h)
+        except Exception:
+            pass
+
+    def search(self):
+        return self.L.ref_frontier_search(self.h)
+
+    def commit(self, dormant=False):
+        self.L.ref_frontier_commit(self.h, int(dormant))
+
+    def clusters(self, which=0):
+        out = []
+        for k in range(self.L.ref_frontier_count(self.h, which)):
+            n = self.L.ref_frontier_cluster_size(self.h, which, k)
+            a = np.empty(n, dtype=np.int32)
+            self.L.ref_frontier_cluster_cells(self.h, which, k, fo._ip(a))
+            out.append(a)
+        return out
+
+    def cluster_info(self, which, k):
+        o = np.empty(9)
+        self.L.ref_frontier_cluster_info(self.h, which, k, fo._dp(o))
+        return o[:3], o[3:6], o[6:9]
+
+    def removed_ids(self):
+        n = self.L.ref_frontier_removed_count(self.h)
+        a = np.empty(n, dtype=np.int32)
+        if n:
+            self.L.ref_frontier_removed_ids(self.h, fo._ip(a))
+        return a
 
 
 class RefMap:
@@ -93,6 +151,9 @@ class RefMap:
         a, b = (C.c_double * 3)(), (C.c_double * 3)()
         self.L.ref_map_get_updated_box(self.h, a, b, int(reset))
         return np.array(a), np.array(b)
+
+    def set_updated_box(self, lo, hi):
+        self.L.ref_map_set_updated_box(self.h, fo._d3(lo), fo._d3(hi))
 
     def reset_buffer(self):
         self.L.ref_map_reset_buffer_all(self.h)

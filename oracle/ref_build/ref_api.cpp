@@ -23,6 +23,7 @@
 #include <plan_env/raycast.h>
 #include <plan_env/edt_environment.h>
 #include <bspline_opt/bspline_optimizer.h>
+#include <active_perception/frontier_finder.h>
 #undef private
 #undef protected
 
@@ -147,6 +148,69 @@ int ref_raycast_cells(ref_map* r, const double start[3], const double end[3], in
     ++n;
   }
   return n;
+}
+
+// ---- FrontierFinder: the reference's own searchFrontiers()/expandFrontier() -----------------------
+// (splitLargeFrontiers is neutralised by the VoxelGrid stand-in returning an empty cloud, so
+// tmp_frontiers_ holds the region-grown clusters)
+struct ref_frontier {
+  std::unique_ptr<fast_planner::FrontierFinder> ff;
+  ref_map* map;
+};
+ref_frontier* ref_frontier_create(ref_map* r, int cluster_min) {
+  ros::NodeHandle nh;
+  nh.num["frontier/cluster_min"] = cluster_min;
+  nh.num["frontier/cluster_size_xy"] = 2.0;
+  nh.num["frontier/cluster_size_z"] = 10.0;
+  nh.num["frontier/down_sample"] = 3;
+  ref_frontier* f = new ref_frontier;
+  f->map = r;
+  f->ff.reset(new fast_planner::FrontierFinder(r->edt, nh));
+  return f;
+}
+void ref_frontier_destroy(ref_frontier* f) { delete f; }
+char* ref_frontier_flags(ref_frontier* f) { return f->ff->frontier_flag_.data(); }
+int ref_frontier_search(ref_frontier* f) {
+  std::streambuf* old = std::cout.rdbuf(nullptr);  // "Before remove: ..." chatter
+  f->ff->searchFrontiers();
+  std::cout.rdbuf(old);
+  return (int)f->ff->tmp_frontiers_.size();
+}
+void ref_frontier_commit(ref_frontier* f, int dormant) {
+  auto& dst = dormant ? f->ff->dormant_frontiers_ : f->ff->frontiers_;
+  dst.insert(dst.end(), f->ff->tmp_frontiers_.begin(), f->ff->tmp_frontiers_.end());
+  f->ff->tmp_frontiers_.clear();
+}
+static std::list<fast_planner::Frontier>& ref_pick(ref_frontier* f, int which) {
+  return which == 0 ? f->ff->tmp_frontiers_ : (which == 1 ? f->ff->frontiers_ : f->ff->dormant_frontiers_);
+}
+int ref_frontier_count(ref_frontier* f, int which) { return (int)ref_pick(f, which).size(); }
+int ref_frontier_cluster_size(ref_frontier* f, int which, int k) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  return (int)it->cells_.size();
+}
+void ref_frontier_cluster_cells(ref_frontier* f, int which, int k, int* adr) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  Eigen::Vector3i idx;
+  for (size_t i = 0; i < it->cells_.size(); ++i) {
+    f->map->map->posToIndex(it->cells_[i], idx);
+    adr[i] = f->map->map->toAddress(idx);
+  }
+}
+void ref_frontier_cluster_info(ref_frontier* f, int which, int k, double* out9) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  for (int i = 0; i < 3; ++i) out9[i] = it->average_(i), out9[3 + i] = it->box_min_(i), out9[6 + i] = it->box_max_(i);
+}
+int ref_frontier_removed_count(ref_frontier* f) { return (int)f->ff->removed_ids_.size(); }
+void ref_frontier_removed_ids(ref_frontier* f, int* ids) {
+  for (size_t i = 0; i < f->ff->removed_ids_.size(); ++i) ids[i] = f->ff->removed_ids_[i];
+}
+void ref_map_set_updated_box(ref_map* r, const double lo[3], const double hi[3]) {
+  for (int i = 0; i < 3; ++i) r->map->md_->update_min_(i) = lo[i], r->map->md_->update_max_(i) = hi[i];
+  r->map->md_->reset_updated_box_ = false;
 }
 
 typedef struct {  // identical to fo_bspline_cfg

@@ -1,0 +1,22 @@
+// ref_frontier_stubs.cpp -- definitions for the out-of-scope collaborators that
+// frontier_finder.cpp links against (PerceptionUtils: camera FOV test for viewpoint sampling;
+// ViewNode: A*/yaw path costs for the TSP cost matrix).  None of them is reached by
+// searchFrontiers()/expandFrontier(), the part oracle/_ref exists to pin.
+#include <active_perception/graph_node.h>
+#include <active_perception/perception_utils.h>
+namespace fast_planner {
+PerceptionUtils::PerceptionUtils(ros::NodeHandle&) {}
+void PerceptionUtils::setPose(const Vector3d&, const double&) {}
+void PerceptionUtils::getFOV(vector<Vector3d>&, vector<Vector3d>&) {}
+bool PerceptionUtils::insideFOV(const Vector3d&) { return false; }
+void PerceptionUtils::getFOVBoundingBox(Vector3d&, Vector3d&) {}
+double ViewNode::vm_ = 0, ViewNode::am_ = 0, ViewNode::yd_ = 0, ViewNode::ydd_ = 0, ViewNode::w_dir_ = 0;
+shared_ptr<Astar> ViewNode::astar_;
+shared_ptr<RayCaster> ViewNode::caster_;
+shared_ptr<SDFMap> ViewNode::map_;
+ViewNode::ViewNode(const Vector3d& p, const double& y) { pos_ = p; yaw_ = y; }
+double ViewNode::costTo(const ViewNode::Ptr&) { return 0; }
+double ViewNode::computeCost(const Vector3d&, const Vector3d&, const double&, const double&, const Vector3d&,
+                             const double&, vector<Vector3d>&) { return 0; }
+double ViewNode::searchPath(const Vector3d&, const Vector3d&, vector<Vector3d>&) { return 0; }
+}

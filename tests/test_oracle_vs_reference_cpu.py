@@ -120,6 +120,53 @@ def test_bspline_combine_cost_matches_reference(cf):
                 assert np.abs(g0 - g1).max() <= 1e-12 * max(1.0, np.abs(g1).max())
 
 
+def test_frontier_search_matches_reference_incrementally():
+    """FrontierFinder::searchFrontiers of the reference (BFS order) vs the oracle: identical cells in
+    identical (BFS) order, identical flags, removed ids and cluster info, over several rounds."""
+    map_size = (20.0, 20.0, 5.0)
+    box = ((-9.0, -9.0, 0.0), (9.0, 9.0, 3.0))
+    om, rm = twin(map_size, box)
+    truth = om.fixture_world(42, 60)
+    of = fo.OracleFrontier(om, 100)
+    rf = ref.RefFrontier(rm, 100)
+    k = 0
+    for r in range(5):
+        for _ in range(12):
+            pose = om.fixture_camera(truth, 7, k, 60, 0.7)
+            k += 1
+            pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+            om.input_points(pts, pose[:3])
+            rm.input_points(pts, pose[:3])
+        assert of.search() == rf.search()
+        for a, b in zip(of.clusters(0), rf.clusters(0)):
+            assert np.array_equal(a, b)  # same cells in the same BFS order
+        assert np.array_equal(of.flags, rf.flags)
+        assert np.array_equal(of.removed_ids(), rf.removed_ids())
+        for c in range(len(of.clusters(0))):
+            for u, v in zip(of.cluster_info(0, c), rf.cluster_info(0, c)):
+                assert np.array_equal(u, v)
+        of.commit(r == 2)
+        rf.commit(r == 2)
+
+
+def test_frontier_low_z_seeds_box_faces_and_small_clusters_match_reference():
+    map_size = (8.0, 6.0, 4.0)
+    box = ((-2.0, -1.5, -0.5), (1.0, 2.0, 1.0))
+    om, rm = twin(map_size, box)
+    truth = om.fixture_world(5, 6)
+    om.fixture_known_state(truth, 5, 6, 1.0, 2.2)
+    rm.occ[:] = om.occ
+    for cmin in (0, 5, 60):
+        of = fo.OracleFrontier(om, cmin)
+        rf = ref.RefFrontier(rm, cmin)
+        for m in (om, rm):
+            m.set_updated_box((-1.0, -1.0, 0.2), (0.5, 1.0, 0.8))
+        assert of.search() == rf.search()
+        for a, b in zip(of.clusters(0), rf.clusters(0)):
+            assert np.array_equal(a, b)
+        assert np.array_equal(of.flags, rf.flags)
+
+
 def test_golden_fixture_agrees_with_reference():
     """The committed known-answer vectors were produced by the oracle; the reference build must
     reproduce them from the same stored inputs."""
@@ -139,6 +186,13 @@ def test_golden_fixture_agrees_with_reference():
     assert np.array_equal(rm.dist.reshape(rm.nvox)[sl], z["distance_box"])
     d, g = rm.dist_grad(z["query_pos"])
     assert np.array_equal(d, z["query_dist"]) and np.array_equal(g, z["query_grad"])
+    rf = ref.RefFrontier(rm, mg.CLUSTER_MIN)
+    n = rf.search()
+    off = z["cluster_offsets"]
+    assert n == len(off) - 1
+    for k, c in enumerate(rf.clusters(0)):
+        assert np.array_equal(np.sort(c), z["cluster_cells"][off[k]:off[k + 1]])
+    assert np.array_equal(rf.flags, z["frontier_flags"])
     ctrl, st, en = z["ctrl"], z["start"], z["end"]
     for c in range(len(ctrl)):
         x = np.concatenate([ctrl[c].reshape(-1), [0.2]])
