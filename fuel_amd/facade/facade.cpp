@@ -1,0 +1,570 @@
+// facade.cpp -- the reference's C++ class interfaces over the libfuelmi C-ABI (host side only;
+// every computation is a HIP kernel behind include/fuelmi.h).  See INTEGRATION.md.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <deque>
+#include <limits>
+
+#include "plan_env/sdf_map.h"
+#include "plan_env/edt_environment.h"
+#include "active_perception/frontier_finder.h"
+#include "bspline_opt/bspline_optimizer.h"
+
+namespace fast_planner {
+
+static void warn(const char* what, int rc) {
+  // error convention of the reference: void returns, log and continue
+  if (rc != FUELMI_OK) std::fprintf(stderr, "[fuelmi] %s failed (%d): %s\n", what, rc, fuelmi_last_error());
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDFMap
+// ------------------------------------------------------------------------------------------------
+SDFMap::SDFMap() : dev_(nullptr), mirror_occ_(true), mirror_infl_(true), mirror_dist_(true) {}
+SDFMap::~SDFMap() {
+  if (dev_) fuelmi_map_destroy(dev_);
+}
+
+void SDFMap::initMap(ros::NodeHandle& nh) {
+  // parameter names and defaults of the reference (plan_env/src/sdf_map.cpp:19-47,78-82)
+  mp_.reset(new MapParam);
+  md_.reset(new MapData);
+  fuelmi_map_cfg c;
+  double x_size, y_size, z_size;
+  nh.param("sdf_map/resolution", c.resolution, -1.0);
+  nh.param("sdf_map/map_size_x", x_size, -1.0);
+  nh.param("sdf_map/map_size_y", y_size, -1.0);
+  nh.param("sdf_map/map_size_z", z_size, -1.0);
+  nh.param("sdf_map/obstacles_inflation", c.obstacles_inflation, -1.0);
+  nh.param("sdf_map/local_bound_inflate", c.local_bound_inflate, 1.0);
+  nh.param("sdf_map/local_map_margin", mp_->local_map_margin_, 1);
+  nh.param("sdf_map/ground_height", c.ground_height, 1.0);
+  nh.param("sdf_map/default_dist", c.default_dist, 5.0);
+  bool optimistic, signed_dist;
+  nh.param("sdf_map/optimistic", optimistic, true);
+  nh.param("sdf_map/signed_dist", signed_dist, false);
+  c.optimistic = optimistic;
+  c.signed_dist = signed_dist;
+  nh.param("sdf_map/p_hit", c.p_hit, 0.70);
+  nh.param("sdf_map/p_miss", c.p_miss, 0.35);
+  nh.param("sdf_map/p_min", c.p_min, 0.12);
+  nh.param("sdf_map/p_max", c.p_max, 0.97);
+  nh.param("sdf_map/p_occ", c.p_occ, 0.80);
+  nh.param("sdf_map/max_ray_length", c.max_ray_length, -0.1);
+  nh.param("sdf_map/virtual_ceil_height", c.virtual_ceil_height, -0.1);
+  int device = 0;
+  nh.param("sdf_map/hip_device", device, 0);  // addition: which GPU hosts this map
+  c.device = device;
+  c.map_size[0] = x_size, c.map_size[1] = y_size, c.map_size[2] = z_size;
+  const double org[3] = {-x_size / 2.0, -y_size / 2.0, c.ground_height};
+  const char* axis[3] = {"x", "y", "z"};
+  for (int i = 0; i < 3; ++i) {
+    nh.param(std::string("sdf_map/box_min_") + axis[i], c.box_min[i], org[i]);
+    nh.param(std::string("sdf_map/box_max_") + axis[i], c.box_max[i], org[i] + c.map_size[i]);
+  }
+  int rc = fuelmi_map_create(&c, &dev_);
+  warn("fuelmi_map_create", rc);
+  if (rc != FUELMI_OK) return;
+  fuelmi_map_info I;
+  fuelmi_map_get_info(dev_, &I);
+  mp_->resolution_ = c.resolution;
+  mp_->resolution_inv_ = I.resolution_inv;
+  mp_->obstacles_inflation_ = c.obstacles_inflation;
+  mp_->local_bound_inflate_ = std::max(c.resolution, c.local_bound_inflate);
+  mp_->ground_height_ = c.ground_height;
+  mp_->virtual_ceil_height_ = c.virtual_ceil_height;
+  mp_->default_dist_ = c.default_dist;
+  mp_->optimistic_ = optimistic;
+  mp_->signed_dist_ = signed_dist;
+  mp_->p_hit_ = c.p_hit, mp_->p_miss_ = c.p_miss, mp_->p_min_ = c.p_min, mp_->p_max_ = c.p_max, mp_->p_occ_ = c.p_occ;
+  mp_->prob_hit_log_ = I.prob_hit_log, mp_->prob_miss_log_ = I.prob_miss_log;
+  mp_->clamp_min_log_ = I.clamp_min_log, mp_->clamp_max_log_ = I.clamp_max_log;
+  mp_->min_occupancy_log_ = I.min_occupancy_log;
+  mp_->max_ray_length_ = c.max_ray_length;
+  mp_->unknown_flag_ = 0.01;
+  for (int i = 0; i < 3; ++i) {
+    mp_->map_origin_(i) = I.origin[i];
+    mp_->map_size_(i) = c.map_size[i];
+    mp_->map_min_boundary_(i) = I.min_boundary[i];
+    mp_->map_max_boundary_(i) = I.max_boundary[i];
+    mp_->map_voxel_num_(i) = I.voxel_num[i];
+    mp_->box_min_(i) = I.box_min[i];
+    mp_->box_max_(i) = I.box_max[i];
+    mp_->box_mind_(i) = c.box_min[i];
+    mp_->box_maxd_(i) = c.box_max[i];
+  }
+  const size_t n = (size_t)getVoxelNum();
+  md_->occupancy_buffer_.assign(n, mp_->clamp_min_log_ - mp_->unknown_flag_);
+  md_->occupancy_buffer_inflate_.assign(n, 0);
+  md_->distance_buffer_.assign(n, mp_->default_dist_);
+  md_->reset_updated_box_ = true;
+  for (int i = 0; i < 3; ++i) {
+    md_->update_min_(i) = md_->update_max_(i) = 0.0;
+    md_->local_bound_min_(i) = md_->local_bound_max_(i) = 0;
+  }
+}
+
+void SDFMap::setHostMirror(bool occupancy, bool inflate, bool distance) {
+  mirror_occ_ = occupancy, mirror_infl_ = inflate, mirror_dist_ = distance;
+}
+
+void SDFMap::pullBounds() {
+  int lo[3], hi[3];
+  double a[3], b[3];
+  fuelmi_map_get_local_bound(dev_, lo, hi);
+  fuelmi_map_get_updated_box(dev_, a, b, 0);
+  for (int i = 0; i < 3; ++i) {
+    md_->local_bound_min_(i) = lo[i], md_->local_bound_max_(i) = hi[i];
+    md_->update_min_(i) = a[i], md_->update_max_(i) = b[i];
+  }
+}
+
+void SDFMap::syncMirrors(const Eigen::Vector3i& bmin, const Eigen::Vector3i& bmax, bool occ, bool infl, bool dist) {
+  if (!(occ || infl || dist)) return;
+  const int lo[3] = {bmin(0), bmin(1), bmin(2)}, hi[3] = {bmax(0), bmax(1), bmax(2)};
+  warn("fuelmi_map_sync_host",
+       fuelmi_map_sync_host(dev_, lo, hi, occ ? md_->occupancy_buffer_.data() : nullptr,
+                            infl ? md_->occupancy_buffer_inflate_.data() : nullptr,
+                            dist ? md_->distance_buffer_.data() : nullptr));
+}
+
+void SDFMap::inputPointCloud(const pcl::PointCloud<pcl::PointXYZ>& points, const int& point_num,
+                             const Eigen::Vector3d& camera_pos) {
+  if (point_num == 0) return;
+  const double cam[3] = {camera_pos(0), camera_pos(1), camera_pos(2)};
+  warn("fuelmi_map_input_points",
+       fuelmi_map_input_points(dev_, &points.points[0].x, (int)sizeof(pcl::PointXYZ), point_num, cam));
+  pullBounds();
+  md_->reset_updated_box_ = false;
+  // fused voxels lie in the index box of camera + end points, inside the inflated local bound
+  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, mirror_occ_, false, false);
+}
+
+void SDFMap::clearAndInflateLocalMap() {
+  warn("fuelmi_map_inflate_local", fuelmi_map_inflate_local(dev_));
+  // stamps spill up to inflate_step voxels outside the box
+  Eigen::Vector3i lo = md_->local_bound_min_, hi = md_->local_bound_max_;
+  const int s = (int)std::ceil(mp_->obstacles_inflation_ / mp_->resolution_);
+  for (int k = 0; k < 3; ++k) lo(k) -= s, hi(k) += s;
+  boundIndex(lo);
+  boundIndex(hi);
+  syncMirrors(lo, hi, false, mirror_infl_, false);
+}
+
+void SDFMap::updateESDF3d() {
+  warn("fuelmi_map_update_esdf", fuelmi_map_update_esdf(dev_));
+  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, false, false, mirror_dist_);
+}
+
+void SDFMap::resetBuffer() {
+  warn("fuelmi_map_reset_buffer_all", fuelmi_map_reset_buffer_all(dev_));
+  pullBounds();
+  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, false, mirror_infl_, mirror_dist_);
+}
+
+void SDFMap::resetBuffer(const Eigen::Vector3d& min_pos, const Eigen::Vector3d& max_pos) {
+  const double a[3] = {min_pos(0), min_pos(1), min_pos(2)}, b[3] = {max_pos(0), max_pos(1), max_pos(2)};
+  warn("fuelmi_map_reset_buffer", fuelmi_map_reset_buffer(dev_, a, b));
+  Eigen::Vector3i lo, hi;
+  posToIndex(min_pos, lo);
+  posToIndex(max_pos, hi);
+  boundIndex(lo);
+  boundIndex(hi);
+  syncMirrors(lo, hi, false, mirror_infl_, mirror_dist_);
+}
+
+void SDFMap::setOccupied(const Eigen::Vector3d& pos, const int& occ) {
+  if (!isInMap(pos)) return;
+  const double p[3] = {pos(0), pos(1), pos(2)};
+  warn("fuelmi_map_set_occupied", fuelmi_map_set_occupied(dev_, p, 1, occ));
+  Eigen::Vector3i id;
+  posToIndex(pos, id);
+  md_->occupancy_buffer_inflate_[toAddress(id)] = (char)occ;
+}
+
+double SDFMap::getDistWithGrad(const Eigen::Vector3d& pos, Eigen::Vector3d& grad) {
+  const double p[3] = {pos(0), pos(1), pos(2)};
+  double d = 0.0, g[3] = {0, 0, 0};
+  warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(dev_, p, 1, &d, g));
+  for (int k = 0; k < 3; ++k) grad(k) = g[k];
+  return d;
+}
+void SDFMap::getDistWithGradBatch(const double* pos_xyz, int n, double* dist, double* grad_xyz) {
+  warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(dev_, pos_xyz, n, dist, grad_xyz));
+}
+
+void SDFMap::getRegion(Eigen::Vector3d& ori, Eigen::Vector3d& size) { ori = mp_->map_origin_, size = mp_->map_size_; }
+void SDFMap::getBox(Eigen::Vector3d& bmin, Eigen::Vector3d& bmax) { bmin = mp_->box_mind_, bmax = mp_->box_maxd_; }
+void SDFMap::getUpdatedBox(Eigen::Vector3d& bmin, Eigen::Vector3d& bmax, bool reset) {
+  double a[3], b[3];
+  fuelmi_map_get_updated_box(dev_, a, b, reset ? 1 : 0);
+  for (int k = 0; k < 3; ++k) bmin(k) = a[k], bmax(k) = b[k];
+  if (reset) md_->reset_updated_box_ = true;
+}
+double SDFMap::getResolution() { return mp_->resolution_; }
+int SDFMap::getVoxelNum() { return mp_->map_voxel_num_(0) * mp_->map_voxel_num_(1) * mp_->map_voxel_num_(2); }
+
+// ------------------------------------------------------------------------------------------------
+// EDTEnvironment (plan_env/src/edt_environment.cpp:7-20,78-97)
+// ------------------------------------------------------------------------------------------------
+void EDTEnvironment::init() {}
+void EDTEnvironment::setMap(shared_ptr<SDFMap>& map) {
+  sdf_map_ = map;
+  resolution_inv_ = 1 / sdf_map_->getResolution();
+}
+void EDTEnvironment::setObjPrediction(ObjPrediction prediction) { obj_prediction_ = prediction; }
+void EDTEnvironment::setObjScale(ObjScale scale) { obj_scale_ = scale; }
+void EDTEnvironment::evaluateEDTWithGrad(const Eigen::Vector3d& pos, double, double& dist, Eigen::Vector3d& grad) {
+  dist = sdf_map_->getDistWithGrad(pos, grad);
+}
+double EDTEnvironment::evaluateCoarseEDT(Eigen::Vector3d& pos, double) { return sdf_map_->getDistance(pos); }
+
+// ------------------------------------------------------------------------------------------------
+// FrontierFinder (grid part)
+// ------------------------------------------------------------------------------------------------
+FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& nh) : edt_env_(edt), dev_(nullptr) {
+  nh.param("frontier/cluster_min", cluster_min_, -1);
+  resolution_ = edt_env_->sdf_map_->getResolution();
+  fuelmi_frontier_cfg c;
+  c.cluster_min = cluster_min_;
+  c.min_z = 0.4;  // literal in frontier_finder.cpp:151
+  warn("fuelmi_frontier_create", fuelmi_frontier_create(edt_env_->sdf_map_->device(), &c, &dev_));
+}
+FrontierFinder::~FrontierFinder() {
+  if (dev_) fuelmi_frontier_destroy(dev_);
+}
+
+void FrontierFinder::pull(int which, list<Frontier>& out) {
+  out.clear();
+  const int n = fuelmi_frontier_count(dev_, which);
+  std::vector<int> adr;
+  for (int k = 0; k < n; ++k) {
+    Frontier f;
+    const int sz = fuelmi_frontier_cluster_size(dev_, which, k);
+    adr.resize(sz);
+    fuelmi_frontier_cluster_cells(dev_, which, k, adr.data());
+    f.cells_.resize(sz);
+    Eigen::Vector3d o, s;
+    edt_env_->sdf_map_->getRegion(o, s);
+    const int ny = (int)std::ceil(s(1) / resolution_), nz = (int)std::ceil(s(2) / resolution_);
+    for (int i = 0; i < sz; ++i) {
+      const int a = adr[i], x = a / (ny * nz), r = a - x * ny * nz, y = r / nz, z = r - y * nz;
+      f.cells_[i] = Vector3d((x + 0.5) * resolution_ + o(0), (y + 0.5) * resolution_ + o(1), (z + 0.5) * resolution_ + o(2));
+    }
+    double info[9];
+    fuelmi_frontier_cluster_info(dev_, which, k, info);
+    for (int i = 0; i < 3; ++i) f.average_(i) = info[i], f.box_min_(i) = info[3 + i], f.box_max_(i) = info[6 + i];
+    f.id_ = k;
+    out.push_back(f);
+  }
+}
+
+void FrontierFinder::searchFrontiers() {
+  int n_new = 0;
+  warn("fuelmi_frontier_search", fuelmi_frontier_search(dev_, &n_new));
+  pull(0, tmp_frontiers_);
+  removed_ids_.resize(fuelmi_frontier_removed_count(dev_));
+  if (!removed_ids_.empty()) fuelmi_frontier_removed_ids(dev_, removed_ids_.data());
+  pull(1, frontiers_);  // clusters dropped as "changed" disappear from the persistent lists
+  pull(2, dormant_frontiers_);
+}
+
+void FrontierFinder::computeFrontiersToVisit() {
+  // reference (:392-423) samples viewpoints and sends clusters without any to dormant_frontiers_;
+  // viewpoint sampling is a "next" row, so every new cluster becomes an active frontier here
+  warn("fuelmi_frontier_commit", fuelmi_frontier_commit(dev_, 0));
+  frontiers_.insert(frontiers_.end(), tmp_frontiers_.begin(), tmp_frontiers_.end());
+  int id = 0;
+  for (auto& f : frontiers_) f.id_ = id++;
+}
+
+void FrontierFinder::getFrontiers(vector<vector<Vector3d>>& clusters) {
+  clusters.clear();
+  for (auto& f : frontiers_) clusters.push_back(f.cells_);
+}
+void FrontierFinder::getDormantFrontiers(vector<vector<Vector3d>>& clusters) {
+  clusters.clear();
+  for (auto& f : dormant_frontiers_) clusters.push_back(f.cells_);
+}
+void FrontierFinder::getFrontierBoxes(vector<pair<Vector3d, Vector3d>>& boxes) {
+  boxes.clear();
+  for (auto& f : frontiers_) boxes.push_back(std::make_pair((f.box_max_ + f.box_min_) * 0.5, f.box_max_ - f.box_min_));
+}
+void FrontierFinder::wrapYaw(double& yaw) {
+  while (yaw < -M_PI) yaw += 2 * M_PI;
+  while (yaw > M_PI) yaw -= 2 * M_PI;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BsplineOptimizer
+// ------------------------------------------------------------------------------------------------
+const int BsplineOptimizer::SMOOTHNESS = FUELMI_COST_SMOOTHNESS;
+const int BsplineOptimizer::DISTANCE = FUELMI_COST_DISTANCE;
+const int BsplineOptimizer::FEASIBILITY = FUELMI_COST_FEASIBILITY;
+const int BsplineOptimizer::START = FUELMI_COST_START;
+const int BsplineOptimizer::END = FUELMI_COST_END;
+const int BsplineOptimizer::GUIDE = FUELMI_COST_GUIDE;
+const int BsplineOptimizer::WAYPOINTS = FUELMI_COST_WAYPOINTS;
+const int BsplineOptimizer::VIEWCONS = FUELMI_COST_VIEWCONS;
+const int BsplineOptimizer::MINTIME = FUELMI_COST_MINTIME;
+const int BsplineOptimizer::GUIDE_PHASE =
+    BsplineOptimizer::SMOOTHNESS | BsplineOptimizer::GUIDE | BsplineOptimizer::START | BsplineOptimizer::END;
+const int BsplineOptimizer::NORMAL_PHASE = BsplineOptimizer::SMOOTHNESS | BsplineOptimizer::DISTANCE |
+    BsplineOptimizer::FEASIBILITY | BsplineOptimizer::START | BsplineOptimizer::END;
+
+void BsplineOptimizer::setParam(ros::NodeHandle& nh) {
+  nh.param("optimization/ld_smooth", cfg_.ld_smooth, -1.0);
+  nh.param("optimization/ld_dist", cfg_.ld_dist, -1.0);
+  nh.param("optimization/ld_feasi", cfg_.ld_feasi, -1.0);
+  nh.param("optimization/ld_start", cfg_.ld_start, -1.0);
+  nh.param("optimization/ld_end", cfg_.ld_end, -1.0);
+  nh.param("optimization/ld_guide", cfg_.ld_guide, -1.0);
+  nh.param("optimization/ld_waypt", cfg_.ld_waypt, -1.0);
+  nh.param("optimization/ld_view", cfg_.ld_view, -1.0);
+  nh.param("optimization/ld_time", cfg_.ld_time, -1.0);
+  nh.param("optimization/dist0", cfg_.dist0, -1.0);
+  nh.param("optimization/max_vel", cfg_.max_vel, -1.0);
+  nh.param("optimization/max_acc", cfg_.max_acc, -1.0);
+  nh.param("optimization/dlmin", cfg_.dlmin, -1.0);
+  nh.param("optimization/wnl", cfg_.wnl, -1.0);
+  const char* nums[4] = {"optimization/max_iteration_num1", "optimization/max_iteration_num2",
+                         "optimization/max_iteration_num3", "optimization/max_iteration_num4"};
+  const char* times[4] = {"optimization/max_iteration_time1", "optimization/max_iteration_time2",
+                          "optimization/max_iteration_time3", "optimization/max_iteration_time4"};
+  for (int i = 0; i < 4; ++i) {
+    nh.param(nums[i], max_iteration_num_[i], -1);
+    nh.param(times[i], max_iteration_time_[i], -1.0);
+  }
+  nh.param("optimization/algorithm1", algorithm1_, -1);
+  nh.param("optimization/algorithm2", algorithm2_, -1);
+  nh.param("manager/bspline_degree", bspline_degree_, 3);
+  cfg_.bspline_degree = bspline_degree_;
+  time_lb_ = -1;
+}
+
+void BsplineOptimizer::setEnvironment(const shared_ptr<EDTEnvironment>& env) {
+  edt_environment_ = env;
+  dynamic_ = false;
+}
+void BsplineOptimizer::setCostFunction(const int& cost_code) { cost_function_ = cost_code; }
+void BsplineOptimizer::setGuidePath(const vector<Eigen::Vector3d>& guide_pt) { guide_pts_ = guide_pt; }
+void BsplineOptimizer::setWaypoints(const vector<Eigen::Vector3d>& waypts, const vector<int>& waypt_idx) {
+  waypoints_ = waypts;
+  waypt_idx_ = waypt_idx;
+}
+void BsplineOptimizer::setViewConstraint(const ViewConstraint& vc) { view_cons_ = vc; }
+void BsplineOptimizer::enableDynamic(double time_start) {
+  dynamic_ = true;  // moving obstacles are out of scope: the static ESDF is used regardless
+  start_time_ = time_start;
+}
+void BsplineOptimizer::setBoundaryStates(const vector<Eigen::Vector3d>& start, const vector<Eigen::Vector3d>& end) {
+  start_state_ = start;
+  end_state_ = end;
+}
+void BsplineOptimizer::setTimeLowerBound(const double& lb) { time_lb_ = lb; }
+
+void BsplineOptimizer::combineCost(const std::vector<double>& x, std::vector<double>& grad, double& cost) {
+  auto t1 = std::chrono::steady_clock::now();
+  fuelmi_bspline_batch b;
+  std::vector<double> st(9, 0.0), en(9, 0.0), guide, wp, vpt(3), vdir(3);
+  for (size_t i = 0; i < start_state_.size() && i < 3; ++i)
+    for (int k = 0; k < 3; ++k) st[3 * i + k] = start_state_[i](k);
+  for (size_t i = 0; i < end_state_.size() && i < 3; ++i)
+    for (int k = 0; k < 3; ++k) en[3 * i + k] = end_state_[i](k);
+  for (auto& g : guide_pts_)
+    for (int k = 0; k < 3; ++k) guide.push_back(g(k));
+  for (auto& w : waypoints_)
+    for (int k = 0; k < 3; ++k) wp.push_back(w(k));
+  for (int k = 0; k < 3; ++k) vpt[k] = view_cons_.pt_(k), vdir[k] = view_cons_.dir_(k);
+  const double tlb = time_lb_;
+  b.cost_function = cost_function_;
+  b.dim = dim_;
+  b.point_num = point_num_;
+  b.n_traj = 1;
+  b.x = x.data();
+  b.pt_dist = &pt_dist_;
+  b.knot_span = &knot_span_;
+  b.time_lb = &tlb;
+  b.start_state = st.data();
+  b.end_state = en.data();
+  b.end_n = (int)std::max<size_t>(1, std::min<size_t>(3, end_state_.size()));
+  b.guide_pts = guide.empty() ? nullptr : guide.data();
+  b.waypoints = wp.empty() ? nullptr : wp.data();
+  b.waypt_idx = waypt_idx_.empty() ? nullptr : waypt_idx_.data();
+  b.n_waypt = (int)waypoints_.size();
+  b.view_pt = vpt.data();
+  b.view_dir = vdir.data();
+  b.view_idx = &view_cons_.idx_;
+  grad.assign(variable_num_, 0.0);
+  warn("fuelmi_bspline_cost_grad",
+       fuelmi_bspline_cost_grad(edt_environment_->sdf_map_->device(), &cfg_, &b, &cost, grad.data()));
+  comb_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+}
+
+void BsplineOptimizer::optimize(Eigen::MatrixXd& points, double& dt, const int& cost_function,
+                                const int& max_num_id, const int& max_time_id) {
+  if (start_state_.empty()) {
+    ROS_ERROR("Initial state undefined!");
+    return;
+  }
+  control_points_ = points;
+  knot_span_ = dt;
+  max_num_id_ = max_num_id;
+  max_time_id_ = max_time_id;
+  setCostFunction(cost_function);
+  dim_ = control_points_.cols();
+  order_ = (dim_ == 1) ? 3 : bspline_degree_;
+  point_num_ = control_points_.rows();
+  optimize_time_ = cost_function_ & MINTIME;
+  variable_num_ = optimize_time_ ? dim_ * point_num_ + 1 : dim_ * point_num_;
+  if (variable_num_ <= 0) {
+    ROS_ERROR("Empty varibale to optimization solver.");
+    return;
+  }
+  pt_dist_ = 0.0;
+  for (int i = 0; i < point_num_ - 1; ++i) {
+    double s = 0.0;
+    for (int j = 0; j < dim_; ++j) {
+      const double e = control_points_(i + 1, j) - control_points_(i, j);
+      s += e * e;
+    }
+    pt_dist_ += std::sqrt(s);
+  }
+  pt_dist_ /= double(point_num_);
+  iter_num_ = 0;
+  min_cost_ = std::numeric_limits<double>::max();
+  comb_time = 0.0;
+  optimize();
+  points = control_points_;
+  dt = knot_span_;
+  start_state_.clear();
+  time_lb_ = -1;
+}
+
+// Box-projected L-BFGS (memory 8, Armijo backtracking) under the reference's stopping criteria.
+// Replaces nlopt::opt (bspline_optimizer.cpp:165-229); iterates are NOT NLopt's.
+void BsplineOptimizer::optimize() {
+  const int n = variable_num_;
+  Eigen::Vector3d bmin, bmax;
+  edt_environment_->sdf_map_->getBox(bmin, bmax);
+  std::vector<double> q(n), lb(n, -1e300), ub(n, 1e300);
+  for (int i = 0; i < point_num_; ++i)
+    for (int j = 0; j < dim_; ++j) {
+      double cij = control_points_(i, j);
+      if (dim_ != 1) cij = std::max(std::min(cij, bmax(j % 3) - 0.1), bmin(j % 3) + 0.1);
+      q[dim_ * i + j] = cij;
+    }
+  if (optimize_time_) q[n - 1] = knot_span_;
+  if (dim_ != 1) {
+    for (int i = 0; i < 3 * point_num_; ++i) {
+      lb[i] = std::max(q[i] - 10.0, bmin(i % 3) + 0.1);
+      ub[i] = std::min(q[i] + 10.0, bmax(i % 3) - 0.1);
+    }
+    if (optimize_time_) lb[n - 1] = 0.0, ub[n - 1] = 5.0;
+  }
+  const int max_eval = max_iteration_num_[max_num_id_];
+  const double max_time = max_iteration_time_[max_time_id_];
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  auto eval = [&](const std::vector<double>& x, std::vector<double>& g) {
+    double f;
+    combineCost(x, g, f);
+    ++iter_num_;
+    if (f < min_cost_) {
+      min_cost_ = f;
+      best_variable_ = x;
+    }
+    return f;
+  };
+  auto project = [&](std::vector<double>& x) {
+    for (int i = 0; i < n; ++i) x[i] = std::min(std::max(x[i], lb[i]), ub[i]);
+  };
+  std::vector<double> g(n), xn(n), gn(n), d(n);
+  double f = eval(q, g);
+  std::deque<std::vector<double>> S, Y;
+  std::deque<double> R;
+  const size_t mem = 8;
+  while (iter_num_ < max_eval && elapsed() < max_time) {
+    // two-loop recursion on the projected gradient
+    for (int i = 0; i < n; ++i) {
+      const bool at_lb = q[i] <= lb[i] && g[i] > 0, at_ub = q[i] >= ub[i] && g[i] < 0;
+      d[i] = (at_lb || at_ub) ? 0.0 : -g[i];
+    }
+    std::vector<double> al(S.size());
+    for (int k = (int)S.size() - 1; k >= 0; --k) {
+      double a = 0;
+      for (int i = 0; i < n; ++i) a += S[k][i] * d[i];
+      a *= R[k];
+      al[k] = a;
+      for (int i = 0; i < n; ++i) d[i] -= a * Y[k][i];
+    }
+    if (!S.empty()) {
+      double yy = 0, sy = 1.0 / R.back();
+      for (int i = 0; i < n; ++i) yy += Y.back()[i] * Y.back()[i];
+      const double gamma = yy > 0 ? sy / yy : 1.0;
+      for (int i = 0; i < n; ++i) d[i] *= gamma;
+    }
+    for (size_t k = 0; k < S.size(); ++k) {
+      double b = 0;
+      for (int i = 0; i < n; ++i) b += Y[k][i] * d[i];
+      b *= R[k];
+      for (int i = 0; i < n; ++i) d[i] += S[k][i] * (al[k] - b);
+    }
+    double gd = 0;
+    for (int i = 0; i < n; ++i) gd += g[i] * d[i];
+    if (!(gd < 0)) {  // not a descent direction: restart with steepest descent
+      S.clear(), Y.clear(), R.clear();
+      gd = 0;
+      for (int i = 0; i < n; ++i) d[i] = -g[i], gd -= g[i] * g[i];
+      if (gd == 0) break;
+    }
+    double step = S.empty() ? 1.0 / std::max(1.0, std::sqrt(-gd)) : 1.0, fn = f;
+    bool ok = false;
+    for (int ls = 0; ls < 20 && iter_num_ < max_eval && elapsed() < max_time; ++ls) {
+      for (int i = 0; i < n; ++i) xn[i] = q[i] + step * d[i];
+      project(xn);
+      fn = eval(xn, gn);
+      double dec = 0;
+      for (int i = 0; i < n; ++i) dec += g[i] * (xn[i] - q[i]);
+      if (fn <= f + 1e-4 * dec) {
+        ok = true;
+        break;
+      }
+      step *= 0.5;
+    }
+    if (!ok) break;
+    std::vector<double> s(n), y(n);
+    double sy = 0, xs = 0, xx = 0;
+    for (int i = 0; i < n; ++i) {
+      s[i] = xn[i] - q[i], y[i] = gn[i] - g[i];
+      sy += s[i] * y[i], xs += s[i] * s[i], xx += xn[i] * xn[i];
+    }
+    q = xn, g = gn, f = fn;
+    if (sy > 1e-12) {
+      S.push_back(s), Y.push_back(y), R.push_back(1.0 / sy);
+      if (S.size() > mem) S.pop_front(), Y.pop_front(), R.pop_front();
+    }
+    if (std::sqrt(xs) <= 1e-5 * std::sqrt(xx)) break;  // xtol_rel 1e-5
+  }
+  for (int i = 0; i < point_num_; ++i)
+    for (int j = 0; j < dim_; ++j) control_points_(i, j) = best_variable_[dim_ * i + j];
+  if (optimize_time_) knot_span_ = best_variable_[n - 1];
+}
+
+vector<Eigen::Vector3d> BsplineOptimizer::matrixToVectors(const Eigen::MatrixXd& ctrl_pts) {
+  vector<Eigen::Vector3d> out;
+  for (int i = 0; i < ctrl_pts.rows(); ++i) {
+    Eigen::Vector3d p(0, 0, 0);
+    for (int j = 0; j < ctrl_pts.cols() && j < 3; ++j) p(j) = ctrl_pts(i, j);
+    out.push_back(p);
+  }
+  return out;
+}
+Eigen::MatrixXd BsplineOptimizer::getControlPoints() { return control_points_; }
+bool BsplineOptimizer::isQuadratic() {
+  return cost_function_ == GUIDE_PHASE || cost_function_ == SMOOTHNESS || cost_function_ == (SMOOTHNESS | WAYPOINTS);
+}
+
+}  // namespace fast_planner

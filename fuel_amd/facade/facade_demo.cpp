@@ -1,0 +1,195 @@
+// facade_demo.cpp -- drives the facade exactly the way the reference's callers drive the original
+// classes (MapROS::depthPoseCallback -> inputPointCloud -> clearAndInflateLocalMap;
+// updateESDFCallback -> updateESDF3d; planExploreMotion -> searchFrontiers;
+// planExploreTraj -> BsplineOptimizer::optimize) and dumps results for tests/test_facade_gpu.py.
+//   facade_demo <scenario.bin> <result.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include <plan_env/sdf_map.h>
+#include <plan_env/edt_environment.h>
+#include <active_perception/frontier_finder.h>
+#include <bspline_opt/bspline_optimizer.h>
+
+namespace fast_planner {
+// the reference's MapROS is a friend of SDFMap and calls its private clearAndInflateLocalMap
+// (plan_env/src/map_ros.cpp:142,170); this stand-in does the same
+class MapROS {
+public:
+  static void inflate(SDFMap& m) { m.clearAndInflateLocalMap(); }
+};
+}  // namespace fast_planner
+
+using namespace fast_planner;
+
+template <typename T>
+static void rd(FILE* f, T* p, size_t n) {
+  if (fread(p, sizeof(T), n, f) != n) {
+    std::fprintf(stderr, "short read\n");
+    std::exit(2);
+  }
+}
+template <typename T>
+static void wr(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  FILE* in = fopen(argv[1], "rb");
+  FILE* out = fopen(argv[2], "wb");
+  if (!in || !out) return 1;
+  double hdr[10];  // map_size[3], box_min[3], box_max[3], cluster_min
+  rd(in, hdr, 10);
+  ros::NodeHandle nh;
+  auto& P = nh.num;
+  P["sdf_map/resolution"] = 0.1;
+  P["sdf_map/map_size_x"] = hdr[0], P["sdf_map/map_size_y"] = hdr[1], P["sdf_map/map_size_z"] = hdr[2];
+  P["sdf_map/obstacles_inflation"] = 0.199, P["sdf_map/local_bound_inflate"] = 0.5, P["sdf_map/ground_height"] = -1.0;
+  P["sdf_map/default_dist"] = 0.0, P["sdf_map/optimistic"] = 0, P["sdf_map/signed_dist"] = 0;
+  P["sdf_map/p_hit"] = 0.65, P["sdf_map/p_miss"] = 0.35, P["sdf_map/p_min"] = 0.12, P["sdf_map/p_max"] = 0.90;
+  P["sdf_map/p_occ"] = 0.80, P["sdf_map/max_ray_length"] = 4.5, P["sdf_map/virtual_ceil_height"] = -10;
+  const char* ax[3] = {"x", "y", "z"};
+  for (int i = 0; i < 3; ++i) {
+    P[std::string("sdf_map/box_min_") + ax[i]] = hdr[3 + i];
+    P[std::string("sdf_map/box_max_") + ax[i]] = hdr[6 + i];
+  }
+  P["frontier/cluster_min"] = hdr[9];
+  P["optimization/ld_smooth"] = 20.0, P["optimization/ld_dist"] = 10.0, P["optimization/ld_feasi"] = 2.0;
+  P["optimization/ld_start"] = 100.0, P["optimization/ld_end"] = 0.5, P["optimization/ld_guide"] = 1.5;
+  P["optimization/ld_waypt"] = 0.3, P["optimization/ld_view"] = 0.0, P["optimization/ld_time"] = 1.0;
+  P["optimization/dist0"] = 0.7, P["optimization/max_vel"] = 2.0, P["optimization/max_acc"] = 2.0;
+  P["optimization/max_iteration_num2"] = 300, P["optimization/max_iteration_time2"] = 5.0;
+  P["optimization/algorithm1"] = 15, P["optimization/algorithm2"] = 11;
+
+  SDFMap::Ptr map(new SDFMap);
+  map->initMap(nh);
+  EDTEnvironment::Ptr edt(new EDTEnvironment);
+  edt->setMap(map);
+
+  int n_frames;
+  rd(in, &n_frames, 1);
+  for (int k = 0; k < n_frames; ++k) {
+    int n;
+    double cam[3];
+    rd(in, &n, 1);
+    rd(in, cam, 3);
+    std::vector<float> xyz((size_t)n * 3);
+    rd(in, xyz.data(), xyz.size());
+    pcl::PointCloud<pcl::PointXYZ> cloud;
+    cloud.points.resize(n);
+    for (int i = 0; i < n; ++i) cloud.points[i] = pcl::PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    map->inputPointCloud(cloud, n, Eigen::Vector3d(cam[0], cam[1], cam[2]));
+    MapROS::inflate(*map);
+    map->updateESDF3d();
+  }
+  // host-side inline getters (compiled into THIS translation unit, reading the host mirrors)
+  Eigen::Vector3d ori, size;
+  map->getRegion(ori, size);
+  const int N = map->getVoxelNum();
+  Eigen::Vector3i id;
+  Eigen::Vector3d far(ori(0) + size(0) - 0.05, ori(1) + size(1) - 0.05, ori(2) + size(2) - 0.05);
+  map->posToIndex(far, id);
+  const int nx = id(0) + 1, ny = id(1) + 1, nz = id(2) + 1;
+  std::vector<signed char> occ(N), infl(N);
+  std::vector<double> dist(N);
+  for (int x = 0; x < nx; ++x)
+    for (int y = 0; y < ny; ++y)
+      for (int z = 0; z < nz; ++z) {
+        Eigen::Vector3i v(x, y, z);
+        const int a = map->toAddress(v);
+        occ[a] = (signed char)map->getOccupancy(v);
+        infl[a] = (signed char)map->getInflateOccupancy(v);
+        dist[a] = map->getDistance(v);
+      }
+  wr(out, &N, 1);
+  wr(out, occ.data(), N);
+  wr(out, infl.data(), N);
+  wr(out, dist.data(), N);
+
+  FrontierFinder ff(edt, nh);
+  ff.searchFrontiers();
+  ff.computeFrontiersToVisit();
+  std::vector<std::vector<Eigen::Vector3d>> clusters;
+  ff.getFrontiers(clusters);
+  int nc = (int)clusters.size();
+  wr(out, &nc, 1);
+  for (auto& c : clusters) {
+    int sz = (int)c.size();
+    wr(out, &sz, 1);
+    for (auto& p : c) {
+      double q[3] = {p(0), p(1), p(2)};
+      wr(out, q, 3);
+    }
+  }
+
+  // trajectory optimisation as planExploreTraj does (planner_manager.cpp:304-312)
+  int npts;
+  double dt;
+  rd(in, &npts, 1);
+  rd(in, &dt, 1);
+  Eigen::MatrixXd ctrl(npts, 3);
+  for (int i = 0; i < npts; ++i) {
+    double p[3];
+    rd(in, p, 3);
+    for (int j = 0; j < 3; ++j) ctrl(i, j) = p[j];
+  }
+  double st[9], en[9];
+  rd(in, st, 9);
+  rd(in, en, 9);
+  std::vector<Eigen::Vector3d> start, end;
+  for (int i = 0; i < 3; ++i) start.push_back(Eigen::Vector3d(st[3 * i], st[3 * i + 1], st[3 * i + 2]));
+  for (int i = 0; i < 3; ++i) end.push_back(Eigen::Vector3d(en[3 * i], en[3 * i + 1], en[3 * i + 2]));
+  BsplineOptimizer opt;
+  opt.setParam(nh);
+  opt.setEnvironment(edt);
+  const int cf = BsplineOptimizer::NORMAL_PHASE | BsplineOptimizer::MINTIME;
+  // cost/gradient at the initial guess (checked against the oracle)
+  {
+    BsplineOptimizer probe;
+    probe.setParam(nh);
+    probe.setEnvironment(edt);
+    probe.setBoundaryStates(start, end);
+    Eigen::MatrixXd c0 = ctrl;
+    double d0 = dt;
+    nh.num["optimization/max_iteration_num1"] = 1;
+    probe.setParam(nh);
+    // one evaluation: max_num_id 0 -> max_iteration_num1 = 1
+    probe.optimize(c0, d0, cf, 0, 1);
+  }
+  opt.setBoundaryStates(start, end);
+  std::vector<double> x0((size_t)npts * 3 + 1), g0;
+  for (int i = 0; i < npts; ++i)
+    for (int j = 0; j < 3; ++j) x0[3 * i + j] = ctrl(i, j);
+  x0.back() = dt;
+  Eigen::MatrixXd cpts = ctrl;
+  double dtt = dt;
+  opt.optimize(cpts, dtt, cf, 1, 1);
+  // evaluate initial and final cost with a fresh optimiser (optimize() clears the start state)
+  BsplineOptimizer ev;
+  ev.setParam(nh);
+  ev.setEnvironment(edt);
+  ev.setBoundaryStates(start, end);
+  Eigen::MatrixXd tmpc = ctrl;
+  double tmpd = dt;
+  nh.num["optimization/max_iteration_num1"] = 1;
+  ev.setParam(nh);
+  ev.optimize(tmpc, tmpd, cf, 0, 1);  // sets dim/point_num/pt_dist from the INITIAL points
+  ev.setBoundaryStates(start, end);
+  double f0, f1;
+  ev.combineCost(x0, g0, f0);
+  std::vector<double> x1(x0.size()), g1;
+  for (int i = 0; i < npts; ++i)
+    for (int j = 0; j < 3; ++j) x1[3 * i + j] = cpts(i, j);
+  x1.back() = dtt;
+  ev.combineCost(x1, g1, f1);
+  wr(out, &f0, 1);
+  wr(out, &f1, 1);
+  int ng = (int)g0.size();
+  wr(out, &ng, 1);
+  wr(out, g0.data(), g0.size());
+  fclose(in);
+  fclose(out);
+  std::printf("facade_demo ok: %d voxels, %d frontier clusters, cost %.6f -> %.6f\n", N, nc, f0, f1);
+  return 0;
+}
