@@ -20,6 +20,7 @@
 // lookup = bit test + popcount rank) -> atomicMin claims -> sizes -> flags.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <unordered_map>
@@ -301,26 +302,152 @@ __device__ __forceinline__ void uf_union(u32* parent, u32 a, u32 b) {
   }
 }
 
-// 26-connectivity: union with the 13 neighbours of lower address
-__global__ void __launch_bounds__(256) k_union(Geo g, FArgs F) {
+// ---- connected components, 26-connectivity -------------------------------------------------------
+// Two levels.  (1) k_ccl_local: a workgroup owns a spatial tile of TX x TY z-lines, labels its Q0
+// voxels in LDS (union-find with LDS atomics: ~40 ns per dependent step instead of ~1 us through
+// memory-side atomics) and writes parent[cell] = compact index of the tile-local root, so every
+// local component leaves the kernel flat.  (2) k_union: only neighbour relations that cross a tile
+// face go through the global lock-free union-find.  (3) k_flatten.
+#define LNONE 0xFFFFFFFFu
+__device__ __forceinline__ u32 lds_find(volatile u32* lab, u32 i) {
+  u32 p = lab[i];
+  while (p != i) {
+    i = p;
+    p = lab[i];
+  }
+  return i;
+}
+__device__ __forceinline__ void lds_union(u32* lab, u32 a, u32 b) {
+  while (true) {
+    a = lds_find(lab, a);
+    b = lds_find(lab, b);
+    if (a == b) return;
+    if (a < b) {
+      u32 t = a;
+      a = b;
+      b = t;
+    }
+    u32 old = atomicMin(&lab[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ccl_local(Geo g, FArgs F, int TX, int TY, int nty) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32* lab = reinterpret_cast<u32*>(smem_raw);  // [TX*TY lines][nz]
+  const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
+  const int x0 = F.qbox.lo[0] + tx * TX, y0 = F.qbox.lo[1] + ty * TY;
+  const int nxl = min(TX, F.qbox.hi[0] - x0 + 1), nyl = min(TY, F.qbox.hi[1] - y0 + 1);
+  const int nz = g.nz, nseg = (nz + 31) >> 5;
+  const int items = TX * TY * nseg;
+  u32* segb = lab + TX * TY * nz;  // [TX*TY][nseg] Q0 bits of each 32-voxel segment
+  u32* segrank = segb + items;     // compact index of the first Q0 voxel at/after the segment start
+  u32* rowr = segrank + items;     // [2*TX] compact index range of each x-row of the tile
+  if ((int)threadIdx.x < 2 * TX) {
+    const int lx = threadIdx.x >> 1, hi = threadIdx.x & 1;
+    u32 rk = 0u;
+    if (lx < nxl) rk = min(rank_q(F, (long)(x0 + lx) * g.nyz + (long)(y0 + (hi ? nyl : 0)) * nz), F.cap_q);
+    rowr[threadIdx.x] = rk;
+  }
+  // Everything below walks SET BITS only (frontier cells are ~1 % of the voxels); the only global
+  // traffic is this prologue and the parent[] stores at the end.
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int line = it / nseg, c = it - line * nseg, lx = line / TY, ly = line - lx * TY;
+    const int zn = min(32, nz - 32 * c);
+    u32 bits = 0u, rk = 0u;
+    if (lx < nxl && ly < nyl) {
+      const long lb = (long)(x0 + lx) * g.nyz + (long)(y0 + ly) * nz + 32 * c;
+      bits = (u32)plane_window(F.qb, lb);
+      if (zn < 32) bits &= (1u << zn) - 1u;
+      if (bits) rk = rank_q(F, lb);
+    }
+    segb[it] = bits;
+    segrank[it] = rk;
+    const u32 l0 = (u32)(line * nz + 32 * c);
+    const u32 all = bits;
+    while (bits) {  // 1: label = start of the cell's z-run inside the segment (runs are pre-joined)
+      const int z = __builtin_ctz(bits);
+      bits &= bits - 1;
+      const u32 holes = ~all & ((1u << z) - 1u);
+      lab[l0 + z] = l0 + (holes ? 32 - __builtin_clz(holes) : 0);
+    }
+  }
+  __syncthreads();
+  // 2 + 3 walk the tile's cells through their COMPACT indices so every lane gets one cell at a time
+  // (a vertical frontier wall puts 20-30 cells into one 32-voxel segment; a per-segment loop would
+  // leave one lane with all the dependent LDS work).  For a fixed x the TY lines of the tile are
+  // contiguous in address, hence contiguous in compact index: TX ranges per tile.
+  for (int lx = 0; lx < nxl; ++lx) {
+    const long a_lo = (long)(x0 + lx) * g.nyz + (long)y0 * nz;
+    const u32 r0 = rowr[2 * lx], r1 = rowr[2 * lx + 1];
+    for (u32 i = r0 + threadIdx.x; i < r1; i += 256) {
+      const int rem = (int)(F.cell_adr[i] - (u32)a_lo);  // offset inside this x-row of the tile
+      const int ly = rem / nz, z = rem - ly * nz;
+      const int line = lx * TY + ly, c = z >> 5, zz = z & 31;
+      const u32 v = (u32)(line * nz + z);
+      // z-runs are pre-joined inside a segment; join across the segment seam ...
+      if (zz == 0 && c > 0 && (segb[line * nseg + c - 1] >> 31)) lds_union(lab, v, v - 1);
+      // ... and with the four lower z-lines of the tile: one 3-bit window (dz -1,0,+1) per line, one
+      // union per run (only the pattern 101 holds two)
+      for (int l = 0; l < 4; ++l) {
+        const int nlx = lx + (l < 3 ? -1 : 0), nly = ly + (l < 3 ? l - 1 : -1);
+        if (nlx < 0 || nly < 0 || nly >= TY) continue;
+        const int nline = nlx * TY + nly;
+        const int zlo = z - 1;
+        const int s0 = max(zlo, 0) >> 5;
+        const unsigned long long w = (unsigned long long)segb[nline * nseg + s0] |
+            ((s0 + 1 < nseg) ? ((unsigned long long)segb[nline * nseg + s0 + 1] << 32) : 0ull);
+        u32 pat = (zlo >= 0) ? (u32)((w >> (zlo - 32 * s0)) & 7ull) : (u32)((w << 1) & 6ull);
+        if (z + 1 >= nz) pat &= 3u;
+        if (!pat) continue;
+        const u32 ln = (u32)(nline * nz + zlo + __builtin_ctz(pat));
+        lds_union(lab, v, ln);
+        if (pat == 5u) lds_union(lab, v, ln + 2);
+      }
+    }
+  }
+  __syncthreads();
+  // 3: parent[cell] = compact index of its tile-local root
+  for (int lx = 0; lx < nxl; ++lx) {
+    const long a_lo = (long)(x0 + lx) * g.nyz + (long)y0 * nz;
+    const u32 r0 = rowr[2 * lx], r1 = rowr[2 * lx + 1];
+    for (u32 i = r0 + threadIdx.x; i < r1; i += 256) {
+      const int rem = (int)(F.cell_adr[i] - (u32)a_lo);
+      const int ly = rem / nz, z = rem - ly * nz;
+      const u32 v = (u32)((lx * TY + ly) * nz + z);
+      const u32 r = lds_find(lab, v);
+      u32 pr = i;
+      if (r != v) {
+        const int rline = (int)(r / (u32)nz), rz = (int)(r - (u32)rline * (u32)nz);
+        const int rs = rline * nseg + (rz >> 5);
+        pr = segrank[rs] + (u32)__popc(segb[rs] & ((1u << (rz & 31)) - 1u));
+      }
+      F.parent[i] = pr;
+    }
+  }
+}
+
+// global merge: neighbour relations crossing a tile face (lower-address side only)
+__global__ void __launch_bounds__(256) k_union(Geo g, FArgs F, int TX, int TY) {
   const u32 nq = F.counts[0];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
     long a = F.cell_adr[i];
     int x = (int)(a / g.nyz);
     int r = (int)(a - (long)x * g.nyz);
     int y = r / g.nz, z = r - y * g.nz;
+    const int lx = (x - F.qbox.lo[0]) % TX, ly = (y - F.qbox.lo[1]) % TY;
     const bool zlo = z > 0, zhi = z < g.nz - 1;
-    // (0,0,-1): the compact predecessor
-    if (zlo && ((F.qb[(a - 1) >> 6] >> ((a - 1) & 63)) & 1ull)) uf_union(F.parent, i, i - 1);
-    // the four lower z-lines (dx,dy) = (-1,-1) (-1,0) (-1,1) (0,-1): one 3-bit window each (dz -1,0,+1),
-    // all four fetched before any dependent work
+    // the four lower z-lines (dx,dy) = (-1,-1) (-1,0) (-1,1) (0,-1): one 3-bit window each (dz -1,0,+1);
+    // a line inside this cell's tile was already handled in LDS
     const int ldx[4] = {-1, -1, -1, 0}, ldy[4] = {-1, 0, 1, -1};
     u32 pat[4];
     long nb0[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const int xx = x + ldx[l], yy = y + ldy[l];
-      const bool ok = xx >= 0 && yy >= 0 && yy < g.ny;
+      const bool cross = (ldx[l] < 0 && lx == 0) || (ldy[l] < 0 && ly == 0) || (ldy[l] > 0 && ly == TY - 1);
+      const bool ok = cross && xx >= 0 && yy >= 0 && yy < g.ny;
       nb0[l] = a + (long)ldx[l] * g.nyz + (long)ldy[l] * g.nz - 1;
       u32 p = ok ? (u32)(plane_window(F.qb, nb0[l]) & 7ull) : 0u;
       if (!zlo) p &= ~1u;
@@ -755,6 +882,10 @@ struct fuelmi_frontier {
   std::vector<void*> allocs;
   std::list<HCluster> frontiers, dormant, tmp;
   std::vector<int> removed_ids;
+  hipStream_t stream = nullptr;  // frontier work runs beside the map's own stream
+  hipEvent_t ev_dep = nullptr;
+  void* d_stage = nullptr;
+  size_t d_stage_bytes = 0;
   void* h_pin = nullptr;  // pinned result staging
   size_t pin_bytes = 0;
   std::vector<int> slot2rank;
@@ -807,10 +938,28 @@ static int dmalloc(fuelmi_frontier* f, T** p, size_t n) {
   return FUELMI_OK;
 }
 
+static int frontier_ensure_stage(fuelmi_frontier* f, size_t bytes) {
+  if (bytes > f->d_stage_bytes) {
+    if (f->d_stage) HIPCHK(hipFree(f->d_stage));
+    f->d_stage = nullptr;
+    f->d_stage_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&f->d_stage, want));
+    f->d_stage_bytes = want;
+  }
+  return FUELMI_OK;
+}
+
 extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (!f) return;
   (void)hipSetDevice(f->map->device);
   (void)hipStreamSynchronize(f->map->stream);
+  if (f->stream) {
+    (void)hipStreamSynchronize(f->stream);
+    (void)hipStreamDestroy(f->stream);
+  }
+  if (f->ev_dep) (void)hipEventDestroy(f->ev_dep);
+  if (f->d_stage) (void)hipFree(f->d_stage);
   for (void* p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
@@ -871,6 +1020,8 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   F.qb = f->qb.p;
   F.sb = f->sb.p;
   HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
   *out = f;
   return FUELMI_OK;
 }
@@ -900,20 +1051,20 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
       cl.push_back((int)k);
     }
   size_t bytes = ncell * sizeof(int);
-  int rc = map_ensure_stage(m, 2 * bytes + cand.size() * sizeof(int) + 64, 0);
+  int rc = frontier_ensure_stage(f, 2 * bytes + cand.size() * sizeof(int) + 64);
   if (rc) return rc;
-  int* d_cells = (int*)m->d_stage;
+  int* d_cells = (int*)f->d_stage;
   int* d_cl = d_cells + ncell;
   int* d_changed = d_cl + ncell;
-  HIPCHK(hipMemcpyAsync(d_cells, cells.data(), bytes, hipMemcpyHostToDevice, m->stream));
-  HIPCHK(hipMemcpyAsync(d_cl, cl.data(), bytes, hipMemcpyHostToDevice, m->stream));
-  HIPCHK(hipMemsetAsync(d_changed, 0, cand.size() * sizeof(int), m->stream));
-  k_check_clusters<<<fblocks((long)ncell, 256), 256, 0, m->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, d_cells,
+  HIPCHK(hipMemcpyAsync(d_cells, cells.data(), bytes, hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(d_cl, cl.data(), bytes, hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemsetAsync(d_changed, 0, cand.size() * sizeof(int), f->stream));
+  k_check_clusters<<<fblocks((long)ncell, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, d_cells,
                                                                     d_cl, (int)ncell, d_changed);
-  k_clear_flags<<<fblocks((long)ncell, 256), 256, 0, m->stream>>>(f->flag.p, d_cells, d_cl, d_changed, (int)ncell);
+  k_clear_flags<<<fblocks((long)ncell, 256), 256, 0, f->stream>>>(f->flag.p, d_cells, d_cl, d_changed, (int)ncell);
   std::vector<int> changed(cand.size());
-  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, cand.size() * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, cand.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
   // removed_ids_ semantics (:74-85): index in the list as it shrinks
   int erased = 0;
   for (size_t k = 0; k < cand.size(); ++k)
@@ -935,7 +1086,11 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   double umin[3], umax[3];
   fuelmi_map_get_updated_box(m, umin, umax, 1);
 
-  StageScope sc(m, FUELMI_K_FRONTIER);
+  // the scan reads only the occupancy state planes: it runs on its own stream, ordered after the
+  // last kernel that rewrote them (fusion / upload), and overlaps the inflation / ESDF / B-spline
+  // kernels the caller has queued on the map's stream for the same cycle
+  HIPCHK(hipStreamWaitEvent(f->stream, m->ev_planes, 0));
+  StageScope sc(m, FUELMI_K_FRONTIER, f->stream);
   f->removed_ids.clear();
   int rc = remove_changed(f, f->frontiers, umin, umax, &f->removed_ids);
   if (rc) return rc;
@@ -983,15 +1138,33 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   int nblocks = (w_hi - F.w0) / 256 + 1;
   F.nwords = nblocks * 256;
 
-  k_pred<<<nblocks, 256, 0, m->stream>>>(g, F);
-  k_scan_sums<<<1, 256, 0, m->stream>>>(F, nblocks);
-  k_compact<<<nblocks, 256, 0, m->stream>>>(g, F);
+  k_pred<<<nblocks, 256, 0, f->stream>>>(g, F);
+  k_scan_sums<<<1, 256, 0, f->stream>>>(F, nblocks);
+  k_compact<<<nblocks, 256, 0, f->stream>>>(g, F);
   const int cgrid = 2048;
-  k_union<<<cgrid, 256, 0, m->stream>>>(g, F);
-  k_flatten<<<cgrid, 256, 0, m->stream>>>(g, F);
-  k_claim<<<cgrid, 256, 0, m->stream>>>(g, F);
-  k_sizes<<<cgrid, 256, 0, m->stream>>>(g, F);  // grid-stride over 1024-cell chunks
-  k_finalize<<<nblocks, 256, 0, m->stream>>>(g, F);
+  {
+    // tile = TX x TY z-lines with u32 labels in LDS (<= 48 KiB so three workgroups share a CU)
+    int TY = 16;
+    int TX = std::max(1, std::min(8, (48 * 1024) / (TY * g.nz * 4)));
+    if (const char* e = getenv("FUELMI_CCL_TILE")) {  // tuning hook: "TXxTY"
+      int a = 0, b = 0;
+      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && b > 0 && (size_t)a * b * g.nz * 4 <= 150 * 1024) TX = a, TY = b;
+    }
+    const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 1, qy = F.qbox.hi[1] - F.qbox.lo[1] + 1;
+    if (qx > 0 && qy > 0 && F.qbox.lo[2] <= F.qbox.hi[2]) {
+      const int ntx = (qx + TX - 1) / TX, nty = (qy + TY - 1) / TY;
+      const size_t lds = ((size_t)TX * TY * g.nz + 2 * (size_t)TX * TY * ((g.nz + 31) / 32) + 2 * (size_t)TX) * sizeof(u32);
+      if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      k_ccl_local<<<ntx * nty, 256, lds, f->stream>>>(g, F, TX, TY, nty);
+      k_union<<<cgrid, 256, 0, f->stream>>>(g, F, TX, TY);
+    }
+  }
+  k_flatten<<<cgrid, 256, 0, f->stream>>>(g, F);
+  k_claim<<<cgrid, 256, 0, f->stream>>>(g, F);
+  k_sizes<<<cgrid, 256, 0, f->stream>>>(g, F);  // grid-stride over 1024-cell chunks
+  k_finalize<<<nblocks, 256, 0, f->stream>>>(g, F);
   HIPCHK(hipGetLastError());
 
   // ---- results: one pinned staging buffer [counts | kept | kept_slots | info | cells] ----
@@ -1008,8 +1181,8 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   u32* h_cells = h_box + (size_t)F.cap_kept * 6;
   // counts and the head of the kept list live contiguously on the device: one copy, one sync
   const u32 head = std::min<u32>(F.cap_kept, 1024u);
-  HIPCHK(hipMemcpyAsync(counts, F.counts, (16 + (size_t)head * 3) * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipMemcpyAsync(counts, F.counts, (16 + (size_t)head * 3) * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
                      counts[1], F.cap_s, counts[3], F.cap_kept);
@@ -1018,8 +1191,8 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   const u32 nq = counts[0], nkept = counts[3];
   if (nkept == 0) return FUELMI_OK;
   if (nkept > head) {
-    HIPCHK(hipMemcpyAsync(h_kept, F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpyAsync(h_kept, F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
   }
   // clusters in creation order = ascending claimer address (the reference's scan order)
   std::vector<u32> order(nkept);
@@ -1034,9 +1207,9 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   }
   const u32 n_out = off[nkept];
   // group the kept cells by cluster on the device (stable: ascending address inside a cluster)
-  HIPCHK(hipMemcpyAsync(F.kept_slots, h_slots, (size_t)nkept * sizeof(u32), hipMemcpyHostToDevice, m->stream));
-  k_ms_set_ranks<<<(nkept + 255) / 256, 256, 0, m->stream>>>(F, (int)nkept);
-  k_ms_keys<<<std::max(fblocks((long)nq, 256, 2048), (int)(nkept + 255) / 256), 256, 0, m->stream>>>(F, nq, (int)nkept);
+  HIPCHK(hipMemcpyAsync(F.kept_slots, h_slots, (size_t)nkept * sizeof(u32), hipMemcpyHostToDevice, f->stream));
+  k_ms_set_ranks<<<(nkept + 255) / 256, 256, 0, f->stream>>>(F, (int)nkept);
+  k_ms_keys<<<std::max(fblocks((long)nq, 256, 2048), (int)(nkept + 255) / 256), 256, 0, f->stream>>>(F, nq, (int)nkept);
   const int nb = (int)((nq + MS_CH - 1) / MS_CH);
   int cur = 0;
   const int passes = nkept <= 256 ? 1 : 2;
@@ -1045,25 +1218,25 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
     const int nbp = (int)((n_in + MS_CH - 1) / MS_CH);
     // digits in use: low pass sees min(nkept,256) values, high pass (nkept-1)>>8 + 1
     const int ndig = (p == 0) ? (int)std::min<u32>(nkept, 256u) : (int)((nkept - 1) >> 8) + 1;
-    k_ms_hist<<<nbp, 256, 0, m->stream>>>(F.ms_key[cur], n_in, 8 * p, F.ms_hist, nbp, ndig);
-    k_ms_scan<<<1, 256, 0, m->stream>>>(F.ms_hist, ndig * nbp, F.counts + 4);
-    k_ms_scatter<<<nbp, 256, 0, m->stream>>>(F.ms_key[cur], F.ms_val[cur], n_in, 8 * p, F.ms_hist, nbp, ndig,
+    k_ms_hist<<<nbp, 256, 0, f->stream>>>(F.ms_key[cur], n_in, 8 * p, F.ms_hist, nbp, ndig);
+    k_ms_scan<<<1, 256, 0, f->stream>>>(F.ms_hist, ndig * nbp, F.counts + 4);
+    k_ms_scatter<<<nbp, 256, 0, f->stream>>>(F.ms_key[cur], F.ms_val[cur], n_in, 8 * p, F.ms_hist, nbp, ndig,
                                             F.ms_key[1 - cur], F.ms_val[1 - cur]);
     cur = 1 - cur;
   }
   (void)nb;
-  if (n_out) k_ms_info<<<fblocks((long)n_out, SZ_CH, 2048), 256, 0, m->stream>>>(g, F.ms_key[cur], F.ms_val[cur], n_out, F);
+  if (n_out) k_ms_info<<<fblocks((long)n_out, SZ_CH, 2048), 256, 0, f->stream>>>(g, F.ms_key[cur], F.ms_val[cur], n_out, F);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h_sum, F.info_sum, (size_t)nkept * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                        m->stream));
-  HIPCHK(hipMemcpyAsync(h_box, F.info_box, (size_t)nkept * 6 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+                        f->stream));
+  HIPCHK(hipMemcpyAsync(h_box, F.info_box, (size_t)nkept * 6 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
   const u32 nchunk = (n_out + SZ_CH - 1) / SZ_CH;
   u32* h_part = h_cells + F.cap_q;
   if (n_out) {
-    HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[cur], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)nchunk * 10 * sizeof(u32), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[cur], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)nchunk * 10 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
   }
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
     const u32 r = rec[0];
@@ -1117,7 +1290,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   f->dormant.clear();
   f->tmp.clear();
   f->removed_ids.clear();
-  HIPCHK(hipMemsetAsync(f->flag.p, 0, (size_t)m->g.W * sizeof(u64), m->stream));
+  HIPCHK(hipMemsetAsync(f->flag.p, 0, (size_t)m->g.W * sizeof(u64), f->stream));
   return FUELMI_OK;
 }
 
@@ -1176,11 +1349,11 @@ extern "C" int fuelmi_frontier_get_flags(fuelmi_frontier* f, char* flags) {
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
   long n = m->g.N;
-  int rc = map_ensure_stage(m, (size_t)n, 0);
+  int rc = frontier_ensure_stage(f, (size_t)n);
   if (rc) return rc;
-  k_expand_flag_bits<<<fblocks(n, 256), 256, 0, m->stream>>>(f->flag.p, n, (char*)m->d_stage);
+  k_expand_flag_bits<<<fblocks(n, 256), 256, 0, f->stream>>>(f->flag.p, n, (char*)f->d_stage);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(flags, m->d_stage, (size_t)n, hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipMemcpyAsync(flags, f->d_stage, (size_t)n, hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
   return FUELMI_OK;
 }

@@ -98,6 +98,7 @@ struct fuelmi_map {
 
   // measurement
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
   unsigned profile_mask = 0;
   ProfileSlot prof[FUELMI_K_COUNT];
 };
@@ -110,7 +111,8 @@ struct StageScope {
   fuelmi_map* m;
   int stage;
   hipEvent_t e1 = nullptr;
-  StageScope(fuelmi_map* m_, int stage_);
+  hipStream_t st = nullptr;
+  StageScope(fuelmi_map* m_, int stage_, hipStream_t stream = nullptr);
   ~StageScope();
 };
 

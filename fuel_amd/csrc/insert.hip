@@ -316,6 +316,7 @@ int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const doub
       g, m->hit_bits.p, m->miss_bits.p, m->occ, m->occ_bits.p, m->unk_bits.p, w_lo, w_hi, I.prob_hit_log,
       I.prob_miss_log, I.clamp_min_log, I.clamp_max_log, I.min_occupancy_log);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(m->ev_planes, m->stream));
   return FUELMI_OK;
 }
 

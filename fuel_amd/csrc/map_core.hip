@@ -37,7 +37,8 @@ static std::mutex g_query_mutex;  // serialises host-staged queries (staging buf
 // ---------------------------------------------------------------------------------------------
 // profiling scopes
 // ---------------------------------------------------------------------------------------------
-StageScope::StageScope(fuelmi_map* m_, int stage_) : m(m_), stage(stage_) {
+StageScope::StageScope(fuelmi_map* m_, int stage_, hipStream_t stream) : m(m_), stage(stage_) {
+  st = stream ? stream : m->stream;
   if (!(m->profile_mask & (1u << stage))) return;
   ProfileSlot& s = m->prof[stage];
   if (s.used + 2 > s.ev.size()) {
@@ -45,12 +46,12 @@ StageScope::StageScope(fuelmi_map* m_, int stage_) : m(m_), stage(stage_) {
     s.ev.resize(old + 64);
     for (size_t i = old; i < s.ev.size(); ++i) (void)hipEventCreate(&s.ev[i]);
   }
-  (void)hipEventRecord(s.ev[s.used], m->stream);
+  (void)hipEventRecord(s.ev[s.used], st);
   e1 = s.ev[s.used + 1];
   s.used += 2;
 }
 StageScope::~StageScope() {
-  if (e1) (void)hipEventRecord(e1, m->stream);
+  if (e1) (void)hipEventRecord(e1, st);
 }
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes) {
@@ -362,6 +363,7 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
   k_state_planes<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(
       g, m->occ, m->occ_bits.p, m->unk_bits.p, I.min_occupancy_log, I.clamp_min_log - 1e-3, 0, g.W - 1);
   if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_planes, hipEventDisableTiming) != hipSuccess ||
       hipStreamSynchronize(m->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
     fuelmi_set_error("device initialisation failed (is this a gfx950 device?)");
     return fail(FUELMI_EHIP);
@@ -385,6 +387,7 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
     for (auto e : s.ev) (void)hipEventDestroy(e);
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
+  if (m->ev_planes) (void)hipEventDestroy(m->ev_planes);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -404,6 +407,7 @@ extern "C" int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ) {
       g, m->occ, m->occ_bits.p, m->unk_bits.p, m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3, 0,
       g.W - 1);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(m->ev_planes, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   return FUELMI_OK;
 }
@@ -434,6 +438,7 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
       k_virtual_ceil<<<blocks_for(n, 256), 256, 0, m->stream>>>(
           g, b, ceil_id, m->info.clamp_max_log, m->occ, m->occ_bits.p, m->unk_bits.p,
           m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3);
+      HIPCHK(hipEventRecord(m->ev_planes, m->stream));
     }
   }
   HIPCHK(hipGetLastError());
