@@ -105,12 +105,15 @@ class GpuCycle:
 
     def step(self):
         m = self.map
-        m.clearAndInflateLocalMap()
-        m.updateESDF3d()
-        self.dev_problem.eval()  # async; needs only the ESDF, independent of the frontier search
+        # the frontier scan reads only the occupancy state: enqueue it first (own stream), then the
+        # inflation -> ESDF -> B-spline chain on the map's stream; collect the clusters last
         self.ff.reset()
         m.setUpdatedBox(self.box[0], self.box[1])
-        self.n_clusters = self.ff.searchFrontiers()
+        self.ff.searchFrontiersBegin()
+        m.clearAndInflateLocalMap()
+        m.updateESDF3d()
+        self.dev_problem.eval()
+        self.n_clusters = self.ff.searchFrontiersEnd()
 
     def finish(self):
         self.map.synchronize()

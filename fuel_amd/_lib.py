@@ -113,6 +113,8 @@ SYMBOLS = {
     "fuelmi_frontier_destroy": (None, [_P]),
     "fuelmi_frontier_reset": (C.c_int, [_P]),
     "fuelmi_frontier_search": (C.c_int, [_P, _ip]),
+    "fuelmi_frontier_search_begin": (C.c_int, [_P]),
+    "fuelmi_frontier_search_end": (C.c_int, [_P, _ip]),
     "fuelmi_frontier_commit": (C.c_int, [_P, C.c_int]),
     "fuelmi_frontier_count": (C.c_int, [_P, C.c_int]),
     "fuelmi_frontier_cluster_size": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -23,12 +23,20 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
 #include "fuelmi_internal.h"
 
 #define NOCLAIM 0xFFFFFFFFu
+
+struct KeptRec {  // one per kept cluster, in rank order (ascending claimer address)
+  u32 addr, slot, size, off;  // off: first position of the cluster in the grouped cell array
+  unsigned long long sum[3];  // voxel-index sums / AABB of cells outside their chunk's leading key
+  u32 box[6];
+  u32 pad[2];
+};
 
 struct FArgs {
   Box3 qbox;  // Q0 index box (isInBox & z >= iz_min), inclusive
@@ -56,13 +64,11 @@ struct FArgs {
   u32 cap_kept;
   // grouping of the kept cells by cluster rank (stable 8-bit radix multisplit)
   int* slot2rank;    // [cap_q + cap_s] valid only at kept slots
-  u32* kept_slots;   // [cap_kept] slot of rank r (uploaded after the host sorted the kept list)
+  struct KeptRec* krec;  // [cap_kept] cluster records in rank order
   u32* ms_key[2];    // [cap_q]
   u32* ms_val[2];    // [cap_q]
   u32* ms_hist;      // [256][ms_nb_max]
   u32 ms_nb_max;
-  unsigned long long* info_sum;  // [cap_kept][3] sum of voxel indices
-  u32* info_box;                 // [cap_kept][6] min xyz, max xyz
   u32* info_part;                // [cap_q / SZ_CH + 1][10] per-chunk records (key, sums, min, max)
 };
 
@@ -216,6 +222,7 @@ __global__ void __launch_bounds__(256) k_scan_sums(FArgs F, int nblocks) {
     F.counts[1] = ns;
     F.counts[2] = ovf;
     F.counts[3] = 0;
+    F.counts[5] = 0;
   }
   __syncthreads();
   u64 run = part[threadIdx.x];
@@ -665,48 +672,85 @@ __global__ void __launch_bounds__(256) k_finalize(Geo g, FArgs F) {
 }
 
 // ---- grouping of kept cells by cluster: stable radix multisplit ---------------------------------
-__global__ void k_ms_set_ranks(FArgs F, int nkept) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nkept) F.slot2rank[F.kept_slots[r]] = r;
-}
-__global__ void __launch_bounds__(256) k_ms_keys(FArgs F, u32 nq, int nkept) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (u32)(3 * nkept)) {
-    // reset the per-cluster accumulators (sum = 0, min = max-int, max = 0)
-    if (i < (u32)nkept) {
-      F.info_sum[3 * i] = F.info_sum[3 * i + 1] = F.info_sum[3 * i + 2] = 0ull;
-      for (int k = 0; k < 3; ++k) {
-        F.info_box[6 * i + k] = 0xFFFFFFFFu;
-        F.info_box[6 * i + 3 + k] = 0u;
+// Every size (nq, nkept, n_out, digits, chunk counts) is read from device memory, so the whole tail
+// is enqueued without a host round trip; grids are launched at their upper bound and surplus
+// blocks exit at once.  counts[]: [0]=nq [1]=ns [2]=overflow [3]=nkept [4]=scratch [5]=n_out.
+
+// rank the kept clusters by claimer address (= the reference's creation order) and lay out the
+// grouped cell array: rank_i = #{j : addr_j < addr_i}, off_i = sum of their cell counts.
+__global__ void __launch_bounds__(256) k_rank_kept(FArgs F) {
+  const u32 nq = F.counts[0];
+  const u32 nkept = min(F.counts[3], F.cap_kept);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nkept; i += gridDim.x * blockDim.x) {
+    const u32 ai = F.kept[3 * i], si = F.kept[3 * i + 1], zi = F.kept[3 * i + 2];
+    u32 rank = 0, off = 0;
+    for (u32 j = 0; j < nkept; ++j) {
+      const u32 aj = F.kept[3 * j];
+      if (aj < ai) {
+        ++rank;
+        off += F.kept[3 * j + 2] - (F.kept[3 * j + 1] >= nq ? 1u : 0u);  // an NQ seed is not a Q0 cell
       }
     }
+    F.slot2rank[si] = (int)rank;
+    KeptRec& r = F.krec[rank];
+    r.addr = ai, r.slot = si, r.size = zi, r.off = off;
+    r.sum[0] = r.sum[1] = r.sum[2] = 0ull;
+    for (int k = 0; k < 3; ++k) r.box[k] = 0xFFFFFFFFu, r.box[3 + k] = 0u;
+    if (rank == nkept - 1) F.counts[5] = off + zi - (si >= nq ? 1u : 0u);
   }
-  for (; i < nq; i += gridDim.x * blockDim.x) {
+}
+__global__ void __launch_bounds__(256) k_ms_keys(FArgs F) {
+  const u32 nq = F.counts[0];
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
     int s = F.cell_slot[i];
     F.ms_key[0][i] = s >= 0 ? (u32)F.slot2rank[s] : NOKEY;
     F.ms_val[0][i] = F.cell_adr[i];
   }
 }
+struct MsPass {
+  bool on;
+  u32 n;
+  int nb, ndig, shift;
+  const u32 *key, *val;
+  u32 *key_out, *val_out;
+};
+__device__ __forceinline__ MsPass ms_pass(const FArgs& F, int pass) {
+  MsPass p;
+  const u32 nkept = min(F.counts[3], F.cap_kept);
+  p.on = nkept > 0 && (pass == 0 || nkept > 256);
+  p.n = pass == 0 ? F.counts[0] : F.counts[5];
+  p.nb = (int)((p.n + MS_CH - 1) / MS_CH);
+  p.ndig = pass == 0 ? (int)min(nkept, 256u) : (int)((nkept - 1) >> 8) + 1;
+  p.shift = 8 * pass;
+  p.key = F.ms_key[pass], p.val = F.ms_val[pass];
+  p.key_out = F.ms_key[1 - pass], p.val_out = F.ms_val[1 - pass];
+  return p;
+}
 // histogram of the current 8-bit digit per block, digit-major: hist[d * nb + block]
-__global__ void __launch_bounds__(256)
-k_ms_hist(const u32* __restrict__ key, u32 n, int shift, u32* __restrict__ hist, int nb, int ndig) {
+__global__ void __launch_bounds__(256) k_ms_hist(FArgs F, int pass) {
   __shared__ u32 h[256];
+  const MsPass P = ms_pass(F, pass);
+  if (!P.on || (int)blockIdx.x >= P.nb) return;
   h[threadIdx.x] = 0;
   __syncthreads();
   const u32 base = blockIdx.x * MS_CH;
   for (int k = 0; k < MS_CH / 256; ++k) {
     u32 i = base + k * 256 + threadIdx.x;
-    if (i < n) {
-      u32 kk = key[i];
-      if (kk != NOKEY) atomicAdd(&h[(kk >> shift) & 255u], 1u);
+    if (i < P.n) {
+      u32 kk = P.key[i];
+      if (kk != NOKEY) atomicAdd(&h[(kk >> P.shift) & 255u], 1u);
     }
   }
   __syncthreads();
-  if ((int)threadIdx.x < ndig) hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+  if ((int)threadIdx.x < P.ndig) F.ms_hist[threadIdx.x * P.nb + blockIdx.x] = h[threadIdx.x];
 }
-// in-place exclusive scan of `cnt` u32 values by one block; total -> *total_out
-__global__ void __launch_bounds__(256) k_ms_scan(u32* v, int cnt, u32* total_out) {
+// in-place exclusive scan of the ndig*nb histogram entries by one block
+__global__ void __launch_bounds__(256) k_ms_scan(FArgs F, int pass) {
   __shared__ u32 part[256];
+  const MsPass P = ms_pass(F, pass);
+  if (!P.on) return;
+  u32* v = F.ms_hist;
+  const int cnt = P.ndig * P.nb;
   const int per = (cnt + 255) / 256;
   const int b0 = threadIdx.x * per, b1 = min(cnt, b0 + per);
   u32 s = 0;
@@ -720,7 +764,6 @@ __global__ void __launch_bounds__(256) k_ms_scan(u32* v, int cnt, u32* total_out
       part[t] = run;
       run += x;
     }
-    *total_out = run;
   }
   __syncthreads();
   u32 run = part[threadIdx.x];
@@ -731,22 +774,21 @@ __global__ void __launch_bounds__(256) k_ms_scan(u32* v, int cnt, u32* total_out
   }
 }
 // stable scatter: position = scanned[d][block] + (# earlier elements of this block with digit d)
-__global__ void __launch_bounds__(256)
-k_ms_scatter(const u32* __restrict__ key, const u32* __restrict__ val, u32 n, int shift,
-             const u32* __restrict__ scanned, int nb, int ndig, u32* __restrict__ key_out,
-             u32* __restrict__ val_out) {
+__global__ void __launch_bounds__(256) k_ms_scatter(FArgs F, int pass) {
   __shared__ u32 running[256];
   __shared__ u32 wcnt[4][256];
+  const MsPass P = ms_pass(F, pass);
+  if (!P.on || (int)blockIdx.x >= P.nb) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  running[threadIdx.x] = (int)threadIdx.x < ndig ? scanned[threadIdx.x * nb + blockIdx.x] : 0u;
+  running[threadIdx.x] = (int)threadIdx.x < P.ndig ? F.ms_hist[threadIdx.x * P.nb + blockIdx.x] : 0u;
   const u32 base = blockIdx.x * MS_CH;
   for (int k = 0; k < MS_CH / 256; ++k) {
     for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
     const u32 i = base + k * 256 + threadIdx.x;
-    u32 kk = (i < n) ? key[i] : NOKEY;
+    u32 kk = (i < P.n) ? P.key[i] : NOKEY;
     const bool active = kk != NOKEY;
-    const u32 d = (kk >> shift) & 255u;
+    const u32 d = (kk >> P.shift) & 255u;
     u32 lane_rank = 0;
     u64 todo = __ballot(active);
     while (todo) {
@@ -761,8 +803,8 @@ k_ms_scatter(const u32* __restrict__ key, const u32* __restrict__ val, u32 n, in
     if (active) {
       u32 pos = running[d] + lane_rank;
       for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
-      key_out[pos] = kk;
-      val_out[pos] = val[i];
+      P.key_out[pos] = kk;
+      P.val_out[pos] = P.val[i];
     }
     __syncthreads();
     running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
@@ -771,22 +813,29 @@ k_ms_scatter(const u32* __restrict__ key, const u32* __restrict__ val, u32 n, in
 }
 // computeFrontierInfo (:374-390) accumulators per cluster: sum of voxel indices and index AABB.
 // Input is grouped by cluster, so a 1024-cell chunk nearly always holds one key: reduce it in the
-// block and issue 9 atomics per chunk; cells of other keys take per-cell atomics.
+// block into a per-chunk record (folded on the host); cells of other keys (a chunk straddling a
+// cluster boundary) are reduced per wave and added to the cluster record with atomics.
 __device__ __forceinline__ void info_atomics(FArgs& F, u32 k, u32 sx, u32 sy, u32 sz, u32 nx_, u32 ny_, u32 nz_,
                                              u32 mx, u32 my, u32 mz) {
-  atomicAdd(&F.info_sum[3 * k], (unsigned long long)sx);
-  atomicAdd(&F.info_sum[3 * k + 1], (unsigned long long)sy);
-  atomicAdd(&F.info_sum[3 * k + 2], (unsigned long long)sz);
-  atomicMin(&F.info_box[6 * k], nx_);
-  atomicMin(&F.info_box[6 * k + 1], ny_);
-  atomicMin(&F.info_box[6 * k + 2], nz_);
-  atomicMax(&F.info_box[6 * k + 3], mx);
-  atomicMax(&F.info_box[6 * k + 4], my);
-  atomicMax(&F.info_box[6 * k + 5], mz);
+  KeptRec& r = F.krec[k];
+  atomicAdd(&r.sum[0], (unsigned long long)sx);
+  atomicAdd(&r.sum[1], (unsigned long long)sy);
+  atomicAdd(&r.sum[2], (unsigned long long)sz);
+  atomicMin(&r.box[0], nx_);
+  atomicMin(&r.box[1], ny_);
+  atomicMin(&r.box[2], nz_);
+  atomicMax(&r.box[3], mx);
+  atomicMax(&r.box[4], my);
+  atomicMax(&r.box[5], mz);
 }
-__global__ void __launch_bounds__(256)
-k_ms_info(Geo g, const u32* __restrict__ key, const u32* __restrict__ val, u32 n, FArgs F) {
+__global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
   __shared__ u32 s_red[4][9];
+  const u32 nkept = min(F.counts[3], F.cap_kept);
+  if (nkept == 0) return;
+  const int fin = nkept <= 256 ? 1 : 0;  // buffer holding the grouped output
+  const u32* key = F.ms_key[fin];
+  const u32* val = F.ms_val[fin];
+  const u32 n = F.counts[5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (u32 base = blockIdx.x * SZ_CH; base < n; base += gridDim.x * SZ_CH) {
     const u32 key0 = key[base];
@@ -802,7 +851,6 @@ k_ms_info(Geo g, const u32* __restrict__ key, const u32* __restrict__ val, u32 n
         nx_ = min(nx_, x), ny_ = min(ny_, y), nz_ = min(nz_, z);
         mx = max(mx, x), my = max(my, y), mz = max(mz, z);
       }
-      // cells of another cluster (chunk straddles a boundary): one set of atomics per key per wave
       u64 todo = __ballot(in && kk != key0);
       while (todo) {
         const int leader = __builtin_ctzll(todo);
@@ -849,8 +897,6 @@ k_ms_info(Geo g, const u32* __restrict__ key, const u32* __restrict__ val, u32 n
         nx_ = min(nx_, s_red[w][3]), ny_ = min(ny_, s_red[w][4]), nz_ = min(nz_, s_red[w][5]);
         mx = max(mx, s_red[w][6]), my = max(my, s_red[w][7]), mz = max(mz, s_red[w][8]);
       }
-      // no atomics for the chunk's leading key (same-address device atomics cost ~60 ns each):
-      // the host folds these per-chunk records into the per-cluster totals
       u32* rec = F.info_part + (size_t)(base / SZ_CH) * 10;
       rec[0] = key0, rec[1] = sx, rec[2] = sy, rec[3] = sz;
       rec[4] = nx_, rec[5] = ny_, rec[6] = nz_, rec[7] = mx, rec[8] = my, rec[9] = mz;
@@ -859,6 +905,10 @@ k_ms_info(Geo g, const u32* __restrict__ key, const u32* __restrict__ val, u32 n
   }
 }
 
+
+__global__ void k_zero_words(u64* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
+}
 __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* __restrict__ out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (char)((bits[i >> 6] >> (i & 63)) & 1ull);
@@ -888,6 +938,10 @@ struct fuelmi_frontier {
   size_t d_stage_bytes = 0;
   void* h_pin = nullptr;  // pinned result staging
   size_t pin_bytes = 0;
+  int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
+  int last_nkept = 0, nb_launch = 0, npass = 1;
+  bool pending = false, search_empty = false;
+  std::unique_ptr<StageScope> scope;
   std::vector<int> slot2rank;
 };
 
@@ -1004,11 +1058,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       (rc = dmalloc(f, &F.cell_adr, F.cap_q)) || (rc = dmalloc(f, &F.parent, F.cap_q)) ||
       (rc = dmalloc(f, &F.claim, F.cap_q)) || (rc = dmalloc(f, &F.cell_slot, F.cap_q)) ||
       (rc = dmalloc(f, &F.seed_adr, F.cap_s)) || (rc = dmalloc(f, &F.csize, (size_t)F.cap_q + F.cap_s)) ||
-      (rc = dmalloc(f, &F.slot2rank, (size_t)F.cap_q + F.cap_s)) || (rc = dmalloc(f, &F.kept_slots, F.cap_kept)) ||
+      (rc = dmalloc(f, &F.slot2rank, (size_t)F.cap_q + F.cap_s)) || (rc = dmalloc(f, &F.krec, F.cap_kept)) ||
       (rc = dmalloc(f, &F.ms_key[0], F.cap_q)) || (rc = dmalloc(f, &F.ms_key[1], F.cap_q)) ||
       (rc = dmalloc(f, &F.ms_val[0], F.cap_q)) || (rc = dmalloc(f, &F.ms_val[1], F.cap_q)) ||
       (rc = dmalloc(f, &F.ms_hist, (size_t)256 * (F.cap_q / MS_CH + 2))) ||
-      (rc = dmalloc(f, &F.info_sum, (size_t)F.cap_kept * 3)) || (rc = dmalloc(f, &F.info_box, (size_t)F.cap_kept * 6)) ||
       (rc = dmalloc(f, &F.info_part, ((size_t)F.cap_q / SZ_CH + 2) * 10))) {
     fuelmi_frontier_destroy(f);
     return rc;
@@ -1076,9 +1129,13 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
   return FUELMI_OK;
 }
 
-extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
-  ARGCHK(f && n_new);
+// searchFrontiers, first half: drops changed clusters and enqueues the whole device pipeline on the
+// frontier's own stream (asynchronous).  The caller may queue other work of the cycle (inflation,
+// ESDF, B-spline evaluation on the map's stream) before collecting the result with _search_end.
+extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
+  ARGCHK(f);
   fuelmi_map* m = f->map;
+  f->pending = false;
   HIPCHK(hipSetDevice(m->device));
   const Geo& g = m->g;
   FArgs& F = f->F;
@@ -1090,7 +1147,7 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   // last kernel that rewrote them (fusion / upload), and overlaps the inflation / ESDF / B-spline
   // kernels the caller has queued on the map's stream for the same cycle
   HIPCHK(hipStreamWaitEvent(f->stream, m->ev_planes, 0));
-  StageScope sc(m, FUELMI_K_FRONTIER, f->stream);
+  f->scope.reset(new StageScope(m, FUELMI_K_FRONTIER, f->stream));
   f->removed_ids.clear();
   int rc = remove_changed(f, f->frontiers, umin, umax, &f->removed_ids);
   if (rc) return rc;
@@ -1123,7 +1180,8 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
       F.qbox.lo[k] = 1;
       F.qbox.hi[k] = 0;
     }
-  *n_new = 0;
+  f->pending = true;
+  f->search_empty = empty;
   if (empty) return FUELMI_OK;
 
   // words to process: everything the BFS could reach = Q box, plus the scan box
@@ -1167,73 +1225,92 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   k_finalize<<<nblocks, 256, 0, f->stream>>>(g, F);
   HIPCHK(hipGetLastError());
 
-  // ---- results: one pinned staging buffer [counts | kept | kept_slots | info | cells] ----
+  // ---- grouping + cluster info, still without touching the host ----
+  k_rank_kept<<<16, 256, 0, f->stream>>>(F);
+  k_ms_keys<<<cgrid, 256, 0, f->stream>>>(F);
+  const int nb_max = (int)(F.cap_q / MS_CH) + 1;
+  const int nb_launch = std::min(nb_max, std::max(64, 2 * f->last_nb + 8));  // surplus blocks exit at once
+  f->nb_launch = nb_launch;
+  // the second radix pass is needed only beyond 256 kept clusters: guess from the previous search
+  f->npass = f->last_nkept > 192 ? 2 : 1;
+  for (int p = 0; p < f->npass; ++p) {
+    k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
+    k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
+    k_ms_scatter<<<nb_launch, 256, 0, f->stream>>>(F, p);
+  }
+  k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
+  HIPCHK(hipGetLastError());
+
+  // ---- results: one pinned staging buffer [counts | cluster records | chunk records | cells] ----
+  const u32 HEAD = std::min<u32>(F.cap_kept, 512u);
   if (!f->h_pin) {
-    f->pin_bytes = 64 + (size_t)F.cap_kept * (12 + 4 + 24 + 24) + (size_t)F.cap_q * 4 +
-        ((size_t)F.cap_q / SZ_CH + 2) * 40;
+    f->pin_bytes = 64 + (size_t)F.cap_kept * sizeof(KeptRec) + ((size_t)F.cap_q / SZ_CH + 2) * 40 + (size_t)F.cap_q * 4;
     HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
   }
   u32* counts = reinterpret_cast<u32*>(f->h_pin);
-  u32* h_kept = counts + 16;
-  u32* h_slots = h_kept + (size_t)F.cap_kept * 3;
-  unsigned long long* h_sum = reinterpret_cast<unsigned long long*>(h_slots + F.cap_kept);
-  u32* h_box = reinterpret_cast<u32*>(h_sum + (size_t)F.cap_kept * 3);
-  u32* h_cells = h_box + (size_t)F.cap_kept * 6;
-  // counts and the head of the kept list live contiguously on the device: one copy, one sync
-  const u32 head = std::min<u32>(F.cap_kept, 1024u);
-  HIPCHK(hipMemcpyAsync(counts, F.counts, (16 + (size_t)head * 3) * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+  KeptRec* h_rec = reinterpret_cast<KeptRec*>(counts + 16);
+  u32* h_part = reinterpret_cast<u32*>(h_rec + F.cap_kept);
+  u32* h_cells = h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
+  HIPCHK(hipMemcpyAsync(counts, F.counts, 16 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
+  return FUELMI_OK;
+}
+
+// searchFrontiers, second half: waits for the pipeline and assembles tmp_frontiers_.
+extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
+  ARGCHK(f && n_new);
+  *n_new = 0;
+  if (!f->pending) {
+    fuelmi_set_error("fuelmi_frontier_search_end without a matching _begin");
+    return FUELMI_EINVAL;
+  }
+  f->pending = false;
+  struct ScopeEnd {  // closes the profiling bracket on every exit path
+    fuelmi_frontier* f;
+    ~ScopeEnd() { f->scope.reset(); }
+  } scope_end{f};
+  if (f->search_empty) return FUELMI_OK;
+  fuelmi_map* m = f->map;
+  HIPCHK(hipSetDevice(m->device));
+  const Geo& g = m->g;
+  FArgs& F = f->F;
+  const int nb_launch = f->nb_launch;
+  const u32 HEAD = std::min<u32>(F.cap_kept, 512u);
+  u32* counts = reinterpret_cast<u32*>(f->h_pin);
+  KeptRec* h_rec = reinterpret_cast<KeptRec*>(counts + 16);
+  u32* h_part = reinterpret_cast<u32*>(h_rec + F.cap_kept);
+  u32* h_cells = h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
   HIPCHK(hipStreamSynchronize(f->stream));
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
                      counts[1], F.cap_s, counts[3], F.cap_kept);
     return FUELMI_ELIMIT;
   }
-  const u32 nq = counts[0], nkept = counts[3];
-  if (nkept == 0) return FUELMI_OK;
-  if (nkept > head) {
-    HIPCHK(hipMemcpyAsync(h_kept, F.kept, (size_t)nkept * 3 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+  const u32 nq = counts[0], nkept = counts[3], n_out = counts[5];
+  f->last_nb = (int)((nq + MS_CH - 1) / MS_CH);
+  f->last_nkept = (int)nkept;
+  if (f->last_nb > nb_launch || (nkept > 256 && f->npass < 2)) {
+    // the launch estimates (compact cells, radix passes) were too small: redo the grouping exactly
+    for (int p = 0; p < 2; ++p) {
+      k_ms_hist<<<f->last_nb, 256, 0, f->stream>>>(F, p);
+      k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
+      k_ms_scatter<<<f->last_nb, 256, 0, f->stream>>>(F, p);
+    }
+    HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
+    // cluster records must be re-initialised before the accumulators are refilled
+    k_rank_kept<<<16, 256, 0, f->stream>>>(F);
+    k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
+    HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
   }
-  // clusters in creation order = ascending claimer address (the reference's scan order)
-  std::vector<u32> order(nkept);
-  for (u32 k = 0; k < nkept; ++k) order[k] = k;
-  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return h_kept[3 * a] < h_kept[3 * b]; });
-  std::vector<u32> off(nkept + 1, 0);
-  for (u32 r = 0; r < nkept; ++r) {
-    const u32 k = order[r];
-    h_slots[r] = h_kept[3 * k + 1];
-    const bool seed = h_kept[3 * k + 1] >= nq;  // an NQ seed is not part of the compact Q0 cells
-    off[r + 1] = off[r] + h_kept[3 * k + 2] - (seed ? 1u : 0u);
-  }
-  const u32 n_out = off[nkept];
-  // group the kept cells by cluster on the device (stable: ascending address inside a cluster)
-  HIPCHK(hipMemcpyAsync(F.kept_slots, h_slots, (size_t)nkept * sizeof(u32), hipMemcpyHostToDevice, f->stream));
-  k_ms_set_ranks<<<(nkept + 255) / 256, 256, 0, f->stream>>>(F, (int)nkept);
-  k_ms_keys<<<std::max(fblocks((long)nq, 256, 2048), (int)(nkept + 255) / 256), 256, 0, f->stream>>>(F, nq, (int)nkept);
-  const int nb = (int)((nq + MS_CH - 1) / MS_CH);
-  int cur = 0;
-  const int passes = nkept <= 256 ? 1 : 2;
-  for (int p = 0; p < passes && nq > 0; ++p) {
-    const u32 n_in = (p == 0) ? nq : n_out;
-    const int nbp = (int)((n_in + MS_CH - 1) / MS_CH);
-    // digits in use: low pass sees min(nkept,256) values, high pass (nkept-1)>>8 + 1
-    const int ndig = (p == 0) ? (int)std::min<u32>(nkept, 256u) : (int)((nkept - 1) >> 8) + 1;
-    k_ms_hist<<<nbp, 256, 0, f->stream>>>(F.ms_key[cur], n_in, 8 * p, F.ms_hist, nbp, ndig);
-    k_ms_scan<<<1, 256, 0, f->stream>>>(F.ms_hist, ndig * nbp, F.counts + 4);
-    k_ms_scatter<<<nbp, 256, 0, f->stream>>>(F.ms_key[cur], F.ms_val[cur], n_in, 8 * p, F.ms_hist, nbp, ndig,
-                                            F.ms_key[1 - cur], F.ms_val[1 - cur]);
-    cur = 1 - cur;
-  }
-  (void)nb;
-  if (n_out) k_ms_info<<<fblocks((long)n_out, SZ_CH, 2048), 256, 0, f->stream>>>(g, F.ms_key[cur], F.ms_val[cur], n_out, F);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(h_sum, F.info_sum, (size_t)nkept * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                        f->stream));
-  HIPCHK(hipMemcpyAsync(h_box, F.info_box, (size_t)nkept * 6 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+  if (nkept == 0) return FUELMI_OK;
+  const int fin = nkept <= 256 ? 1 : 0;
   const u32 nchunk = (n_out + SZ_CH - 1) / SZ_CH;
-  u32* h_part = h_cells + F.cap_q;
+  if (nkept > HEAD)
+    HIPCHK(hipMemcpyAsync(h_rec + HEAD, F.krec + HEAD, (size_t)(nkept - HEAD) * sizeof(KeptRec), hipMemcpyDeviceToHost,
+                          f->stream));
   if (n_out) {
-    HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[cur], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[fin], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)nchunk * 10 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
   }
   HIPCHK(hipStreamSynchronize(f->stream));
@@ -1242,25 +1319,27 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
     const u32 r = rec[0];
     if (r >= nkept) continue;
     for (int q = 0; q < 3; ++q) {
-      h_sum[3 * r + q] += rec[1 + q];
-      h_box[6 * r + q] = std::min(h_box[6 * r + q], rec[4 + q]);
-      h_box[6 * r + 3 + q] = std::max(h_box[6 * r + 3 + q], rec[7 + q]);
+      h_rec[r].sum[q] += rec[1 + q];
+      h_rec[r].box[q] = std::min(h_rec[r].box[q], rec[4 + q]);
+      h_rec[r].box[3 + q] = std::max(h_rec[r].box[3 + q], rec[7 + q]);
     }
   }
 
-  // host: bulk copies only (+ inserting an NQ seed where a seed started the cluster)
+  // host: bulk copies only (+ inserting an NQ seed where a seed started the cluster); records are
+  // already in creation order (ascending claimer address = the reference's scan order)
   for (u32 r = 0; r < nkept; ++r) {
-    const u32 k = order[r];
+    const KeptRec& kr = h_rec[r];
     f->tmp.emplace_back();
     HCluster& c = f->tmp.back();
-    const u32 cnt = off[r + 1] - off[r];
+    const bool seed = kr.slot >= nq;
+    const u32 cnt = kr.size - (seed ? 1u : 0u);
     c.cells.resize(cnt);
-    if (cnt) memcpy(c.cells.data(), h_cells + off[r], (size_t)cnt * sizeof(int));
-    unsigned long long sum[3] = {h_sum[3 * r], h_sum[3 * r + 1], h_sum[3 * r + 2]};
-    u32 lo[3] = {h_box[6 * r], h_box[6 * r + 1], h_box[6 * r + 2]};
-    u32 hi[3] = {h_box[6 * r + 3], h_box[6 * r + 4], h_box[6 * r + 5]};
-    if (h_kept[3 * k + 1] >= nq) {
-      const int a = (int)h_kept[3 * k];
+    if (cnt) memcpy(c.cells.data(), h_cells + kr.off, (size_t)cnt * sizeof(int));
+    unsigned long long sum[3] = {kr.sum[0], kr.sum[1], kr.sum[2]};
+    u32 lo[3] = {kr.box[0], kr.box[1], kr.box[2]};
+    u32 hi[3] = {kr.box[3], kr.box[4], kr.box[5]};
+    if (seed) {
+      const int a = (int)kr.addr;
       c.cells.insert(std::lower_bound(c.cells.begin(), c.cells.end(), a), a);
       const u32 x = (u32)a / (u32)g.nyz, rr = (u32)a - x * (u32)g.nyz, y = rr / (u32)g.nz, z = rr - y * (u32)g.nz;
       const u32 id[3] = {x, y, z};
@@ -1282,6 +1361,14 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   return FUELMI_OK;
 }
 
+
+extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
+  ARGCHK(f && n_new);
+  int rc = fuelmi_frontier_search_begin(f);
+  if (rc) return rc;
+  return fuelmi_frontier_search_end(f, n_new);
+}
+
 extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   ARGCHK(f);
   fuelmi_map* m = f->map;
@@ -1290,7 +1377,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   f->dormant.clear();
   f->tmp.clear();
   f->removed_ids.clear();
-  HIPCHK(hipMemsetAsync(f->flag.p, 0, (size_t)m->g.W * sizeof(u64), f->stream));
+  k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
   return FUELMI_OK;
 }
 

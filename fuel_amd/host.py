@@ -237,6 +237,14 @@ class FrontierFinder:
         check(self.L.fuelmi_frontier_search(self.h, C.byref(n)))
         return n.value
 
+    def searchFrontiersBegin(self):
+        check(self.L.fuelmi_frontier_search_begin(self.h))
+
+    def searchFrontiersEnd(self):
+        n = C.c_int()
+        check(self.L.fuelmi_frontier_search_end(self.h, C.byref(n)))
+        return n.value
+
     def commit(self, dormant=False):
         check(self.L.fuelmi_frontier_commit(self.h, int(dormant)))
 

@@ -141,6 +141,12 @@ int fuelmi_frontier_reset(fuelmi_frontier* f);
  * (getUpdatedBox(reset=true)), drops changed clusters, scans, clusters.  *n_new = number of new
  * clusters (tmp_frontiers_.size()). */
 int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new);
+/* The same search split in two: _begin drops changed clusters and enqueues the device pipeline on
+ * the frontier's own HIP stream without waiting; _end waits and assembles the clusters.  Work
+ * queued on the map between the two calls (inflation, ESDF, B-spline evaluation) overlaps the
+ * scan, which only reads the occupancy state.  Do not fuse points between _begin and _end. */
+int fuelmi_frontier_search_begin(fuelmi_frontier* f);
+int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new);
 /* move tmp_frontiers_ into frontiers_ (dormant=0) or dormant_frontiers_ (dormant=1) */
 int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant);
 /* which: 0 tmp_frontiers_, 1 frontiers_, 2 dormant_frontiers_ */
