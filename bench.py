@@ -249,6 +249,17 @@ def main():
             "bspline": ctrl.shape[0] * ctrl.shape[1] * 56.0,
         }
         achieved = alg_bytes[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes,
+        # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/), else null
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            key = {"esdf_zy": "k_esdf_zy4<0>", "esdf_x": "k_esdf_x4<0>", "inflate": "k_inflate",
+                   "bspline": "k_bspline_cost_grad"}[dominant]
+            if args.workload == "G400":
+                traffic = pmc[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "plan_cycles_per_sec",
             "value": fleet_value(n_gpus, args.steps, elapsed),
@@ -269,7 +280,7 @@ def main():
                        "parallelism": "independent map per GPU (no collective)"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes[dominant]},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,15 @@
 #include "fuelmi_internal.h"
 
 #define NOCLAIM 0xFFFFFFFFu
+// FUELMI_DEBUG_SYNC=1: synchronise and name every frontier kernel (locates device faults)
+#define FDBG(name)                                                                     \
+  do {                                                                                 \
+    static const bool on__ = getenv("FUELMI_DEBUG_SYNC") != nullptr;                   \
+    if (on__) {                                                                        \
+      hipError_t e__ = hipStreamSynchronize(f->stream);                                \
+      std::fprintf(stderr, "[fuelmi] %s: %s\n", name, hipGetErrorString(e__));         \
+    }                                                                                  \
+  } while (0)
 
 struct KeptRec {  // one per kept cluster, in rank order (ascending claimer address)
   u32 addr, slot, size, off;  // off: first position of the cluster in the grouped cell array
@@ -730,19 +739,22 @@ __device__ __forceinline__ MsPass ms_pass(const FArgs& F, int pass) {
 __global__ void __launch_bounds__(256) k_ms_hist(FArgs F, int pass) {
   __shared__ u32 h[256];
   const MsPass P = ms_pass(F, pass);
-  if (!P.on || (int)blockIdx.x >= P.nb) return;
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const u32 base = blockIdx.x * MS_CH;
-  for (int k = 0; k < MS_CH / 256; ++k) {
-    u32 i = base + k * 256 + threadIdx.x;
-    if (i < P.n) {
-      u32 kk = P.key[i];
-      if (kk != NOKEY) atomicAdd(&h[(kk >> P.shift) & 255u], 1u);
+  if (!P.on) return;
+  for (int chunk = blockIdx.x; chunk < P.nb; chunk += gridDim.x) {  // any grid size covers all chunks
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 base = (u32)chunk * MS_CH;
+    for (int k = 0; k < MS_CH / 256; ++k) {
+      u32 i = base + k * 256 + threadIdx.x;
+      if (i < P.n) {
+        u32 kk = P.key[i];
+        if (kk != NOKEY) atomicAdd(&h[(kk >> P.shift) & 255u], 1u);
+      }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < P.ndig) F.ms_hist[threadIdx.x * P.nb + chunk] = h[threadIdx.x];
+    __syncthreads();
   }
-  __syncthreads();
-  if ((int)threadIdx.x < P.ndig) F.ms_hist[threadIdx.x * P.nb + blockIdx.x] = h[threadIdx.x];
 }
 // in-place exclusive scan of the ndig*nb histogram entries by one block
 __global__ void __launch_bounds__(256) k_ms_scan(FArgs F, int pass) {
@@ -778,10 +790,11 @@ __global__ void __launch_bounds__(256) k_ms_scatter(FArgs F, int pass) {
   __shared__ u32 running[256];
   __shared__ u32 wcnt[4][256];
   const MsPass P = ms_pass(F, pass);
-  if (!P.on || (int)blockIdx.x >= P.nb) return;
+  if (!P.on) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  running[threadIdx.x] = (int)threadIdx.x < P.ndig ? F.ms_hist[threadIdx.x * P.nb + blockIdx.x] : 0u;
-  const u32 base = blockIdx.x * MS_CH;
+  for (int chunk = blockIdx.x; chunk < P.nb; chunk += gridDim.x) {
+  running[threadIdx.x] = (int)threadIdx.x < P.ndig ? F.ms_hist[threadIdx.x * P.nb + chunk] : 0u;
+  const u32 base = (u32)chunk * MS_CH;
   for (int k = 0; k < MS_CH / 256; ++k) {
     for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
@@ -809,6 +822,7 @@ __global__ void __launch_bounds__(256) k_ms_scatter(FArgs F, int pass) {
     __syncthreads();
     running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
     __syncthreads();
+  }
   }
 }
 // computeFrontierInfo (:374-390) accumulators per cluster: sum of voxel indices and index AABB.
@@ -843,8 +857,11 @@ __global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
 #pragma unroll
     for (int k = 0; k < SZ_CH / 256; ++k) {
       const u32 i = base + k * 256 + threadIdx.x;
-      const bool in = i < n;
-      const u32 kk = in ? key[i] : key0, a = in ? val[i] : 0u;
+      u32 kk = i < n ? key[i] : key0;
+      // keys >= nkept can only appear when the radix-pass estimate was wrong and this buffer is not
+      // the grouped one yet (the host then re-runs the grouping and this kernel): ignore them
+      const bool in = i < n && kk < nkept;
+      const u32 a = in ? val[i] : 0u;
       const u32 x = a / (u32)g.nyz, r = a - x * (u32)g.nyz, y = r / (u32)g.nz, z = r - y * (u32)g.nz;
       if (in && kk == key0) {
         sx += x, sy += y, sz += z;
@@ -1114,7 +1131,9 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
   HIPCHK(hipMemsetAsync(d_changed, 0, cand.size() * sizeof(int), f->stream));
   k_check_clusters<<<fblocks((long)ncell, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, d_cells,
                                                                     d_cl, (int)ncell, d_changed);
+  FDBG("k_check_clusters");
   k_clear_flags<<<fblocks((long)ncell, 256), 256, 0, f->stream>>>(f->flag.p, d_cells, d_cl, d_changed, (int)ncell);
+  FDBG("k_clear_flags");
   std::vector<int> changed(cand.size());
   HIPCHK(hipMemcpyAsync(changed.data(), d_changed, cand.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
@@ -1197,8 +1216,11 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   F.nwords = nblocks * 256;
 
   k_pred<<<nblocks, 256, 0, f->stream>>>(g, F);
+  FDBG("k_pred");
   k_scan_sums<<<1, 256, 0, f->stream>>>(F, nblocks);
+  FDBG("k_scan_sums");
   k_compact<<<nblocks, 256, 0, f->stream>>>(g, F);
+  FDBG("k_compact");
   const int cgrid = 2048;
   {
     // tile = TX x TY z-lines with u32 labels in LDS (<= 48 KiB so three workgroups share a CU)
@@ -1216,29 +1238,40 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       k_ccl_local<<<ntx * nty, 256, lds, f->stream>>>(g, F, TX, TY, nty);
+  FDBG("k_ccl_local");
       k_union<<<cgrid, 256, 0, f->stream>>>(g, F, TX, TY);
+  FDBG("k_union");
     }
   }
   k_flatten<<<cgrid, 256, 0, f->stream>>>(g, F);
+  FDBG("k_flatten");
   k_claim<<<cgrid, 256, 0, f->stream>>>(g, F);
-  k_sizes<<<cgrid, 256, 0, f->stream>>>(g, F);  // grid-stride over 1024-cell chunks
+  FDBG("k_claim");
+  k_sizes<<<cgrid, 256, 0, f->stream>>>(g, F);
+  FDBG("k_sizes");  // grid-stride over 1024-cell chunks
   k_finalize<<<nblocks, 256, 0, f->stream>>>(g, F);
+  FDBG("k_finalize");
   HIPCHK(hipGetLastError());
 
   // ---- grouping + cluster info, still without touching the host ----
   k_rank_kept<<<16, 256, 0, f->stream>>>(F);
+  FDBG("k_rank_kept");
   k_ms_keys<<<cgrid, 256, 0, f->stream>>>(F);
-  const int nb_max = (int)(F.cap_q / MS_CH) + 1;
-  const int nb_launch = std::min(nb_max, std::max(64, 2 * f->last_nb + 8));  // surplus blocks exit at once
+  FDBG("k_ms_keys");
+  const int nb_launch = 256;  // the kernels stride over however many 2048-cell chunks there are
   f->nb_launch = nb_launch;
   // the second radix pass is needed only beyond 256 kept clusters: guess from the previous search
   f->npass = f->last_nkept > 192 ? 2 : 1;
   for (int p = 0; p < f->npass; ++p) {
     k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
+  FDBG("k_ms_hist");
     k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
+  FDBG("k_ms_scan");
     k_ms_scatter<<<nb_launch, 256, 0, f->stream>>>(F, p);
+  FDBG("k_ms_scatter");
   }
   k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
+  FDBG("k_ms_info");
   HIPCHK(hipGetLastError());
 
   // ---- results: one pinned staging buffer [counts | cluster records | chunk records | cells] ----
@@ -1289,17 +1322,22 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   const u32 nq = counts[0], nkept = counts[3], n_out = counts[5];
   f->last_nb = (int)((nq + MS_CH - 1) / MS_CH);
   f->last_nkept = (int)nkept;
-  if (f->last_nb > nb_launch || (nkept > 256 && f->npass < 2)) {
-    // the launch estimates (compact cells, radix passes) were too small: redo the grouping exactly
-    for (int p = 0; p < 2; ++p) {
-      k_ms_hist<<<f->last_nb, 256, 0, f->stream>>>(F, p);
+  if (nkept > 256 && f->npass < 2) {
+    // more than 256 clusters but only one radix pass was enqueued: run the high-digit pass now
+    for (int p = 1; p < 2; ++p) {
+      k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
+  FDBG("k_ms_hist");
       k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
-      k_ms_scatter<<<f->last_nb, 256, 0, f->stream>>>(F, p);
+  FDBG("k_ms_scan");
+      k_ms_scatter<<<nb_launch, 256, 0, f->stream>>>(F, p);
+  FDBG("k_ms_scatter");
     }
     HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
     // cluster records must be re-initialised before the accumulators are refilled
     k_rank_kept<<<16, 256, 0, f->stream>>>(F);
+  FDBG("k_rank_kept");
     k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
+  FDBG("k_ms_info");
     HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
   }
@@ -1378,6 +1416,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   f->tmp.clear();
   f->removed_ids.clear();
   k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
+  FDBG("k_zero_words");
   return FUELMI_OK;
 }
 
@@ -1439,6 +1478,7 @@ extern "C" int fuelmi_frontier_get_flags(fuelmi_frontier* f, char* flags) {
   int rc = frontier_ensure_stage(f, (size_t)n);
   if (rc) return rc;
   k_expand_flag_bits<<<fblocks(n, 256), 256, 0, f->stream>>>(f->flag.p, n, (char*)f->d_stage);
+  FDBG("k_expand_flag_bits");
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(flags, f->d_stage, (size_t)n, hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));

@@ -404,3 +404,83 @@ def test_full_size_g400_cycle_against_oracle_and_properties(fa):
         co, go = fo.bspline_cost_grad(om, x[c], 32, cf, ptd[c], st[c], en[c], 3, 3, 0.175)
         assert abs(cg[c] - co) <= 1e-6 * max(1.0, abs(co)) and np.abs(gg[c] - go).max() <= GRAD_TOL
     gm.close()
+
+
+def test_g800_streaming_inserts_incremental_esdf_and_frontier(fa):
+    """BASELINE.json configs[3]: 800x800x200 @ 0.1 m, streaming depth frames -> fusion ->
+    box-local inflate + ESDF -> incremental frontier search, frame by frame against the oracle."""
+    map_size = (80.0, 80.0, 20.0)
+    box = ((-39.0, -39.0, 0.0), (39.0, 39.0, 15.0))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    assert gm.nvox == (800, 800, 200)
+    truth = om.fixture_world(42, 3200)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    n_frames = 16
+    touched_lo = np.array(om.nvox)
+    touched_hi = np.zeros(3, dtype=int)
+    for k in range(n_frames):
+        pose = om.fixture_camera(truth, 7, k, 400, 0.3)  # a short stretch of the tour
+        pts = om.fixture_render(truth, pose, 320, 240, 2, 2)
+        om.input_points(pts, pose[:3])
+        gm.inputPointCloud(pts, pose[:3])
+        lo, hi = om.get_local_bound()
+        assert (lo, hi) == gm.getLocalBound()
+        om.inflate_local()
+        om.update_esdf()
+        gm.clearAndInflateLocalMap()
+        gm.updateESDF3d()
+        touched_lo = np.minimum(touched_lo, lo)
+        touched_hi = np.maximum(touched_hi, hi)
+        if k % 4 == 3:
+            n_o, n_g = of.search(), gf.searchFrontiers()
+            assert n_o == n_g
+            for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+                assert np.array_equal(a, b)
+            assert np.array_equal(of.removed_ids(), gf.removedIds())
+            of.commit()
+            gf.commit()
+    sl = tuple(slice(int(touched_lo[i]), int(touched_hi[i]) + 1) for i in range(3))
+    bx = (tuple(int(v) for v in touched_lo), tuple(int(v) for v in touched_hi))
+    h = gm.syncHost(occupancy=True, inflate=True, distance=True, box=bx)
+    for name, ref_arr in (("occupancy", om.occ), ("inflate", om.infl)):
+        assert np.array_equal(h[name].reshape(om.nvox)[sl], ref_arr.reshape(om.nvox)[sl]), name
+    assert np.abs(np.clip(h["distance"].reshape(om.nvox)[sl], -BIG, BIG) -
+                  np.clip(om.dist.reshape(om.nvox)[sl], -BIG, BIG)).max() <= ESDF_TOL
+    assert np.array_equal(of.flags, gf.flags())
+    gm.close()
+
+
+def test_frontier_many_small_clusters_two_radix_passes(fa):
+    """cluster_min = 0 keeps every cluster (hundreds to thousands of tiny ones): exercises the second
+    radix pass of the device grouping (> 256 clusters), the > 512-record download and the launch
+    re-estimation path."""
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    rng = np.random.default_rng(11)
+    # sprinkle isolated unknown voxels into free space: each creates a little frontier shell
+    occ = om.occ.reshape(om.nvox)
+    free = np.argwhere((occ >= om.l_min - 1e-3) & (occ <= om.l_occ))
+    pick = free[np.all(free % 5 == 2, axis=1)]  # a lattice: the shells stay separate clusters
+    occ[tuple(pick.T)] = om.l_min - 0.01
+    gm = gpu_twin(fa, om, box)
+    for cmin in (0, 3):
+        of = fo.OracleFrontier(om, cmin)
+        gf = fa.FrontierFinder(gm, cluster_min=cmin)
+        for rnd in range(2):  # second round: estimates from the first search are reused
+            om.set_updated_box(*box)
+            gm.setUpdatedBox(*box)
+            n_o, n_g = of.search(), gf.searchFrontiers()
+            assert n_o == n_g
+            if rnd == 0:
+                assert n_o > 512
+            for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+                assert np.array_equal(a, b)
+            assert np.array_equal(of.flags, gf.flags())
+            for c in range(0, n_o, 37):
+                for u, v in zip(of.cluster_info(0, c), gf.clusterInfo(0, c)):
+                    assert np.abs(u - v).max() < 1e-9
+            of.commit()
+            gf.commit()
+        gf.close()
+    gm.close()
