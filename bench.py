@@ -103,6 +103,17 @@ class GpuCycle:
         self.dev_problem = self.opt.deviceProblem(self.problem)
         self.n_clusters = 0
 
+    def step_serial(self):
+        """Diagnostic order (--serial-stages): no overlap between the ESDF chain and the frontier scan."""
+        m = self.map
+        m.clearAndInflateLocalMap()
+        m.updateESDF3d()
+        self.dev_problem.eval()
+        m.synchronize()
+        self.ff.reset()
+        m.setUpdatedBox(self.box[0], self.box[1])
+        self.n_clusters = self.ff.searchFrontiers()
+
     def step(self):
         m = self.map
         # the frontier scan reads only the occupancy state: enqueue it first (own stream), then the
@@ -194,6 +205,8 @@ def main():
     ap.add_argument("--workload", default="G400", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--serial-stages", action="store_true",
+                    help="diagnostic: run the frontier scan after the ESDF chain instead of beside it")
     args = ap.parse_args()
 
     import torch
@@ -214,6 +227,8 @@ def main():
     from fuel_amd import _lib
     map_size, box, occ, ctrl, n_known = build_inputs(args.workload, seed=42 + rank)
     cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank)
+    if args.serial_stages:
+        cyc.step = cyc.step_serial
 
     # W untimed warmup steps, then a short untimed pass with every stage bracketed by HIP events
     # (on the map's own stream) to find the dominant kernel

@@ -231,11 +231,11 @@ __device__ __forceinline__ int line_src_up(const u64* __restrict__ infl, const u
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp,
            int ZC, int nzc, int z0a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short* tile = reinterpret_cast<unsigned short*>(smem_raw);  // [ylen][ZC], ZC % 4 == 0, ZC <= 64
+  u32* tile = reinterpret_cast<u32*>(smem_raw);  // [ylen][ZC] dz^2 or INF32 (u32: the scan loop adds without sentinel tests), ZC % 4 == 0, ZC <= 64
   const int x = b.lo[0] + blockIdx.x / nzc;
   const int zc0 = z0a + (blockIdx.x % nzc) * ZC;
   const int ylen = b.hi[1] - b.lo[1] + 1;
@@ -243,7 +243,7 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   // z pass: one lane per row of the chunk; chunk source bits live in one register
   const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);  // in-box part of the chunk
   for (int yi = threadIdx.x; yi < ylen; yi += T) {
-    unsigned short* row = tile + yi * ZC;
+    u32* row = tile + yi * ZC;
     const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
     u64 bits = 0ull;
     int below = -1, above = -1;
@@ -256,7 +256,7 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
       above = line_src_up<MODE>(infl, unk, linebit, ze + 1, b.hi[2]);
     }
     for (int zi = 0; zi < ZC; ++zi) {
-      unsigned short v = INF16;
+      u32 v = INF32;
       const int z = zc0 + zi;
       if (z >= zs && z <= ze) {
         u64 lowm = bits & (~0ull >> (63 - zi));
@@ -266,7 +266,7 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
         int d = 0x7FFF;
         if (pb >= 0) d = z - pb;
         if (pa >= 0) d = min(d, pa - z);
-        if (d != 0x7FFF) v = (unsigned short)(d * d);
+        if (d != 0x7FFF) v = (u32)(d * d);
       }
       row[zi] = v;
     }
@@ -278,20 +278,20 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   const int dyi = T / G, dgi = T - dyi * G;
   int yi = threadIdx.x / G, gi = threadIdx.x - yi * G;
   for (int o = threadIdx.x; o < total; o += T) {
-    const ushort4 v0 = *reinterpret_cast<const ushort4*>(tile + yi * ZC + 4 * gi);
-    u32 b0 = v0.x == INF16 ? INF32 : v0.x, b1 = v0.y == INF16 ? INF32 : v0.y;
-    u32 b2 = v0.z == INF16 ? INF32 : v0.z, b3 = v0.w == INF16 ? INF32 : v0.w;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(tile + yi * ZC + 4 * gi);
+    u32 b0 = v0.x, b1 = v0.y, b2 = v0.z, b3 = v0.w;
     u32 mx = max(max(b0, b1), max(b2, b3));
     const int rmax = max(yi, ylen - 1 - yi);
     for (int r = 1; r <= rmax && (u32)(r * r) < mx; ++r) {
       const u32 rr = (u32)(r * r);
-      const ushort4 va = *reinterpret_cast<const ushort4*>(tile + max(yi - r, 0) * ZC + 4 * gi);
-      const ushort4 vb = *reinterpret_cast<const ushort4*>(tile + min(yi + r, ylen - 1) * ZC + 4 * gi);
-      // a clamped row repeats a candidate already seen with a smaller r: harmless
-      b0 = min(b0, min(va.x == INF16 ? INF32 : va.x + rr, vb.x == INF16 ? INF32 : vb.x + rr));
-      b1 = min(b1, min(va.y == INF16 ? INF32 : va.y + rr, vb.y == INF16 ? INF32 : vb.y + rr));
-      b2 = min(b2, min(va.z == INF16 ? INF32 : va.z + rr, vb.z == INF16 ? INF32 : vb.z + rr));
-      b3 = min(b3, min(va.w == INF16 ? INF32 : va.w + rr, vb.w == INF16 ? INF32 : vb.w + rr));
+      const uint4 va = *reinterpret_cast<const uint4*>(tile + max(yi - r, 0) * ZC + 4 * gi);
+      const uint4 vb = *reinterpret_cast<const uint4*>(tile + min(yi + r, ylen - 1) * ZC + 4 * gi);
+      // a clamped row repeats a candidate already seen with a smaller r: harmless; INF32 + r^2 stays
+      // above every finite value and below 2^31
+      b0 = min(b0, min(va.x, vb.x) + rr);
+      b1 = min(b1, min(va.y, vb.y) + rr);
+      b2 = min(b2, min(va.z, vb.z) + rr);
+      b3 = min(b3, min(va.w, vb.w) + rr);
       mx = max(max(b0, b1), max(b2, b3));
     }
     const int z = zc0 + 4 * gi;
@@ -324,7 +324,7 @@ __device__ __forceinline__ float esdf_merge_neg(float cur, u32 best, double res)
 
 // x pass, 32 columns (8 lanes x 4) per tile row; a wave covers 8 x-rows x 32 columns
 template <int OUT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][8] of uint4
@@ -332,7 +332,8 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   const int ylen = b.hi[1] - b.lo[1] + 1;
   const int ncol = ylen * zlen_a;
   const int seg = threadIdx.x & 7;
-  const int row0 = threadIdx.x >> 3;  // 0..31
+  const int row0 = threadIdx.x >> 3;  // 0..rows-1
+  const int rows = blockDim.x >> 3;
   const int col = blockIdx.x * 32 + seg * 4;
   const bool valid = col < ncol;
   const int yy = valid ? col / zlen_a : 0;
@@ -340,12 +341,12 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
   const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
 #pragma unroll 4
-  for (int xi = row0; xi < xlen; xi += 32)
+  for (int xi = row0; xi < xlen; xi += rows)
     tile[xi * 8 + seg] = valid ? *reinterpret_cast<const uint4*>(tmp + (long)(b.lo[0] + xi) * g.nyz + coloff) : inf4;
   __syncthreads();
   if (!valid) return;
   const bool full = z >= b.lo[2] && z + 3 <= b.hi[2];
-  for (int xi = row0; xi < xlen; xi += 32) {
+  for (int xi = row0; xi < xlen; xi += rows) {
     uint4 bb = tile[xi * 8 + seg];
     u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
     const int rmax = max(xi, xlen - 1 - xi);
@@ -387,12 +388,12 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
-  int zc_max = std::max(4, ((16 * 1024) / (2 * ylen)) & ~3);
+  int zc_max = std::max(4, ((32 * 1024) / (4 * ylen)) & ~3);
   zc_max = std::min(zc_max, std::min(zlen_a, 64));
   int nzc = (zlen_a + zc_max - 1) / zc_max;
   int ZC = (((zlen_a + nzc - 1) / nzc) + 3) & ~3;
   nzc = (zlen_a + ZC - 1) / ZC;
-  size_t lds = (size_t)ylen * ZC * sizeof(unsigned short);
+  size_t lds = (size_t)ylen * ZC * sizeof(u32);
   if (lds > 160 * 1024) {
     fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
     return FUELMI_ELIMIT;
@@ -400,7 +401,7 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_esdf_zy4<MODE><<<xlen * nzc, 256, lds, m->stream>>>(g, b, m->infl_bits.p, m->unk_bits.p, m->esdf_tmp, ZC, nzc,
+  k_esdf_zy4<MODE><<<xlen * nzc, 512, lds, m->stream>>>(g, b, m->infl_bits.p, m->unk_bits.p, m->esdf_tmp, ZC, nzc,
                                                         z0a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
@@ -417,7 +418,7 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int ncol = ylen * zlen_a;
-  k_esdf_x4<OUT><<<(ncol + 31) / 32, 256, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a, zlen_a);
+  k_esdf_x4<OUT><<<(ncol + 31) / 32, 1024, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a, zlen_a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }

@@ -1090,7 +1090,13 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   F.qb = f->qb.p;
   F.sb = f->sb.p;
   HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  {
+    // the scan is a chain of short latency-bound kernels and is the critical path of a plan cycle:
+    // give its stream the highest priority so the wide ESDF kernels of the map stream fill in around it
+    int lo_p = 0, hi_p = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+    HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi_p));
+  }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
   *out = f;
   return FUELMI_OK;
