@@ -137,6 +137,18 @@ k_esdf_zy(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ u
   }
 }
 
+// distance_buffer_ value of a squared voxel distance.  f32 arithmetic: best < 2^24 is exact in f32,
+// sqrtf is correctly rounded, so the result is within ~1.2 ulp (< 5e-6 m at 40 m) of the reference's
+// f64 res*sqrt(D) -- the f64 sqrt sequence made the x pass VALU-bound.
+__device__ __forceinline__ float esdf_out(u32 best, float res) {
+  return (best >= INF32) ? INFINITY : res * sqrtf((float)best);
+}
+__device__ __forceinline__ float esdf_merge_neg(float cur, u32 best, float res) {
+  if (best >= INF32) return -INFINITY;  // reference: += -(res*sqrt(DBL_MAX)) + res
+  if (best == 0u) return cur;
+  return cur - res * sqrtf((float)best) + res;
+}
+
 // x pass.  The (y,z) columns of the box are enumerated j = yy*zlen + zz; a block stages S
 // consecutive columns for every x of the box in LDS (rows of S*4 B are contiguous in memory
 // whenever the box spans full z-lines) and every lane scans its own column.
@@ -159,6 +171,7 @@ k_esdf_x(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist) {
   const int zz = valid ? col - yy * zlen : 0;
   const long coloff = (long)(b.lo[1] + yy) * g.nz + b.lo[2] + zz;
   const int rows = blockDim.x / S;
+  const float resf = (float)g.res;
   for (int xi = threadIdx.x / S; xi < xlen; xi += rows)
     tile[xi * S + c] = valid ? tmp[(long)(b.lo[0] + xi) * g.nyz + coloff] : INF32;
   __syncthreads();
@@ -174,16 +187,10 @@ k_esdf_x(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist) {
       }
     }
     const long a = (long)(b.lo[0] + xi) * g.nyz + coloff;
-    if (OUT == 0) {
-      dist[a] = (best >= INF32) ? INFINITY : (float)(g.res * sqrt((double)best));
-    } else {
-      if (best >= INF32) {
-        dist[a] = -INFINITY;  // reference: += -(res*sqrt(DBL_MAX)) + res
-      } else if (best > 0u) {
-        double dneg = g.res * sqrt((double)best);
-        dist[a] = (float)((double)dist[a] - dneg + g.res);
-      }
-    }
+    if (OUT == 0)
+      dist[a] = esdf_out(best, resf);
+    else
+      dist[a] = esdf_merge_neg(dist[a], best, resf);
   }
 }
 
@@ -255,20 +262,41 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
       below = line_src_down<MODE>(infl, unk, linebit, b.lo[2], zs - 1);
       above = line_src_up<MODE>(infl, unk, linebit, ze + 1, b.hi[2]);
     }
-    for (int zi = 0; zi < ZC; ++zi) {
-      u32 v = INF32;
-      const int z = zc0 + zi;
-      if (z >= zs && z <= ze) {
-        u64 lowm = bits & (~0ull >> (63 - zi));
-        int pb = lowm ? (63 - __builtin_clzll(lowm)) + zc0 : below;
-        u64 him = bits >> zi;
-        int pa = him ? zi + __builtin_ctzll(him) + zc0 : above;
-        int d = 0x7FFF;
-        if (pb >= 0) d = z - pb;
-        if (pa >= 0) d = min(d, pa - z);
-        if (d != 0x7FFF) v = (u32)(d * d);
-      }
-      row[zi] = v;
+    // two sweeps over the chunk (distance to the nearest source below / above), 4 voxels per LDS
+    // access.  Columns outside the box get garbage that the y pass never stores nor mixes in (a
+    // column only reads itself in other rows).
+    const u32 BIGD = 1u << 20;  // "no source yet": stays >= BIGD after any number of +1 steps
+    u32 d = below >= 0 ? (u32)(zs - 1 - below) : BIGD;
+    for (int zi = 0; zi < ZC; zi += 4) {
+      const u32 nib = (u32)(bits >> zi);
+      uint4 o;
+      d = (nib & 1u) ? 0u : d + 1u;
+      o.x = d;
+      d = (nib & 2u) ? 0u : d + 1u;
+      o.y = d;
+      d = (nib & 4u) ? 0u : d + 1u;
+      o.z = d;
+      d = (nib & 8u) ? 0u : d + 1u;
+      o.w = d;
+      *reinterpret_cast<uint4*>(row + zi) = o;
+    }
+    d = above >= 0 ? (u32)(above - (ze + 1)) : BIGD;
+    for (int zi = ZC - 4; zi >= 0; zi -= 4) {
+      const u32 nib = (u32)(bits >> zi);
+      uint4 o = *reinterpret_cast<const uint4*>(row + zi);
+      d = (nib & 8u) ? 0u : d + 1u;
+      o.w = min(o.w, d);
+      d = (nib & 4u) ? 0u : d + 1u;
+      o.z = min(o.z, d);
+      d = (nib & 2u) ? 0u : d + 1u;
+      o.y = min(o.y, d);
+      d = (nib & 1u) ? 0u : d + 1u;
+      o.x = min(o.x, d);
+      o.x = o.x >= BIGD ? INF32 : o.x * o.x;
+      o.y = o.y >= BIGD ? INF32 : o.y * o.y;
+      o.z = o.z >= BIGD ? INF32 : o.z * o.z;
+      o.w = o.w >= BIGD ? INF32 : o.w * o.w;
+      *reinterpret_cast<uint4*>(row + zi) = o;
     }
   }
   __syncthreads();
@@ -313,15 +341,6 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   }
 }
 
-__device__ __forceinline__ float esdf_out(u32 best, double res) {
-  return (best >= INF32) ? INFINITY : (float)(res * sqrt((double)best));
-}
-__device__ __forceinline__ float esdf_merge_neg(float cur, u32 best, double res) {
-  if (best >= INF32) return -INFINITY;
-  if (best == 0u) return cur;
-  return (float)((double)cur - res * sqrt((double)best) + res);
-}
-
 // x pass, 32 columns (8 lanes x 4) per tile row; a wave covers 8 x-rows x 32 columns
 template <int OUT>
 __global__ void __launch_bounds__(1024)
@@ -340,6 +359,7 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   const int z = z0a + (valid ? col - yy * zlen_a : 0);
   const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
   const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
+  const float resf = (float)g.res;
 #pragma unroll 4
   for (int xi = row0; xi < xlen; xi += rows)
     tile[xi * 8 + seg] = valid ? *reinterpret_cast<const uint4*>(tmp + (long)(b.lo[0] + xi) * g.nyz + coloff) : inf4;
@@ -364,18 +384,18 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
     if (OUT == 0) {
       if (full) {
         *reinterpret_cast<float4*>(dst) =
-            make_float4(esdf_out(bb.x, g.res), esdf_out(bb.y, g.res), esdf_out(bb.z, g.res), esdf_out(bb.w, g.res));
+            make_float4(esdf_out(bb.x, resf), esdf_out(bb.y, resf), esdf_out(bb.z, resf), esdf_out(bb.w, resf));
       } else {
-        if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_out(bb.x, g.res);
-        if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_out(bb.y, g.res);
-        if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_out(bb.z, g.res);
-        if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_out(bb.w, g.res);
+        if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_out(bb.x, resf);
+        if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_out(bb.y, resf);
+        if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_out(bb.z, resf);
+        if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_out(bb.w, resf);
       }
     } else {
-      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_merge_neg(dst[0], bb.x, g.res);
-      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_merge_neg(dst[1], bb.y, g.res);
-      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_merge_neg(dst[2], bb.z, g.res);
-      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_merge_neg(dst[3], bb.w, g.res);
+      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_merge_neg(dst[0], bb.x, resf);
+      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_merge_neg(dst[1], bb.y, resf);
+      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_merge_neg(dst[2], bb.z, resf);
+      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_merge_neg(dst[3], bb.w, resf);
     }
   }
 }

@@ -394,10 +394,19 @@ __global__ void __launch_bounds__(256) k_ccl_local(Geo g, FArgs F, int TX, int T
   // (a vertical frontier wall puts 20-30 cells into one 32-voxel segment; a per-segment loop would
   // leave one lane with all the dependent LDS work).  For a fixed x the TY lines of the tile are
   // contiguous in address, hence contiguous in compact index: TX ranges per tile.
-  for (int lx = 0; lx < nxl; ++lx) {
-    const long a_lo = (long)(x0 + lx) * g.nyz + (long)y0 * nz;
-    const u32 r0 = rowr[2 * lx], r1 = rowr[2 * lx + 1];
-    for (u32 i = r0 + threadIdx.x; i < r1; i += 256) {
+  u32 total = 0u;
+  for (int lx = 0; lx < nxl; ++lx) total += rowr[2 * lx + 1] - rowr[2 * lx];
+  for (u32 t = threadIdx.x; t < total; t += 256) {
+    {
+      int lx = 0;
+      u32 tt = t;
+      for (; lx < nxl - 1; ++lx) {  // which x-row of the tile holds the t-th cell (<= TX steps)
+        const u32 n = rowr[2 * lx + 1] - rowr[2 * lx];
+        if (tt < n) break;
+        tt -= n;
+      }
+      const u32 i = rowr[2 * lx] + tt;
+      const long a_lo = (long)(x0 + lx) * g.nyz + (long)y0 * nz;
       const int rem = (int)(F.cell_adr[i] - (u32)a_lo);  // offset inside this x-row of the tile
       const int ly = rem / nz, z = rem - ly * nz;
       const int line = lx * TY + ly, c = z >> 5, zz = z & 31;
@@ -425,10 +434,17 @@ __global__ void __launch_bounds__(256) k_ccl_local(Geo g, FArgs F, int TX, int T
   }
   __syncthreads();
   // 3: parent[cell] = compact index of its tile-local root
-  for (int lx = 0; lx < nxl; ++lx) {
-    const long a_lo = (long)(x0 + lx) * g.nyz + (long)y0 * nz;
-    const u32 r0 = rowr[2 * lx], r1 = rowr[2 * lx + 1];
-    for (u32 i = r0 + threadIdx.x; i < r1; i += 256) {
+  for (u32 t = threadIdx.x; t < total; t += 256) {
+    {
+      int lx = 0;
+      u32 tt = t;
+      for (; lx < nxl - 1; ++lx) {
+        const u32 n = rowr[2 * lx + 1] - rowr[2 * lx];
+        if (tt < n) break;
+        tt -= n;
+      }
+      const u32 i = rowr[2 * lx] + tt;
+      const long a_lo = (long)(x0 + lx) * g.nyz + (long)y0 * nz;
       const int rem = (int)(F.cell_adr[i] - (u32)a_lo);
       const int ly = rem / nz, z = rem - ly * nz;
       const u32 v = (u32)((lx * TY + ly) * nz + z);
@@ -957,6 +973,8 @@ struct fuelmi_frontier {
   size_t pin_bytes = 0;
   int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
   int last_nkept = 0, nb_launch = 0, npass = 1;
+  u32 last_nout = 0, spec_cells = 0;
+  int spec_fin = 1;
   bool pending = false, search_empty = false;
   std::unique_ptr<StageScope> scope;
   std::vector<int> slot2rank;
@@ -1292,6 +1310,15 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   u32* h_cells = h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
   HIPCHK(hipMemcpyAsync(counts, F.counts, 16 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
+  // speculative copy of the grouped cells + chunk records, sized from the previous search, so that
+  // _search_end normally needs a single wait instead of a second host round trip
+  f->spec_fin = f->last_nkept > 256 ? 0 : 1;
+  f->spec_cells = (u32)std::min<size_t>(F.cap_q, std::max<size_t>(65536, (size_t)f->last_nout * 5 / 4 + 4096));
+  const u32 spec_chunks = (f->spec_cells + SZ_CH - 1) / SZ_CH;
+  HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[f->spec_fin], (size_t)f->spec_cells * sizeof(u32), hipMemcpyDeviceToHost,
+                        f->stream));
+  HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)spec_chunks * 10 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+  (void)h_cells;
   return FUELMI_OK;
 }
 
@@ -1328,7 +1355,9 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   const u32 nq = counts[0], nkept = counts[3], n_out = counts[5];
   f->last_nb = (int)((nq + MS_CH - 1) / MS_CH);
   f->last_nkept = (int)nkept;
+  bool redone = false;
   if (nkept > 256 && f->npass < 2) {
+    redone = true;
     // more than 256 clusters but only one radix pass was enqueued: run the high-digit pass now
     for (int p = 1; p < 2; ++p) {
       k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
@@ -1353,11 +1382,14 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   if (nkept > HEAD)
     HIPCHK(hipMemcpyAsync(h_rec + HEAD, F.krec + HEAD, (size_t)(nkept - HEAD) * sizeof(KeptRec), hipMemcpyDeviceToHost,
                           f->stream));
-  if (n_out) {
+  f->last_nout = n_out;
+  bool more = nkept > HEAD;
+  if (n_out && (redone || fin != f->spec_fin || n_out > f->spec_cells)) {  // speculation missed: fetch it all
     HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[fin], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)nchunk * 10 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+    more = true;
   }
-  HIPCHK(hipStreamSynchronize(f->stream));
+  if (more) HIPCHK(hipStreamSynchronize(f->stream));
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
     const u32 r = rec[0];
