@@ -79,6 +79,11 @@ struct FArgs {
   u32* ms_hist;      // [256][ms_nb_max]
   u32 ms_nb_max;
   u32* info_part;                // [cap_q / SZ_CH + 1][10] per-chunk records (key, sums, min, max)
+  // result staging in pinned HOST memory, written by the last kernels themselves (no blit copies):
+  u32* h_counts;          // [16]
+  struct KeptRec* h_rec;  // [cap_kept]
+  u32* h_part;            // like info_part
+  u32* h_cells;           // [cap_q] grouped cell addresses
 };
 
 #define MS_CH 2048  // cells per multisplit block (256 threads x 8)
@@ -460,41 +465,70 @@ __global__ void __launch_bounds__(256) k_ccl_local(Geo g, FArgs F, int TX, int T
   }
 }
 
-// global merge: neighbour relations crossing a tile face (lower-address side only)
+// global merge: neighbour relations crossing a tile face (lower-address side only).
+// A wall crossing a tile face yields dozens of adjacent cell pairs that all join the same two
+// tile-local components; since k_ccl_local left parent[] flat, the pair of tile roots identifies the
+// union, and each wave issues one union per DISTINCT root pair (the dependent atomics of the
+// lock-free union-find, and the same-address traffic on a huge component's roots, are what costs).
 __global__ void __launch_bounds__(256) k_union(Geo g, FArgs F, int TX, int TY) {
   const u32 nq = F.counts[0];
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
-    long a = F.cell_adr[i];
-    int x = (int)(a / g.nyz);
-    int r = (int)(a - (long)x * g.nyz);
-    int y = r / g.nz, z = r - y * g.nz;
-    const int lx = (x - F.qbox.lo[0]) % TX, ly = (y - F.qbox.lo[1]) % TY;
-    const bool zlo = z > 0, zhi = z < g.nz - 1;
+  const u32 nq_r = (nq + 63u) & ~63u;
+  const int lane = threadIdx.x & 63;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq_r; i += gridDim.x * blockDim.x) {
+    const bool live = i < nq;
     // the four lower z-lines (dx,dy) = (-1,-1) (-1,0) (-1,1) (0,-1): one 3-bit window each (dz -1,0,+1);
     // a line inside this cell's tile was already handled in LDS
     const int ldx[4] = {-1, -1, -1, 0}, ldy[4] = {-1, 0, 1, -1};
-    u32 pat[4];
-    long nb0[4];
+    u32 pat[4] = {0u, 0u, 0u, 0u};
+    long nb0[4] = {0, 0, 0, 0};
+    u32 ri = 0u;
+    if (live) {
+      long a = F.cell_adr[i];
+      int x = (int)(a / g.nyz);
+      int r = (int)(a - (long)x * g.nyz);
+      int y = r / g.nz, z = r - y * g.nz;
+      const int lx = (x - F.qbox.lo[0]) % TX, ly = (y - F.qbox.lo[1]) % TY;
+      const bool zlo = z > 0, zhi = z < g.nz - 1;
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const int xx = x + ldx[l], yy = y + ldy[l];
-      const bool cross = (ldx[l] < 0 && lx == 0) || (ldy[l] < 0 && ly == 0) || (ldy[l] > 0 && ly == TY - 1);
-      const bool ok = cross && xx >= 0 && yy >= 0 && yy < g.ny;
-      nb0[l] = a + (long)ldx[l] * g.nyz + (long)ldy[l] * g.nz - 1;
-      u32 p = ok ? (u32)(plane_window(F.qb, nb0[l]) & 7ull) : 0u;
-      if (!zlo) p &= ~1u;
-      if (!zhi) p &= ~4u;
-      pat[l] = p;
+      for (int l = 0; l < 4; ++l) {
+        const int xx = x + ldx[l], yy = y + ldy[l];
+        const bool cross = (ldx[l] < 0 && lx == 0) || (ldy[l] < 0 && ly == 0) || (ldy[l] > 0 && ly == TY - 1);
+        const bool ok = cross && xx >= 0 && yy >= 0 && yy < g.ny;
+        nb0[l] = a + (long)ldx[l] * g.nyz + (long)ldy[l] * g.nz - 1;
+        u32 p = ok ? (u32)(plane_window(F.qb, nb0[l]) & 7ull) : 0u;
+        if (!zlo) p &= ~1u;
+        if (!zhi) p &= ~4u;
+        pat[l] = p;
+      }
+      if (pat[0] | pat[1] | pat[2] | pat[3]) ri = F.parent[i];  // tile root (or already an ancestor of it)
     }
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-      if (pat[l] == 0u) continue;
+      if (!__ballot(pat[l] != 0u)) continue;
       // z-adjacent neighbours of one line are joined by their own (0,0,-1) unions: link once per
       // run; only the pattern 101 holds two separate runs
-      const u32 j = rank_q(F, nb0[l] + __builtin_ctz(pat[l]));
-      if (j < F.cap_q) {
-        uf_union(F.parent, i, j);
-        if (pat[l] == 5u && j + 1 < F.cap_q) uf_union(F.parent, i, j + 1);
+      u32 j = F.cap_q;
+      if (pat[l]) j = rank_q(F, nb0[l] + __builtin_ctz(pat[l]));
+      for (int k = 0; k < 2; ++k) {
+        bool act = (k == 0) ? (pat[l] != 0u) : (pat[l] == 5u);
+        const u32 jj = j + (u32)k;
+        u32 rj = 0u;
+        if (act) act = jj < F.cap_q;
+        if (act) {
+          rj = F.parent[jj];
+          act = rj != ri;
+        }
+        u64 todo = __ballot(act);
+        if (!todo) continue;
+        bool lead = false;
+        while (todo) {
+          const int leader = __builtin_ctzll(todo);
+          const u32 ki = (u32)__shfl((int)ri, leader, 64), kj = (u32)__shfl((int)rj, leader, 64);
+          const u64 same = __ballot(act && ri == ki && rj == kj) & todo;
+          if (lane == leader) lead = true;
+          todo &= ~same;
+        }
+        if (lead) uf_union(F.parent, ri, rj);
       }
     }
   }
@@ -532,46 +566,97 @@ __device__ __forceinline__ void wave_min_claim(u32* claim, bool active, u32 root
 // claims: own cells inside the scan box, then NQ seeds adjacent to a component
 __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
   const u32 nq = F.counts[0], ns = F.counts[1];
-  const u32 nq_r = (nq + 63u) & ~63u, ns_r = (ns + 63u) & ~63u;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq_r; i += gridDim.x * blockDim.x) {
-    bool active = false;
-    u32 a = 0, r = 0;
-    if (i < nq) {
-      a = F.cell_adr[i];
-      if (in_box(g, F.sbox, a)) {
-        active = true;
-        r = F.parent[i];
+  const u32 ns_r = (ns + 63u) & ~63u;
+  // Own cells: cell_adr ascends with the compact index, so the lowest claimer of a component inside
+  // a 1024-cell chunk is simply its first active cell.  One atomic per chunk for the chunk's leading
+  // component (a frontier surface is mostly ONE component: per-wave atomics on its claim word were
+  // thousands of same-address operations), wave-aggregated atomics for the other components.
+  __shared__ u32 s_root[16], s_adr[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 base = blockIdx.x * 1024u; base < nq; base += gridDim.x * 1024u) {
+    bool act[4];
+    u32 rt[4], ad[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = base + (u32)k * 256u + threadIdx.x;
+      act[k] = false;
+      rt[k] = 0u;
+      ad[k] = 0u;
+      if (i < nq) {
+        ad[k] = F.cell_adr[i];
+        if (in_box(g, F.sbox, ad[k])) {
+          act[k] = true;
+          rt[k] = F.parent[i];
+        }
+      }
+      const u64 m = __ballot(act[k]);
+      if (lane == 0) s_root[k * 4 + wave] = NOCLAIM;
+      if (m && lane == __builtin_ctzll(m)) {
+        s_root[k * 4 + wave] = rt[k];
+        s_adr[k * 4 + wave] = ad[k];
       }
     }
-    wave_min_claim(F.claim, active, r, a);
+    __syncthreads();
+    u32 key0 = NOCLAIM, adr0 = 0u;
+    for (int e = 15; e >= 0; --e)
+      if (s_root[e] != NOCLAIM) {
+        key0 = s_root[e];
+        adr0 = s_adr[e];
+      }
+    if (threadIdx.x == 0 && key0 != NOCLAIM) atomicMin(&F.claim[key0], adr0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool slow = act[k] && rt[k] != key0;
+      if (__ballot(slow)) wave_min_claim(F.claim, slow, rt[k], ad[k]);
+    }
+    __syncthreads();
   }
+  // NQ seeds: claim every component touching the seed's 26-neighbourhood.  The nine z-lines around
+  // the seed are read as 3-bit windows first (independent loads); only lines that hold Q0 cells
+  // take the dependent rank -> root -> claim chain, once per run (101 holds two runs).
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < ns_r; i += gridDim.x * blockDim.x) {
     const bool live = i < ns;
-    long a = live ? F.seed_adr[i] : 0;
-    int x = (int)(a / g.nyz);
-    int rr = (int)(a - (long)x * g.nyz);
-    int y = rr / g.nz, z = rr - y * g.nz;
+    const long a = live ? F.seed_adr[i] : 0;
+    u32 pats = 0u;
+    if (live) {
+      const int x = (int)(a / g.nyz);
+      const int rr = (int)(a - (long)x * g.nyz);
+      const int y = rr / g.nz, z = rr - y * g.nz;
+#pragma unroll
+      for (int l = 0; l < 9; ++l) {
+        const int dx = l / 3 - 1, dy = l % 3 - 1;
+        const int xx = x + dx, yy = y + dy;
+        if (xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny) continue;
+        u32 p = (u32)(plane_window(F.qb, a + (long)dx * g.nyz + (long)dy * g.nz - 1) & 7ull);
+        if (z == 0) p &= ~1u;
+        if (z == g.nz - 1) p &= ~4u;
+        pats |= p << (3 * l);
+      }
+    }
     u32 last = NOCLAIM;
-    for (int k = 0; k < 27; ++k) {
-      if (k == 13) continue;
-      int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
-      int xx = x + dx, yy = y + dy, zz = z + dz;
-      bool active = live && !(xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz);
-      u32 r = 0;
+    while (__ballot(pats != 0u)) {
+      bool active = pats != 0u;
+      u32 r = 0u, r2 = 0u;
+      bool two = false;
       if (active) {
-        long an = a + (long)dx * g.nyz + (long)dy * g.nz + dz;
-        active = (F.qb[an >> 6] >> (an & 63)) & 1ull;
+        const int l = __builtin_ctz(pats) / 3;
+        const u32 p = (pats >> (3 * l)) & 7u;
+        pats &= ~(7u << (3 * l));
+        const int dx = l / 3 - 1, dy = l % 3 - 1;
+        const u32 j = rank_q(F, a + (long)dx * g.nyz + (long)dy * g.nz - 1 + __builtin_ctz(p));
+        active = j < F.cap_q;
         if (active) {
-          u32 j = rank_q(F, an);
-          active = j < F.cap_q;
-          if (active) {
-            r = F.parent[j];
-            if (r == last) active = false;  // this seed already claimed that component
-            last = r;
+          r = F.parent[j];
+          if (p == 5u && j + 1 < F.cap_q) {
+            r2 = F.parent[j + 1];
+            two = r2 != r;
           }
+          if (r == last) active = false;  // this seed already claimed that component
+          last = r;
         }
       }
       if (__ballot(active)) wave_min_claim(F.claim, active, r, (u32)a);
+      if (__ballot(two)) wave_min_claim(F.claim, two, r2, (u32)a);
     }
   }
 }
@@ -878,6 +963,7 @@ __global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
       // the grouped one yet (the host then re-runs the grouping and this kernel): ignore them
       const bool in = i < n && kk < nkept;
       const u32 a = in ? val[i] : 0u;
+      if (i < n) F.h_cells[i] = a;  // posted write over PCIe, 16 B.. 256 B per wave, coalesced
       const u32 x = a / (u32)g.nyz, r = a - x * (u32)g.nyz, y = r / (u32)g.nz, z = r - y * (u32)g.nz;
       if (in && kk == key0) {
         sx += x, sy += y, sz += z;
@@ -930,7 +1016,7 @@ __global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
         nx_ = min(nx_, s_red[w][3]), ny_ = min(ny_, s_red[w][4]), nz_ = min(nz_, s_red[w][5]);
         mx = max(mx, s_red[w][6]), my = max(my, s_red[w][7]), mz = max(mz, s_red[w][8]);
       }
-      u32* rec = F.info_part + (size_t)(base / SZ_CH) * 10;
+      u32* rec = F.h_part + (size_t)(base / SZ_CH) * 10;
       rec[0] = key0, rec[1] = sx, rec[2] = sy, rec[3] = sz;
       rec[4] = nx_, rec[5] = ny_, rec[6] = nz_, rec[7] = mx, rec[8] = my, rec[9] = mz;
     }
@@ -938,6 +1024,15 @@ __global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
   }
 }
 
+// counts + cluster records -> pinned host memory (after k_ms_info's atomics on the records)
+__global__ void __launch_bounds__(256) k_pack(FArgs F) {
+  const u32 nkept = min(F.counts[3], F.cap_kept);
+  const u32 words = nkept * (u32)(sizeof(KeptRec) / 4);
+  const u32* src = reinterpret_cast<const u32*>(F.krec);
+  u32* dst = reinterpret_cast<u32*>(F.h_rec);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < 16) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
+}
 
 __global__ void k_zero_words(u64* p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
@@ -973,8 +1068,6 @@ struct fuelmi_frontier {
   size_t pin_bytes = 0;
   int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
   int last_nkept = 0, nb_launch = 0, npass = 1;
-  u32 last_nout = 0, spec_cells = 0;
-  int spec_fin = 1;
   bool pending = false, search_empty = false;
   std::unique_ptr<StageScope> scope;
   std::vector<int> slot2rank;
@@ -1227,6 +1320,16 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->search_empty = empty;
   if (empty) return FUELMI_OK;
 
+  // results land in one pinned host buffer [counts | cluster records | chunk records | cells]
+  if (!f->h_pin) {
+    f->pin_bytes = 64 + (size_t)F.cap_kept * sizeof(KeptRec) + ((size_t)F.cap_q / SZ_CH + 2) * 40 + (size_t)F.cap_q * 4;
+    HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
+    F.h_counts = reinterpret_cast<u32*>(f->h_pin);
+    F.h_rec = reinterpret_cast<KeptRec*>(F.h_counts + 16);
+    F.h_part = reinterpret_cast<u32*>(F.h_rec + F.cap_kept);
+    F.h_cells = F.h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
+  }
+
   // words to process: everything the BFS could reach = Q box, plus the scan box
   auto adr = [&](const int* id) { return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2]; };
   long a_lo = adr(F.sbox.lo), a_hi = adr(F.sbox.hi);
@@ -1298,27 +1401,9 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   FDBG("k_ms_info");
   HIPCHK(hipGetLastError());
 
-  // ---- results: one pinned staging buffer [counts | cluster records | chunk records | cells] ----
-  const u32 HEAD = std::min<u32>(F.cap_kept, 512u);
-  if (!f->h_pin) {
-    f->pin_bytes = 64 + (size_t)F.cap_kept * sizeof(KeptRec) + ((size_t)F.cap_q / SZ_CH + 2) * 40 + (size_t)F.cap_q * 4;
-    HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
-  }
-  u32* counts = reinterpret_cast<u32*>(f->h_pin);
-  KeptRec* h_rec = reinterpret_cast<KeptRec*>(counts + 16);
-  u32* h_part = reinterpret_cast<u32*>(h_rec + F.cap_kept);
-  u32* h_cells = h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
-  HIPCHK(hipMemcpyAsync(counts, F.counts, 16 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
-  HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
-  // speculative copy of the grouped cells + chunk records, sized from the previous search, so that
-  // _search_end normally needs a single wait instead of a second host round trip
-  f->spec_fin = f->last_nkept > 256 ? 0 : 1;
-  f->spec_cells = (u32)std::min<size_t>(F.cap_q, std::max<size_t>(65536, (size_t)f->last_nout * 5 / 4 + 4096));
-  const u32 spec_chunks = (f->spec_cells + SZ_CH - 1) / SZ_CH;
-  HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[f->spec_fin], (size_t)f->spec_cells * sizeof(u32), hipMemcpyDeviceToHost,
-                        f->stream));
-  HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)spec_chunks * 10 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
-  (void)h_cells;
+  k_pack<<<8, 256, 0, f->stream>>>(F);
+  FDBG("k_pack");
+  HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
 
@@ -1341,11 +1426,10 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   const Geo& g = m->g;
   FArgs& F = f->F;
   const int nb_launch = f->nb_launch;
-  const u32 HEAD = std::min<u32>(F.cap_kept, 512u);
-  u32* counts = reinterpret_cast<u32*>(f->h_pin);
-  KeptRec* h_rec = reinterpret_cast<KeptRec*>(counts + 16);
-  u32* h_part = reinterpret_cast<u32*>(h_rec + F.cap_kept);
-  u32* h_cells = h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
+  u32* counts = F.h_counts;
+  KeptRec* h_rec = F.h_rec;
+  const u32* h_part = F.h_part;
+  const u32* h_cells = F.h_cells;
   HIPCHK(hipStreamSynchronize(f->stream));
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
@@ -1355,41 +1439,27 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   const u32 nq = counts[0], nkept = counts[3], n_out = counts[5];
   f->last_nb = (int)((nq + MS_CH - 1) / MS_CH);
   f->last_nkept = (int)nkept;
-  bool redone = false;
   if (nkept > 256 && f->npass < 2) {
-    redone = true;
     // more than 256 clusters but only one radix pass was enqueued: run the high-digit pass now
     for (int p = 1; p < 2; ++p) {
       k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
-  FDBG("k_ms_hist");
+      FDBG("k_ms_hist");
       k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
-  FDBG("k_ms_scan");
+      FDBG("k_ms_scan");
       k_ms_scatter<<<nb_launch, 256, 0, f->stream>>>(F, p);
-  FDBG("k_ms_scatter");
+      FDBG("k_ms_scatter");
     }
-    HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
     // cluster records must be re-initialised before the accumulators are refilled
     k_rank_kept<<<16, 256, 0, f->stream>>>(F);
-  FDBG("k_rank_kept");
+    FDBG("k_rank_kept");
     k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
-  FDBG("k_ms_info");
-    HIPCHK(hipMemcpyAsync(h_rec, F.krec, (size_t)HEAD * sizeof(KeptRec), hipMemcpyDeviceToHost, f->stream));
+    FDBG("k_ms_info");
+    k_pack<<<8, 256, 0, f->stream>>>(F);
+    FDBG("k_pack");
     HIPCHK(hipStreamSynchronize(f->stream));
   }
   if (nkept == 0) return FUELMI_OK;
-  const int fin = nkept <= 256 ? 1 : 0;
   const u32 nchunk = (n_out + SZ_CH - 1) / SZ_CH;
-  if (nkept > HEAD)
-    HIPCHK(hipMemcpyAsync(h_rec + HEAD, F.krec + HEAD, (size_t)(nkept - HEAD) * sizeof(KeptRec), hipMemcpyDeviceToHost,
-                          f->stream));
-  f->last_nout = n_out;
-  bool more = nkept > HEAD;
-  if (n_out && (redone || fin != f->spec_fin || n_out > f->spec_cells)) {  // speculation missed: fetch it all
-    HIPCHK(hipMemcpyAsync(h_cells, F.ms_val[fin], (size_t)n_out * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(h_part, F.info_part, (size_t)nchunk * 10 * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
-    more = true;
-  }
-  if (more) HIPCHK(hipStreamSynchronize(f->stream));
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
     const u32 r = rec[0];

@@ -1,8 +1,8 @@
 #!/bin/bash
 # tuning aid: k_ccl_local / k_union time vs tile shape
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for t in 7x16 4x8 2x8 8x32 4x32 1x16; do
-  FUELMI_CCL_TILE=$t rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sweep_$t -o s -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+for t in ${TILES:-7x16 4x8 2x8 8x32 4x32 1x16}; do
+  FUELMI_CCL_TILE=$t rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sweep_$t -o s -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --serial-stages > /dev/null 2>&1
   python - <<PY
 import csv
 rows=list(csv.reader(open('gpurun_out/sweep_$t/s_kernel_stats.csv')))
