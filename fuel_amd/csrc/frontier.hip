@@ -47,11 +47,19 @@ struct KeptRec {  // one per kept cluster, in rank order (ascending claimer addr
   u32 pad[2];
 };
 
+// the per-search part of the arguments lives in device memory (refreshed by k_load_var from a pinned
+// host copy), so that the kernel chain can be replayed as a hipGraph with constant kernel arguments
+struct FVar {
+  Box3 sbox;   // scanned index box, inclusive
+  int w0;      // first word processed (multiple of 256)
+  int nwords;  // words processed (multiple of 256)
+  int nblocks; // nwords / 256
+  int pad;
+};
+
 struct FArgs {
   Box3 qbox;  // Q0 index box (isInBox & z >= iz_min), inclusive
-  Box3 sbox;  // scanned index box, inclusive
-  int w0;     // first word processed (multiple of 256)
-  int nwords; // words processed (multiple of 256)
+  const FVar* var;
   u32 cap_q, cap_s;
   int cluster_min;
   const u64* occ;
@@ -176,12 +184,14 @@ __global__ void k_clear_flags(u64* flag, const int* __restrict__ cells, const in
 // predicate planes + in-block packed prefix of their popcounts
 __global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
   __shared__ u64 wsum[4];
+  const FVar& V = *F.var;
+  if ((int)blockIdx.x >= V.nblocks) return;
   const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = F.w0 + rel;
+  const int w = V.w0 + rel;
   u64 q = 0ull, s = 0ull;
   if (w < g.W) {
     u64 z0, zl, y0, yl, mq, ms;
-    word_masks(g, w, F.qbox, F.sbox, z0, zl, y0, yl, mq, ms);
+    word_masks(g, w, F.qbox, V.sbox, z0, zl, y0, yl, mq, ms);
     if ((mq | ms) != 0ull) {
       u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~F.flag[w];
       q = f1 & mq;
@@ -207,7 +217,8 @@ __global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
 }
 
 // exclusive scan of the block sums (single block) + totals
-__global__ void __launch_bounds__(256) k_scan_sums(FArgs F, int nblocks) {
+__global__ void __launch_bounds__(256) k_scan_sums(FArgs F) {
+  const int nblocks = F.var->nblocks;
   __shared__ u64 part[256];
   const int per = (nblocks + 255) / 256;
   const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
@@ -249,21 +260,22 @@ __global__ void __launch_bounds__(256) k_scan_sums(FArgs F, int nblocks) {
 
 __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
   int w = (int)(a >> 6);
-  int rel = w - F.w0;
+  int rel = w - F.var->w0;
   u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
   return (u32)pk + (u32)__popcll(F.qb[w] & ((1ull << (a & 63)) - 1ull));
 }
 __device__ __forceinline__ u32 rank_s(const FArgs& F, long a) {
   int w = (int)(a >> 6);
-  int rel = w - F.w0;
+  int rel = w - F.var->w0;
   u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
   return (u32)(pk >> 32) + (u32)__popcll(F.sb[w] & ((1ull << (a & 63)) - 1ull));
 }
 
 // ordered compaction of Q0 cells and NQ seeds
 __global__ void __launch_bounds__(256) k_compact(Geo g, FArgs F) {
+  if ((int)blockIdx.x >= F.var->nblocks) return;
   const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = F.w0 + rel;
+  const int w = F.var->w0 + rel;
   if (w >= g.W) return;
   u64 q = F.qb[w], s = F.sb[w];
   if ((q | s) == 0ull) return;
@@ -567,6 +579,7 @@ __device__ __forceinline__ void wave_min_claim(u32* claim, bool active, u32 root
 __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
   const u32 nq = F.counts[0], ns = F.counts[1];
   const u32 ns_r = (ns + 63u) & ~63u;
+  const Box3 sbox = F.var->sbox;
   // Own cells: cell_adr ascends with the compact index, so the lowest claimer of a component inside
   // a 1024-cell chunk is simply its first active cell.  One atomic per chunk for the chunk's leading
   // component (a frontier surface is mostly ONE component: per-wave atomics on its claim word were
@@ -584,7 +597,7 @@ __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
       ad[k] = 0u;
       if (i < nq) {
         ad[k] = F.cell_adr[i];
-        if (in_box(g, F.sbox, ad[k])) {
+        if (in_box(g, sbox, ad[k])) {
           act[k] = true;
           rt[k] = F.parent[i];
         }
@@ -727,8 +740,9 @@ __global__ void __launch_bounds__(256) k_sizes(Geo g, FArgs F) {
 
 // flags (all claimed cells + all NQ seeds), kept-cluster list, per-cell kept slot
 __global__ void __launch_bounds__(256) k_finalize(Geo g, FArgs F) {
+  if ((int)blockIdx.x >= F.var->nblocks) return;
   const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = F.w0 + rel;
+  const int w = F.var->w0 + rel;
   if (w >= g.W) return;
   u64 q = F.qb[w], s = F.sb[w];
   if ((q | s) == 0ull) return;
@@ -1034,6 +1048,10 @@ __global__ void __launch_bounds__(256) k_pack(FArgs F) {
   if (blockIdx.x == 0 && threadIdx.x < 16) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
 }
 
+__global__ void k_load_var(const FVar* __restrict__ h, FVar* __restrict__ d) {
+  const int n = (int)(sizeof(FVar) / 4);
+  if ((int)threadIdx.x < n) reinterpret_cast<u32*>(d)[threadIdx.x] = reinterpret_cast<const u32*>(h)[threadIdx.x];
+}
 __global__ void k_zero_words(u64* p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
 }
@@ -1048,6 +1066,34 @@ __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* _
 struct HCluster {
   std::vector<int> cells;  // ascending voxel addresses
   double avg[3], bmin[3], bmax[3];
+  // A freshly found cluster (tmp_frontiers_) still lives in the pinned result buffer: its cell list is
+  // copied out only when somebody keeps it (commit) -- a 140 k-cell surface costs ~25 us to copy,
+  // 10 % of a plan cycle, and the buffer stays valid until the next search.
+  const int* lazy = nullptr;
+  u32 lazy_n = 0;
+  int lazy_seed = -1;  // NQ seed address to merge in, or -1
+  size_t size() const { return lazy ? (size_t)lazy_n + (lazy_seed >= 0 ? 1u : 0u) : cells.size(); }
+  void copy_to(int* out) const {  // ascending addresses
+    if (!lazy) {
+      if (!cells.empty()) memcpy(out, cells.data(), cells.size() * sizeof(int));
+      return;
+    }
+    if (lazy_seed < 0) {
+      if (lazy_n) memcpy(out, lazy, (size_t)lazy_n * sizeof(int));
+      return;
+    }
+    const size_t k = (size_t)(std::lower_bound(lazy, lazy + lazy_n, lazy_seed) - lazy);
+    if (k) memcpy(out, lazy, k * sizeof(int));
+    out[k] = lazy_seed;
+    if (lazy_n > k) memcpy(out + k + 1, lazy + k, (lazy_n - k) * sizeof(int));
+  }
+  void materialize() {
+    if (!lazy) return;
+    std::vector<int> v(size());
+    copy_to(v.data());
+    cells.swap(v);
+    lazy = nullptr;
+  }
 };
 
 struct fuelmi_frontier {
@@ -1068,6 +1114,11 @@ struct fuelmi_frontier {
   size_t pin_bytes = 0;
   int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
   int last_nkept = 0, nb_launch = 0, npass = 1;
+  FVar* h_var = nullptr;  // pinned per-search arguments
+  FVar* d_var = nullptr;
+  int TX = 1, TY = 16, ccl_tiles = 0, ccl_nty = 0;
+  size_t ccl_lds = 0;
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
   bool pending = false, search_empty = false;
   std::unique_ptr<StageScope> scope;
   std::vector<int> slot2rank;
@@ -1144,6 +1195,9 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->d_stage) (void)hipFree(f->d_stage);
   for (void* p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
+  if (f->h_var) (void)hipHostFree(f->h_var);
+  for (hipGraphExec_t e : f->graph_exec)
+    if (e) (void)hipGraphExecDestroy(e);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
@@ -1209,6 +1263,60 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi_p));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
+
+  // ---- everything below is constant for the life of the object (the kernel chain is replayed
+  // as a graph with these arguments baked in) ----
+  // Q box: isInBox(idx) (min <= id < max) and z >= iz_min, inside the map
+  const int nv[3] = {g.nx, g.ny, g.nz};
+  for (int k = 0; k < 3; ++k) {
+    F.qbox.lo[k] = std::max(m->info.box_min[k], 0);
+    F.qbox.hi[k] = std::min(m->info.box_max[k] - 1, nv[k] - 1);
+  }
+  F.qbox.lo[2] = std::max(F.qbox.lo[2], f->iz_min);
+  for (int k = 0; k < 3; ++k)
+    if (F.qbox.lo[k] > F.qbox.hi[k]) {  // degenerate exploration box: nothing can be added
+      F.qbox.lo[k] = 1;
+      F.qbox.hi[k] = 0;
+    }
+  // per-search arguments: pinned host copy + device copy
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_var), sizeof(FVar), hipHostMallocDefault));
+  memset(f->h_var, 0, sizeof(FVar));
+  if ((rc = dmalloc(f, &f->d_var, 1))) {
+    fuelmi_frontier_destroy(f);
+    return rc;
+  }
+  F.var = f->d_var;
+  // results land in one pinned host buffer [counts | cluster records | chunk records | cells]
+  f->pin_bytes = 64 + (size_t)F.cap_kept * sizeof(KeptRec) + ((size_t)F.cap_q / SZ_CH + 2) * 40 + (size_t)F.cap_q * 4;
+  HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
+  F.h_counts = reinterpret_cast<u32*>(f->h_pin);
+  F.h_rec = reinterpret_cast<KeptRec*>(F.h_counts + 16);
+  F.h_part = reinterpret_cast<u32*>(F.h_rec + F.cap_kept);
+  F.h_cells = F.h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
+  // CCL tile = TX x TY z-lines with u32 labels in LDS (<= 48 KiB so three workgroups share a CU)
+  f->TY = 16;
+  f->TX = std::max(1, std::min(8, (48 * 1024) / (f->TY * g.nz * 4)));
+  if (const char* e = getenv("FUELMI_CCL_TILE")) {  // tuning hook: "TXxTY"
+    int a = 0, b = 0;
+    if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && b > 0 && (size_t)a * b * g.nz * 4 <= 150 * 1024) f->TX = a, f->TY = b;
+  }
+  const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 1, qy = F.qbox.hi[1] - F.qbox.lo[1] + 1;
+  f->ccl_tiles = 0;
+  if (qx > 0 && qy > 0 && F.qbox.lo[2] <= F.qbox.hi[2]) {
+    const int TX = f->TX, TY = f->TY;
+    const int ntx = (qx + TX - 1) / TX, nty = (qy + TY - 1) / TY;
+    f->ccl_nty = nty;
+    f->ccl_tiles = ntx * nty;
+    f->ccl_lds = ((size_t)TX * TY * g.nz + 2 * (size_t)TX * TY * ((g.nz + 31) / 32) + 2 * (size_t)TX) * sizeof(u32);
+    if (f->ccl_lds > 160 * 1024) {
+      fuelmi_set_error("frontier CCL tile of %d z-lines x %d voxels does not fit the LDS", TX * TY, g.nz);
+      fuelmi_frontier_destroy(f);
+      return FUELMI_ELIMIT;
+    }
+    if (f->ccl_lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->ccl_lds));
+  }
   *out = f;
   return FUELMI_OK;
 }
@@ -1265,6 +1373,55 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
   return FUELMI_OK;
 }
 
+// the device pipeline of one search (all on f->stream; capturable)
+static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
+  const Geo& g = f->map->g;
+  FArgs& F = f->F;
+  const int nb_max = (g.W + 255) / 256 + 1;  // surplus blocks exit on F.var->nblocks
+  const int cgrid = 2048;
+  k_load_var<<<1, 64, 0, f->stream>>>(f->h_var, f->d_var);
+  FDBG("k_load_var");
+  k_pred<<<nb_max, 256, 0, f->stream>>>(g, F);
+  FDBG("k_pred");
+  k_scan_sums<<<1, 256, 0, f->stream>>>(F);
+  FDBG("k_scan_sums");
+  k_compact<<<nb_max, 256, 0, f->stream>>>(g, F);
+  FDBG("k_compact");
+  if (f->ccl_tiles > 0) {
+    k_ccl_local<<<f->ccl_tiles, 256, f->ccl_lds, f->stream>>>(g, F, f->TX, f->TY, f->ccl_nty);
+    FDBG("k_ccl_local");
+    k_union<<<cgrid, 256, 0, f->stream>>>(g, F, f->TX, f->TY);
+    FDBG("k_union");
+  }
+  k_flatten<<<cgrid, 256, 0, f->stream>>>(g, F);
+  FDBG("k_flatten");
+  k_claim<<<cgrid, 256, 0, f->stream>>>(g, F);
+  FDBG("k_claim");
+  k_sizes<<<cgrid, 256, 0, f->stream>>>(g, F);
+  FDBG("k_sizes");  // grid-stride over 1024-cell chunks
+  k_finalize<<<nb_max, 256, 0, f->stream>>>(g, F);
+  FDBG("k_finalize");
+  // ---- grouping + cluster info, still without touching the host ----
+  k_rank_kept<<<16, 256, 0, f->stream>>>(F);
+  FDBG("k_rank_kept");
+  k_ms_keys<<<cgrid, 256, 0, f->stream>>>(F);
+  FDBG("k_ms_keys");
+  for (int p = 0; p < npass; ++p) {
+    k_ms_hist<<<f->nb_launch, 256, 0, f->stream>>>(F, p);
+    FDBG("k_ms_hist");
+    k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
+    FDBG("k_ms_scan");
+    k_ms_scatter<<<f->nb_launch, 256, 0, f->stream>>>(F, p);
+    FDBG("k_ms_scatter");
+  }
+  k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
+  FDBG("k_ms_info");
+  k_pack<<<8, 256, 0, f->stream>>>(F);
+  FDBG("k_pack");
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
 // searchFrontiers, first half: drops changed clusters and enqueues the whole device pipeline on the
 // frontier's own stream (asynchronous).  The caller may queue other work of the cycle (inflation,
 // ESDF, B-spline evaluation on the map's stream) before collecting the result with _search_end.
@@ -1292,6 +1449,8 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
 
   // scan box (:95-106): updated box +- (1,1,0.5) clipped to the exploration box, as indices
   const int nv[3] = {g.nx, g.ny, g.nz};
+  FVar hv;
+  memset(&hv, 0, sizeof(hv));
   bool empty = false;
   for (int k = 0; k < 3; ++k) {
     double infl = (k == 2) ? 0.5 : 1.0;
@@ -1301,109 +1460,48 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     int hi = (int)std::floor((smax - g.org[k]) * g.res_inv);
     lo = std::max(lo, 0);
     hi = std::min(hi, nv[k] - 1);  // the reference would index out of the map here (UB)
-    F.sbox.lo[k] = lo;
-    F.sbox.hi[k] = hi;
+    hv.sbox.lo[k] = lo;
+    hv.sbox.hi[k] = hi;
     if (lo > hi) empty = true;
   }
-  // Q box: isInBox(idx) (min <= id < max) and z >= iz_min, inside the map
-  for (int k = 0; k < 3; ++k) {
-    F.qbox.lo[k] = std::max(m->info.box_min[k], 0);
-    F.qbox.hi[k] = std::min(m->info.box_max[k] - 1, nv[k] - 1);
-  }
-  F.qbox.lo[2] = std::max(F.qbox.lo[2], f->iz_min);
-  for (int k = 0; k < 3; ++k)
-    if (F.qbox.lo[k] > F.qbox.hi[k]) {  // degenerate exploration box: nothing can be added
-      F.qbox.lo[k] = 1;
-      F.qbox.hi[k] = 0;
-    }
   f->pending = true;
   f->search_empty = empty;
   if (empty) return FUELMI_OK;
 
-  // results land in one pinned host buffer [counts | cluster records | chunk records | cells]
-  if (!f->h_pin) {
-    f->pin_bytes = 64 + (size_t)F.cap_kept * sizeof(KeptRec) + ((size_t)F.cap_q / SZ_CH + 2) * 40 + (size_t)F.cap_q * 4;
-    HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
-    F.h_counts = reinterpret_cast<u32*>(f->h_pin);
-    F.h_rec = reinterpret_cast<KeptRec*>(F.h_counts + 16);
-    F.h_part = reinterpret_cast<u32*>(F.h_rec + F.cap_kept);
-    F.h_cells = F.h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
-  }
-
   // words to process: everything the BFS could reach = Q box, plus the scan box
   auto adr = [&](const int* id) { return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2]; };
-  long a_lo = adr(F.sbox.lo), a_hi = adr(F.sbox.hi);
+  long a_lo = adr(hv.sbox.lo), a_hi = adr(hv.sbox.hi);
   if (F.qbox.lo[0] <= F.qbox.hi[0] && F.qbox.lo[1] <= F.qbox.hi[1] && F.qbox.lo[2] <= F.qbox.hi[2]) {
     a_lo = std::min(a_lo, adr(F.qbox.lo));
     a_hi = std::max(a_hi, adr(F.qbox.hi));
   }
-  F.w0 = (int)((a_lo >> 6) & ~255L);
-  int w_hi = (int)(a_hi >> 6);
-  int nblocks = (w_hi - F.w0) / 256 + 1;
-  F.nwords = nblocks * 256;
+  hv.w0 = (int)((a_lo >> 6) & ~255L);
+  const int w_hi = (int)(a_hi >> 6);
+  hv.nblocks = (w_hi - hv.w0) / 256 + 1;
+  hv.nwords = hv.nblocks * 256;
+  *f->h_var = hv;  // pinned; the previous search has been collected (_search_end synchronises)
 
-  k_pred<<<nblocks, 256, 0, f->stream>>>(g, F);
-  FDBG("k_pred");
-  k_scan_sums<<<1, 256, 0, f->stream>>>(F, nblocks);
-  FDBG("k_scan_sums");
-  k_compact<<<nblocks, 256, 0, f->stream>>>(g, F);
-  FDBG("k_compact");
-  const int cgrid = 2048;
-  {
-    // tile = TX x TY z-lines with u32 labels in LDS (<= 48 KiB so three workgroups share a CU)
-    int TY = 16;
-    int TX = std::max(1, std::min(8, (48 * 1024) / (TY * g.nz * 4)));
-    if (const char* e = getenv("FUELMI_CCL_TILE")) {  // tuning hook: "TXxTY"
-      int a = 0, b = 0;
-      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && b > 0 && (size_t)a * b * g.nz * 4 <= 150 * 1024) TX = a, TY = b;
-    }
-    const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 1, qy = F.qbox.hi[1] - F.qbox.lo[1] + 1;
-    if (qx > 0 && qy > 0 && F.qbox.lo[2] <= F.qbox.hi[2]) {
-      const int ntx = (qx + TX - 1) / TX, nty = (qy + TY - 1) / TY;
-      const size_t lds = ((size_t)TX * TY * g.nz + 2 * (size_t)TX * TY * ((g.nz + 31) / 32) + 2 * (size_t)TX) * sizeof(u32);
-      if (lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      k_ccl_local<<<ntx * nty, 256, lds, f->stream>>>(g, F, TX, TY, nty);
-  FDBG("k_ccl_local");
-      k_union<<<cgrid, 256, 0, f->stream>>>(g, F, TX, TY);
-  FDBG("k_union");
-    }
-  }
-  k_flatten<<<cgrid, 256, 0, f->stream>>>(g, F);
-  FDBG("k_flatten");
-  k_claim<<<cgrid, 256, 0, f->stream>>>(g, F);
-  FDBG("k_claim");
-  k_sizes<<<cgrid, 256, 0, f->stream>>>(g, F);
-  FDBG("k_sizes");  // grid-stride over 1024-cell chunks
-  k_finalize<<<nblocks, 256, 0, f->stream>>>(g, F);
-  FDBG("k_finalize");
-  HIPCHK(hipGetLastError());
-
-  // ---- grouping + cluster info, still without touching the host ----
-  k_rank_kept<<<16, 256, 0, f->stream>>>(F);
-  FDBG("k_rank_kept");
-  k_ms_keys<<<cgrid, 256, 0, f->stream>>>(F);
-  FDBG("k_ms_keys");
-  const int nb_launch = 256;  // the kernels stride over however many 2048-cell chunks there are
-  f->nb_launch = nb_launch;
   // the second radix pass is needed only beyond 256 kept clusters: guess from the previous search
   f->npass = f->last_nkept > 192 ? 2 : 1;
-  for (int p = 0; p < f->npass; ++p) {
-    k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
-  FDBG("k_ms_hist");
-    k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
-  FDBG("k_ms_scan");
-    k_ms_scatter<<<nb_launch, 256, 0, f->stream>>>(F, p);
-  FDBG("k_ms_scatter");
-  }
-  k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
-  FDBG("k_ms_info");
-  HIPCHK(hipGetLastError());
+  f->nb_launch = 256;  // the multisplit kernels stride over however many 2048-cell chunks there are
 
-  k_pack<<<8, 256, 0, f->stream>>>(F);
-  FDBG("k_pack");
-  HIPCHK(hipGetLastError());
+  // The chain is ~23 dependent launches whose arguments never change (everything per-search sits
+  // behind F.var): replay it as a hipGraph -- the host-side launch cost of the individual kernels
+  // (~6 us each) was longer than the kernels themselves.
+  static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || getenv("FUELMI_DEBUG_SYNC") != nullptr;
+  if (no_graph) return frontier_enqueue_chain(f, f->npass);
+  hipGraphExec_t& exec = f->graph_exec[f->npass - 1];
+  if (!exec) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
+    const int rc2 = frontier_enqueue_chain(f, f->npass);
+    const hipError_t ec = hipStreamEndCapture(f->stream, &graph);
+    if (rc2) return rc2;
+    HIPCHK(ec);
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+  }
+  HIPCHK(hipGraphLaunch(exec, f->stream));
   return FUELMI_OK;
 }
 
@@ -1430,7 +1528,14 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   KeptRec* h_rec = F.h_rec;
   const u32* h_part = F.h_part;
   const u32* h_cells = F.h_cells;
-  HIPCHK(hipStreamSynchronize(f->stream));
+  // poll instead of a blocking wait: the caller is about to consume the result and the chain is
+  // ~200 us long, an interrupt-driven wake-up costs a noticeable fraction of that
+  {
+    hipError_t q;
+    while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {
+    }
+    HIPCHK(q);
+  }
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
                      counts[1], F.cap_s, counts[3], F.cap_kept);
@@ -1479,14 +1584,14 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     HCluster& c = f->tmp.back();
     const bool seed = kr.slot >= nq;
     const u32 cnt = kr.size - (seed ? 1u : 0u);
-    c.cells.resize(cnt);
-    if (cnt) memcpy(c.cells.data(), h_cells + kr.off, (size_t)cnt * sizeof(int));
+    c.lazy = reinterpret_cast<const int*>(h_cells) + kr.off;
+    c.lazy_n = cnt;
     unsigned long long sum[3] = {kr.sum[0], kr.sum[1], kr.sum[2]};
     u32 lo[3] = {kr.box[0], kr.box[1], kr.box[2]};
     u32 hi[3] = {kr.box[3], kr.box[4], kr.box[5]};
     if (seed) {
       const int a = (int)kr.addr;
-      c.cells.insert(std::lower_bound(c.cells.begin(), c.cells.end(), a), a);
+      c.lazy_seed = a;
       const u32 x = (u32)a / (u32)g.nyz, rr = (u32)a - x * (u32)g.nyz, y = rr / (u32)g.nz, z = rr - y * (u32)g.nz;
       const u32 id[3] = {x, y, z};
       for (int q = 0; q < 3; ++q) {
@@ -1496,7 +1601,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       }
     }
     // computeFrontierInfo (:374-390): mean of voxel centres = centre of the mean index
-    const double nn = (double)c.cells.size();
+    const double nn = (double)c.size();
     for (int q = 0; q < 3; ++q) {
       c.avg[q] = ((double)sum[q] / nn + 0.5) * g.res + g.org[q];
       c.bmin[q] = ((int)lo[q] + 0.5) * g.res + g.org[q];
@@ -1531,6 +1636,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
 extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
   ARGCHK(f);
   auto& dst = dormant ? f->dormant : f->frontiers;
+  for (HCluster& c : f->tmp) c.materialize();
   dst.splice(dst.end(), f->tmp);
   return FUELMI_OK;
 }
@@ -1553,13 +1659,13 @@ extern "C" int fuelmi_frontier_cluster_size(const fuelmi_frontier* f, int which,
   ARGCHK(f);
   const HCluster* c = nth(f, which, k);
   ARGCHK(c);
-  return (int)c->cells.size();
+  return (int)c->size();
 }
 extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which, int k, int* adr) {
   ARGCHK(f && adr);
   const HCluster* c = nth(f, which, k);
   ARGCHK(c);
-  memcpy(adr, c->cells.data(), c->cells.size() * sizeof(int));
+  c->copy_to(adr);
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_cluster_info(const fuelmi_frontier* f, int which, int k, double out9[9]) {
