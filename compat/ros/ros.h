@@ -7,15 +7,20 @@
 #include <map>
 #include <string>
 namespace ros {
-struct Duration { double s; double toSec() const { return s; } };
+struct Duration { double s; Duration(double s_ = 0) : s(s_) {} double toSec() const { return s; } };
 struct Time {
   double t = 0;
   static Time now() { Time r; r.t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); return r; }
   double toSec() const { return t; }
 };
 inline Duration operator-(const Time& a, const Time& b) { return Duration{a.t - b.t}; }
+struct TimerEvent { Time current_real, last_real; };
+struct Timer {};
+struct Publisher { template <typename M> void publish(const M&) const {} };
 class NodeHandle {
 public:
+  template <typename M> Publisher advertise(const std::string&, int) { return Publisher(); }
+  template <typename F, typename O> Timer createTimer(Duration, F, O*) { return Timer(); }
   std::map<std::string, double> num;
   std::map<std::string, std::string> str;
   template <typename T> bool param(const std::string& k, T& v, const T& def) const {

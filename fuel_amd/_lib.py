@@ -40,6 +40,17 @@ class MapCfg(C.Structure):
     ]
 
 
+class DepthCfg(C.Structure):
+    """map_ros/... parameters of MapROS (plan_env/src/map_ros.cpp:22-30); defaults = exploration.launch / algorithm.xml."""
+    _fields_ = [
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("depth_filter_maxdist", C.c_double), ("depth_filter_mindist", C.c_double),
+        ("depth_filter_margin", C.c_int),
+        ("k_depth_scaling_factor", C.c_double),
+        ("skip_pixel", C.c_int),
+    ]
+
+
 class MapInfo(C.Structure):
     _fields_ = [
         ("voxel_num", C.c_int * 3),
@@ -94,6 +105,10 @@ SYMBOLS = {
     "fuelmi_map_destroy": (None, [_P]),
     "fuelmi_map_get_info": (C.c_int, [_P, C.POINTER(MapInfo)]),
     "fuelmi_map_input_points": (C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, _dp]),
+    "fuelmi_map_input_depth": (C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(DepthCfg), _dp, _dp,
+                                         C.POINTER(C.c_int)]),
+    "fuelmi_map_project_depth": (C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(DepthCfg), _dp, _dp,
+                                           C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "fuelmi_map_inflate_local": (C.c_int, [_P]),
     "fuelmi_map_update_esdf": (C.c_int, [_P]),
     "fuelmi_map_reset_buffer_all": (C.c_int, [_P]),

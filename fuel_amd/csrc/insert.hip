@@ -56,6 +56,7 @@ __device__ __forceinline__ bool in_map_pos(const Geo& g, const double p[3]) {
 // classify one point exactly like sdf_map.cpp:276-303; returns false if the point is dropped
 __device__ __forceinline__ bool classify(const Geo& g, const InsertArgs& A, int i, double pt[3], int& flag) {
   const float* p = reinterpret_cast<const float*>(A.pts + (size_t)i * A.stride);
+  if (isnan(p[0])) return false;  // empty slot of a device-projected depth frame (see k_project_depth)
   pt[0] = p[0];
   pt[1] = p[1];
   pt[2] = p[2];
@@ -246,27 +247,21 @@ k_insert_update(Geo g, u64* __restrict__ hit, u64* __restrict__ miss, double* __
   unk_bits[w] = ub;
 }
 
-int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const double cam[3]) {
+// fusion of n point records already resident on the device.  d_head: 64-byte device scratch
+// ([0..5] sortable-encoded bbox, [6] number of valid points when `counted`).  Frames whose slots are
+// all empty leave the map untouched, like `if (point_num == 0) return;` (:260).
+static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stride, int n, const double cam[3],
+                             u64* d_bbox, bool counted, int* n_valid) {
   const Geo& g = m->g;
   const fuelmi_map_info& I = m->info;
+  const signed char num_before = m->raycast_num;
   m->raycast_num = (signed char)(m->raycast_num + 1);  // char wrap like the reference
-  if (m->reset_updated_box) {
-    for (int k = 0; k < 3; ++k) m->upd_min[k] = m->upd_max[k] = cam[k];
-    m->reset_updated_box = false;
-  }
-  size_t pbytes = (size_t)n * stride;
-  int rc = map_ensure_stage(m, pbytes + 64, 0);
-  if (rc) return rc;
-  u64* d_bbox = reinterpret_cast<u64*>(m->d_stage);
-  unsigned char* d_pts = reinterpret_cast<unsigned char*>(m->d_stage) + 64;
-  u64 h_bbox[6];
+  u64 h_bbox[8];
   for (int k = 0; k < 3; ++k) {
     h_bbox[k] = enc_f64_host(cam[k]);  // update_min = update_max = camera_pos (:265-266)
     h_bbox[3 + k] = h_bbox[k];
   }
-  StageScope sc(m, FUELMI_K_INSERT);
-  HIPCHK(hipMemcpyAsync(d_bbox, h_bbox, sizeof(h_bbox), hipMemcpyHostToDevice, m->stream));
-  HIPCHK(hipMemcpyAsync(d_pts, xyz, pbytes, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d_bbox, h_bbox, 6 * sizeof(u64), hipMemcpyHostToDevice, m->stream));
   InsertArgs A;
   A.pts = d_pts;
   A.stride = stride;
@@ -285,6 +280,17 @@ int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const doub
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
+  if (counted) {
+    if (n_valid) *n_valid = (int)h_bbox[6];
+    if (h_bbox[6] == 0) {  // nothing projected: the reference returns before touching any state
+      m->raycast_num = num_before;
+      return FUELMI_OK;
+    }
+  }
+  if (m->reset_updated_box) {
+    for (int k = 0; k < 3; ++k) m->upd_min[k] = m->upd_max[k] = cam[k];
+    m->reset_updated_box = false;
+  }
   double umin[3], umax[3];
   for (int k = 0; k < 3; ++k) {
     umin[k] = dec_f64(h_bbox[k]);
@@ -318,6 +324,157 @@ int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const doub
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ev_planes, m->stream));
   return FUELMI_OK;
+}
+
+int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const double cam[3]) {
+  size_t pbytes = (size_t)n * stride;
+  int rc = map_ensure_stage(m, pbytes + 64, 0);
+  if (rc) return rc;
+  u64* d_bbox = reinterpret_cast<u64*>(m->d_stage);
+  unsigned char* d_pts = reinterpret_cast<unsigned char*>(m->d_stage) + 64;
+  StageScope sc(m, FUELMI_K_INSERT);
+  HIPCHK(hipMemcpyAsync(d_pts, xyz, pbytes, hipMemcpyHostToDevice, m->stream));
+  return insert_points_dev(m, d_pts, stride, n, cam, d_bbox, false, nullptr);
+}
+
+// ---- depth image -> world points on the device (MapROS::proessDepthImage, plan_env/src/map_ros.cpp:176-215)
+// One lane per sampled pixel (v, u) = margin + k*skip.  Arithmetic in f64 in the reference's order
+// (depth = px * (1/scale); pt = R * [(u-cx)*d/fx, (v-cy)*d/fy, d] + t; stored as float).  Quirk kept:
+// the depth comes from pixel u, the zero test reads the pixel `skip` further (the row pointer is
+// advanced in between, :190-198); past the end of the image (reference: out-of-bounds read) it
+// counts as 0.  Output slot s = iv*nu + iu keeps the reference's point order; a pixel dropped by the
+// min-distance filter leaves x = NaN in its slot, which the fusion kernels skip.
+struct DepthArgs {
+  const unsigned short* img;
+  int rows, cols, margin, skip, nu, nslots;
+  double fx, fy, cx, cy, maxdist, mindist, inv_factor;
+  double R[9], t[3];
+  float* out;  // [nslots][4]
+  u64* count;  // valid points
+};
+__global__ void __launch_bounds__(256) k_project_depth(DepthArgs D) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (s < D.nslots) {
+    const int iv = s / D.nu, iu = s - iv * D.nu;
+    const int v = D.margin + iv * D.skip, u = D.margin + iu * D.skip;
+    const long at = (long)v * D.cols + u;
+    double depth = (double)D.img[at] * D.inv_factor;
+    const long nxt = at + D.skip;
+    const unsigned short ztest = nxt < (long)D.rows * D.cols ? D.img[nxt] : (unsigned short)0;
+    valid = true;
+    if (ztest == 0 || depth > D.maxdist)
+      depth = D.maxdist;
+    else if (depth < D.mindist)
+      valid = false;
+    float4 o = make_float4(NAN, 0.f, 0.f, 1.f);
+    if (valid) {
+      const double c0 = (u - D.cx) * depth / D.fx, c1 = (v - D.cy) * depth / D.fy, c2 = depth;
+      const double w0 = D.R[0] * c0 + D.R[1] * c1 + D.R[2] * c2 + D.t[0];
+      const double w1 = D.R[3] * c0 + D.R[4] * c1 + D.R[5] * c2 + D.t[1];
+      const double w2 = D.R[6] * c0 + D.R[7] * c1 + D.R[8] * c2 + D.t[2];
+      o = make_float4((float)w0, (float)w1, (float)w2, 1.f);
+    }
+    reinterpret_cast<float4*>(D.out)[s] = o;
+  }
+  const u64 m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.count, (u64)__popcll(m));
+}
+
+static void quat_to_rot(const double q[4], double R[9]) {  // Eigen's toRotationMatrix(), q = (w,x,y,z)
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz), R[1] = txy - twz, R[2] = txz + twy;
+  R[3] = txy + twz, R[4] = 1.0 - (txx + tzz), R[5] = tyz - twx;
+  R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1.0 - (txx + tyy);
+}
+
+// uploads the image, projects it; *d_pts_out / *d_head_out point into the map's device staging area
+static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
+                             const fuelmi_depth_cfg* c, const double pos[3], const double q[4], float** d_pts_out,
+                             u64** d_head_out, int* nslots_out) {
+  const int margin = c->depth_filter_margin, skip = c->skip_pixel;
+  const int nu = cols - 2 * margin > 0 ? (cols - 2 * margin + skip - 1) / skip : 0;
+  const int nvv = rows - 2 * margin > 0 ? (rows - 2 * margin + skip - 1) / skip : 0;
+  const int nslots = nu * nvv;
+  *nslots_out = nslots;
+  const size_t img_bytes = ((size_t)rows * cols * 2 + 255) & ~(size_t)255;
+  int rc = map_ensure_stage(m, 64 + img_bytes + (size_t)nslots * 16 + 256, 0);
+  if (rc) return rc;
+  u64* d_head = reinterpret_cast<u64*>(m->d_stage);
+  unsigned short* d_img = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(m->d_stage) + 256);
+  float* d_pts = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(m->d_stage) + 256 + img_bytes);
+  *d_pts_out = d_pts;
+  *d_head_out = d_head;
+  HIPCHK(hipMemsetAsync(d_head, 0, 64, m->stream));
+  if (nslots == 0) return FUELMI_OK;
+  HIPCHK(hipMemcpyAsync(d_img, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
+  DepthArgs D;
+  D.img = d_img;
+  D.rows = rows, D.cols = cols, D.margin = margin, D.skip = skip, D.nu = nu, D.nslots = nslots;
+  D.fx = c->fx, D.fy = c->fy, D.cx = c->cx, D.cy = c->cy;
+  D.maxdist = c->depth_filter_maxdist, D.mindist = c->depth_filter_mindist;
+  D.inv_factor = 1.0 / c->k_depth_scaling_factor;
+  quat_to_rot(q, D.R);
+  for (int k = 0; k < 3; ++k) D.t[k] = pos[k];
+  D.out = d_pts;
+  D.count = d_head + 6;
+  k_project_depth<<<(nslots + 255) / 256, 256, 0, m->stream>>>(D);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+static bool depth_args_ok(const fuelmi_depth_cfg* c, int rows, int cols) {
+  return c && rows > 0 && cols > 0 && c->skip_pixel > 0 && c->depth_filter_margin >= 0 && c->fx != 0.0 &&
+         c->fy != 0.0 && c->k_depth_scaling_factor != 0.0;
+}
+
+extern "C" int fuelmi_map_project_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
+                                        const fuelmi_depth_cfg* cfg, const double cam_pos[3],
+                                        const double cam_q_wxyz[4], float* xyz, int cap, int* n_points) {
+  ARGCHK(m && depth && cam_pos && cam_q_wxyz && n_points && depth_args_ok(cfg, rows, cols) && (cap == 0 || xyz));
+  HIPCHK(hipSetDevice(m->device));
+  float* d_pts;
+  u64* d_head;
+  int nslots;
+  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &d_head, &nslots);
+  if (rc) return rc;
+  std::vector<float> h((size_t)nslots * 4);
+  if (nslots) HIPCHK(hipMemcpyAsync(h.data(), d_pts, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  int n = 0;
+  for (int s = 0; s < nslots; ++s) {
+    if (std::isnan(h[4 * (size_t)s])) continue;
+    if (n < cap) memcpy(xyz + 3 * (size_t)n, &h[4 * (size_t)s], 3 * sizeof(float));
+    ++n;
+  }
+  *n_points = n;
+  return FUELMI_OK;
+}
+
+// MapROS::depthPoseCallback (:121-150) minus the ROS plumbing: projection + inputPointCloud without
+// the points ever leaving the device.  The caller follows with fuelmi_map_inflate_local like the
+// reference does when local_updated_ is set.
+extern "C" int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
+                                      const fuelmi_depth_cfg* cfg, const double cam_pos[3],
+                                      const double cam_q_wxyz[4], int* n_points) {
+  ARGCHK(m && depth && cam_pos && cam_q_wxyz && depth_args_ok(cfg, rows, cols));
+  if (n_points) *n_points = 0;
+  const Geo& g = m->g;
+  for (int k = 0; k < 3; ++k)  // if (!map_->isInMap(camera_pos_)) return;
+    if (cam_pos[k] < g.minb[k] + 1e-4 || cam_pos[k] > g.maxb[k] - 1e-4) return FUELMI_OK;
+  HIPCHK(hipSetDevice(m->device));
+  StageScope sc(m, FUELMI_K_INSERT);
+  float* d_pts;
+  u64* d_head;
+  int nslots;
+  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &d_head, &nslots);
+  if (rc || nslots == 0) return rc;
+  return insert_points_dev(m, reinterpret_cast<const unsigned char*>(d_pts), 16, nslots, cam_pos, d_head, true,
+                           n_points);
 }
 
 extern "C" int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,

@@ -93,6 +93,35 @@ class SDFMap:
         pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         check(self.L.fuelmi_map_input_points(self.h, pts.ctypes.data, 12, len(pts), _d3(camera_pos)))
 
+    @staticmethod
+    def depthConfig(fx=387.229248046875, fy=387.229248046875, cx=321.04638671875, cy=243.44969177246094,
+                    maxdist=5.0, mindist=0.2, margin=2, scaling=1000.0, skip=2):
+        """map_ros/* parameters (exploration.launch:38-41, algorithm.xml:62-69)."""
+        return _lib.DepthCfg(fx, fy, cx, cy, maxdist, mindist, margin, scaling, skip)
+
+    def inputDepthImage(self, depth, camera_pos, camera_q_wxyz, cfg=None):
+        """MapROS::depthPoseCallback's projection + fusion (map_ros.cpp:121-150,176-215) on the device.
+        Returns proj_points_cnt."""
+        img = np.ascontiguousarray(depth, dtype=np.uint16)
+        cfg = cfg or self.depthConfig()
+        n = C.c_int(0)
+        q = (C.c_double * 4)(*[float(v) for v in camera_q_wxyz])
+        check(self.L.fuelmi_map_input_depth(self.h, img.ctypes.data, img.shape[0], img.shape[1], C.byref(cfg),
+                                            _d3(camera_pos), q, C.byref(n)))
+        return n.value
+
+    def projectDepthImage(self, depth, camera_pos, camera_q_wxyz, cfg=None):
+        """MapROS::proessDepthImage only: the projected world points (float32 [n,3])."""
+        img = np.ascontiguousarray(depth, dtype=np.uint16)
+        cfg = cfg or self.depthConfig()
+        cap = img.shape[0] * img.shape[1]
+        out = np.empty((cap, 3), dtype=np.float32)
+        n = C.c_int(0)
+        q = (C.c_double * 4)(*[float(v) for v in camera_q_wxyz])
+        check(self.L.fuelmi_map_project_depth(self.h, img.ctypes.data, img.shape[0], img.shape[1], C.byref(cfg),
+                                              _d3(camera_pos), q, out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value].copy()
+
     def clearAndInflateLocalMap(self):
         check(self.L.fuelmi_map_inflate_local(self.h))
 

@@ -46,6 +46,9 @@ def lib():
         L.synth_render.argtypes = [G, C.c_void_p, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_void_p, C.c_int]
+        L.synth_depth_image.restype = None
+        L.synth_depth_image.argtypes = [G, C.c_void_p, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_double, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -102,3 +105,35 @@ class World:
                                 skip, margin, CAM["fx"] * s, CAM["fy"] * s, CAM["cx"] * s, CAM["cy"] * s,
                                 maxdist, mindist, out.ctypes.data, cap)
         return out[:n].copy()
+
+    def depth_image(self, truth, pose, width=640, height=480, max_range=7.0):
+        """16UC1 depth frame (mm, 0 = no return) for `pose` = (x, y, z, yaw, pitch)."""
+        img = np.zeros((height, width), dtype=np.uint16)
+        s = width / 640.0
+        self.L.synth_depth_image(C.byref(self.g), truth.ctypes.data, (C.c_double * 5)(*pose), width, height,
+                                 C.c_double(CAM["fx"] * s), C.c_double(CAM["fy"] * s), C.c_double(CAM["cx"] * s),
+                                 C.c_double(CAM["cy"] * s), C.c_double(max_range), img.ctypes.data)
+        return img
+
+    @staticmethod
+    def pose_quaternion(pose):
+        """Orientation quaternion (w, x, y, z) of the camera frame of `pose`: columns of R are the
+        camera's x (right), y (down) and z (forward) axes in the world."""
+        yaw, pitch = pose[3], pose[4]
+        cyw, syw, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+        R = np.array([[syw, cyw * sp, cyw * cp], [-cyw, syw * sp, syw * cp], [0.0, -cp, sp]])
+        tr = np.trace(R)
+        if tr > 0:
+            s4 = np.sqrt(tr + 1.0) * 2
+            q = [0.25 * s4, (R[2, 1] - R[1, 2]) / s4, (R[0, 2] - R[2, 0]) / s4, (R[1, 0] - R[0, 1]) / s4]
+        else:
+            i = int(np.argmax(np.diag(R)))
+            j, k = (i + 1) % 3, (i + 2) % 3
+            s4 = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+            q = [0.0] * 4
+            q[0] = (R[k, j] - R[j, k]) / s4
+            q[1 + i] = 0.25 * s4
+            q[1 + j] = (R[j, i] + R[i, j]) / s4
+            q[1 + k] = (R[k, i] + R[i, k]) / s4
+        q = np.array(q)
+        return q / np.linalg.norm(q)

@@ -236,4 +236,56 @@ int synth_render(const synth_grid* G, const unsigned char* truth, const double p
   return n;
 }
 
+// Full-resolution 16UC1 depth image (millimetres, 0 = no return within max_range) of the truth grid
+// seen from `pose` -- what the simulator's depth_render_node publishes
+// (uav_simulator/local_sensing/src/depth_render_node.cpp:112-168) and MapROS consumes.
+void synth_depth_image(const synth_grid* G, const unsigned char* truth, const double pose[5], int width,
+                       int height, double fx, double fy, double cx, double cy, double max_range,
+                       unsigned short* img) {
+  const int* nv = G->nv;
+  const double* org = G->origin;
+  const double vres = G->res;
+  const double yaw = pose[3], pitch = pose[4];
+  double cyw = std::cos(yaw), syw = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+  double fwd[3] = {cyw * cp, syw * cp, sp};
+  double right[3] = {syw, -cyw, 0};
+  double down[3] = {cyw * sp, syw * sp, -cp};
+  for (int v = 0; v < height; ++v)
+    for (int u = 0; u < width; ++u) {
+      double dc[3] = {(u - cx) / fx, (v - cy) / fy, 1.0};
+      double d[3];
+      for (int i = 0; i < 3; ++i) d[i] = right[i] * dc[0] + down[i] * dc[1] + fwd[i] * dc[2];
+      double p[3] = {(pose[0] - org[0]) / vres, (pose[1] - org[1]) / vres, (pose[2] - org[2]) / vres};
+      int c[3], st[3];
+      double tmax[3], tdel[3];
+      for (int i = 0; i < 3; ++i) {
+        c[i] = (int)std::floor(p[i]);
+        double di = d[i] / vres;
+        st[i] = di > 0 ? 1 : (di < 0 ? -1 : 0);
+        if (st[i] == 0) {
+          tmax[i] = 1e300;
+          tdel[i] = 1e300;
+        } else {
+          double nb = st[i] > 0 ? (c[i] + 1 - p[i]) : (p[i] - c[i]);
+          tmax[i] = nb / std::fabs(di);
+          tdel[i] = 1.0 / std::fabs(di);
+        }
+      }
+      double depth = -1.0, t = 0.0;
+      while (t <= max_range) {
+        if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= nv[0] || c[1] >= nv[1] || c[2] >= nv[2]) break;
+        if (truth[((long)c[0] * nv[1] + c[1]) * nv[2] + c[2]]) {
+          depth = t;
+          break;
+        }
+        int a = (tmax[0] < tmax[1]) ? (tmax[0] < tmax[2] ? 0 : 2) : (tmax[1] < tmax[2] ? 1 : 2);
+        t = tmax[a];
+        tmax[a] += tdel[a];
+        c[a] += st[a];
+      }
+      long mm = depth < 0 ? 0 : std::lround((depth + 0.05) * 1000.0);  // hit slightly inside the surface
+      img[(long)v * width + u] = (unsigned short)(mm > 65535 ? 65535 : mm);
+    }
+}
+
 }  // extern "C"

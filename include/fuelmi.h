@@ -81,6 +81,27 @@ int fuelmi_map_get_info(const fuelmi_map* m, fuelmi_map_info* info);
  * each stride_bytes record (12 for packed, 16 for pcl::PointXYZ); host memory. */
 int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,
                             const double camera_pos[3]);
+/* Depth-image front end of the fusion: MapROS::proessDepthImage (plan_env/src/map_ros.cpp:176-215) and
+ * the part of MapROS::depthPoseCallback (:121-150) around it.  Parameters are the map_ros/... ROS
+ * parameters of the same names (map_ros.cpp:22-30). */
+typedef struct {
+  double fx, fy, cx, cy;
+  double depth_filter_maxdist, depth_filter_mindist;
+  int depth_filter_margin;
+  double k_depth_scaling_factor; /* raw 16-bit depth units per metre (1000 for millimetres) */
+  int skip_pixel;
+} fuelmi_depth_cfg;
+/* depth: rows x cols row-major 16UC1 image in host memory; cam_q_wxyz: camera orientation quaternion
+ * (pose->orientation, w first).  Projects on the device and fuses the points without a host round
+ * trip; a frame taken from outside the map is ignored like the reference does.  *n_points (may be
+ * NULL) receives proj_points_cnt.  Follow with fuelmi_map_inflate_local (local_updated_ branch). */
+int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
+                           const fuelmi_depth_cfg* cfg, const double cam_pos[3], const double cam_q_wxyz[4],
+                           int* n_points);
+/* projection only: the reference's point_cloud_[0..proj_points_cnt) as packed float xyz (host). */
+int fuelmi_map_project_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
+                             const fuelmi_depth_cfg* cfg, const double cam_pos[3], const double cam_q_wxyz[4],
+                             float* xyz, int cap, int* n_points);
 /* SDFMap::clearAndInflateLocalMap (sdf_map.cpp:434-471) over the current local bound */
 int fuelmi_map_inflate_local(fuelmi_map* m);
 /* SDFMap::updateESDF3d (sdf_map.cpp:152-241) over the current local bound */

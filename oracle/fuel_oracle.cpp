@@ -1024,3 +1024,44 @@ void fo_bspline_cost_grad(const fo_map* m, const fo_bspline_cfg* cfg, const fo_b
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// MapROS::proessDepthImage (plan_env/src/map_ros.cpp:176-215): 16-bit depth image -> world points.
+// Restated literally, including the pointer quirk: `depth` is read from pixel u, then the row
+// pointer advances by skip_pixel and the zero test dereferences THAT pixel (:190-198).  A read past
+// the end of the image (undefined in the reference) is defined here as 0.
+// Rotation: Eigen's Quaterniond::toRotationMatrix(); pt_world = R * pt_cur + t evaluated row by
+// row, left to right; stored as float (pcl::PointXYZ).
+// ---------------------------------------------------------------------------------------------
+extern "C" int fo_project_depth(const unsigned short* img, int rows, int cols, const fo_depth_cfg* c,
+                                const double pos[3], const double q[4], float* xyz, int cap) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double R[3][3] = {{1.0 - (tyy + tzz), txy - twz, txz + twy},
+                          {txy + twz, 1.0 - (txx + tzz), tyz - twx},
+                          {txz - twy, tyz + twx, 1.0 - (txx + tyy)}};
+  const double inv_factor = 1.0 / c->k_depth_scaling_factor;
+  const long total = (long)rows * cols;
+  int cnt = 0;
+  for (int v = c->depth_filter_margin; v < rows - c->depth_filter_margin; v += c->skip_pixel) {
+    long at = (long)v * cols + c->depth_filter_margin;  // row_ptr
+    for (int u = c->depth_filter_margin; u < cols - c->depth_filter_margin; u += c->skip_pixel) {
+      double depth = img[at] * inv_factor;
+      at += c->skip_pixel;
+      const unsigned short nxt = at < total ? img[at] : (unsigned short)0;
+      if (nxt == 0 || depth > c->depth_filter_maxdist)
+        depth = c->depth_filter_maxdist;
+      else if (depth < c->depth_filter_mindist)
+        continue;
+      const double pc[3] = {(u - c->cx) * depth / c->fx, (v - c->cy) * depth / c->fy, depth};
+      if (cnt < cap)
+        for (int i = 0; i < 3; ++i)
+          xyz[3 * cnt + i] = (float)(R[i][0] * pc[0] + R[i][1] * pc[1] + R[i][2] * pc[2] + pos[i]);
+      ++cnt;
+    }
+  }
+  return cnt;
+}

@@ -162,6 +162,18 @@ double fo_bspline_pt_dist(const double* ctrl_pts, int n, int dim);
 void fo_bspline_cost_grad(const fo_map* m, const fo_bspline_cfg* cfg, const fo_bspline_problem* pb,
                           const double* x, double* cost, double* grad);
 
+/* MapROS::proessDepthImage (plan_env/src/map_ros.cpp:176-215); parameters map_ros.cpp:22-30 */
+typedef struct {
+  double fx, fy, cx, cy;
+  double depth_filter_maxdist, depth_filter_mindist;
+  int depth_filter_margin;
+  double k_depth_scaling_factor;
+  int skip_pixel;
+} fo_depth_cfg;
+/* returns proj_points_cnt; at most cap points are written */
+int fo_project_depth(const unsigned short* img, int rows, int cols, const fo_depth_cfg* c, const double pos[3],
+                     const double quat_wxyz[4], float* xyz, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,16 @@ class BsplineProblem(C.Structure):
     ]
 
 
+class DepthCfg(C.Structure):
+    _fields_ = [
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("depth_filter_maxdist", C.c_double), ("depth_filter_mindist", C.c_double),
+        ("depth_filter_margin", C.c_int),
+        ("k_depth_scaling_factor", C.c_double),
+        ("skip_pixel", C.c_int),
+    ]
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libfuel_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("fuel_oracle.cpp", "fuel_oracle.h")]
@@ -122,8 +132,27 @@ def lib():
         L.fo_bspline_pt_dist.restype = C.c_double
         L.fo_bspline_pt_dist.argtypes = [dp, C.c_int, C.c_int]
         L.fo_bspline_cost_grad.argtypes = [P, C.POINTER(BsplineCfg), C.POINTER(BsplineProblem), dp, dp, dp]
+        L.fo_project_depth.restype = C.c_int
+        L.fo_project_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(DepthCfg), dp, dp, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
+
+
+def depth_cfg(fx=387.229248046875, fy=387.229248046875, cx=321.04638671875, cy=243.44969177246094,
+              maxdist=5.0, mindist=0.2, margin=2, scaling=1000.0, skip=2):
+    return DepthCfg(fx, fy, cx, cy, maxdist, mindist, margin, scaling, skip)
+
+
+def project_depth(img, pos, quat_wxyz, cfg=None):
+    """MapROS::proessDepthImage restated (map_ros.cpp:176-215): float32 [n,3] world points."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    cfg = cfg or depth_cfg()
+    cap = img.shape[0] * img.shape[1]
+    out = np.empty((cap, 3), dtype=np.float32)
+    n = lib().fo_project_depth(img.ctypes.data, img.shape[0], img.shape[1], C.byref(cfg),
+                               (C.c_double * 3)(*[float(v) for v in pos]),
+                               (C.c_double * 4)(*[float(v) for v in quat_wxyz]), out.ctypes.data, cap)
+    return out[:n].copy()
 
 
 def _dp(a):

@@ -207,3 +207,37 @@ def bspline_cost_grad(rmap, x, point_num, cost_function, pt_dist, start_state, e
     grad = np.zeros(len(x))
     L.ref_bspline_cost_grad(rmap.h, C.byref(cfg), C.byref(pb), fo._dp(x), C.byref(cost), fo._dp(grad))
     return cost.value, grad
+
+
+# ---- MapROS::proessDepthImage from the real map_ros.cpp (separate shared object) ------------------
+SO_MAPROS = os.path.join(os.path.dirname(_HERE), "_ref", "libfuel_ref_mapros.so")
+_LIB_MR = None
+
+
+def mapros_available():
+    return os.path.exists(SO_MAPROS)
+
+
+def project_depth(img, pos, quat_wxyz, cfg=None):
+    """The reference's own proessDepthImage on a 16UC1 image: float32 [n,3]."""
+    global _LIB_MR
+    if _LIB_MR is None:
+        _LIB_MR = C.CDLL(SO_MAPROS)
+        _LIB_MR.ref_process_depth.restype = C.c_int
+        _LIB_MR.ref_process_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.c_void_p, C.c_int]
+
+    class RefDepthCfg(C.Structure):  # field order of ref_depth_api.cpp
+        _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                    ("maxdist", C.c_double), ("mindist", C.c_double), ("scaling", C.c_double),
+                    ("margin", C.c_int), ("skip", C.c_int)]
+    c = cfg or fo.depth_cfg()
+    rc = RefDepthCfg(c.fx, c.fy, c.cx, c.cy, c.depth_filter_maxdist, c.depth_filter_mindist,
+                     c.k_depth_scaling_factor, c.depth_filter_margin, c.skip_pixel)
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    cap = img.shape[0] * img.shape[1]
+    out = np.empty((cap, 3), dtype=np.float32)
+    n = _LIB_MR.ref_process_depth(img.ctypes.data, img.shape[0], img.shape[1], C.byref(rc),
+                                  (C.c_double * 3)(*[float(v) for v in pos]),
+                                  (C.c_double * 4)(*[float(v) for v in quat_wxyz]), out.ctypes.data, cap)
+    return out[:n].copy()

@@ -484,3 +484,76 @@ def test_frontier_many_small_clusters_two_radix_passes(fa):
             gf.commit()
         gf.close()
     gm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# depth projection on the device (MapROS::proessDepthImage, map_ros.cpp:176-215)
+# ------------------------------------------------------------------------------------------------
+def _depth_frames(w, truth, n, width, height, seed=3):
+    from fuel_amd import synth
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        pose = w.camera(truth, 5, k, n, 0.9)
+        img = w.depth_image(truth, pose, width, height, max_range=7.0)
+        img[rng.random(img.shape) < 0.02] = 0
+        img[rng.random(img.shape) < 0.01] = rng.integers(1, 199)
+        out.append((img, pose, synth.World.pose_quaternion(pose)))
+    return out
+
+
+def _scaled_cfg(mod, width, **kw):
+    s = width / 640.0
+    return mod(fx=387.229248046875 * s, fy=387.229248046875 * s, cx=321.04638671875 * s,
+               cy=243.44969177246094 * s, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("margin,skip", [(2, 2), (0, 3), (1, 1), (5, 4)])
+def test_depth_projection_bit_exact(fa, margin, skip):
+    """Projected float points identical to the oracle's (same order), incl. margin 0 where the zero test
+    runs into the next row and, on the last row, past the image (defined as 0)."""
+    from fuel_amd import synth
+    map_size = (10.0, 8.0, 4.0)
+    gm = fa.SDFMap(map_size, (-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    w = synth.World.for_map_size(map_size)
+    truth = w.world(3, 14)
+    for img, pose, q in _depth_frames(w, truth, 5, 200, 150):
+        a = fo.project_depth(img, pose[:3], q, _scaled_cfg(fo.depth_cfg, 200, margin=margin, skip=skip))
+        b = gm.projectDepthImage(img, pose[:3], q, _scaled_cfg(gm.depthConfig, 200, margin=margin, skip=skip))
+        assert a.shape == b.shape and np.array_equal(a, b)
+    gm.close()
+
+
+@pytest.mark.gpu
+def test_depth_image_fusion_matches_projection_plus_insert(fa):
+    """fuelmi_map_input_depth == oracle projection followed by the oracle's inputPointCloud: bit-exact
+    log-odds, bounds and update box over a frame sequence; frames from outside the map and frames
+    whose pixels are all filtered out leave the map (and raycast_num_) untouched."""
+    from fuel_amd import synth
+    map_size = (10.0, 8.0, 4.0)
+    box = ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    w = synth.World.for_map_size(map_size)
+    truth = w.world(3, 14)
+    ocfg, gcfg = _scaled_cfg(fo.depth_cfg, 160), _scaled_cfg(gm.depthConfig, 160)
+    frames = _depth_frames(w, truth, 20, 160, 120)
+    for k, (img, pose, q) in enumerate(frames):
+        if k == 7:  # every pixel closer than depth_filter_mindist: proj_points_cnt = 0 -> early return
+            near = np.full_like(img, 100)
+            assert gm.inputDepthImage(near, pose[:3], q, gcfg) == 0
+            assert len(fo.project_depth(near, pose[:3], q, ocfg)) == 0
+        if k == 11:  # camera outside the map: depthPoseCallback returns before projecting
+            assert gm.inputDepthImage(img, (50.0, 0.0, 1.0), q, gcfg) == 0
+        pts = fo.project_depth(img, pose[:3], q, ocfg)
+        om.input_points(pts, pose[:3])
+        assert gm.inputDepthImage(img, pose[:3], q, gcfg) == len(pts)
+        assert om.get_local_bound() == gm.getLocalBound()
+        assert np.array_equal(np.concatenate(om.get_updated_box()), np.concatenate(gm.getUpdatedBox()))
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    assert_map_equal(om, gm, om.get_local_bound())
+    gm.close()

@@ -199,3 +199,53 @@ def test_golden_fixture_agrees_with_reference():
         f, gr = ref.bspline_cost_grad(rm, x, ctrl.shape[1], 0x11F, fo.bspline_pt_dist(ctrl[c]), st[c], en[c], 3, 3, 0.2)
         assert abs(f - z["bspline_cost"][c]) <= 1e-12 * abs(f)
         assert np.abs(gr - z["bspline_grad"][c]).max() <= 1e-12 * np.abs(gr).max()
+
+
+def _depth_frames(seed=3, n=6, width=160, height=120):
+    """Synthetic 16UC1 frames with no-return pixels (0), near hits (< mindist) and far hits (> maxdist)."""
+    from fuel_amd import synth
+    w = synth.World.for_map_size((10.0, 8.0, 4.0))
+    truth = w.world(seed, 14)
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        pose = w.camera(truth, 5, k, n, 0.9)
+        img = w.depth_image(truth, pose, width, height, max_range=7.0)
+        img[rng.random(img.shape) < 0.02] = 0                       # dropouts
+        img[rng.random(img.shape) < 0.01] = rng.integers(1, 199)    # closer than depth_filter_mindist
+        out.append((img, pose, synth.World.pose_quaternion(pose)))
+    return out
+
+
+@pytest.mark.skipif(not ref.mapros_available(), reason="oracle/_ref/libfuel_ref_mapros.so not built")
+@pytest.mark.parametrize("margin,skip", [(2, 2), (2, 1), (3, 3), (1, 1)])
+def test_depth_projection_bit_exact_against_real_map_ros(margin, skip):
+    """proessDepthImage (map_ros.cpp:176-215): same float points in the same order, including the
+    'zero test one sample ahead' quirk.  Configurations keep u+skip inside the row (skip <= margin) or
+    at least inside the image, where the reference's read is defined."""
+    total = 0
+    for img, pose, q in _depth_frames():
+        s = img.shape[1] / 640.0
+        cfg = fo.depth_cfg(fx=387.229248046875 * s, fy=387.229248046875 * s, cx=321.04638671875 * s,
+                           cy=243.44969177246094 * s, margin=margin, skip=skip)
+        a = fo.project_depth(img, pose[:3], q, cfg)
+        b = ref.project_depth(img, pose[:3], q, cfg)
+        assert a.shape == b.shape and np.array_equal(a, b)
+        total += len(a)
+    assert total > 8000
+
+
+@pytest.mark.skipif(not ref.mapros_available(), reason="oracle/_ref/libfuel_ref_mapros.so not built")
+def test_depth_projection_quirk_is_real():
+    """A zero one sample AHEAD of a valid pixel turns that pixel into a max-range miss."""
+    img = np.full((12, 16), 1500, dtype=np.uint16)
+    img[4, 8] = 0
+    cfg = fo.depth_cfg(fx=20.0, fy=20.0, cx=8.0, cy=6.0, margin=2, skip=2)
+    q = (1.0, 0.0, 0.0, 0.0)
+    a = fo.project_depth(img, (0, 0, 0), q, cfg)
+    b = ref.project_depth(img, (0, 0, 0), q, cfg)
+    assert np.array_equal(a, b)
+    # rows v = 2,4,6,8 x columns u = 2,...,12; in row v=4: u=6 reads the zero at u=8 -> max range;
+    # u=8 itself has depth 0 but passes the zero test (reads u=10) and is dropped by the min filter
+    assert len(a) == 23
+    assert np.array_equal(a[6:11, 2], np.float32([1.5, 1.5, 5.0, 1.5, 1.5]))
