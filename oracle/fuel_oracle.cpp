@@ -597,15 +597,77 @@ void fo_map_dist_grad(const fo_map* m, const double* pos, int n, double* dist, d
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct Cluster {
-  std::vector<V3d> cells;  // voxel centres, BFS order
+  std::vector<V3d> cells;     // voxel centres, BFS order
+  std::vector<V3d> filtered;  // filtered_cells_: VoxelGrid centroids (float precision, like pcl::PointXYZ)
   V3d average, bmin, bmax;
 };
+
+// pcl::VoxelGrid<pcl::PointXYZ>::applyFilter restated (PCL is a third-party dependency that is not
+// under /root/reference; PCL 1.8-1.12 filters/include/pcl/filters/impl/voxel_grid.hpp): float
+// arithmetic throughout, leaves aligned to global multiples of the leaf size, one centroid per
+// occupied leaf, output sorted by leaf index (x fastest).  PCL sorts with std::sort (order of equal
+// keys unspecified, which only permutes the float summation inside a leaf); this restatement sums in
+// input order.  PARITY UNPINNED against PCL itself.
+void voxel_grid_downsample(const std::vector<V3d>& in, double leaf_d, std::vector<V3d>& out) {
+  out.clear();
+  if (in.empty()) return;
+  struct P { float x, y, z; };
+  std::vector<P> pts;
+  pts.reserve(in.size());
+  for (auto& c : in) pts.push_back(P{(float)c[0], (float)c[1], (float)c[2]});  // emplace_back(cell[0..2]) -> float
+  const float leaf = (float)leaf_d;  // setLeafSize(float, float, float)
+  const float inv = 1.0f / leaf;
+  float mn[3] = {pts[0].x, pts[0].y, pts[0].z}, mx[3] = {pts[0].x, pts[0].y, pts[0].z};
+  for (auto& p : pts) {
+    const float v[3] = {p.x, p.y, p.z};
+    for (int i = 0; i < 3; ++i) {
+      mn[i] = std::min(mn[i], v[i]);
+      mx[i] = std::max(mx[i], v[i]);
+    }
+  }
+  int min_b[3], max_b[3], div_b[3];
+  for (int i = 0; i < 3; ++i) {
+    min_b[i] = (int)std::floor(mn[i] * inv);
+    max_b[i] = (int)std::floor(mx[i] * inv);
+    div_b[i] = max_b[i] - min_b[i] + 1;
+  }
+  const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+  std::vector<std::pair<unsigned, unsigned>> iv;  // (leaf idx, point index)
+  iv.reserve(pts.size());
+  for (unsigned k = 0; k < pts.size(); ++k) {
+    const int i0 = (int)(std::floor(pts[k].x * inv) - (float)min_b[0]);
+    const int i1 = (int)(std::floor(pts[k].y * inv) - (float)min_b[1]);
+    const int i2 = (int)(std::floor(pts[k].z * inv) - (float)min_b[2]);
+    iv.emplace_back((unsigned)(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), k);
+  }
+  std::stable_sort(iv.begin(), iv.end(),
+                   [](const std::pair<unsigned, unsigned>& a, const std::pair<unsigned, unsigned>& b) {
+                     return a.first < b.first;
+                   });
+  size_t i = 0;
+  while (i < iv.size()) {
+    size_t j = i;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    while (j < iv.size() && iv[j].first == iv[i].first) {
+      sx += pts[iv[j].second].x;
+      sy += pts[iv[j].second].y;
+      sz += pts[iv[j].second].z;
+      ++j;
+    }
+    const float n = (float)(j - i);
+    out.push_back(mk((double)(sx / n), (double)(sy / n), (double)(sz / n)));
+    i = j;
+  }
+}
 }  // namespace
 
 struct fo_frontier {
   fo_map* map;
   int cluster_min;
   double min_z;
+  double cluster_size_xy = 2.0;
+  int down_sample = 3;
+  int split = 0;
   std::vector<char> flag;
   std::list<Cluster> frontiers, dormant, tmp;
   std::vector<int> removed_ids;
@@ -635,7 +697,89 @@ struct fo_frontier {
     }
     return false;
   }
-  static void computeInfo(Cluster& c) {
+  // downsample (:757-774): leaf = resolution * down_sample_
+  void downsample(const std::vector<V3d>& in, std::vector<V3d>& out) const {
+    voxel_grid_downsample(in, map->res * down_sample, out);
+  }
+
+  // splitHorizontally (:179-242).  The principal direction comes from Eigen::EigenSolver<Matrix2d>
+  // in the reference (Eigen: third-party, absent); restated as the closed-form symmetric 2x2
+  // decomposition with the convention v = normalise(b, lambda_max - a) (fallbacks for b == 0) -- the
+  // SIGN of the eigenvector decides which half is emitted first and is UNPINNED against Eigen.
+  static void principal_dir(double c00, double c01, double c10, double c11, double pc[2]) {
+    const double a = c00, b = 0.5 * (c01 + c10), d = c11;
+    const double tr = a + d, det = a * d - b * b, disc = std::sqrt(std::fmax(tr * tr / 4 - det, 0.0));
+    const double l = tr / 2 + disc;
+    double vx = b, vy = l - a;
+    if (std::fabs(vx) + std::fabs(vy) < 1e-300) {
+      vx = l - d;
+      vy = b;
+    }
+    if (std::fabs(vx) + std::fabs(vy) < 1e-300) {
+      vx = 1;
+      vy = 0;
+    }
+    const double n = std::sqrt(vx * vx + vy * vy);
+    pc[0] = vx / n;
+    pc[1] = vy / n;
+  }
+  bool splitHorizontally(const Cluster& ftr, std::list<Cluster>& splits) const {
+    const double mean[2] = {ftr.average[0], ftr.average[1]};
+    bool need_split = false;
+    for (auto& cell : ftr.filtered) {
+      const double dx = cell[0] - mean[0], dy = cell[1] - mean[1];
+      if (std::sqrt(dx * dx + dy * dy) > cluster_size_xy) {
+        need_split = true;
+        break;
+      }
+    }
+    if (!need_split) return false;
+    double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    for (auto& cell : ftr.filtered) {
+      const double dx = cell[0] - mean[0], dy = cell[1] - mean[1];
+      c00 += dx * dx;
+      c01 += dx * dy;
+      c10 += dy * dx;
+      c11 += dy * dy;
+    }
+    const double nf = double(ftr.filtered.size());
+    c00 /= nf, c01 /= nf, c10 /= nf, c11 /= nf;
+    double pc[2];
+    principal_dir(c00, c01, c10, c11, pc);
+    Cluster f1, f2;
+    for (auto& cell : ftr.cells) {
+      if ((cell[0] - mean[0]) * pc[0] + (cell[1] - mean[1]) * pc[1] >= 0)
+        f1.cells.push_back(cell);
+      else
+        f2.cells.push_back(cell);
+    }
+    // (the reference would dereference cells_.front() of an empty half: cannot happen for a cluster
+    // whose cells straddle their own mean along pc, which need_split implies)
+    Cluster* halves[2] = {&f1, &f2};
+    for (Cluster* h : halves) {
+      if (h->cells.empty()) continue;
+      computeInfo(*h);
+      std::list<Cluster> sub;
+      if (splitHorizontally(*h, sub))
+        splits.insert(splits.end(), sub.begin(), sub.end());
+      else
+        splits.push_back(*h);
+    }
+    return true;
+  }
+  void splitLarge(std::list<Cluster>& L) const {  // splitLargeFrontiers (:166-177)
+    std::list<Cluster> tmps, splits;
+    for (auto& c : L) {
+      if (splitHorizontally(c, splits)) {
+        tmps.insert(tmps.end(), splits.begin(), splits.end());
+        splits.clear();
+      } else
+        tmps.push_back(c);
+    }
+    L = tmps;
+  }
+
+  void computeInfo(Cluster& c) const {
     c.average = mk(0, 0, 0);
     c.bmax = c.cells.front();
     c.bmin = c.cells.front();
@@ -647,6 +791,7 @@ struct fo_frontier {
       }
     }
     c.average = c.average / double(c.cells.size());
+    if (down_sample > 0) downsample(c.cells, c.filtered);
   }
 
   void expand(const V3i& first) {
@@ -736,6 +881,7 @@ struct fo_frontier {
           V3i cur{{x, y, z}};
           if (flag[map->adr(cur)] == 0 && isFrontier(cur)) expand(cur);
         }
+    if (split) splitLarge(tmp);  // :120
     return (int)tmp.size();
   }
 };
@@ -747,6 +893,9 @@ fo_frontier* fo_frontier_create(fo_map* m, const fo_frontier_cfg* cfg) {
   f->map = m;
   f->cluster_min = cfg->cluster_min;
   f->min_z = cfg->min_z;
+  f->cluster_size_xy = cfg->cluster_size_xy;
+  f->down_sample = cfg->down_sample;  // <= 0: filtered_cells_ not computed (F1-F4 contract only)
+  f->split = cfg->split;
   f->flag.assign((size_t)m->total(), 0);
   return f;
 }
@@ -781,6 +930,14 @@ void fo_frontier_cluster_cells(const fo_frontier* f, int which, int k, int* adr)
 void fo_frontier_cluster_info(const fo_frontier* f, int which, int k, double* out9) {
   const Cluster& c = nth(pick(f, which), k);
   for (int i = 0; i < 3; ++i) out9[i] = c.average[i], out9[3 + i] = c.bmin[i], out9[6 + i] = c.bmax[i];
+}
+int fo_frontier_cluster_filtered_size(const fo_frontier* f, int which, int k) {
+  return (int)nth(pick(f, which), k).filtered.size();
+}
+void fo_frontier_cluster_filtered(const fo_frontier* f, int which, int k, double* xyz) {
+  const Cluster& c = nth(pick(f, which), k);
+  for (size_t i = 0; i < c.filtered.size(); ++i)
+    for (int q = 0; q < 3; ++q) xyz[3 * i + q] = c.filtered[i][q];
 }
 int fo_frontier_removed_count(const fo_frontier* f) { return (int)f->removed_ids.size(); }
 void fo_frontier_removed_ids(const fo_frontier* f, int* ids) {

@@ -103,13 +103,20 @@ int fo_raycast_cells(const fo_map* m, const double start[3], const double end[3]
 typedef struct {
   int cluster_min;         /* frontier/cluster_min */
   double min_z;            /* the hard-coded 0.4 in frontier_finder.cpp:151 */
+  double cluster_size_xy;  /* frontier/cluster_size_xy (2.0) */
+  int down_sample;         /* frontier/down_sample (3): VoxelGrid leaf = down_sample * resolution; <= 0: skip */
+  int split;               /* 0: stop before splitLargeFrontiers (the F1-F4 contract); 1: run it */
 } fo_frontier_cfg;
 typedef struct fo_frontier fo_frontier;
 
 fo_frontier* fo_frontier_create(fo_map* m, const fo_frontier_cfg* cfg);
 void fo_frontier_destroy(fo_frontier* f);
 char* fo_frontier_flags(fo_frontier* f);
-/* searchFrontiers up to (not including) splitLargeFrontiers: removes changed clusters
+/* down-sampled cells of a cluster (Frontier::filtered_cells_, frontier_finder.cpp:757-774): count and
+   xyz triples in the VoxelGrid's output order */
+int fo_frontier_cluster_filtered_size(const fo_frontier* f, int which, int k);
+void fo_frontier_cluster_filtered(const fo_frontier* f, int which, int k, double* xyz);
+/* searchFrontiers up to (not including) splitLargeFrontiers unless cfg.split: removes changed clusters
    (frontiers_ and dormant_), scans, grows clusters into tmp_frontiers_.  Returns number of
    new clusters (tmp_frontiers_.size()). */
 int fo_frontier_search(fo_frontier* f);

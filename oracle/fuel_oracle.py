@@ -37,7 +37,8 @@ class MapCfg(C.Structure):
 
 
 class FrontierCfg(C.Structure):
-    _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double)]
+    _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double), ("cluster_size_xy", C.c_double),
+                ("down_sample", C.c_int), ("split", C.c_int)]
 
 
 class BsplineCfg(C.Structure):
@@ -127,6 +128,8 @@ def lib():
         L.fo_frontier_cluster_size.argtypes = [P, C.c_int, C.c_int]
         L.fo_frontier_cluster_cells.argtypes = [P, C.c_int, C.c_int, ip]
         L.fo_frontier_cluster_info.argtypes = [P, C.c_int, C.c_int, dp]
+        L.fo_frontier_cluster_filtered_size.argtypes = [P, C.c_int, C.c_int]
+        L.fo_frontier_cluster_filtered.argtypes = [P, C.c_int, C.c_int, dp]
         L.fo_frontier_removed_count.argtypes = [P]
         L.fo_frontier_removed_ids.argtypes = [P, ip]
         L.fo_bspline_pt_dist.restype = C.c_double
@@ -307,10 +310,13 @@ class OracleMap:
 
 
 class OracleFrontier:
-    def __init__(self, omap, cluster_min=100, min_z=0.4):
+    def __init__(self, omap, cluster_min=100, min_z=0.4, cluster_size_xy=2.0, down_sample=0, split=False):
+        """down_sample=3 fills filtered_cells_; split=True runs splitLargeFrontiers (needs down_sample)."""
         self.L = lib()
         self.map = omap
-        cfg = FrontierCfg(cluster_min, min_z)
+        if split and down_sample <= 0:
+            down_sample = 3
+        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split))
         self.h = self.L.fo_frontier_create(omap.h, C.byref(cfg))
         self.flags = np.ctypeslib.as_array(
             C.cast(self.L.fo_frontier_flags(self.h), C.POINTER(C.c_int8)), shape=(omap.N,))
@@ -340,6 +346,14 @@ class OracleFrontier:
         o = np.empty(9)
         self.L.fo_frontier_cluster_info(self.h, which, k, _dp(o))
         return o[:3], o[3:6], o[6:9]
+
+    def filtered(self, which, k):
+        """Frontier::filtered_cells_ of cluster k: float64 [n,3] (values carry float32 precision)."""
+        n = self.L.fo_frontier_cluster_filtered_size(self.h, which, k)
+        o = np.empty((n, 3))
+        if n:
+            self.L.fo_frontier_cluster_filtered(self.h, which, k, _dp(o))
+        return o
 
     def removed_ids(self):
         n = self.L.fo_frontier_removed_count(self.h)

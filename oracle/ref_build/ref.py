@@ -47,7 +47,7 @@ def lib():
         L.ref_bspline_cost_grad.argtypes = [P, C.POINTER(fo.BsplineCfg), C.POINTER(fo.BsplineProblem), dp, dp, dp]
         L.ref_map_set_updated_box.argtypes = [P, dp, dp]
         L.ref_frontier_create.restype = P
-        L.ref_frontier_create.argtypes = [P, C.c_int]
+        L.ref_frontier_create.argtypes = [P, C.c_int, C.c_double]
         L.ref_frontier_destroy.argtypes = [P]
         L.ref_frontier_flags.restype = C.POINTER(C.c_char)
         L.ref_frontier_flags.argtypes = [P]
@@ -57,6 +57,8 @@ def lib():
         L.ref_frontier_cluster_size.argtypes = [P, C.c_int, C.c_int]
         L.ref_frontier_cluster_cells.argtypes = [P, C.c_int, C.c_int, ip]
         L.ref_frontier_cluster_info.argtypes = [P, C.c_int, C.c_int, dp]
+        L.ref_frontier_cluster_filtered_size.argtypes = [P, C.c_int, C.c_int]
+        L.ref_frontier_cluster_filtered.argtypes = [P, C.c_int, C.c_int, dp]
         L.ref_frontier_removed_count.argtypes = [P]
         L.ref_frontier_removed_ids.argtypes = [P, ip]
         _LIB = L
@@ -66,10 +68,11 @@ def lib():
 class RefFrontier:
     """fast_planner::FrontierFinder (the reference's own searchFrontiers / expandFrontier)."""
 
-    def __init__(self, rmap, cluster_min=100):
+    def __init__(self, rmap, cluster_min=100, cluster_size_xy=-1.0):
+        """cluster_size_xy < 0: splitLargeFrontiers never splits (region-grown clusters only)."""
         self.L = lib()
         self.map = rmap
-        self.h = self.L.ref_frontier_create(rmap.h, cluster_min)
+        self.h = self.L.ref_frontier_create(rmap.h, cluster_min, C.c_double(cluster_size_xy))
         self.flags = np.ctypeslib.as_array(C.cast(self.L.ref_frontier_flags(self.h), C.POINTER(C.c_int8)),
                                            shape=(rmap.N,))
 
@@ -98,6 +101,13 @@ class RefFrontier:
         o = np.empty(9)
         self.L.ref_frontier_cluster_info(self.h, which, k, fo._dp(o))
         return o[:3], o[3:6], o[6:9]
+
+    def filtered(self, which, k):
+        n = self.L.ref_frontier_cluster_filtered_size(self.h, which, k)
+        o = np.empty((n, 3))
+        if n:
+            self.L.ref_frontier_cluster_filtered(self.h, which, k, fo._dp(o))
+        return o
 
     def removed_ids(self):
         n = self.L.ref_frontier_removed_count(self.h)

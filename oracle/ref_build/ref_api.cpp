@@ -151,16 +151,18 @@ int ref_raycast_cells(ref_map* r, const double start[3], const double end[3], in
 }
 
 // ---- FrontierFinder: the reference's own searchFrontiers()/expandFrontier() -----------------------
-// (splitLargeFrontiers is neutralised by the VoxelGrid stand-in returning an empty cloud, so
-// tmp_frontiers_ holds the region-grown clusters)
+// cluster_size_xy < 0: a huge value is used, so splitHorizontally never splits and tmp_frontiers_ holds
+// the region-grown clusters (the F1-F4 contract); otherwise splitLargeFrontiers runs with it (the
+// down-sampled cells come from the pcl::VoxelGrid restatement in compat/, the principal direction
+// from the Eigen::EigenSolver stand-in: both third-party libraries that are absent here).
 struct ref_frontier {
   std::unique_ptr<fast_planner::FrontierFinder> ff;
   ref_map* map;
 };
-ref_frontier* ref_frontier_create(ref_map* r, int cluster_min) {
+ref_frontier* ref_frontier_create(ref_map* r, int cluster_min, double cluster_size_xy) {
   ros::NodeHandle nh;
   nh.num["frontier/cluster_min"] = cluster_min;
-  nh.num["frontier/cluster_size_xy"] = 2.0;
+  nh.num["frontier/cluster_size_xy"] = cluster_size_xy < 0 ? 1e18 : cluster_size_xy;
   nh.num["frontier/cluster_size_z"] = 10.0;
   nh.num["frontier/down_sample"] = 3;
   ref_frontier* f = new ref_frontier;
@@ -203,6 +205,17 @@ void ref_frontier_cluster_info(ref_frontier* f, int which, int k, double* out9) 
   auto it = ref_pick(f, which).begin();
   std::advance(it, k);
   for (int i = 0; i < 3; ++i) out9[i] = it->average_(i), out9[3 + i] = it->box_min_(i), out9[6 + i] = it->box_max_(i);
+}
+int ref_frontier_cluster_filtered_size(ref_frontier* f, int which, int k) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  return (int)it->filtered_cells_.size();
+}
+void ref_frontier_cluster_filtered(ref_frontier* f, int which, int k, double* xyz) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  for (size_t i = 0; i < it->filtered_cells_.size(); ++i)
+    for (int q = 0; q < 3; ++q) xyz[3 * i + q] = it->filtered_cells_[i](q);
 }
 int ref_frontier_removed_count(ref_frontier* f) { return (int)f->ff->removed_ids_.size(); }
 void ref_frontier_removed_ids(ref_frontier* f, int* ids) {

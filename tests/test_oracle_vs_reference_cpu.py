@@ -249,3 +249,41 @@ def test_depth_projection_quirk_is_real():
     # u=8 itself has depth 0 but passes the zero test (reads u=10) and is dropped by the min filter
     assert len(a) == 23
     assert np.array_equal(a[6:11, 2], np.float32([1.5, 1.5, 5.0, 1.5, 1.5]))
+
+
+def _explored_pair(seed=42, n_frames=28):
+    """Same explored state in the oracle map and the real SDFMap (own fusion each; bit-equal)."""
+    om, truth, frames, box = helpers.explored_oracle_map((16.0, 14.0, 4.0), 30, n_frames, seed=seed)
+    rm = ref.RefMap((16.0, 14.0, 4.0), *box)
+    for pts, cam in frames:
+        rm.input_points(pts, cam)
+    assert np.array_equal(om.occ, rm.occ)
+    return om, rm
+
+
+@pytest.mark.parametrize("seed,size_xy", [(42, 2.0), (7, 1.2), (11, 3.0)])
+def test_split_large_frontiers_against_real_reference(seed, size_xy):
+    """searchFrontiers INCLUDING splitLargeFrontiers (frontier_finder.cpp:166-242,374-390,757-774) run by
+    the real frontier_finder.cpp (with the VoxelGrid / EigenSolver stand-ins of compat/) equals the oracle:
+    same clusters in the same order, same cell order (BFS order survives the partition), bit-equal
+    averages / boxes / filtered cells."""
+    om, rm = _explored_pair(seed)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    rf = ref.RefFrontier(rm, cluster_min=60, cluster_size_xy=size_xy)
+    plain = fo.OracleFrontier(om, cluster_min=60)
+    ub = om.get_updated_box(reset=False)
+    for m_ in (om, rm):
+        m_.set_updated_box(*ub)
+    n0 = plain.search()
+    om.set_updated_box(*ub)
+    n1, n2 = of.search(), rf.search()
+    assert n1 == n2 and n1 > n0 > 0  # something was actually split
+    ca, cb = of.clusters(0), rf.clusters(0)
+    for k in range(n1):
+        assert np.array_equal(ca[k], cb[k])
+        for x, y in zip(of.cluster_info(0, k), rf.cluster_info(0, k)):
+            assert np.array_equal(x, y)
+        fa_, fb_ = of.filtered(0, k), rf.filtered(0, k)
+        assert fa_.shape == fb_.shape and np.array_equal(fa_, fb_) and len(fa_) > 0
+    # the split is a partition of the region-grown clusters
+    assert np.array_equal(np.sort(np.concatenate(ca)), np.sort(np.concatenate(plain.clusters(0))))
