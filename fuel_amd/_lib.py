@@ -70,7 +70,8 @@ class MapInfo(C.Structure):
 
 
 class FrontierCfg(C.Structure):
-    _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double)]
+    _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double), ("cluster_size_xy", C.c_double),
+                ("down_sample", C.c_int), ("split", C.c_int)]
 
 
 class BsplineCfg(C.Structure):
@@ -124,6 +125,8 @@ SYMBOLS = {
     "fuelmi_map_coarse_dist": (C.c_int, [_P, _dp, C.c_int, _dp]),
     "fuelmi_map_query_state": (C.c_int, [_P, _ip, C.c_int, _ip, _ip]),
     "fuelmi_map_synchronize": (C.c_int, [_P]),
+    "fuelmi_frontier_cluster_filtered_size": (C.c_int, [_P, C.c_int, C.c_int]),
+    "fuelmi_frontier_cluster_filtered": (C.c_int, [_P, C.c_int, C.c_int, C.c_void_p]),
     "fuelmi_frontier_create": (C.c_int, [_P, C.POINTER(FrontierCfg), _PP]),
     "fuelmi_frontier_destroy": (None, [_P]),
     "fuelmi_frontier_reset": (C.c_int, [_P]),

@@ -28,8 +28,8 @@
 #include <vector>
 
 #include "fuelmi_internal.h"
+#include "frontier_internal.h"
 
-#define NOCLAIM 0xFFFFFFFFu
 // FUELMI_DEBUG_SYNC=1: synchronise and name every frontier kernel (locates device faults)
 #define FDBG(name)                                                                     \
   do {                                                                                 \
@@ -39,63 +39,6 @@
       std::fprintf(stderr, "[fuelmi] %s: %s\n", name, hipGetErrorString(e__));         \
     }                                                                                  \
   } while (0)
-
-struct KeptRec {  // one per kept cluster, in rank order (ascending claimer address)
-  u32 addr, slot, size, off;  // off: first position of the cluster in the grouped cell array
-  unsigned long long sum[3];  // voxel-index sums / AABB of cells outside their chunk's leading key
-  u32 box[6];
-  u32 pad[2];
-};
-
-// the per-search part of the arguments lives in device memory (refreshed by k_load_var from a pinned
-// host copy), so that the kernel chain can be replayed as a hipGraph with constant kernel arguments
-struct FVar {
-  Box3 sbox;   // scanned index box, inclusive
-  int w0;      // first word processed (multiple of 256)
-  int nwords;  // words processed (multiple of 256)
-  int nblocks; // nwords / 256
-  int pad;
-};
-
-struct FArgs {
-  Box3 qbox;  // Q0 index box (isInBox & z >= iz_min), inclusive
-  const FVar* var;
-  u32 cap_q, cap_s;
-  int cluster_min;
-  const u64* occ;
-  const u64* unk;
-  u64* flag;
-  u64* qb;
-  u64* sb;
-  u64* pref;       // per word: packed in-block exclusive prefix (lo = q count, hi = s count)
-  u64* blocksum;   // per 256-word block: packed totals
-  u64* blockscan;  // exclusive scan of blocksum
-  u32* counts;     // [0]=nq [1]=ns [2]=overflow [3]=n_kept
-  u32* cell_adr;   // [cap_q]
-  u32* parent;     // [cap_q]
-  u32* claim;      // [cap_q] per root: claimer address
-  int* cell_slot;  // [cap_q] slot of the owning cluster if kept, else -1
-  u32* seed_adr;   // [cap_s]
-  u32* csize;      // [cap_q + cap_s] cluster sizes by slot
-  u32* kept;       // [.. x 3] (claimer address, slot, size)
-  u32 cap_kept;
-  // grouping of the kept cells by cluster rank (stable 8-bit radix multisplit)
-  int* slot2rank;    // [cap_q + cap_s] valid only at kept slots
-  struct KeptRec* krec;  // [cap_kept] cluster records in rank order
-  u32* ms_key[2];    // [cap_q]
-  u32* ms_val[2];    // [cap_q]
-  u32* ms_hist;      // [256][ms_nb_max]
-  u32 ms_nb_max;
-  u32* info_part;                // [cap_q / SZ_CH + 1][10] per-chunk records (key, sums, min, max)
-  // result staging in pinned HOST memory, written by the last kernels themselves (no blit copies):
-  u32* h_counts;          // [16]
-  struct KeptRec* h_rec;  // [cap_kept]
-  u32* h_part;            // like info_part
-  u32* h_cells;           // [cap_q] grouped cell addresses
-};
-
-#define MS_CH 2048  // cells per multisplit block (256 threads x 8)
-#define NOKEY 0xFFFFFFFFu
 
 // ---- per-word masks ---------------------------------------------------------------------------
 __device__ __forceinline__ void word_masks(const Geo& g, int w, const Box3& qb, const Box3& sb, u64& z0,
@@ -691,7 +634,6 @@ __device__ __forceinline__ void wave_agg_add(u32* base, bool active, u32 key) {
 // A frontier surface is typically ONE huge cluster, so per-lane (even per-wave) atomics on its
 // counter serialise: every 1024-cell chunk is reduced in the block for its leading slot (key0) and
 // only cells of other slots take the wave-aggregated atomic path.
-#define SZ_CH 1024
 __global__ void __launch_bounds__(256) k_sizes(Geo g, FArgs F) {
   __shared__ u32 s_key0;
   __shared__ u32 s_part[4];
@@ -1063,67 +1005,6 @@ __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* _
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-struct HCluster {
-  std::vector<int> cells;  // ascending voxel addresses
-  double avg[3], bmin[3], bmax[3];
-  // A freshly found cluster (tmp_frontiers_) still lives in the pinned result buffer: its cell list is
-  // copied out only when somebody keeps it (commit) -- a 140 k-cell surface costs ~25 us to copy,
-  // 10 % of a plan cycle, and the buffer stays valid until the next search.
-  const int* lazy = nullptr;
-  u32 lazy_n = 0;
-  int lazy_seed = -1;  // NQ seed address to merge in, or -1
-  size_t size() const { return lazy ? (size_t)lazy_n + (lazy_seed >= 0 ? 1u : 0u) : cells.size(); }
-  void copy_to(int* out) const {  // ascending addresses
-    if (!lazy) {
-      if (!cells.empty()) memcpy(out, cells.data(), cells.size() * sizeof(int));
-      return;
-    }
-    if (lazy_seed < 0) {
-      if (lazy_n) memcpy(out, lazy, (size_t)lazy_n * sizeof(int));
-      return;
-    }
-    const size_t k = (size_t)(std::lower_bound(lazy, lazy + lazy_n, lazy_seed) - lazy);
-    if (k) memcpy(out, lazy, k * sizeof(int));
-    out[k] = lazy_seed;
-    if (lazy_n > k) memcpy(out + k + 1, lazy + k, (lazy_n - k) * sizeof(int));
-  }
-  void materialize() {
-    if (!lazy) return;
-    std::vector<int> v(size());
-    copy_to(v.data());
-    cells.swap(v);
-    lazy = nullptr;
-  }
-};
-
-struct fuelmi_frontier {
-  fuelmi_map* map = nullptr;
-  fuelmi_frontier_cfg cfg;
-  int iz_min = 0;
-  Plane flag, qb, sb;
-  FArgs F;
-  size_t nwords_alloc = 0;
-  std::vector<void*> allocs;
-  std::list<HCluster> frontiers, dormant, tmp;
-  std::vector<int> removed_ids;
-  hipStream_t stream = nullptr;  // frontier work runs beside the map's own stream
-  hipEvent_t ev_dep = nullptr;
-  void* d_stage = nullptr;
-  size_t d_stage_bytes = 0;
-  void* h_pin = nullptr;  // pinned result staging
-  size_t pin_bytes = 0;
-  int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
-  int last_nkept = 0, nb_launch = 0, npass = 1;
-  FVar* h_var = nullptr;  // pinned per-search arguments
-  FVar* d_var = nullptr;
-  int TX = 1, TY = 16, ccl_tiles = 0, ccl_nty = 0;
-  size_t ccl_lds = 0;
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
-  bool pending = false, search_empty = false;
-  std::unique_ptr<StageScope> scope;
-  std::vector<int> slot2rank;
-};
-
 static inline int fblocks(long n, int t, int cap = 1 << 16) {
   long b = (n + t - 1) / t;
   return (int)std::max(1L, std::min((long)cap, b));
@@ -1196,6 +1077,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   for (void* p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   if (f->h_var) (void)hipHostFree(f->h_var);
+  frontier_split_free(f);
   for (hipGraphExec_t e : f->graph_exec)
     if (e) (void)hipGraphExecDestroy(e);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
@@ -1370,6 +1252,19 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
       L.erase(cand[k]);
       ++erased;
     }
+  return FUELMI_OK;
+}
+
+int frontier_regroup(fuelmi_frontier* f, const FArgs& F2, int npass) {
+  const Geo& g = f->map->g;
+  for (int p = 0; p < npass; ++p) {
+    k_ms_hist<<<256, 256, 0, f->stream>>>(F2, p);
+    k_ms_scan<<<1, 256, 0, f->stream>>>(F2, p);
+    k_ms_scatter<<<256, 256, 0, f->stream>>>(F2, p);
+  }
+  k_ms_info<<<256, 256, 0, f->stream>>>(g, F2);
+  k_pack<<<8, 256, 0, f->stream>>>(F2);
+  HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
 
@@ -1564,11 +1459,18 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     HIPCHK(hipStreamSynchronize(f->stream));
   }
   if (nkept == 0) return FUELMI_OK;
-  const u32 nchunk = (n_out + SZ_CH - 1) / SZ_CH;
+  u32 ncl = nkept, ncells = n_out;
+  std::vector<std::vector<float>> filtered;
+  const bool split_mode = f->cfg.split != 0;
+  if (split_mode) {  // splitLargeFrontiers (:120) on the device; the pinned buffers then hold the pieces
+    int rc = frontier_split_run(f, nq, nkept, n_out, nkept <= 256 ? 1 : 0, &ncl, &ncells, &filtered);
+    if (rc) return rc;
+  }
+  const u32 nchunk = (ncells + SZ_CH - 1) / SZ_CH;
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
     const u32 r = rec[0];
-    if (r >= nkept) continue;
+    if (r >= ncl) continue;
     for (int q = 0; q < 3; ++q) {
       h_rec[r].sum[q] += rec[1 + q];
       h_rec[r].box[q] = std::min(h_rec[r].box[q], rec[4 + q]);
@@ -1578,17 +1480,25 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
 
   // host: bulk copies only (+ inserting an NQ seed where a seed started the cluster); records are
   // already in creation order (ascending claimer address = the reference's scan order)
-  for (u32 r = 0; r < nkept; ++r) {
+  for (u32 r = 0; r < ncl; ++r) {
     const KeptRec& kr = h_rec[r];
     f->tmp.emplace_back();
     HCluster& c = f->tmp.back();
-    const bool seed = kr.slot >= nq;
+    const bool seed = !split_mode && kr.slot >= nq;
     const u32 cnt = kr.size - (seed ? 1u : 0u);
     c.lazy = reinterpret_cast<const int*>(h_cells) + kr.off;
     c.lazy_n = cnt;
     unsigned long long sum[3] = {kr.sum[0], kr.sum[1], kr.sum[2]};
     u32 lo[3] = {kr.box[0], kr.box[1], kr.box[2]};
     u32 hi[3] = {kr.box[3], kr.box[4], kr.box[5]};
+    if (split_mode) {
+      // an NQ seed travels as the LAST cell of its piece (already in the sums): restore address order
+      if (cnt > 1 && c.lazy[cnt - 1] < c.lazy[cnt - 2]) {
+        c.lazy_seed = c.lazy[cnt - 1];
+        c.lazy_n = cnt - 1;
+      }
+      c.filtered.swap(filtered[r]);
+    }
     if (seed) {
       const int a = (int)kr.addr;
       c.lazy_seed = a;
@@ -1666,6 +1576,19 @@ extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which
   const HCluster* c = nth(f, which, k);
   ARGCHK(c);
   c->copy_to(adr);
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_frontier_cluster_filtered_size(const fuelmi_frontier* f, int which, int k) {
+  ARGCHK(f);
+  const HCluster* c = nth(f, which, k);
+  ARGCHK(c);
+  return (int)(c->filtered.size() / 3);
+}
+extern "C" int fuelmi_frontier_cluster_filtered(const fuelmi_frontier* f, int which, int k, float* xyz) {
+  ARGCHK(f && xyz);
+  const HCluster* c = nth(f, which, k);
+  ARGCHK(c);
+  if (!c->filtered.empty()) memcpy(xyz, c->filtered.data(), c->filtered.size() * sizeof(float));
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_cluster_info(const fuelmi_frontier* f, int which, int k, double out9[9]) {

@@ -1,0 +1,156 @@
+// frontier_internal.h -- structures shared by frontier.hip (scan + clustering) and
+// frontier_split.hip (splitLargeFrontiers / down-sampling on the device).
+#ifndef FUELMI_FRONTIER_INTERNAL_H_
+#define FUELMI_FRONTIER_INTERNAL_H_
+
+#include <algorithm>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <vector>
+
+#include "fuelmi_internal.h"
+
+#define NOCLAIM 0xFFFFFFFFu
+#define SZ_CH 1024
+
+struct KeptRec {  // one per kept cluster, in rank order (ascending claimer address)
+  u32 addr, slot, size, off;  // off: first position of the cluster in the grouped cell array
+  unsigned long long sum[3];  // voxel-index sums / AABB of cells outside their chunk's leading key
+  u32 box[6];
+  u32 pad[2];
+};
+
+// the per-search part of the arguments lives in device memory (refreshed by k_load_var from a pinned
+// host copy), so that the kernel chain can be replayed as a hipGraph with constant kernel arguments
+struct FVar {
+  Box3 sbox;   // scanned index box, inclusive
+  int w0;      // first word processed (multiple of 256)
+  int nwords;  // words processed (multiple of 256)
+  int nblocks; // nwords / 256
+  int pad;
+};
+
+struct FArgs {
+  Box3 qbox;  // Q0 index box (isInBox & z >= iz_min), inclusive
+  const FVar* var;
+  u32 cap_q, cap_s;
+  int cluster_min;
+  const u64* occ;
+  const u64* unk;
+  u64* flag;
+  u64* qb;
+  u64* sb;
+  u64* pref;       // per word: packed in-block exclusive prefix (lo = q count, hi = s count)
+  u64* blocksum;   // per 256-word block: packed totals
+  u64* blockscan;  // exclusive scan of blocksum
+  u32* counts;     // [0]=nq [1]=ns [2]=overflow [3]=n_kept
+  u32* cell_adr;   // [cap_q]
+  u32* parent;     // [cap_q]
+  u32* claim;      // [cap_q] per root: claimer address
+  int* cell_slot;  // [cap_q] slot of the owning cluster if kept, else -1
+  u32* seed_adr;   // [cap_s]
+  u32* csize;      // [cap_q + cap_s] cluster sizes by slot
+  u32* kept;       // [.. x 3] (claimer address, slot, size)
+  u32 cap_kept;
+  // grouping of the kept cells by cluster rank (stable 8-bit radix multisplit)
+  int* slot2rank;    // [cap_q + cap_s] valid only at kept slots
+  struct KeptRec* krec;  // [cap_kept] cluster records in rank order
+  u32* ms_key[2];    // [cap_q]
+  u32* ms_val[2];    // [cap_q]
+  u32* ms_hist;      // [256][ms_nb_max]
+  u32 ms_nb_max;
+  u32* info_part;                // [cap_q / SZ_CH + 1][10] per-chunk records (key, sums, min, max)
+  // result staging in pinned HOST memory, written by the last kernels themselves (no blit copies):
+  u32* h_counts;          // [16]
+  struct KeptRec* h_rec;  // [cap_kept]
+  u32* h_part;            // like info_part
+  u32* h_cells;           // [cap_q] grouped cell addresses
+};
+
+#define MS_CH 2048  // cells per multisplit block (256 threads x 8)
+#define NOKEY 0xFFFFFFFFu
+
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct HCluster {
+  std::vector<int> cells;  // ascending voxel addresses
+  double avg[3], bmin[3], bmax[3];
+  // A freshly found cluster (tmp_frontiers_) still lives in the pinned result buffer: its cell list is
+  // copied out only when somebody keeps it (commit) -- a 140 k-cell surface costs ~25 us to copy,
+  // 10 % of a plan cycle, and the buffer stays valid until the next search.
+  std::vector<float> filtered;  // filtered_cells_ (xyz triples), only for clusters found with cfg.split
+  const int* lazy = nullptr;
+  u32 lazy_n = 0;
+  int lazy_seed = -1;  // NQ seed address to merge in, or -1
+  size_t size() const { return lazy ? (size_t)lazy_n + (lazy_seed >= 0 ? 1u : 0u) : cells.size(); }
+  void copy_to(int* out) const {  // ascending addresses
+    if (!lazy) {
+      if (!cells.empty()) memcpy(out, cells.data(), cells.size() * sizeof(int));
+      return;
+    }
+    if (lazy_seed < 0) {
+      if (lazy_n) memcpy(out, lazy, (size_t)lazy_n * sizeof(int));
+      return;
+    }
+    const size_t k = (size_t)(std::lower_bound(lazy, lazy + lazy_n, lazy_seed) - lazy);
+    if (k) memcpy(out, lazy, k * sizeof(int));
+    out[k] = lazy_seed;
+    if (lazy_n > k) memcpy(out + k + 1, lazy + k, (lazy_n - k) * sizeof(int));
+  }
+  void materialize() {
+    if (!lazy) return;
+    std::vector<int> v(size());
+    copy_to(v.data());
+    cells.swap(v);
+    lazy = nullptr;
+  }
+};
+
+struct fuelmi_frontier {
+  fuelmi_map* map = nullptr;
+  fuelmi_frontier_cfg cfg;
+  int iz_min = 0;
+  Plane flag, qb, sb;
+  FArgs F;
+  size_t nwords_alloc = 0;
+  std::vector<void*> allocs;
+  std::list<HCluster> frontiers, dormant, tmp;
+  std::vector<int> removed_ids;
+  hipStream_t stream = nullptr;  // frontier work runs beside the map's own stream
+  hipEvent_t ev_dep = nullptr;
+  void* d_stage = nullptr;
+  size_t d_stage_bytes = 0;
+  void* h_pin = nullptr;  // pinned result staging
+  size_t pin_bytes = 0;
+  int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
+  int last_nkept = 0, nb_launch = 0, npass = 1;
+  FVar* h_var = nullptr;  // pinned per-search arguments
+  FVar* d_var = nullptr;
+  int TX = 1, TY = 16, ccl_tiles = 0, ccl_nty = 0;
+  size_t ccl_lds = 0;
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
+  bool pending = false, search_empty = false;
+  std::unique_ptr<StageScope> scope;
+  std::vector<int> slot2rank;
+  struct SplitScratch* split = nullptr;  // device buffers of the split stage (frontier_split.hip)
+};
+void frontier_split_free(fuelmi_frontier* f);
+
+
+// runs the stable radix multisplit of F2.ms_key[0]/ms_val[0] (F2.counts[0] items, F2.counts[3] keys,
+// key records F2.krec already laid out), the per-cluster accumulators and the copy-out to the pinned
+// host buffers of F2, on f->stream (defined in frontier.hip; used by the split stage with its own
+// argument block)
+int frontier_regroup(fuelmi_frontier* f, const FArgs& F2, int npass);
+// splitLargeFrontiers on the device (frontier_split.hip)
+// in: the unsplit result of this search (nkept clusters, n_out grouped Q0 cells in F.ms_val[fin] with
+// their cluster rank in F.ms_key[fin], records in F.h_rec).  out: F.h_counts/h_rec/h_part/h_cells hold
+// the clusters after splitting (*n_final clusters, *n_cells cells, NQ seeds included as last cell of
+// their cluster); filtered[r] = down-sampled cells of final cluster r.
+int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin, u32* n_final, u32* n_cells,
+                       std::vector<std::vector<float>>* filtered);
+
+#endif

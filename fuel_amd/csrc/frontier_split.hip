@@ -1,0 +1,590 @@
+// frontier_split.hip -- FrontierFinder::splitLargeFrontiers / splitHorizontally / downsample /
+// computeFrontierInfo (active_perception/src/frontier_finder.cpp:166-242, 374-390, 757-774) on the
+// device.
+//
+// The reference recurses cluster by cluster: down-sample the cells with a pcl::VoxelGrid (leaf =
+// down_sample * resolution, leaves aligned to GLOBAL multiples of the leaf size), test whether any
+// down-sampled cell lies farther than cluster_size_xy from the mean (xy), and if so cut the cluster
+// by the line through the mean perpendicular to the first principal direction of the down-sampled
+// cells, then recurse into both halves (dot >= 0 first).  Here all clusters advance one recursion
+// LEVEL at a time:
+//   k_sp_sums     per cell   : cell count / voxel-index sums of every node evaluated at this level
+//                              (block-local LDS table, one global atomic per node and block)
+//   k_sp_leaf     per cell   : (node, leaf) -> open-addressing hash table: count + index sums.
+//                              The leaf of a voxel is floor(float(centre) * (1/leaf)) exactly like PCL.
+//   k_sp_stats    per slot   : centroid; need_split |= dist_xy > cluster_size_xy; covariance sums
+//                              (wave-reduced per node, then f64 atomics)
+//   k_sp_decide   per node   : FINAL, or SPLIT with the principal direction and two child nodes
+//   k_sp_emit     per slot   : centroids of nodes that became FINAL -> filtered-cell output
+//   k_sp_part     per cell   : cells of SPLIT nodes move to the child on their side of the cut
+// until a level splits nothing (one 64-byte read-back per level).  The leaves of the split forest in
+// depth-first order (dot >= 0 half first) are the reference's output order; the cells are regrouped
+// by that rank with the same stable multisplit the clustering uses, which keeps them in ascending
+// address order, and the per-piece mean / AABB come from the same accumulator kernel.
+//
+// Arithmetic: node means and centroids are exact rationals of integer voxel-index sums evaluated
+// in f64 (the reference accumulates f64 cell centres, PCL accumulates float centroids: both are
+// within 1e-5 m of the exact value, the centroid is rounded to float like pcl::PointXYZ).  The
+// principal direction uses the closed-form symmetric 2x2 decomposition with the sign convention of
+// the oracle (Eigen::EigenSolver is third-party; its sign is unpinned).
+#include <cmath>
+#include <cstdlib>
+
+#include "frontier_internal.h"
+
+namespace {
+
+enum : u32 { N_ACTIVE = 0, N_SPLIT = 1, N_FINAL = 2, N_DEAD = 3 };
+
+struct SNode {
+  u32 orig;    // rank of the region-grown cluster this piece comes from
+  u32 path;    // split decisions from the root, 0 = "dot >= 0" half, most recent in bit 0
+  u32 depth;   // number of decisions
+  u32 level;   // level at which the node is evaluated
+  u32 state;
+  u32 child0;  // children are child0, child0 + 1
+  u32 n;       // cells
+  u32 need_split;
+  unsigned long long sx, sy, sz;  // voxel-index sums
+  unsigned long long nfilt;
+  double cov[4];                  // sums of dx*dx, dx*dy, dy*dx, dy*dy over the centroids
+  double pc[2];
+  u32 rank;  // final rank (FINAL nodes)
+  u32 pad;
+};
+
+struct LeafAcc {
+  u32 cnt, sx, sy, sz;
+};
+
+#define SP_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define SP_LBITS 14  // signed leaf coordinate bits per axis (+-8192 leaves)
+#define SP_LOFF (1 << (SP_LBITS - 1))
+
+struct SArgs {
+  u32 n;         // cells (Q0 cells + appended NQ seeds)
+  u32* cells;    // voxel addresses
+  u32* node;     // current node of every cell
+  SNode* nodes;
+  u32 cap_nodes;
+  u32* ctr;      // [0] n_nodes [1] splits of this level [2] n_filtered [3] overflow [4] n_final
+  u64* hkeys;
+  LeafAcc* hvals;
+  u32 hmask;
+  // filtered-cell output
+  u32* f_node;
+  u64* f_leaf;
+  float* f_xyz;
+  u32 cap_filt;
+  double size_xy;
+  float inv_leaf;
+};
+
+__device__ __forceinline__ void decode(const Geo& g, u32 a, u32& x, u32& y, u32& z) {
+  x = a / (u32)g.nyz;
+  const u32 r = a - x * (u32)g.nyz;
+  y = r / (u32)g.nz;
+  z = r - y * (u32)g.nz;
+}
+
+__global__ void __launch_bounds__(256)
+k_sp_init(SArgs S, const u32* __restrict__ cells_in, const u32* __restrict__ rank_in, u32 n_out,
+          const u32* __restrict__ seeds, u32 nseeds, u32 nkept) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_out) {
+    S.cells[i] = cells_in[i];
+    S.node[i] = rank_in[i];
+  } else if (i < n_out + nseeds) {
+    S.cells[i] = seeds[2 * (i - n_out)];
+    S.node[i] = seeds[2 * (i - n_out) + 1];
+  }
+  if (i < nkept) {
+    SNode nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.orig = i;
+    nd.state = N_ACTIVE;
+    S.nodes[i] = nd;
+  }
+  if (i == 0) {
+    S.ctr[0] = nkept;
+    S.ctr[1] = S.ctr[2] = S.ctr[3] = S.ctr[4] = 0u;
+  }
+}
+
+// per-node cell count and index sums for the nodes evaluated at `level`
+__global__ void __launch_bounds__(256) k_sp_sums(Geo g, SArgs S, u32 level) {
+  __shared__ u32 t_key[128];
+  __shared__ u32 t_acc[128][4];
+  for (u32 base = blockIdx.x * 1024u; base < S.n; base += gridDim.x * 1024u) {
+    if (threadIdx.x < 128) {
+      t_key[threadIdx.x] = 0xFFFFFFFFu;
+      t_acc[threadIdx.x][0] = t_acc[threadIdx.x][1] = t_acc[threadIdx.x][2] = t_acc[threadIdx.x][3] = 0u;
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = base + (u32)k * 256u + threadIdx.x;
+      if (i >= S.n) continue;
+      const u32 nd = S.node[i];
+      const SNode& N = S.nodes[nd];
+      if (N.state != N_ACTIVE || N.level != level) continue;
+      u32 x, y, z;
+      decode(g, S.cells[i], x, y, z);
+      u32 h = (nd * 2654435761u) >> 25;  // 7 bits
+      bool done = false;
+      for (int probe = 0; probe < 128 && !done; ++probe) {
+        const u32 old = atomicCAS(&t_key[h], 0xFFFFFFFFu, nd);
+        if (old == 0xFFFFFFFFu || old == nd) {
+          atomicAdd(&t_acc[h][0], 1u);
+          atomicAdd(&t_acc[h][1], x);
+          atomicAdd(&t_acc[h][2], y);
+          atomicAdd(&t_acc[h][3], z);
+          done = true;
+        }
+        h = (h + 1) & 127u;
+      }
+      if (!done) {  // more than 128 distinct nodes in one 1024-cell chunk: straight to memory
+        atomicAdd(&S.nodes[nd].n, 1u);
+        atomicAdd(&S.nodes[nd].sx, (unsigned long long)x);
+        atomicAdd(&S.nodes[nd].sy, (unsigned long long)y);
+        atomicAdd(&S.nodes[nd].sz, (unsigned long long)z);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128 && t_key[threadIdx.x] != 0xFFFFFFFFu) {
+      SNode& N = S.nodes[t_key[threadIdx.x]];
+      atomicAdd(&N.n, t_acc[threadIdx.x][0]);
+      atomicAdd(&N.sx, (unsigned long long)t_acc[threadIdx.x][1]);
+      atomicAdd(&N.sy, (unsigned long long)t_acc[threadIdx.x][2]);
+      atomicAdd(&N.sz, (unsigned long long)t_acc[threadIdx.x][3]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_sp_clear(u64* keys, LeafAcc* vals, u32 n) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    keys[i] = SP_EMPTY;
+    vals[i] = LeafAcc{0u, 0u, 0u, 0u};
+  }
+}
+
+__device__ __forceinline__ u64 sp_mix(u64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+// (node, leaf) accumulation.  Leaf coordinates as pcl::VoxelGrid computes them: floor(p * inv_leaf)
+// in float on the float-converted centre.
+__global__ void __launch_bounds__(256) k_sp_leaf(Geo g, SArgs S, u32 level) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < S.n; i += gridDim.x * blockDim.x) {
+    const u32 nd = S.node[i];
+    const SNode& N = S.nodes[nd];
+    if (N.state != N_ACTIVE || N.level != level) continue;
+    u32 x, y, z;
+    decode(g, S.cells[i], x, y, z);
+    const float px = (float)(((double)x + 0.5) * g.res + g.org[0]);
+    const float py = (float)(((double)y + 0.5) * g.res + g.org[1]);
+    const float pz = (float)(((double)z + 0.5) * g.res + g.org[2]);
+    const int lx = (int)floorf(px * S.inv_leaf), ly = (int)floorf(py * S.inv_leaf), lz = (int)floorf(pz * S.inv_leaf);
+    const u64 lk = ((u64)(u32)(lz + SP_LOFF) << (2 * SP_LBITS)) | ((u64)(u32)(ly + SP_LOFF) << SP_LBITS) |
+                   (u64)(u32)(lx + SP_LOFF);
+    const u64 key = ((u64)nd << (3 * SP_LBITS)) | lk;
+    u32 h = (u32)sp_mix(key) & S.hmask;
+    while (true) {
+      const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&S.hkeys[h]), SP_EMPTY, key);
+      if (old == SP_EMPTY || old == key) break;
+      h = (h + 1) & S.hmask;
+    }
+    atomicAdd(&S.hvals[h].cnt, 1u);
+    atomicAdd(&S.hvals[h].sx, x);
+    atomicAdd(&S.hvals[h].sy, y);
+    atomicAdd(&S.hvals[h].sz, z);
+  }
+}
+
+__device__ __forceinline__ void centroid_of(const Geo& g, const LeafAcc& a, float c[3]) {
+  const double n = (double)a.cnt;
+  c[0] = (float)(((double)a.sx / n + 0.5) * g.res + g.org[0]);
+  c[1] = (float)(((double)a.sy / n + 0.5) * g.res + g.org[1]);
+  c[2] = (float)(((double)a.sz / n + 0.5) * g.res + g.org[2]);
+}
+__device__ __forceinline__ void node_mean_xy(const Geo& g, const SNode& N, double m[2]) {
+  const double n = (double)N.n;
+  m[0] = ((double)N.sx / n + 0.5) * g.res + g.org[0];
+  m[1] = ((double)N.sy / n + 0.5) * g.res + g.org[1];
+}
+
+// need_split and covariance sums of every evaluated node from its centroids
+__global__ void __launch_bounds__(256) k_sp_stats(Geo g, SArgs S) {
+  const int lane = threadIdx.x & 63;
+  const u32 tsize = S.hmask + 1u;
+  const u32 tsize_r = (tsize + 63u) & ~63u;
+  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < tsize_r; h += gridDim.x * blockDim.x) {
+    const u64 key = h < tsize ? S.hkeys[h] : SP_EMPTY;
+    bool active = key != SP_EMPTY;
+    u32 nd = 0u;
+    double dx = 0.0, dy = 0.0;
+    if (active) {
+      nd = (u32)(key >> (3 * SP_LBITS));
+      float c[3];
+      centroid_of(g, S.hvals[h], c);
+      double m[2];
+      node_mean_xy(g, S.nodes[nd], m);
+      dx = (double)c[0] - m[0];
+      dy = (double)c[1] - m[1];
+      // atomic, not a plain store: the same cache line receives memory-side atomics from other XCDs
+      if (sqrt(dx * dx + dy * dy) > S.size_xy) atomicOr(&S.nodes[nd].need_split, 1u);
+    }
+    u64 todo = __ballot(active);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const u32 kn = (u32)__shfl((int)nd, leader, 64);
+      const bool mine = active && nd == kn;
+      const u64 same = __ballot(mine) & todo;
+      double v0 = mine ? dx * dx : 0.0, v1 = mine ? dx * dy : 0.0, v2 = mine ? dy * dx : 0.0,
+             v3 = mine ? dy * dy : 0.0;
+      for (int off = 32; off > 0; off >>= 1) {
+        v0 += __shfl_xor(v0, off, 64);
+        v1 += __shfl_xor(v1, off, 64);
+        v2 += __shfl_xor(v2, off, 64);
+        v3 += __shfl_xor(v3, off, 64);
+      }
+      if (lane == leader) {
+        SNode& N = S.nodes[kn];
+        atomicAdd(&N.cov[0], v0);
+        atomicAdd(&N.cov[1], v1);
+        atomicAdd(&N.cov[2], v2);
+        atomicAdd(&N.cov[3], v3);
+        atomicAdd(&N.nfilt, (unsigned long long)__popcll(same));
+      }
+      todo &= ~same;
+    }
+  }
+}
+
+// splitHorizontally's decision and principal direction per evaluated node
+__global__ void __launch_bounds__(256) k_sp_decide(SArgs S, u32 level, u32 n_nodes) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  SNode& N = S.nodes[i];
+  if (N.state != N_ACTIVE || N.level != level) return;
+  if (N.n == 0u) {
+    N.state = N_DEAD;  // an empty half (the reference would read cells_.front() of an empty vector)
+    return;
+  }
+  if (!N.need_split || N.depth >= 31u) {
+    N.state = N_FINAL;
+    atomicAdd(&S.ctr[4], 1u);
+    return;
+  }
+  const double nf = (double)N.nfilt;
+  const double c00 = N.cov[0] / nf, c01 = N.cov[1] / nf, c10 = N.cov[2] / nf, c11 = N.cov[3] / nf;
+  const double a = c00, b = 0.5 * (c01 + c10), d = c11;
+  const double tr = a + d, det = a * d - b * b, disc = sqrt(fmax(tr * tr / 4 - det, 0.0));
+  const double l = tr / 2 + disc;
+  double vx = b, vy = l - a;
+  if (fabs(vx) + fabs(vy) < 1e-300) {
+    vx = l - d;
+    vy = b;
+  }
+  if (fabs(vx) + fabs(vy) < 1e-300) {
+    vx = 1;
+    vy = 0;
+  }
+  const double nn = sqrt(vx * vx + vy * vy);
+  N.pc[0] = vx / nn;
+  N.pc[1] = vy / nn;
+  const u32 c0 = atomicAdd(&S.ctr[0], 2u);
+  if (c0 + 2u > S.cap_nodes) {
+    S.ctr[3] = 1u;
+    N.state = N_FINAL;
+    atomicAdd(&S.ctr[4], 1u);
+    return;
+  }
+  for (u32 k = 0; k < 2u; ++k) {
+    SNode ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.orig = N.orig;
+    ch.path = (N.path << 1) | k;
+    ch.depth = N.depth + 1u;
+    ch.level = level + 1u;
+    ch.state = N_ACTIVE;
+    S.nodes[c0 + k] = ch;
+  }
+  N.child0 = c0;
+  N.state = N_SPLIT;
+  atomicAdd(&S.ctr[1], 1u);
+}
+
+// centroids of the nodes that became FINAL at this level = their filtered_cells_
+__global__ void __launch_bounds__(256) k_sp_emit(Geo g, SArgs S, u32 level) {
+  const u32 tsize = S.hmask + 1u;
+  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < tsize; h += gridDim.x * blockDim.x) {
+    const u64 key = S.hkeys[h];
+    if (key == SP_EMPTY) continue;
+    const u32 nd = (u32)(key >> (3 * SP_LBITS));
+    const SNode& N = S.nodes[nd];
+    if (N.state != N_FINAL || N.level != level) continue;
+    const u32 o = atomicAdd(&S.ctr[2], 1u);
+    if (o >= S.cap_filt) {
+      S.ctr[3] = 1u;
+      continue;
+    }
+    float c[3];
+    centroid_of(g, S.hvals[h], c);
+    S.f_node[o] = nd;
+    S.f_leaf[o] = key & ((1ull << (3 * SP_LBITS)) - 1ull);  // (lz, ly, lx): PCL's output order
+    S.f_xyz[3 * o] = c[0], S.f_xyz[3 * o + 1] = c[1], S.f_xyz[3 * o + 2] = c[2];
+  }
+}
+
+// cells of SPLIT nodes go to the child on their side: (cell_xy - mean_xy) . pc >= 0 -> first child
+__global__ void __launch_bounds__(256) k_sp_part(Geo g, SArgs S, u32 level) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < S.n; i += gridDim.x * blockDim.x) {
+    const u32 nd = S.node[i];
+    const SNode& N = S.nodes[nd];
+    if (N.state != N_SPLIT || N.level != level) continue;
+    u32 x, y, z;
+    decode(g, S.cells[i], x, y, z);
+    double m[2];
+    node_mean_xy(g, N, m);
+    const double px = ((double)x + 0.5) * g.res + g.org[0], py = ((double)y + 0.5) * g.res + g.org[1];
+    const double dot = (px - m[0]) * N.pc[0] + (py - m[1]) * N.pc[1];
+    S.node[i] = N.child0 + (dot >= 0 ? 0u : 1u);
+  }
+}
+
+__global__ void k_sp_next_level(SArgs S) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) S.ctr[1] = 0u;
+}
+
+// depth-first order of the FINAL nodes: key = (orig, path left-aligned); rank + cell offsets, and
+// the cluster records the regrouping stage expects
+__global__ void __launch_bounds__(256) k_sp_rank(SArgs S, u32 n_nodes, KeptRec* krec, u32* counts) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  SNode& N = S.nodes[i];
+  if (N.state != N_FINAL) return;
+  auto key_of = [](const SNode& M) {
+    const u32 pl = M.depth ? (M.path << (32u - M.depth)) : 0u;
+    return ((u64)M.orig << 32) | pl;
+  };
+  const u64 ki = key_of(N);
+  u32 rank = 0u, off = 0u;
+  for (u32 j = 0; j < n_nodes; ++j) {
+    const SNode& M = S.nodes[j];
+    if (M.state != N_FINAL) continue;
+    if (key_of(M) < ki) {
+      ++rank;
+      off += M.n;
+    }
+  }
+  N.rank = rank;
+  KeptRec& r = krec[rank];
+  r.addr = 0u, r.slot = 0u, r.size = N.n, r.off = off;
+  r.sum[0] = r.sum[1] = r.sum[2] = 0ull;
+  for (int k = 0; k < 3; ++k) r.box[k] = 0xFFFFFFFFu, r.box[3 + k] = 0u;
+  if (rank == S.ctr[4] - 1u) {
+    counts[0] = S.n;
+    counts[1] = 0u;
+    counts[2] = 0u;
+    counts[3] = S.ctr[4];
+    counts[5] = S.n;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sp_keys(SArgs S, u32* key_out, u32* val_out) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < S.n; i += gridDim.x * blockDim.x) {
+    const SNode& N = S.nodes[S.node[i]];
+    key_out[i] = N.state == N_FINAL ? N.rank : 0xFFFFFFFFu;
+    val_out[i] = S.cells[i];
+  }
+}
+__global__ void __launch_bounds__(256) k_sp_filt_rank(SArgs S, u32 nfilt) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nfilt; i += gridDim.x * blockDim.x)
+    S.f_node[i] = S.nodes[S.f_node[i]].rank;
+}
+
+}  // namespace
+
+struct SplitScratch {
+  u32 cap_cells = 0, cap_nodes = 0, cap_filt = 0, tsize = 0;
+  u32 *cells = nullptr, *node = nullptr, *ctr = nullptr, *seeds = nullptr, *counts = nullptr;
+  SNode* nodes = nullptr;
+  u64* hkeys = nullptr;
+  LeafAcc* hvals = nullptr;
+  u32* f_node = nullptr;
+  u64* f_leaf = nullptr;
+  float* f_xyz = nullptr;
+  u32* h_ctr = nullptr;  // pinned [16]
+};
+
+void frontier_split_free(fuelmi_frontier* f) {
+  SplitScratch* s = f->split;
+  if (!s) return;
+  void* dev[] = {s->cells, s->node, s->ctr, s->seeds, s->counts, s->nodes, s->hkeys, s->hvals, s->f_node, s->f_leaf, s->f_xyz};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (s->h_ctr) (void)hipHostFree(s->h_ctr);
+  delete s;
+  f->split = nullptr;
+}
+
+template <typename T>
+static int sp_alloc(T** p, size_t n) {
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return FUELMI_OK;
+}
+
+static int split_ensure(fuelmi_frontier* f, u32 n) {
+  if (!f->split) f->split = new SplitScratch;
+  SplitScratch* s = f->split;
+  int rc;
+  if (!s->ctr) {
+    s->cap_nodes = 2u * f->F.cap_kept;
+    if ((rc = sp_alloc(&s->ctr, 16)) || (rc = sp_alloc(&s->counts, 16)) || (rc = sp_alloc(&s->nodes, s->cap_nodes)) ||
+        (rc = sp_alloc(&s->seeds, 2 * (size_t)f->F.cap_kept)))
+      return rc;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), 64, hipHostMallocDefault));
+  }
+  if (n > s->cap_cells) {
+    void* old[] = {s->cells, s->node, s->hkeys, s->hvals, s->f_node, s->f_leaf, s->f_xyz};
+    for (void* p : old)
+      if (p) HIPCHK(hipFree(p));
+    s->cells = s->node = s->f_node = nullptr;
+    s->hkeys = s->f_leaf = nullptr;
+    s->hvals = nullptr;
+    s->f_xyz = nullptr;
+    s->cap_cells = 0;
+    const u32 cap = n + n / 4 + 4096;
+    u32 t = 1024;
+    while (t < 2u * cap) t <<= 1;
+    if ((rc = sp_alloc(&s->cells, cap)) || (rc = sp_alloc(&s->node, cap)) || (rc = sp_alloc(&s->hkeys, t)) ||
+        (rc = sp_alloc(&s->hvals, t)) || (rc = sp_alloc(&s->f_node, cap)) || (rc = sp_alloc(&s->f_leaf, cap)) ||
+        (rc = sp_alloc(&s->f_xyz, 3 * (size_t)cap)))
+      return rc;
+    s->cap_cells = cap;
+    s->cap_filt = cap;
+    s->tsize = t;
+  }
+  return FUELMI_OK;
+}
+
+int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin, u32* n_final, u32* n_cells,
+                       std::vector<std::vector<float>>* filtered) {
+  fuelmi_map* m = f->map;
+  const Geo& g = m->g;
+  FArgs& F = f->F;
+  hipStream_t st = f->stream;
+  if (f->cfg.down_sample <= 0 || !(f->cfg.cluster_size_xy > 0.0)) {
+    fuelmi_set_error("frontier split needs down_sample > 0 and cluster_size_xy > 0");
+    return FUELMI_EINVAL;
+  }
+  if (nkept >= (1u << (64 - 3 * SP_LBITS - 1))) {
+    fuelmi_set_error("frontier split: too many clusters (%u)", nkept);
+    return FUELMI_ELIMIT;
+  }
+  // NQ seeds that started a kept cluster are not in the grouped Q0 array: append them
+  std::vector<u32> seeds;
+  for (u32 r = 0; r < nkept; ++r)
+    if (F.h_rec[r].slot >= nq) {
+      seeds.push_back(F.h_rec[r].addr);
+      seeds.push_back(r);
+    }
+  const u32 nseeds = (u32)(seeds.size() / 2);
+  const u32 n = n_out + nseeds;
+  if (n > F.cap_q) {
+    fuelmi_set_error("frontier split: %u cells exceed the capacity %u", n, F.cap_q);
+    return FUELMI_ELIMIT;
+  }
+  int rc = split_ensure(f, n);
+  if (rc) return rc;
+  SplitScratch* s = f->split;
+  if (nseeds) HIPCHK(hipMemcpyAsync(s->seeds, seeds.data(), seeds.size() * sizeof(u32), hipMemcpyHostToDevice, st));
+
+  SArgs S;
+  S.n = n;
+  S.cells = s->cells, S.node = s->node, S.nodes = s->nodes, S.cap_nodes = s->cap_nodes, S.ctr = s->ctr;
+  S.hkeys = s->hkeys, S.hvals = s->hvals;
+  u32 t = 1024;  // table sized to this search (cleared every level)
+  while (t < 2u * n) t <<= 1;
+  S.hmask = t - 1u;
+  S.f_node = s->f_node, S.f_leaf = s->f_leaf, S.f_xyz = s->f_xyz, S.cap_filt = s->cap_filt;
+  S.size_xy = f->cfg.cluster_size_xy;
+  const float leaf = (float)(g.res * (double)f->cfg.down_sample);  // setLeafSize(float...)
+  S.inv_leaf = 1.0f / leaf;
+
+  const int gb = (int)std::min<u32>(2048u, (n + 255u) / 256u);
+  const int gb4 = (int)std::min<u32>(2048u, (n + 1023u) / 1024u);
+  const int gt = (int)std::min<u32>(2048u, (t + 255u) / 256u);
+  k_sp_init<<<(std::max(n, nkept) + 255) / 256, 256, 0, st>>>(S, F.ms_val[fin], F.ms_key[fin], n_out, s->seeds, nseeds,
+                                                                nkept);
+  u32 n_nodes = nkept;
+  for (u32 level = 0; level < 40u; ++level) {
+    k_sp_sums<<<gb4, 256, 0, st>>>(g, S, level);
+    k_sp_clear<<<gt, 256, 0, st>>>(S.hkeys, S.hvals, t);
+    k_sp_leaf<<<gb, 256, 0, st>>>(g, S, level);
+    k_sp_stats<<<gt, 256, 0, st>>>(g, S);
+    k_sp_decide<<<(n_nodes + 255) / 256, 256, 0, st>>>(S, level, n_nodes);
+    k_sp_emit<<<gt, 256, 0, st>>>(g, S, level);
+    k_sp_part<<<gb, 256, 0, st>>>(g, S, level);
+    HIPCHK(hipMemcpyAsync(s->h_ctr, s->ctr, 16 * sizeof(u32), hipMemcpyDeviceToHost, st));
+    k_sp_next_level<<<1, 64, 0, st>>>(S);
+    HIPCHK(hipStreamSynchronize(st));
+    if (s->h_ctr[3]) {
+      fuelmi_set_error("frontier split capacity exceeded (nodes %u/%u, filtered %u/%u)", s->h_ctr[0], s->cap_nodes,
+                       s->h_ctr[2], s->cap_filt);
+      return FUELMI_ELIMIT;
+    }
+    n_nodes = s->h_ctr[0];
+    if (s->h_ctr[1] == 0u) break;
+  }
+  const u32 nfinal = s->h_ctr[4], nfilt = s->h_ctr[2];
+  if (nfinal == 0u || nfinal > F.cap_kept) {
+    fuelmi_set_error("frontier split produced %u clusters (capacity %u)", nfinal, F.cap_kept);
+    return FUELMI_ELIMIT;
+  }
+
+  // regroup the cells by depth-first rank and refill the result buffers
+  FArgs F2 = F;
+  F2.counts = s->counts;
+  HIPCHK(hipMemsetAsync(s->counts, 0, 16 * sizeof(u32), st));
+  k_sp_rank<<<(n_nodes + 255) / 256, 256, 0, st>>>(S, n_nodes, F.krec, s->counts);
+  k_sp_keys<<<gb, 256, 0, st>>>(S, F.ms_key[0], F.ms_val[0]);
+  if (nfilt) k_sp_filt_rank<<<(nfilt + 255) / 256, 256, 0, st>>>(S, nfilt);
+  HIPCHK(hipGetLastError());
+  rc = frontier_regroup(f, F2, nfinal > 256 ? 2 : 1);
+  if (rc) return rc;
+  std::vector<u32> fn(nfilt);
+  std::vector<u64> fl(nfilt);
+  std::vector<float> fx(3 * (size_t)nfilt);
+  if (nfilt) {
+    HIPCHK(hipMemcpyAsync(fn.data(), s->f_node, nfilt * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(fl.data(), s->f_leaf, nfilt * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(fx.data(), s->f_xyz, 3 * (size_t)nfilt * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+
+  // filtered cells per piece, ascending leaf index (z-major like PCL's idx = i + j*dx + k*dx*dy)
+  std::vector<u32> order(nfilt);
+  for (u32 i = 0; i < nfilt; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+    return fn[a] != fn[b] ? fn[a] < fn[b] : fl[a] < fl[b];
+  });
+  filtered->assign(nfinal, std::vector<float>());
+  for (u32 k = 0; k < nfilt; ++k) {
+    const u32 i = order[k];
+    if (fn[i] >= nfinal) continue;
+    std::vector<float>& v = (*filtered)[fn[i]];
+    v.push_back(fx[3 * (size_t)i]);
+    v.push_back(fx[3 * (size_t)i + 1]);
+    v.push_back(fx[3 * (size_t)i + 2]);
+  }
+  *n_final = nfinal;
+  *n_cells = n;
+  return FUELMI_OK;
+}

@@ -35,7 +35,7 @@ struct Viewpoint {
 
 struct Frontier {
   vector<Vector3d> cells_;           // voxel centres, ascending voxel address (reference: BFS order)
-  vector<Vector3d> filtered_cells_;  // left empty (PCL down-sampling is a "next" row)
+  vector<Vector3d> filtered_cells_;  // VoxelGrid centroids (filled when frontier/cluster_size_xy and down_sample are set)
   Vector3d average_;
   int id_;
   vector<Viewpoint> viewpoints_;

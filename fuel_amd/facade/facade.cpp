@@ -227,9 +227,18 @@ double EDTEnvironment::evaluateCoarseEDT(Eigen::Vector3d& pos, double) { return 
 FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& nh) : edt_env_(edt), dev_(nullptr) {
   nh.param("frontier/cluster_min", cluster_min_, -1);
   resolution_ = edt_env_->sdf_map_->getResolution();
+  double cluster_size_xy = -1.0;
+  int down_sample = -1;
+  nh.param("frontier/cluster_size_xy", cluster_size_xy, -1.0);
+  nh.param("frontier/down_sample", down_sample, -1);
   fuelmi_frontier_cfg c;
   c.cluster_min = cluster_min_;
   c.min_z = 0.4;  // literal in frontier_finder.cpp:151
+  c.cluster_size_xy = cluster_size_xy;
+  c.down_sample = down_sample;
+  // searchFrontiers ends with splitLargeFrontiers (:120); without its two parameters the search stops
+  // at the region-grown clusters
+  c.split = (cluster_size_xy > 0.0 && down_sample > 0) ? 1 : 0;
   warn("fuelmi_frontier_create", fuelmi_frontier_create(edt_env_->sdf_map_->device(), &c, &dev_));
 }
 FrontierFinder::~FrontierFinder() {
@@ -256,6 +265,13 @@ void FrontierFinder::pull(int which, list<Frontier>& out) {
     double info[9];
     fuelmi_frontier_cluster_info(dev_, which, k, info);
     for (int i = 0; i < 3; ++i) f.average_(i) = info[i], f.box_min_(i) = info[3 + i], f.box_max_(i) = info[6 + i];
+    const int nf = fuelmi_frontier_cluster_filtered_size(dev_, which, k);
+    if (nf > 0) {
+      std::vector<float> xyz(3 * (size_t)nf);
+      fuelmi_frontier_cluster_filtered(dev_, which, k, xyz.data());
+      f.filtered_cells_.resize(nf);
+      for (int i = 0; i < nf; ++i) f.filtered_cells_[i] = Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    }
     f.id_ = k;
     out.push_back(f);
   }

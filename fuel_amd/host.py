@@ -242,10 +242,12 @@ class EDTEnvironment:
 class FrontierFinder:
     """Grid part of fast_planner::FrontierFinder (searchFrontiers / expandFrontier)."""
 
-    def __init__(self, edt_or_map, cluster_min=100, min_z=0.4):
+    def __init__(self, edt_or_map, cluster_min=100, min_z=0.4, cluster_size_xy=2.0, down_sample=3, split=False):
+        """split=True: searchFrontiers ends with splitLargeFrontiers (frontier_finder.cpp:120,166-242) and
+        every new cluster carries its down-sampled filtered_cells_."""
         self.L = lib()
         self.map = edt_or_map.sdf_map_ if isinstance(edt_or_map, EDTEnvironment) else edt_or_map
-        cfg = FrontierCfg(cluster_min, min_z)
+        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split))
         h = C.c_void_p()
         check(self.L.fuelmi_frontier_create(self.map.h, C.byref(cfg), C.byref(h)))
         self.h = h
@@ -290,6 +292,16 @@ class FrontierFinder:
             a = np.empty(n, dtype=np.int32)
             check(self.L.fuelmi_frontier_cluster_cells(self.h, which, k, _ip(a)))
             out.append(a)
+        return out
+
+    def filtered(self, which, k):
+        """Frontier::filtered_cells_ of cluster k: float32 [n,3] (split=True searches only)."""
+        n = self.L.fuelmi_frontier_cluster_filtered_size(self.h, which, k)
+        if n < 0:
+            check(n)
+        out = np.empty((n, 3), dtype=np.float32)
+        if n:
+            check(self.L.fuelmi_frontier_cluster_filtered(self.h, which, k, out.ctypes.data))
         return out
 
     def getFrontiers(self):

@@ -149,6 +149,11 @@ int fuelmi_map_synchronize(fuelmi_map* m);
 typedef struct {
   int cluster_min; /* frontier/cluster_min */
   double min_z;    /* the literal 0.4 at frontier_finder.cpp:151 */
+  /* splitLargeFrontiers (frontier_finder.cpp:166-242) + computeFrontierInfo's down-sampling (:374-390,757-774) */
+  double cluster_size_xy; /* frontier/cluster_size_xy (2.0) */
+  int down_sample;        /* frontier/down_sample (3): VoxelGrid leaf = down_sample * resolution */
+  int split;              /* 0: search stops before splitLargeFrontiers; 1: it runs, and every new cluster
+                             carries its filtered_cells_ */
 } fuelmi_frontier_cfg;
 
 typedef struct fuelmi_frontier fuelmi_frontier;
@@ -158,6 +163,10 @@ void fuelmi_frontier_destroy(fuelmi_frontier* f);
 /* forget all clusters and clear frontier_flag_ (== constructing a fresh FrontierFinder,
  * frontier_finder.cpp:23-27) */
 int fuelmi_frontier_reset(fuelmi_frontier* f);
+/* Frontier::filtered_cells_ of cluster k (VoxelGrid centroids, float xyz, ascending leaf index like PCL);
+ * empty unless the cluster was found with cfg.split != 0 */
+int fuelmi_frontier_cluster_filtered_size(const fuelmi_frontier* f, int which, int k);
+int fuelmi_frontier_cluster_filtered(const fuelmi_frontier* f, int which, int k, float* xyz);
 /* searchFrontiers up to (not including) splitLargeFrontiers: consumes the map's updated box
  * (getUpdatedBox(reset=true)), drops changed clusters, scans, clusters.  *n_new = number of new
  * clusters (tmp_frontiers_.size()). */

@@ -557,3 +557,64 @@ def test_depth_image_fusion_matches_projection_plus_insert(fa):
     gm.updateESDF3d()
     assert_map_equal(om, gm, om.get_local_bound())
     gm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# splitLargeFrontiers + down-sampling on the device
+# ------------------------------------------------------------------------------------------------
+def _assert_split_equal(of, gf, om, n):
+    """Same pieces in the same order; cells as sets (the oracle keeps BFS order, the device address
+    order); mean/AABB to 1e-9; filtered cells equal as leaf-ordered lists to 2e-5 m (PCL accumulates the
+    centroid in float in input order, the device from exact integer sums)."""
+    ca, cb = of.clusters(0), gf.clusters(0)
+    assert len(ca) == len(cb) == n
+    for k in range(n):
+        assert np.array_equal(np.sort(ca[k]), cb[k]), "piece %d differs" % k
+        ia, ib = of.cluster_info(0, k), gf.clusterInfo(0, k)
+        for x, y in zip(ia, ib):
+            assert np.abs(np.asarray(x) - np.asarray(y)).max() <= 1e-9
+        fa_, fb_ = of.filtered(0, k), gf.filtered(0, k)
+        assert fa_.shape == fb_.shape and len(fa_) > 0
+        assert np.abs(fa_ - fb_).max() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,size_xy", [(42, 2.0), (7, 1.2), (11, 3.0)])
+def test_split_large_frontiers_matches_oracle(fa, seed, size_xy):
+    om, truth, frames, box = helpers.explored_oracle_map((16.0, 14.0, 4.0), 30, 28, seed=seed)
+    gm = gpu_twin(fa, om, box)
+    ub = om.get_updated_box(reset=False)
+    gm.setUpdatedBox(*ub)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    gf = fa.FrontierFinder(gm, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    plain = fo.OracleFrontier(om, cluster_min=60)
+    n0 = plain.search()
+    om.set_updated_box(*ub)
+    n1 = of.search()
+    n2 = gf.searchFrontiers()
+    assert n1 == n2 and n1 > n0 > 0
+    _assert_split_equal(of, gf, om, n1)
+    # committed pieces survive as ordinary clusters (cells materialised in address order)
+    gf.commit()
+    of.commit()
+    for a, b in zip(of.clusters(1), gf.clusters(1)):
+        assert np.array_equal(np.sort(a), b)
+    gf.close()
+    gm.close()
+
+
+@pytest.mark.gpu
+def test_split_with_low_z_seed_clusters(fa):
+    """Pieces of clusters that were started by a seed below min_z (an NQ seed: part of the cluster,
+    never grown from) keep that seed cell through the split."""
+    om, truth, frames, box = helpers.explored_oracle_map((12.0, 12.0, 4.0), 16, 22, seed=5, extent=0.8)
+    gm = gpu_twin(fa, om, box)
+    ub = om.get_updated_box(reset=False)
+    gm.setUpdatedBox(*ub)
+    of = fo.OracleFrontier(om, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True)
+    gf = fa.FrontierFinder(gm, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True)
+    n1, n2 = of.search(), gf.searchFrontiers()
+    assert n1 == n2 > 0
+    _assert_split_equal(of, gf, om, n1)
+    gf.close()
+    gm.close()
