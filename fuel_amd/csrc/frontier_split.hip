@@ -218,51 +218,99 @@ __device__ __forceinline__ void node_mean_xy(const Geo& g, const SNode& N, doubl
   m[1] = ((double)N.sy / n + 0.5) * g.res + g.org[1];
 }
 
-// need_split and covariance sums of every evaluated node from its centroids
+// need_split and covariance sums of every evaluated node from its centroids.  Table slots are in
+// hash order, so a block meets the nodes of the level in random mix: partial sums are collected in a
+// block-local LDS table keyed by node (f64 LDS atomics; a wave whose lanes all hold the same node --
+// the early levels -- reduces by shuffles first) and flushed with one set of global atomics per node
+// and block.
 __global__ void __launch_bounds__(256) k_sp_stats(Geo g, SArgs S) {
+  __shared__ u32 t_key[256];
+  __shared__ double t_cov[256][4];
+  __shared__ u32 t_cnt[256];
+  __shared__ u32 t_far[256];
   const int lane = threadIdx.x & 63;
   const u32 tsize = S.hmask + 1u;
-  const u32 tsize_r = (tsize + 63u) & ~63u;
-  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < tsize_r; h += gridDim.x * blockDim.x) {
-    const u64 key = h < tsize ? S.hkeys[h] : SP_EMPTY;
-    bool active = key != SP_EMPTY;
-    u32 nd = 0u;
-    double dx = 0.0, dy = 0.0;
-    if (active) {
-      nd = (u32)(key >> (3 * SP_LBITS));
-      float c[3];
-      centroid_of(g, S.hvals[h], c);
-      double m[2];
-      node_mean_xy(g, S.nodes[nd], m);
-      dx = (double)c[0] - m[0];
-      dy = (double)c[1] - m[1];
-      // atomic, not a plain store: the same cache line receives memory-side atomics from other XCDs
-      if (sqrt(dx * dx + dy * dy) > S.size_xy) atomicOr(&S.nodes[nd].need_split, 1u);
-    }
-    u64 todo = __ballot(active);
-    while (todo) {
-      const int leader = __builtin_ctzll(todo);
-      const u32 kn = (u32)__shfl((int)nd, leader, 64);
-      const bool mine = active && nd == kn;
-      const u64 same = __ballot(mine) & todo;
-      double v0 = mine ? dx * dx : 0.0, v1 = mine ? dx * dy : 0.0, v2 = mine ? dy * dx : 0.0,
-             v3 = mine ? dy * dy : 0.0;
-      for (int off = 32; off > 0; off >>= 1) {
-        v0 += __shfl_xor(v0, off, 64);
-        v1 += __shfl_xor(v1, off, 64);
-        v2 += __shfl_xor(v2, off, 64);
-        v3 += __shfl_xor(v3, off, 64);
+  t_far[threadIdx.x] = 0u;
+  // few, long-lived blocks: the flush is one set of same-address global atomics per node and block
+  t_key[threadIdx.x] = 0xFFFFFFFFu;
+  t_cnt[threadIdx.x] = 0u;
+  t_cov[threadIdx.x][0] = t_cov[threadIdx.x][1] = t_cov[threadIdx.x][2] = t_cov[threadIdx.x][3] = 0.0;
+  __syncthreads();
+  for (u32 base = blockIdx.x * 1024u; base < tsize; base += gridDim.x * 1024u) {
+    for (int k = 0; k < 4; ++k) {
+      const u32 h = base + (u32)k * 256u + threadIdx.x;
+      const u64 key = h < tsize ? S.hkeys[h] : SP_EMPTY;
+      const bool active = key != SP_EMPTY;
+      u32 nd = 0u;
+      double dx = 0.0, dy = 0.0;
+      u32 far = 0u;
+      if (active) {
+        nd = (u32)(key >> (3 * SP_LBITS));
+        float c[3];
+        centroid_of(g, S.hvals[h], c);
+        double m[2];
+        node_mean_xy(g, S.nodes[nd], m);
+        dx = (double)c[0] - m[0];
+        dy = (double)c[1] - m[1];
+        far = sqrt(dx * dx + dy * dy) > S.size_xy ? 1u : 0u;
       }
-      if (lane == leader) {
-        SNode& N = S.nodes[kn];
-        atomicAdd(&N.cov[0], v0);
-        atomicAdd(&N.cov[1], v1);
-        atomicAdd(&N.cov[2], v2);
-        atomicAdd(&N.cov[3], v3);
-        atomicAdd(&N.nfilt, (unsigned long long)__popcll(same));
+      const u64 am = __ballot(active);
+      if (!am) continue;
+      const u32 first = (u32)__shfl((int)nd, __builtin_ctzll(am), 64);
+      double v0 = active ? dx * dx : 0.0, v1 = active ? dx * dy : 0.0, v2 = active ? dy * dx : 0.0,
+             v3 = active ? dy * dy : 0.0;
+      u32 cnt = active ? 1u : 0u;
+      bool add = active;
+      if (__ballot(active && nd != first) == 0ull) {  // one node in the whole wave
+        for (int off = 32; off > 0; off >>= 1) {
+          v0 += __shfl_xor(v0, off, 64);
+          v1 += __shfl_xor(v1, off, 64);
+          v2 += __shfl_xor(v2, off, 64);
+          v3 += __shfl_xor(v3, off, 64);
+          cnt += (u32)__shfl_xor((int)cnt, off, 64);
+        }
+        far = __ballot(far != 0u) ? 1u : 0u;
+        add = lane == __builtin_ctzll(am);
+        nd = first;
       }
-      todo &= ~same;
+      if (add) {
+        u32 hh = (nd * 2654435761u) >> 24;  // 8 bits
+        bool done = false;
+        for (int probe = 0; probe < 256 && !done; ++probe) {
+          const u32 old = atomicCAS(&t_key[hh], 0xFFFFFFFFu, nd);
+          if (old == 0xFFFFFFFFu || old == nd) {
+            atomicAdd(&t_cov[hh][0], v0);
+            atomicAdd(&t_cov[hh][1], v1);
+            atomicAdd(&t_cov[hh][2], v2);
+            atomicAdd(&t_cov[hh][3], v3);
+            atomicAdd(&t_cnt[hh], cnt);
+            if (far) atomicOr(&t_far[hh], 1u);
+            done = true;
+          }
+          hh = (hh + 1) & 255u;
+        }
+        if (!done) {  // > 256 distinct nodes in 1024 slots
+          SNode& N = S.nodes[nd];
+          atomicAdd(&N.cov[0], v0);
+          atomicAdd(&N.cov[1], v1);
+          atomicAdd(&N.cov[2], v2);
+          atomicAdd(&N.cov[3], v3);
+          atomicAdd(&N.nfilt, (unsigned long long)cnt);
+          if (far) atomicOr(&N.need_split, 1u);
+        }
+      }
     }
+  }
+  __syncthreads();
+  if (t_key[threadIdx.x] != 0xFFFFFFFFu) {
+    SNode& N = S.nodes[t_key[threadIdx.x]];
+    atomicAdd(&N.cov[0], t_cov[threadIdx.x][0]);
+    atomicAdd(&N.cov[1], t_cov[threadIdx.x][1]);
+    atomicAdd(&N.cov[2], t_cov[threadIdx.x][2]);
+    atomicAdd(&N.cov[3], t_cov[threadIdx.x][3]);
+    atomicAdd(&N.nfilt, (unsigned long long)t_cnt[threadIdx.x]);
+    // (atomic, not a plain store: the line also receives memory-side atomics from other XCDs)
+    if (t_far[threadIdx.x]) atomicOr(&N.need_split, 1u);
   }
 }
 
@@ -365,24 +413,32 @@ __global__ void k_sp_next_level(SArgs S) {
 // depth-first order of the FINAL nodes: key = (orig, path left-aligned); rank + cell offsets, and
 // the cluster records the regrouping stage expects
 __global__ void __launch_bounds__(256) k_sp_rank(SArgs S, u32 n_nodes, KeptRec* krec, u32* counts) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes) return;
-  SNode& N = S.nodes[i];
-  if (N.state != N_FINAL) return;
+  __shared__ u64 t_key[256];
+  __shared__ u32 t_n[256];
   auto key_of = [](const SNode& M) {
     const u32 pl = M.depth ? (M.path << (32u - M.depth)) : 0u;
     return ((u64)M.orig << 32) | pl;
   };
-  const u64 ki = key_of(N);
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool mine = i < n_nodes && S.nodes[i].state == N_FINAL;
+  const u64 ki = mine ? key_of(S.nodes[i]) : 0ull;
   u32 rank = 0u, off = 0u;
-  for (u32 j = 0; j < n_nodes; ++j) {
-    const SNode& M = S.nodes[j];
-    if (M.state != N_FINAL) continue;
-    if (key_of(M) < ki) {
-      ++rank;
-      off += M.n;
-    }
+  for (u32 base = 0; base < n_nodes; base += 256u) {  // all nodes, one LDS tile at a time
+    const u32 j = base + threadIdx.x;
+    const bool fin = j < n_nodes && S.nodes[j].state == N_FINAL;
+    t_key[threadIdx.x] = fin ? key_of(S.nodes[j]) : ~0ull;
+    t_n[threadIdx.x] = fin ? S.nodes[j].n : 0u;
+    __syncthreads();
+    if (mine)
+      for (int t = 0; t < 256; ++t)
+        if (t_key[t] < ki) {
+          ++rank;
+          off += t_n[t];
+        }
+    __syncthreads();
   }
+  if (!mine) return;
+  SNode& N = S.nodes[i];
   N.rank = rank;
   KeptRec& r = krec[rank];
   r.addr = 0u, r.slot = 0u, r.size = N.n, r.off = off;
@@ -528,7 +584,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
     k_sp_sums<<<gb4, 256, 0, st>>>(g, S, level);
     k_sp_clear<<<gt, 256, 0, st>>>(S.hkeys, S.hvals, t);
     k_sp_leaf<<<gb, 256, 0, st>>>(g, S, level);
-    k_sp_stats<<<gt, 256, 0, st>>>(g, S);
+    k_sp_stats<<<(int)std::min<u32>(64u, (t + 1023u) / 1024u), 256, 0, st>>>(g, S);
     k_sp_decide<<<(n_nodes + 255) / 256, 256, 0, st>>>(S, level, n_nodes);
     k_sp_emit<<<gt, 256, 0, st>>>(g, S, level);
     k_sp_part<<<gb, 256, 0, st>>>(g, S, level);

@@ -104,7 +104,7 @@ __device__ __forceinline__ long pos_adr(const Geo& g, const double p[3]) {
   return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2];
 }
 
-__global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
+__global__ void __launch_bounds__(1024) k_insert_classify(Geo g, InsertArgs A) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   double pt[3];
   int flag = 0;
@@ -121,7 +121,10 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
     } else
       ok = false;
   }
-  // bounding box of the kept end points (update_min/max, :303-306): wave reduce, then atomics
+  // bounding box of the kept end points (update_min/max, :303-306): wave reduce, block reduce in LDS,
+  // then one set of atomics per 1024-point block (per-wave atomics on these six words were the
+  // kernel: ~1200 same-address operations per frame)
+  __shared__ u64 s_lo[16][3], s_hi[16][3];
   u64 lo[3], hi[3];
   for (int k = 0; k < 3; ++k) {
     lo[k] = ok ? enc_f64(pt[k]) : ~0ull;
@@ -133,11 +136,19 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
       hi[k] = max(hi[k], t);
     }
   }
-  if ((threadIdx.x & 63) == 0 && lo[0] != ~0ull)
-    for (int k = 0; k < 3; ++k) {
-      atomicMin(&A.bbox[k], lo[k]);
-      atomicMax(&A.bbox[3 + k], hi[k]);
+  const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; ++k) s_lo[wave][k] = lo[k], s_hi[wave][k] = hi[k];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    u64 l = ~0ull, h = 0ull;
+    for (int w = 0; w < nwave; ++w) l = min(l, s_lo[w][k]), h = max(h, s_hi[w][k]);
+    if (l != ~0ull) {
+      atomicMin(&A.bbox[k], l);
+      atomicMax(&A.bbox[3 + k], h);
     }
+  }
 }
 
 // RayCaster helpers (raycast.cpp:6-23)
@@ -275,7 +286,7 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   A.flag_rayend = m->flag_rayend;
   A.bbox = d_bbox;
   int nb = (n + 255) / 256;
-  k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
+  k_insert_classify<<<(n + 1023) / 1024, 1024, 0, m->stream>>>(g, A);
   k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, m->stream));

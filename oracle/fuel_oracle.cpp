@@ -172,6 +172,12 @@ struct fo_map {
       if (id[i] < box_min[i] || id[i] >= box_max[i]) return false;
     return true;
   }
+  // sdf_map.h:180-187 (position version: strictly inside the box)
+  bool isInBoxPos(const V3d& p) const {
+    for (int i = 0; i < 3; ++i)
+      if (p[i] <= box_mind[i] || p[i] >= box_maxd[i]) return false;
+    return true;
+  }
   // sdf_map.h:196-203
   int getOccupancy(const V3i& id) const {
     if (!isInMap(id)) return -1;
@@ -596,7 +602,13 @@ void fo_map_dist_grad(const fo_map* m, const double* pos, int n, double* dist, d
 //   :811-829 sixNeighbors, :848-860 allNeighbors, :862-877 isNeighborUnknown/knownfree
 // ---------------------------------------------------------------------------------------------
 namespace {
+struct Viewpoint {
+  V3d pos;
+  double yaw;
+  int visib_num;
+};
 struct Cluster {
+  std::vector<Viewpoint> viewpoints;
   std::vector<V3d> cells;     // voxel centres, BFS order
   std::vector<V3d> filtered;  // filtered_cells_: VoxelGrid centroids (float precision, like pcl::PointXYZ)
   V3d average, bmin, bmax;
@@ -668,6 +680,129 @@ struct fo_frontier {
   double cluster_size_xy = 2.0;
   int down_sample = 3;
   int split = 0;
+  fo_viewpoint_cfg vp{};
+  // PerceptionUtils state (perception_utils.cpp:6-19 constructor, :49-69 setPose)
+  V3d pu_pos;
+  V3d pu_normals[4];
+
+  void setPose(const V3d& pos, double yaw) {
+    pu_pos = pos;
+    const double hp = M_PI_2;
+    const V3d n_cam[4] = {mk(0.0, std::sin(hp - vp.top_angle), std::cos(hp - vp.top_angle)),
+                          mk(0.0, -std::sin(hp - vp.top_angle), std::cos(hp - vp.top_angle)),
+                          mk(std::sin(hp - vp.left_angle), 0.0, std::cos(hp - vp.left_angle)),
+                          mk(-std::sin(hp - vp.right_angle), 0.0, std::cos(hp - vp.right_angle))};
+    // R_wc = R_wb(yaw) * R_bc with T_bc = inverse(T_cb), T_cb = [0 -1 0; 0 0 1; 1 0 0]: the products with
+    // the 0 / +-1 entries are exact, leaving R_wc = [s 0 c; -c 0 s; 0 1 0]
+    const double c = std::cos(yaw), s = std::sin(yaw);
+    const double R[3][3] = {{s, 0.0, c}, {-c, 0.0, s}, {0.0, 1.0, 0.0}};
+    for (int k = 0; k < 4; ++k)
+      for (int i = 0; i < 3; ++i)
+        pu_normals[k][i] = R[i][0] * n_cam[k][0] + R[i][1] * n_cam[k][1] + R[i][2] * n_cam[k][2];
+  }
+  bool insideFOV(const V3d& point) const {  // :84-93
+    V3d dir = point - pu_pos;
+    const double nrm = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    if (nrm > vp.max_dist) return false;
+    dir = dir / nrm;
+    for (auto& n : pu_normals)
+      if (dir[0] * n[0] + dir[1] * n[1] + dir[2] * n[2] < 0.0) return false;
+    return true;
+  }
+  bool isNearUnknown(const V3d& pos) const {  // :721-731
+    const int vox_num = (int)std::floor(vp.min_candidate_clearance / map->res);
+    for (int x = -vox_num; x <= vox_num; ++x)
+      for (int y = -vox_num; y <= vox_num; ++y)
+        for (int z = -1; z <= 1; ++z) {
+          const V3d vox = mk(pos[0] + x * map->res, pos[1] + y * map->res, pos[2] + z * map->res);
+          V3i id;
+          map->posToIndex(vox, id);
+          if (map->getOccupancy(id) == 0) return true;
+        }
+    return false;
+  }
+  int countVisibleCells(const V3d& pos, double yaw, const std::vector<V3d>& cluster) {  // :733-755
+    setPose(pos, yaw);
+    int visib_num = 0;
+    RayWalk rc;
+    rc.setParams(map->res, map->origin);
+    for (auto& cell : cluster) {
+      if (!insideFOV(cell)) continue;
+      rc.input(cell, pos);
+      bool visib = true;
+      V3i idx;
+      while (rc.nextId(idx)) {
+        if (fo_map_get_inflate_idx(map, idx.v) == 1 || map->getOccupancy(idx) == 0) {
+          visib = false;
+          break;
+        }
+      }
+      if (visib) visib_num += 1;
+    }
+    return visib_num;
+  }
+  static void wrapYaw(double& yaw) {
+    while (yaw < -M_PI) yaw += 2 * M_PI;
+    while (yaw > M_PI) yaw -= 2 * M_PI;
+  }
+  void sampleViewpoints(Cluster& ftr) {  // :662-695
+    for (double rc = vp.candidate_rmin, dr = (vp.candidate_rmax - vp.candidate_rmin) / vp.candidate_rnum;
+         rc <= vp.candidate_rmax + 1e-3; rc += dr)
+      for (double phi = -M_PI; phi < M_PI; phi += vp.candidate_dphi) {
+        const V3d sample_pos = ftr.average + rc * mk(std::cos(phi), std::sin(phi), 0);
+        V3i sid;
+        map->posToIndex(sample_pos, sid);
+        if (!map->isInBoxPos(sample_pos) || fo_map_get_inflate_idx(map, sid.v) == 1 || isNearUnknown(sample_pos))
+          continue;
+        auto& cells = ftr.filtered;
+        auto normalized = [](const V3d& v) {
+          return v / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        };
+        const V3d ref_dir = normalized(cells.front() - sample_pos);
+        double avg_yaw = 0.0;
+        for (size_t i = 1; i < cells.size(); ++i) {
+          const V3d dir = normalized(cells[i] - sample_pos);
+          double yaw = std::acos(dir[0] * ref_dir[0] + dir[1] * ref_dir[1] + dir[2] * ref_dir[2]);
+          if (ref_dir[0] * dir[1] - ref_dir[1] * dir[0] < 0) yaw = -yaw;  // ref_dir.cross(dir)[2]
+          avg_yaw += yaw;
+        }
+        avg_yaw = avg_yaw / cells.size() + std::atan2(ref_dir[1], ref_dir[0]);
+        wrapYaw(avg_yaw);
+        const int visib_num = countVisibleCells(sample_pos, avg_yaw, cells);
+        if (visib_num > vp.min_visib_num) ftr.viewpoints.push_back(Viewpoint{sample_pos, avg_yaw, visib_num});
+      }
+  }
+  void computeFrontiersToVisit() {  // :392-423
+    for (auto& t : tmp) {
+      sampleViewpoints(t);
+      if (!t.viewpoints.empty()) {
+        frontiers.push_back(t);
+        auto& v = frontiers.back().viewpoints;
+        std::sort(v.begin(), v.end(), [](const Viewpoint& a, const Viewpoint& b) { return a.visib_num > b.visib_num; });
+      } else
+        dormant.push_back(t);
+    }
+    // (tmp_frontiers_ is not cleared by the reference; the next searchFrontiers() clears it)
+  }
+  bool isFrontierCovered() {  // :697-719
+    V3d umin, umax;
+    fo_map_get_updated_box(map, umin.v, umax.v, 0);
+    auto check = [&](const std::list<Cluster>& L) {
+      for (auto& ftr : L) {
+        if (!haveOverlap(ftr.bmin, ftr.bmax, umin, umax)) continue;
+        const int change_thresh = vp.min_view_finish_fraction * ftr.cells.size();
+        int change_num = 0;
+        for (auto& cell : ftr.cells) {
+          V3i idx;
+          map->posToIndex(cell, idx);
+          if (!isFrontier(idx) && ++change_num >= change_thresh) return true;
+        }
+      }
+      return false;
+    };
+    return check(frontiers) || check(dormant);
+  }
+
   std::vector<char> flag;
   std::list<Cluster> frontiers, dormant, tmp;
   std::vector<int> removed_ids;
@@ -930,6 +1065,20 @@ void fo_frontier_cluster_cells(const fo_frontier* f, int which, int k, int* adr)
 void fo_frontier_cluster_info(const fo_frontier* f, int which, int k, double* out9) {
   const Cluster& c = nth(pick(f, which), k);
   for (int i = 0; i < 3; ++i) out9[i] = c.average[i], out9[3 + i] = c.bmin[i], out9[6 + i] = c.bmax[i];
+}
+void fo_frontier_set_viewpoint_cfg(fo_frontier* f, const fo_viewpoint_cfg* c) { f->vp = *c; }
+void fo_frontier_compute_to_visit(fo_frontier* f) { f->computeFrontiersToVisit(); }
+int fo_frontier_is_covered(fo_frontier* f) { return f->isFrontierCovered() ? 1 : 0; }
+int fo_frontier_viewpoint_count(const fo_frontier* f, int which, int k) {
+  return (int)nth(pick(f, which), k).viewpoints.size();
+}
+void fo_frontier_viewpoints(const fo_frontier* f, int which, int k, double* pos_yaw4, int* visib) {
+  const Cluster& c = nth(pick(f, which), k);
+  for (size_t i = 0; i < c.viewpoints.size(); ++i) {
+    for (int q = 0; q < 3; ++q) pos_yaw4[4 * i + q] = c.viewpoints[i].pos[q];
+    pos_yaw4[4 * i + 3] = c.viewpoints[i].yaw;
+    visib[i] = c.viewpoints[i].visib_num;
+  }
 }
 int fo_frontier_cluster_filtered_size(const fo_frontier* f, int which, int k) {
   return (int)nth(pick(f, which), k).filtered.size();

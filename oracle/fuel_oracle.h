@@ -112,6 +112,25 @@ typedef struct fo_frontier fo_frontier;
 fo_frontier* fo_frontier_create(fo_map* m, const fo_frontier_cfg* cfg);
 void fo_frontier_destroy(fo_frontier* f);
 char* fo_frontier_flags(fo_frontier* f);
+/* Viewpoint sampling (frontier_finder.cpp:392-423,662-755) + camera FOV (perception_utils.cpp:6-19,49-69,84-93) */
+typedef struct {
+  double candidate_rmin, candidate_rmax; /* frontier/candidate_rmin|rmax (1.5, 2.5) */
+  int candidate_rnum;                    /* frontier/candidate_rnum (3) */
+  double candidate_dphi;                 /* frontier/candidate_dphi (15 * 3.1415926 / 180) */
+  double min_candidate_clearance;        /* frontier/min_candidate_clearance (0.21) */
+  int min_visib_num;                     /* frontier/min_visib_num (15) */
+  double min_candidate_dist;             /* frontier/min_candidate_dist (0.75) */
+  double min_view_finish_fraction;       /* frontier/min_view_finish_fraction (0.2) */
+  double top_angle, left_angle, right_angle, max_dist; /* perception_utils/... */
+} fo_viewpoint_cfg;
+void fo_frontier_set_viewpoint_cfg(fo_frontier* f, const fo_viewpoint_cfg* c);
+/* computeFrontiersToVisit (:392-423): sampleViewpoints for every tmp cluster; clusters with viewpoints go
+   to frontiers_ (viewpoints sorted by visib_num, best first), the others to dormant_frontiers_ */
+void fo_frontier_compute_to_visit(fo_frontier* f);
+int fo_frontier_viewpoint_count(const fo_frontier* f, int which, int k);
+void fo_frontier_viewpoints(const fo_frontier* f, int which, int k, double* pos_yaw4, int* visib);
+/* isFrontierCovered (:697-719) against the map's current updated box (not reset) */
+int fo_frontier_is_covered(fo_frontier* f);
 /* down-sampled cells of a cluster (Frontier::filtered_cells_, frontier_finder.cpp:757-774): count and
    xyz triples in the VoxelGrid's output order */
 int fo_frontier_cluster_filtered_size(const fo_frontier* f, int which, int k);

@@ -61,6 +61,22 @@ class BsplineProblem(C.Structure):
     ]
 
 
+class ViewpointCfg(C.Structure):
+    """frontier/candidate_* + perception_utils/* (algorithm.xml:106-121)."""
+    _fields_ = [("candidate_rmin", C.c_double), ("candidate_rmax", C.c_double), ("candidate_rnum", C.c_int),
+                ("candidate_dphi", C.c_double), ("min_candidate_clearance", C.c_double),
+                ("min_visib_num", C.c_int), ("min_candidate_dist", C.c_double),
+                ("min_view_finish_fraction", C.c_double), ("top_angle", C.c_double), ("left_angle", C.c_double),
+                ("right_angle", C.c_double), ("max_dist", C.c_double)]
+
+
+def viewpoint_cfg(rmin=1.5, rmax=2.5, rnum=3, dphi=15 * 3.1415926 / 180.0, clearance=0.21, min_visib_num=15,
+                  min_candidate_dist=0.75, min_view_finish_fraction=0.2, top_angle=0.56125, left_angle=0.69222,
+                  right_angle=0.68901, max_dist=4.5, cls=None):
+    return (cls or ViewpointCfg)(rmin, rmax, rnum, dphi, clearance, min_visib_num, min_candidate_dist,
+                                 min_view_finish_fraction, top_angle, left_angle, right_angle, max_dist)
+
+
 class DepthCfg(C.Structure):
     _fields_ = [
         ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
@@ -128,6 +144,11 @@ def lib():
         L.fo_frontier_cluster_size.argtypes = [P, C.c_int, C.c_int]
         L.fo_frontier_cluster_cells.argtypes = [P, C.c_int, C.c_int, ip]
         L.fo_frontier_cluster_info.argtypes = [P, C.c_int, C.c_int, dp]
+        L.fo_frontier_set_viewpoint_cfg.argtypes = [P, C.POINTER(ViewpointCfg)]
+        L.fo_frontier_compute_to_visit.argtypes = [P]
+        L.fo_frontier_is_covered.argtypes = [P]
+        L.fo_frontier_viewpoint_count.argtypes = [P, C.c_int, C.c_int]
+        L.fo_frontier_viewpoints.argtypes = [P, C.c_int, C.c_int, dp, ip]
         L.fo_frontier_cluster_filtered_size.argtypes = [P, C.c_int, C.c_int]
         L.fo_frontier_cluster_filtered.argtypes = [P, C.c_int, C.c_int, dp]
         L.fo_frontier_removed_count.argtypes = [P]
@@ -346,6 +367,25 @@ class OracleFrontier:
         o = np.empty(9)
         self.L.fo_frontier_cluster_info(self.h, which, k, _dp(o))
         return o[:3], o[3:6], o[6:9]
+
+    def set_viewpoint_cfg(self, cfg):
+        self.L.fo_frontier_set_viewpoint_cfg(self.h, C.byref(cfg))
+
+    def compute_to_visit(self):
+        """computeFrontiersToVisit: viewpoints for tmp clusters, then frontiers_ / dormant_frontiers_."""
+        self.L.fo_frontier_compute_to_visit(self.h)
+
+    def is_covered(self):
+        return bool(self.L.fo_frontier_is_covered(self.h))
+
+    def viewpoints(self, which, k):
+        """(pos_yaw float64 [n,4], visib_num int32 [n]) of cluster k, best coverage first."""
+        n = self.L.fo_frontier_viewpoint_count(self.h, which, k)
+        py = np.empty((n, 4))
+        vis = np.empty(n, dtype=np.int32)
+        if n:
+            self.L.fo_frontier_viewpoints(self.h, which, k, _dp(py), _ip(vis))
+        return py, vis
 
     def filtered(self, which, k):
         """Frontier::filtered_cells_ of cluster k: float64 [n,3] (values carry float32 precision)."""

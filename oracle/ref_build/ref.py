@@ -57,6 +57,12 @@ def lib():
         L.ref_frontier_cluster_size.argtypes = [P, C.c_int, C.c_int]
         L.ref_frontier_cluster_cells.argtypes = [P, C.c_int, C.c_int, ip]
         L.ref_frontier_cluster_info.argtypes = [P, C.c_int, C.c_int, dp]
+        L.ref_frontier_create_full.restype = P
+        L.ref_frontier_create_full.argtypes = [P, C.c_int, C.c_double, dp]
+        L.ref_frontier_compute_to_visit.argtypes = [P]
+        L.ref_frontier_is_covered.argtypes = [P]
+        L.ref_frontier_viewpoint_count.argtypes = [P, C.c_int, C.c_int]
+        L.ref_frontier_viewpoints.argtypes = [P, C.c_int, C.c_int, dp, ip]
         L.ref_frontier_cluster_filtered_size.argtypes = [P, C.c_int, C.c_int]
         L.ref_frontier_cluster_filtered.argtypes = [P, C.c_int, C.c_int, dp]
         L.ref_frontier_removed_count.argtypes = [P]
@@ -68,11 +74,20 @@ def lib():
 class RefFrontier:
     """fast_planner::FrontierFinder (the reference's own searchFrontiers / expandFrontier)."""
 
-    def __init__(self, rmap, cluster_min=100, cluster_size_xy=-1.0):
-        """cluster_size_xy < 0: splitLargeFrontiers never splits (region-grown clusters only)."""
+    def __init__(self, rmap, cluster_min=100, cluster_size_xy=-1.0, viewpoint_cfg=None):
+        """cluster_size_xy < 0: splitLargeFrontiers never splits (region-grown clusters only).
+        viewpoint_cfg: fo.ViewpointCfg -> the frontier/candidate_* and perception_utils/* parameters."""
         self.L = lib()
         self.map = rmap
-        self.h = self.L.ref_frontier_create(rmap.h, cluster_min, C.c_double(cluster_size_xy))
+        if viewpoint_cfg is None:
+            self.h = self.L.ref_frontier_create(rmap.h, cluster_min, C.c_double(cluster_size_xy))
+        else:
+            v = viewpoint_cfg
+            vp = np.array([v.candidate_rmin, v.candidate_rmax, v.candidate_rnum, v.candidate_dphi,
+                           v.min_candidate_clearance, v.min_visib_num, v.min_candidate_dist,
+                           v.min_view_finish_fraction, v.top_angle, v.left_angle, v.right_angle, v.max_dist],
+                          dtype=np.float64)
+            self.h = self.L.ref_frontier_create_full(rmap.h, cluster_min, C.c_double(cluster_size_xy), fo._dp(vp))
         self.flags = np.ctypeslib.as_array(C.cast(self.L.ref_frontier_flags(self.h), C.POINTER(C.c_int8)),
                                            shape=(rmap.N,))
 
@@ -101,6 +116,20 @@ class RefFrontier:
         o = np.empty(9)
         self.L.ref_frontier_cluster_info(self.h, which, k, fo._dp(o))
         return o[:3], o[3:6], o[6:9]
+
+    def compute_to_visit(self):
+        self.L.ref_frontier_compute_to_visit(self.h)
+
+    def is_covered(self):
+        return bool(self.L.ref_frontier_is_covered(self.h))
+
+    def viewpoints(self, which, k):
+        n = self.L.ref_frontier_viewpoint_count(self.h, which, k)
+        py = np.empty((n, 4))
+        vis = np.empty(n, dtype=np.int32)
+        if n:
+            self.L.ref_frontier_viewpoints(self.h, which, k, fo._dp(py), fo._ip(vis))
+        return py, vis
 
     def filtered(self, which, k):
         n = self.L.ref_frontier_cluster_filtered_size(self.h, which, k)

@@ -170,6 +170,41 @@ ref_frontier* ref_frontier_create(ref_map* r, int cluster_min, double cluster_si
   f->ff.reset(new fast_planner::FrontierFinder(r->edt, nh));
   return f;
 }
+// full parameter set: vp = {candidate_rmin, candidate_rmax, candidate_rnum, candidate_dphi,
+// min_candidate_clearance, min_visib_num, min_candidate_dist, min_view_finish_fraction,
+// top_angle, left_angle, right_angle, max_dist}
+ref_frontier* ref_frontier_create_full(ref_map* r, int cluster_min, double cluster_size_xy, const double* vp) {
+  ros::NodeHandle nh;
+  nh.num["frontier/cluster_min"] = cluster_min;
+  nh.num["frontier/cluster_size_xy"] = cluster_size_xy < 0 ? 1e18 : cluster_size_xy;
+  nh.num["frontier/cluster_size_z"] = 10.0;
+  nh.num["frontier/down_sample"] = 3;
+  nh.num["frontier/candidate_rmin"] = vp[0];
+  nh.num["frontier/candidate_rmax"] = vp[1];
+  nh.num["frontier/candidate_rnum"] = vp[2];
+  nh.num["frontier/candidate_dphi"] = vp[3];
+  nh.num["frontier/min_candidate_clearance"] = vp[4];
+  nh.num["frontier/min_visib_num"] = vp[5];
+  nh.num["frontier/min_candidate_dist"] = vp[6];
+  nh.num["frontier/min_view_finish_fraction"] = vp[7];
+  nh.num["perception_utils/top_angle"] = vp[8];
+  nh.num["perception_utils/left_angle"] = vp[9];
+  nh.num["perception_utils/right_angle"] = vp[10];
+  nh.num["perception_utils/max_dist"] = vp[11];
+  nh.num["perception_utils/vis_dist"] = 1.0;
+  ref_frontier* f = new ref_frontier;
+  f->map = r;
+  f->ff.reset(new fast_planner::FrontierFinder(r->edt, nh));
+  return f;
+}
+// computeFrontiersToVisit (:392-423): samples viewpoints for tmp_frontiers_, moves them to
+// frontiers_ (viewpoints sorted by coverage) or dormant_frontiers_
+void ref_frontier_compute_to_visit(ref_frontier* f) {
+  std::streambuf* old = std::cout.rdbuf(nullptr);
+  f->ff->computeFrontiersToVisit();
+  std::cout.rdbuf(old);
+}
+int ref_frontier_is_covered(ref_frontier* f) { return f->ff->isFrontierCovered() ? 1 : 0; }
 void ref_frontier_destroy(ref_frontier* f) { delete f; }
 char* ref_frontier_flags(ref_frontier* f) { return f->ff->frontier_flag_.data(); }
 int ref_frontier_search(ref_frontier* f) {
@@ -216,6 +251,20 @@ void ref_frontier_cluster_filtered(ref_frontier* f, int which, int k, double* xy
   std::advance(it, k);
   for (size_t i = 0; i < it->filtered_cells_.size(); ++i)
     for (int q = 0; q < 3; ++q) xyz[3 * i + q] = it->filtered_cells_[i](q);
+}
+int ref_frontier_viewpoint_count(ref_frontier* f, int which, int k) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  return (int)it->viewpoints_.size();
+}
+void ref_frontier_viewpoints(ref_frontier* f, int which, int k, double* pos_yaw, int* visib) {
+  auto it = ref_pick(f, which).begin();
+  std::advance(it, k);
+  for (size_t i = 0; i < it->viewpoints_.size(); ++i) {
+    for (int q = 0; q < 3; ++q) pos_yaw[4 * i + q] = it->viewpoints_[i].pos_(q);
+    pos_yaw[4 * i + 3] = it->viewpoints_[i].yaw_;
+    visib[i] = it->viewpoints_[i].visib_num_;
+  }
 }
 int ref_frontier_removed_count(ref_frontier* f) { return (int)f->ff->removed_ids_.size(); }
 void ref_frontier_removed_ids(ref_frontier* f, int* ids) {

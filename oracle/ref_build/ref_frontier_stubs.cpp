@@ -1,15 +1,11 @@
-// ref_frontier_stubs.cpp -- definitions for the out-of-scope collaborators that
-// frontier_finder.cpp links against (PerceptionUtils: camera FOV test for viewpoint sampling;
-// ViewNode: A*/yaw path costs for the TSP cost matrix).  None of them is reached by
-// searchFrontiers()/expandFrontier(), the part oracle/_ref exists to pin.
+// ref_frontier_stubs.cpp -- definitions for the out-of-scope collaborator that frontier_finder.cpp
+// links against (ViewNode: A*/yaw path costs for the TSP cost matrix).  It is not reached by
+// searchFrontiers / splitLargeFrontiers / computeFrontiersToVisit / sampleViewpoints /
+// isFrontierCovered, the parts oracle/_ref exists to pin.  PerceptionUtils is the REAL
+// active_perception/src/perception_utils.cpp.
 #include <active_perception/graph_node.h>
 #include <active_perception/perception_utils.h>
 namespace fast_planner {
-PerceptionUtils::PerceptionUtils(ros::NodeHandle&) {}
-void PerceptionUtils::setPose(const Vector3d&, const double&) {}
-void PerceptionUtils::getFOV(vector<Vector3d>&, vector<Vector3d>&) {}
-bool PerceptionUtils::insideFOV(const Vector3d&) { return false; }
-void PerceptionUtils::getFOVBoundingBox(Vector3d&, Vector3d&) {}
 double ViewNode::vm_ = 0, ViewNode::am_ = 0, ViewNode::yd_ = 0, ViewNode::ydd_ = 0, ViewNode::w_dir_ = 0;
 shared_ptr<Astar> ViewNode::astar_;
 shared_ptr<RayCaster> ViewNode::caster_;

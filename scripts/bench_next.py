@@ -1,0 +1,57 @@
+"""Measurement of the SURVEY 8(f) 'next' rows on the bench map (G400): GPU (C-ABI) beside the CPU oracle.
+Prints one JSON object; copy it to profiles/ (dev aid, not part of bench.py's contract)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import fuel_amd
+from fuel_amd import synth
+from oracle import fuel_oracle as fo
+
+out = {}
+map_size, box, occ, ctrl, n_known = bench.build_inputs("G400", seed=42)
+
+# ---- rank 2: searchFrontiers incl. splitLargeFrontiers -------------------------------------------
+gm = fuel_amd.SDFMap(map_size, box[0], box[1], device=0)
+gm.uploadOccupancy(occ)
+gf = fuel_amd.FrontierFinder(gm, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True)
+ts = []
+for it in range(12):
+    gf.reset()
+    gm.setUpdatedBox(box[0], box[1])
+    t0 = time.perf_counter()
+    n = gf.searchFrontiers()
+    ts.append(time.perf_counter() - t0)
+gpu_ms = float(np.median(ts[2:]) * 1e3)
+om = fo.OracleMap(map_size, box[0], box[1])
+om.occ[:] = occ
+of = fo.OracleFrontier(om, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True)
+om.set_updated_box(box[0], box[1])
+t0 = time.perf_counter()
+n_o = of.search()
+cpu_ms = (time.perf_counter() - t0) * 1e3
+out["frontier_search_with_split"] = {"gpu_ms": gpu_ms, "cpu_oracle_ms": cpu_ms, "pieces_gpu": n, "pieces_cpu": n_o,
+                                     "cells": int(sum(len(c) for c in gf.clusters(0)))}
+
+# ---- rank 3: depth frame -> fused map ----------------------------------------------------------------
+w = synth.World.for_map_size(map_size)
+truth = w.world(42, bench.WORKLOADS["G400"][1])
+gm2 = fuel_amd.SDFMap(map_size, box[0], box[1], device=0)
+om2 = fo.OracleMap(map_size, box[0], box[1])
+frames = []
+for k in range(12):
+    pose = w.camera(truth, 7, k, 12, 0.7)
+    frames.append((w.depth_image(truth, pose, 640, 480), pose, synth.World.pose_quaternion(pose)))
+tg, tc = [], []
+for img, pose, q in frames:
+    t0 = time.perf_counter()
+    npts = gm2.inputDepthImage(img, pose[:3], q)
+    gm2.synchronize()
+    tg.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    pts = fo.project_depth(img, pose[:3], q)
+    om2.input_points(pts, pose[:3])
+    tc.append(time.perf_counter() - t0)
+out["depth_frame_640x480_project_and_fuse"] = {"gpu_ms": float(np.median(tg[2:]) * 1e3),
+                                               "cpu_oracle_ms": float(np.median(tc[2:]) * 1e3), "points": int(npts)}
+print(json.dumps(out))

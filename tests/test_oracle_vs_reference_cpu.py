@@ -287,3 +287,48 @@ def test_split_large_frontiers_against_real_reference(seed, size_xy):
         assert fa_.shape == fb_.shape and np.array_equal(fa_, fb_) and len(fa_) > 0
     # the split is a partition of the region-grown clusters
     assert np.array_equal(np.sort(np.concatenate(ca)), np.sort(np.concatenate(plain.clusters(0))))
+
+
+@pytest.mark.parametrize("seed,size_xy", [(42, 2.0), (7, 1.2)])
+def test_viewpoint_sampling_against_real_reference(seed, size_xy):
+    """computeFrontiersToVisit / sampleViewpoints / countVisibleCells / isNearUnknown (frontier_finder.cpp:
+    392-423,662-755) with the REAL perception_utils.cpp: same frontiers_/dormant split, and per cluster the
+    same viewpoints (bit-equal positions, yaws, coverage counts, same order after the coverage sort);
+    then isFrontierCovered (:697-719) after further fusion."""
+    om, rm = _explored_pair(seed)
+    for m_ in (om, rm):
+        m_.inflate_local()
+    assert np.array_equal(om.infl, rm.infl)
+    vcfg = fo.viewpoint_cfg(min_visib_num=5)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    of.set_viewpoint_cfg(vcfg)
+    rf = ref.RefFrontier(rm, cluster_min=60, cluster_size_xy=size_xy, viewpoint_cfg=vcfg)
+    ub = om.get_updated_box(reset=False)
+    rm.set_updated_box(*ub)
+    assert of.search() == rf.search() > 0
+    of.compute_to_visit()
+    rf.compute_to_visit()
+    n_act, n_dor = len(of.clusters(1)), len(of.clusters(2))
+    assert n_act == len(rf.clusters(1)) and n_dor == len(rf.clusters(2)) and n_act > 0
+    total = 0
+    for k in range(n_act):
+        (pa, va), (pb, vb) = of.viewpoints(1, k), rf.viewpoints(1, k)
+        assert np.array_equal(va, vb) and np.array_equal(pa, pb) and len(va) > 0
+        assert np.all(va[:-1] >= va[1:])
+        total += len(va)
+    assert total > 20
+    for a, b in zip(of.clusters(1) + of.clusters(2), rf.clusters(1) + rf.clusters(2)):
+        assert np.array_equal(a, b)
+    # isFrontierCovered: nothing changed yet -> False; after more fusion near a frontier -> same answer
+    assert of.is_covered() == rf.is_covered()
+    truth = om.fixture_world(seed, 30)
+    flips = 0
+    for k in range(6):
+        pose = om.fixture_camera(truth, 99, k, 6, 0.6)
+        pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+        om.input_points(pts, pose[:3])
+        rm.input_points(pts, pose[:3])
+        a, b = of.is_covered(), rf.is_covered()
+        assert a == b
+        flips += int(a)
+    assert flips > 0
