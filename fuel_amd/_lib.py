@@ -74,6 +74,15 @@ class FrontierCfg(C.Structure):
                 ("down_sample", C.c_int), ("split", C.c_int)]
 
 
+class ViewpointCfg(C.Structure):
+    """frontier/candidate_* + perception_utils/* parameters (algorithm.xml:106-121)."""
+    _fields_ = [("candidate_rmin", C.c_double), ("candidate_rmax", C.c_double), ("candidate_rnum", C.c_int),
+                ("candidate_dphi", C.c_double), ("min_candidate_clearance", C.c_double),
+                ("min_visib_num", C.c_int), ("min_candidate_dist", C.c_double),
+                ("min_view_finish_fraction", C.c_double), ("top_angle", C.c_double), ("left_angle", C.c_double),
+                ("right_angle", C.c_double), ("max_dist", C.c_double)]
+
+
 class BsplineCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("ld_smooth", "ld_dist", "ld_feasi", "ld_start", "ld_end", "ld_guide", "ld_waypt",
@@ -125,6 +134,11 @@ SYMBOLS = {
     "fuelmi_map_coarse_dist": (C.c_int, [_P, _dp, C.c_int, _dp]),
     "fuelmi_map_query_state": (C.c_int, [_P, _ip, C.c_int, _ip, _ip]),
     "fuelmi_map_synchronize": (C.c_int, [_P]),
+    "fuelmi_frontier_set_viewpoint_cfg": (C.c_int, [_P, C.POINTER(ViewpointCfg)]),
+    "fuelmi_frontier_compute_to_visit": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fuelmi_frontier_viewpoint_count": (C.c_int, [_P, C.c_int, C.c_int]),
+    "fuelmi_frontier_viewpoints": (C.c_int, [_P, C.c_int, C.c_int, _dp, C.POINTER(C.c_int)]),
+    "fuelmi_frontier_is_covered": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fuelmi_frontier_cluster_filtered_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "fuelmi_frontier_cluster_filtered": (C.c_int, [_P, C.c_int, C.c_int, C.c_void_p]),
     "fuelmi_frontier_create": (C.c_int, [_P, C.POINTER(FrontierCfg), _PP]),

@@ -75,7 +75,13 @@ struct FArgs {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+struct HViewpoint {  // Viewpoint (frontier_finder.h:25-33)
+  double pos[3];
+  double yaw;
+  int visib_num;
+};
 struct HCluster {
+  std::vector<HViewpoint> viewpoints;
   std::vector<int> cells;  // ascending voxel addresses
   double avg[3], bmin[3], bmax[3];
   // A freshly found cluster (tmp_frontiers_) still lives in the pinned result buffer: its cell list is
@@ -135,6 +141,8 @@ struct fuelmi_frontier {
   bool pending = false, search_empty = false;
   std::unique_ptr<StageScope> scope;
   std::vector<int> slot2rank;
+  fuelmi_viewpoint_cfg vcfg;
+  bool have_vcfg = false;
   struct SplitScratch* split = nullptr;  // device buffers of the split stage (frontier_split.hip)
 };
 void frontier_split_free(fuelmi_frontier* f);

@@ -22,9 +22,10 @@
 // by that rank with the same stable multisplit the clustering uses, which keeps them in ascending
 // address order, and the per-piece mean / AABB come from the same accumulator kernel.
 //
-// Arithmetic: node means and centroids are exact rationals of integer voxel-index sums evaluated
-// in f64 (the reference accumulates f64 cell centres, PCL accumulates float centroids: both are
-// within 1e-5 m of the exact value, the centroid is rounded to float like pcl::PointXYZ).  The
+// Arithmetic: node means are exact rationals of integer voxel-index sums evaluated in f64 (the
+// reference accumulates f64 cell centres: ~1e-15 apart).  Leaf centroids reproduce pcl::VoxelGrid's
+// FLOAT accumulation, over the member cells in ascending voxel address (k_sp_centroid) -- the
+// reference feeds PCL the cells in BFS order, so its last float bit can differ; see DESIGN.md.  The
 // principal direction uses the closed-form symmetric 2x2 decomposition with the sign convention of
 // the oracle (Eigen::EigenSolver is third-party; its sign is unpinned).
 #include <cmath>
@@ -54,7 +55,8 @@ struct SNode {
 };
 
 struct LeafAcc {
-  u32 cnt, sx, sy, sz;
+  u32 cnt;      // member cells
+  float c[3];   // centroid (k_sp_centroid)
 };
 
 #define SP_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -70,6 +72,8 @@ struct SArgs {
   u32* ctr;      // [0] n_nodes [1] splits of this level [2] n_filtered [3] overflow [4] n_final
   u64* hkeys;
   LeafAcc* hvals;
+  u32* hmemb;    // [table size][memb_cap] voxel addresses of the members of every (node, leaf)
+  u32 memb_cap;
   u32 hmask;
   // filtered-cell output
   u32* f_node;
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(256) k_sp_sums(Geo g, SArgs S, u32 level) {
 __global__ void k_sp_clear(u64* keys, LeafAcc* vals, u32 n) {
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     keys[i] = SP_EMPTY;
-    vals[i] = LeafAcc{0u, 0u, 0u, 0u};
+    vals[i] = LeafAcc{0u, {0.f, 0.f, 0.f}};
   }
 }
 
@@ -199,18 +203,51 @@ __global__ void __launch_bounds__(256) k_sp_leaf(Geo g, SArgs S, u32 level) {
       if (old == SP_EMPTY || old == key) break;
       h = (h + 1) & S.hmask;
     }
-    atomicAdd(&S.hvals[h].cnt, 1u);
-    atomicAdd(&S.hvals[h].sx, x);
-    atomicAdd(&S.hvals[h].sy, y);
-    atomicAdd(&S.hvals[h].sz, z);
+    const u32 arr = atomicAdd(&S.hvals[h].cnt, 1u);
+    if (arr < S.memb_cap)
+      S.hmemb[(size_t)h * S.memb_cap + arr] = S.cells[i];
+    else
+      S.ctr[3] = 1u;
   }
 }
 
-__device__ __forceinline__ void centroid_of(const Geo& g, const LeafAcc& a, float c[3]) {
-  const double n = (double)a.cnt;
-  c[0] = (float)(((double)a.sx / n + 0.5) * g.res + g.org[0]);
-  c[1] = (float)(((double)a.sy / n + 0.5) * g.res + g.org[1]);
-  c[2] = (float)(((double)a.sz / n + 0.5) * g.res + g.org[2]);
+// Centroid of every (node, leaf): the float accumulation of pcl::VoxelGrid (centroid += point;
+// centroid /= n, all in float) over the member cells in ASCENDING VOXEL ADDRESS -- the order this
+// library lists cells in.  Centroids of voxel centres land exactly on voxel faces whenever the members
+// are symmetric, so the last float bit decides in which voxel a visibility ray starts: the sum must
+// be reproducible, not merely accurate.
+__global__ void __launch_bounds__(256) k_sp_centroid(Geo g, SArgs S) {
+  const u32 tsize = S.hmask + 1u;
+  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < tsize; h += gridDim.x * blockDim.x) {
+    if (S.hkeys[h] == SP_EMPTY) continue;
+    const u32 n = min(S.hvals[h].cnt, S.memb_cap);
+    u32* mb = S.hmemb + (size_t)h * S.memb_cap;
+    for (u32 i = 1; i < n; ++i) {  // insertion sort in place (n <= (down_sample + 1)^3)
+      const u32 v = mb[i];
+      u32 j = i;
+      while (j > 0 && mb[j - 1] > v) {
+        mb[j] = mb[j - 1];
+        --j;
+      }
+      mb[j] = v;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u32 i = 0; i < n; ++i) {
+      u32 x, y, z;
+      decode(g, mb[i], x, y, z);
+      sx += (float)(((double)x + 0.5) * g.res + g.org[0]);
+      sy += (float)(((double)y + 0.5) * g.res + g.org[1]);
+      sz += (float)(((double)z + 0.5) * g.res + g.org[2]);
+    }
+    const float fn = (float)n;
+    S.hvals[h].c[0] = sx / fn;
+    S.hvals[h].c[1] = sy / fn;
+    S.hvals[h].c[2] = sz / fn;
+  }
+}
+
+__device__ __forceinline__ void centroid_of(const Geo&, const LeafAcc& a, float c[3]) {
+  c[0] = a.c[0], c[1] = a.c[1], c[2] = a.c[2];
 }
 __device__ __forceinline__ void node_mean_xy(const Geo& g, const SNode& N, double m[2]) {
   const double n = (double)N.n;
@@ -473,6 +510,8 @@ struct SplitScratch {
   SNode* nodes = nullptr;
   u64* hkeys = nullptr;
   LeafAcc* hvals = nullptr;
+  u32* hmemb = nullptr;
+  u32 memb_cap = 0;
   u32* f_node = nullptr;
   u64* f_leaf = nullptr;
   float* f_xyz = nullptr;
@@ -482,7 +521,8 @@ struct SplitScratch {
 void frontier_split_free(fuelmi_frontier* f) {
   SplitScratch* s = f->split;
   if (!s) return;
-  void* dev[] = {s->cells, s->node, s->ctr, s->seeds, s->counts, s->nodes, s->hkeys, s->hvals, s->f_node, s->f_leaf, s->f_xyz};
+  void* dev[] = {s->cells, s->node,  s->ctr,    s->seeds,  s->counts, s->nodes,
+                 s->hkeys, s->hvals, s->hmemb, s->f_node, s->f_leaf, s->f_xyz};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (s->h_ctr) (void)hipHostFree(s->h_ctr);
@@ -507,20 +547,27 @@ static int split_ensure(fuelmi_frontier* f, u32 n) {
       return rc;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), 64, hipHostMallocDefault));
   }
+  const u32 ds1 = (u32)f->cfg.down_sample + 1u;  // a leaf holds down_sample^3 voxel centres; +1 per axis of slack
+  if (s->memb_cap != ds1 * ds1 * ds1) {
+    s->memb_cap = ds1 * ds1 * ds1;
+    s->cap_cells = 0;  // force (re)allocation of the table with the new member capacity
+  }
   if (n > s->cap_cells) {
-    void* old[] = {s->cells, s->node, s->hkeys, s->hvals, s->f_node, s->f_leaf, s->f_xyz};
+    void* old[] = {s->cells, s->node, s->hkeys, s->hvals, s->hmemb, s->f_node, s->f_leaf, s->f_xyz};
     for (void* p : old)
       if (p) HIPCHK(hipFree(p));
     s->cells = s->node = s->f_node = nullptr;
     s->hkeys = s->f_leaf = nullptr;
     s->hvals = nullptr;
+    s->hmemb = nullptr;
     s->f_xyz = nullptr;
     s->cap_cells = 0;
     const u32 cap = n + n / 4 + 4096;
     u32 t = 1024;
     while (t < 2u * cap) t <<= 1;
     if ((rc = sp_alloc(&s->cells, cap)) || (rc = sp_alloc(&s->node, cap)) || (rc = sp_alloc(&s->hkeys, t)) ||
-        (rc = sp_alloc(&s->hvals, t)) || (rc = sp_alloc(&s->f_node, cap)) || (rc = sp_alloc(&s->f_leaf, cap)) ||
+        (rc = sp_alloc(&s->hvals, t)) || (rc = sp_alloc(&s->hmemb, (size_t)t * s->memb_cap)) ||
+        (rc = sp_alloc(&s->f_node, cap)) || (rc = sp_alloc(&s->f_leaf, cap)) ||
         (rc = sp_alloc(&s->f_xyz, 3 * (size_t)cap)))
       return rc;
     s->cap_cells = cap;
@@ -536,8 +583,8 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   const Geo& g = m->g;
   FArgs& F = f->F;
   hipStream_t st = f->stream;
-  if (f->cfg.down_sample <= 0 || !(f->cfg.cluster_size_xy > 0.0)) {
-    fuelmi_set_error("frontier split needs down_sample > 0 and cluster_size_xy > 0");
+  if (f->cfg.down_sample <= 0 || f->cfg.down_sample > 6 || !(f->cfg.cluster_size_xy > 0.0)) {
+    fuelmi_set_error("frontier split needs 0 < down_sample <= 6 and cluster_size_xy > 0");
     return FUELMI_EINVAL;
   }
   if (nkept >= (1u << (64 - 3 * SP_LBITS - 1))) {
@@ -565,7 +612,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   SArgs S;
   S.n = n;
   S.cells = s->cells, S.node = s->node, S.nodes = s->nodes, S.cap_nodes = s->cap_nodes, S.ctr = s->ctr;
-  S.hkeys = s->hkeys, S.hvals = s->hvals;
+  S.hkeys = s->hkeys, S.hvals = s->hvals, S.hmemb = s->hmemb, S.memb_cap = s->memb_cap;
   u32 t = 1024;  // table sized to this search (cleared every level)
   while (t < 2u * n) t <<= 1;
   S.hmask = t - 1u;
@@ -584,6 +631,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
     k_sp_sums<<<gb4, 256, 0, st>>>(g, S, level);
     k_sp_clear<<<gt, 256, 0, st>>>(S.hkeys, S.hvals, t);
     k_sp_leaf<<<gb, 256, 0, st>>>(g, S, level);
+    k_sp_centroid<<<gt, 256, 0, st>>>(g, S);
     k_sp_stats<<<(int)std::min<u32>(64u, (t + 1023u) / 1024u), 256, 0, st>>>(g, S);
     k_sp_decide<<<(n_nodes + 255) / 256, 256, 0, st>>>(S, level, n_nodes);
     k_sp_emit<<<gt, 256, 0, st>>>(g, S, level);

@@ -294,6 +294,58 @@ class FrontierFinder:
             out.append(a)
         return out
 
+    @staticmethod
+    def viewpointConfig(rmin=1.5, rmax=2.5, rnum=3, dphi=15 * 3.1415926 / 180.0, clearance=0.21, min_visib_num=15,
+                        min_candidate_dist=0.75, min_view_finish_fraction=0.2, top_angle=0.56125,
+                        left_angle=0.69222, right_angle=0.68901, max_dist=4.5):
+        """frontier/candidate_* and perception_utils/* of algorithm.xml:106-121."""
+        return _lib.ViewpointCfg(rmin, rmax, rnum, dphi, clearance, min_visib_num, min_candidate_dist,
+                                 min_view_finish_fraction, top_angle, left_angle, right_angle, max_dist)
+
+    def setViewpointConfig(self, cfg):
+        self.vcfg = cfg
+        check(self.L.fuelmi_frontier_set_viewpoint_cfg(self.h, C.byref(cfg)))
+
+    def computeFrontiersToVisit(self):
+        """sampleViewpoints for the new clusters, then frontiers_ / dormant_frontiers_ (reference :392-423).
+        Returns (new active, new dormant)."""
+        a, d = C.c_int(), C.c_int()
+        check(self.L.fuelmi_frontier_compute_to_visit(self.h, C.byref(a), C.byref(d)))
+        return a.value, d.value
+
+    def viewpoints(self, which, k):
+        """(pos_yaw [n,4], visib_num [n]) of cluster k, best coverage first."""
+        n = self.L.fuelmi_frontier_viewpoint_count(self.h, which, k)
+        if n < 0:
+            check(n)
+        py = np.empty((n, 4))
+        vis = np.empty(n, dtype=np.int32)
+        if n:
+            check(self.L.fuelmi_frontier_viewpoints(self.h, which, k, _dp(py), _ip(vis)))
+        return py, vis
+
+    def isFrontierCovered(self):
+        c = C.c_int()
+        check(self.L.fuelmi_frontier_is_covered(self.h, C.byref(c)))
+        return bool(c.value)
+
+    def getTopViewpointsInfo(self, cur_pos):
+        """reference :425-450: per active frontier the best viewpoint farther than min_candidate_dist."""
+        cur = np.asarray(cur_pos, dtype=float)
+        pts, yaws, avgs = [], [], []
+        for k in range(self.L.fuelmi_frontier_count(self.h, 1)):
+            py, _ = self.viewpoints(1, k)
+            pick = py[0]
+            for v in py:
+                if np.linalg.norm(v[:3] - cur) < self.vcfg.min_candidate_dist:
+                    continue
+                pick = v
+                break
+            pts.append(pick[:3].copy())
+            yaws.append(float(pick[3]))
+            avgs.append(self.clusterInfo(1, k)[0])
+        return pts, yaws, avgs
+
     def filtered(self, which, k):
         """Frontier::filtered_cells_ of cluster k: float32 [n,3] (split=True searches only)."""
         n = self.L.fuelmi_frontier_cluster_filtered_size(self.h, which, k)

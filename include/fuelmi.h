@@ -163,6 +163,29 @@ void fuelmi_frontier_destroy(fuelmi_frontier* f);
 /* forget all clusters and clear frontier_flag_ (== constructing a fresh FrontierFinder,
  * frontier_finder.cpp:23-27) */
 int fuelmi_frontier_reset(fuelmi_frontier* f);
+/* Viewpoint sampling and coverage (frontier_finder.cpp:392-423,662-755,697-719; camera frustum
+ * perception_utils.cpp:6-19,49-69,84-93).  Fields are the ROS parameters of the same names. */
+typedef struct {
+  double candidate_rmin, candidate_rmax; /* frontier/candidate_rmin, candidate_rmax */
+  int candidate_rnum;                    /* frontier/candidate_rnum */
+  double candidate_dphi;                 /* frontier/candidate_dphi */
+  double min_candidate_clearance;        /* frontier/min_candidate_clearance */
+  int min_visib_num;                     /* frontier/min_visib_num */
+  double min_candidate_dist;             /* frontier/min_candidate_dist (used by the Top/ViewpointsInfo getters) */
+  double min_view_finish_fraction;       /* frontier/min_view_finish_fraction */
+  double top_angle, left_angle, right_angle, max_dist; /* perception_utils/... */
+} fuelmi_viewpoint_cfg;
+int fuelmi_frontier_set_viewpoint_cfg(fuelmi_frontier* f, const fuelmi_viewpoint_cfg* cfg);
+/* computeFrontiersToVisit: samples viewpoints for every new cluster (needs cfg.split, i.e. filtered
+ * cells, and the map's CURRENT inflated occupancy); clusters with at least one viewpoint are appended
+ * to frontiers_ with their viewpoints sorted by coverage (best first), the others to
+ * dormant_frontiers_.  The new-cluster list is left empty. */
+int fuelmi_frontier_compute_to_visit(fuelmi_frontier* f, int* n_active_new, int* n_dormant_new);
+int fuelmi_frontier_viewpoint_count(const fuelmi_frontier* f, int which, int k);
+/* pos_yaw4: x, y, z, yaw per viewpoint; visib: Viewpoint::visib_num_ */
+int fuelmi_frontier_viewpoints(const fuelmi_frontier* f, int which, int k, double* pos_yaw4, int* visib);
+/* isFrontierCovered against the map's accumulated updated box (the box is not consumed) */
+int fuelmi_frontier_is_covered(fuelmi_frontier* f, int* covered);
 /* Frontier::filtered_cells_ of cluster k (VoxelGrid centroids, float xyz, ascending leaf index like PCL);
  * empty unless the cluster was found with cfg.split != 0 */
 int fuelmi_frontier_cluster_filtered_size(const fuelmi_frontier* f, int which, int k);

@@ -680,6 +680,7 @@ struct fo_frontier {
   double cluster_size_xy = 2.0;
   int down_sample = 3;
   int split = 0;
+  int canonical_order = 0;
   fo_viewpoint_cfg vp{};
   // PerceptionUtils state (perception_utils.cpp:6-19 constructor, :49-69 setPose)
   V3d pu_pos;
@@ -834,7 +835,22 @@ struct fo_frontier {
   }
   // downsample (:757-774): leaf = resolution * down_sample_
   void downsample(const std::vector<V3d>& in, std::vector<V3d>& out) const {
-    voxel_grid_downsample(in, map->res * down_sample, out);
+    if (!canonical_order) {
+      voxel_grid_downsample(in, map->res * down_sample, out);
+      return;
+    }
+    std::vector<std::pair<int, size_t>> order;  // (voxel address, position in `in`)
+    order.reserve(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+      V3i id;
+      map->posToIndex(in[i], id);
+      order.emplace_back(map->adr(id), i);
+    }
+    std::sort(order.begin(), order.end());
+    std::vector<V3d> sorted;
+    sorted.reserve(in.size());
+    for (auto& o : order) sorted.push_back(in[o.second]);
+    voxel_grid_downsample(sorted, map->res * down_sample, out);
   }
 
   // splitHorizontally (:179-242).  The principal direction comes from Eigen::EigenSolver<Matrix2d>
@@ -926,6 +942,19 @@ struct fo_frontier {
       }
     }
     c.average = c.average / double(c.cells.size());
+    if (canonical_order) {
+      // order-free evaluation of the same mean: exact integer sum of the voxel indices, one rounding
+      // chain at the end (the sequential f64 sum above carries ~1e-13 of order-dependent noise, enough
+      // to move a mean that sits exactly on a voxel face -- e.g. the z of a full-height wall -- across it)
+      long long sum[3] = {0, 0, 0};
+      for (auto& cell : c.cells) {
+        V3i id;
+        map->posToIndex(cell, id);
+        for (int i = 0; i < 3; ++i) sum[i] += id[i];
+      }
+      for (int i = 0; i < 3; ++i)
+        c.average[i] = ((double)sum[i] / double(c.cells.size()) + 0.5) * map->res + map->origin[i];
+    }
     if (down_sample > 0) downsample(c.cells, c.filtered);
   }
 
@@ -1031,6 +1060,7 @@ fo_frontier* fo_frontier_create(fo_map* m, const fo_frontier_cfg* cfg) {
   f->cluster_size_xy = cfg->cluster_size_xy;
   f->down_sample = cfg->down_sample;  // <= 0: filtered_cells_ not computed (F1-F4 contract only)
   f->split = cfg->split;
+  f->canonical_order = cfg->canonical_order;
   f->flag.assign((size_t)m->total(), 0);
   return f;
 }

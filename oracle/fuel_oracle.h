@@ -106,6 +106,10 @@ typedef struct {
   double cluster_size_xy;  /* frontier/cluster_size_xy (2.0) */
   int down_sample;         /* frontier/down_sample (3): VoxelGrid leaf = down_sample * resolution; <= 0: skip */
   int split;               /* 0: stop before splitLargeFrontiers (the F1-F4 contract); 1: run it */
+  int canonical_order;     /* 0: cells reach the VoxelGrid in BFS order (the reference); 1: in ascending voxel
+                              address (the order libfuelmi lists cells in), and cluster means are
+                              evaluated order-free from exact integer index sums -- changes only the float
+                              summation order inside a leaf and the last bits (~1e-13) of the means */
 } fo_frontier_cfg;
 typedef struct fo_frontier fo_frontier;
 

@@ -564,18 +564,18 @@ def test_depth_image_fusion_matches_projection_plus_insert(fa):
 # ------------------------------------------------------------------------------------------------
 def _assert_split_equal(of, gf, om, n):
     """Same pieces in the same order; cells as sets (the oracle keeps BFS order, the device address
-    order); mean/AABB to 1e-9; filtered cells equal as leaf-ordered lists to 2e-5 m (PCL accumulates the
-    centroid in float in input order, the device from exact integer sums)."""
+    order); mean/AABB to 1e-9; filtered cells bit-equal as leaf-ordered float lists (the oracle runs
+    with canonical_order: the VoxelGrid's float sums then see the cells in address order on both sides)."""
     ca, cb = of.clusters(0), gf.clusters(0)
     assert len(ca) == len(cb) == n
     for k in range(n):
         assert np.array_equal(np.sort(ca[k]), cb[k]), "piece %d differs" % k
         ia, ib = of.cluster_info(0, k), gf.clusterInfo(0, k)
         for x, y in zip(ia, ib):
-            assert np.abs(np.asarray(x) - np.asarray(y)).max() <= 1e-9
+            assert np.array_equal(np.asarray(x), np.asarray(y))  # order-free means: bit-equal
         fa_, fb_ = of.filtered(0, k), gf.filtered(0, k)
         assert fa_.shape == fb_.shape and len(fa_) > 0
-        assert np.abs(fa_ - fb_).max() <= 2e-5
+        assert np.array_equal(fa_.astype(np.float32), fb_)
 
 
 @pytest.mark.gpu
@@ -585,7 +585,8 @@ def test_split_large_frontiers_matches_oracle(fa, seed, size_xy):
     gm = gpu_twin(fa, om, box)
     ub = om.get_updated_box(reset=False)
     gm.setUpdatedBox(*ub)
-    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True,
+                           canonical_order=True)
     gf = fa.FrontierFinder(gm, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
     plain = fo.OracleFrontier(om, cluster_min=60)
     n0 = plain.search()
@@ -611,10 +612,67 @@ def test_split_with_low_z_seed_clusters(fa):
     gm = gpu_twin(fa, om, box)
     ub = om.get_updated_box(reset=False)
     gm.setUpdatedBox(*ub)
-    of = fo.OracleFrontier(om, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True)
+    of = fo.OracleFrontier(om, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True, canonical_order=True)
     gf = fa.FrontierFinder(gm, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True)
     n1, n2 = of.search(), gf.searchFrontiers()
     assert n1 == n2 > 0
     _assert_split_equal(of, gf, om, n1)
+    gf.close()
+    gm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# viewpoint sampling / coverage on the device
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,size_xy", [(42, 2.0), (7, 1.2)])
+def test_viewpoint_sampling_and_coverage_match_oracle(fa, seed, size_xy):
+    """computeFrontiersToVisit: same active/dormant partition, per cluster the same viewpoints in the same
+    order with identical coverage counts; positions to 1e-9 m (cluster means come from exact integer
+    sums on the device, from a sequential f64 sum in the reference), yaws to 1e-9 rad (device libm, tree
+    sum).  Then isFrontierCovered after more fusion, step by step."""
+    om, truth, frames, box = helpers.explored_oracle_map((16.0, 14.0, 4.0), 30, 28, seed=seed)
+    om.inflate_local()
+    gm = gpu_twin(fa, om, box)
+    gm.setLocalBound(*om.get_local_bound())
+    gm.clearAndInflateLocalMap()
+    ub = om.get_updated_box(reset=False)
+    gm.setUpdatedBox(*ub)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True,
+                           canonical_order=True)
+    of.set_viewpoint_cfg(fo.viewpoint_cfg(min_visib_num=5))
+    gf = fa.FrontierFinder(gm, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    gf.setViewpointConfig(gf.viewpointConfig(min_visib_num=5))
+    assert of.search() == gf.searchFrontiers() > 0
+    of.compute_to_visit()
+    na, nd = gf.computeFrontiersToVisit()
+    assert na == len(of.clusters(1)) > 0 and nd == len(of.clusters(2))
+    total = 0
+    for k in range(na):
+        (pa, va), (pb, vb) = of.viewpoints(1, k), gf.viewpoints(1, k)
+        assert np.array_equal(va, vb), "coverage counts of cluster %d differ" % k
+        assert np.array_equal(pa[:, :3], pb[:, :3])
+        dyaw = np.abs(pa[:, 3] - pb[:, 3])
+        assert np.minimum(dyaw, 2 * np.pi - dyaw).max() <= 1e-9
+        total += len(va)
+    assert total > 20
+    for which in (1, 2):
+        for a, b in zip(of.clusters(which), gf.clusters(which)):
+            assert np.array_equal(np.sort(a), b)
+    # getTopViewpointsInfo mirror: one entry per active frontier
+    pts, yaws, avgs = gf.getTopViewpointsInfo((0.0, 0.0, 1.0))
+    assert len(pts) == na
+    # coverage check while the map keeps changing
+    assert of.is_covered() == gf.isFrontierCovered()
+    seen = 0
+    for k in range(6):
+        pose = om.fixture_camera(truth, 99, k, 6, 0.6)
+        pts_ = om.fixture_render(truth, pose, 160, 120, 2, 2)
+        om.input_points(pts_, pose[:3])
+        gm.inputPointCloud(pts_, pose[:3])
+        a, b = of.is_covered(), gf.isFrontierCovered()
+        assert a == b
+        seen += int(a)
+    assert seen > 0
     gf.close()
     gm.close()

@@ -350,3 +350,22 @@ def test_golden_fixture_is_reproduced():
             assert np.allclose(a, b, rtol=0, atol=1e-12), k
         else:
             assert np.array_equal(a, b), k
+
+
+def test_canonical_cell_order_is_the_same_algorithm():
+    """canonical_order only permutes the float summation inside a VoxelGrid leaf and evaluates the means
+    order-free: same pieces (as cell sets, same order), filtered cells within 2e-5 m and means within
+    1e-11 m of the BFS-order run."""
+    om, truth, frames, box = helpers.explored_oracle_map((16.0, 14.0, 4.0), 30, 28, seed=42)
+    ub = om.get_updated_box(reset=False)
+    a = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=2.0, down_sample=3, split=True)
+    b = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=2.0, down_sample=3, split=True, canonical_order=True)
+    na = a.search()
+    om.set_updated_box(*ub)
+    nb = b.search()
+    assert na == nb > 3
+    for k in range(na):
+        assert np.array_equal(a.clusters(0)[k], b.clusters(0)[k])
+        fa_, fb_ = a.filtered(0, k), b.filtered(0, k)
+        assert fa_.shape == fb_.shape and np.abs(fa_ - fb_).max() <= 2e-5
+        assert np.abs(a.cluster_info(0, k)[0] - b.cluster_info(0, k)[0]).max() <= 1e-11
