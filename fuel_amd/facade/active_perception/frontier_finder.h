@@ -55,6 +55,14 @@ public:
   void getFrontiers(vector<vector<Vector3d>>& clusters);
   void getDormantFrontiers(vector<vector<Vector3d>>& clusters);
   void getFrontierBoxes(vector<pair<Vector3d, Vector3d>>& boxes);
+  // Get viewpoint with highest coverage for each frontier
+  void getTopViewpointsInfo(const Vector3d& cur_pos, vector<Vector3d>& points, vector<double>& yaws,
+                            vector<Vector3d>& averages);
+  // Get several viewpoints for a subset of frontiers
+  void getViewpointsInfo(const Vector3d& cur_pos, const vector<int>& ids, const int& view_num,
+                         const double& max_decay, vector<vector<Vector3d>>& points,
+                         vector<vector<double>>& yaws);
+  bool isFrontierCovered();
   void wrapYaw(double& yaw);
 
   // additions: clusters found by the last searchFrontiers() and ids removed by it
@@ -70,6 +78,8 @@ private:
   vector<int> removed_ids_;
   int cluster_min_;
   double resolution_;
+  double min_candidate_dist_;
+  bool have_viewpoints_;  // frontier/candidate_* and perception_utils/* were all given
 };
 }  // namespace fast_planner
 #endif

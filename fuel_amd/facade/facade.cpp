@@ -240,6 +240,23 @@ FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeH
   // at the region-grown clusters
   c.split = (cluster_size_xy > 0.0 && down_sample > 0) ? 1 : 0;
   warn("fuelmi_frontier_create", fuelmi_frontier_create(edt_env_->sdf_map_->device(), &c, &dev_));
+  // viewpoint sampling parameters (frontier_finder.cpp:32-43, perception_utils.cpp:7-11)
+  fuelmi_viewpoint_cfg v;
+  nh.param("frontier/candidate_rmin", v.candidate_rmin, -1.0);
+  nh.param("frontier/candidate_rmax", v.candidate_rmax, -1.0);
+  nh.param("frontier/candidate_rnum", v.candidate_rnum, -1);
+  nh.param("frontier/candidate_dphi", v.candidate_dphi, -1.0);
+  nh.param("frontier/min_candidate_clearance", v.min_candidate_clearance, -1.0);
+  nh.param("frontier/min_visib_num", v.min_visib_num, -1);
+  nh.param("frontier/min_candidate_dist", v.min_candidate_dist, -1.0);
+  nh.param("frontier/min_view_finish_fraction", v.min_view_finish_fraction, -1.0);
+  nh.param("perception_utils/top_angle", v.top_angle, -1.0);
+  nh.param("perception_utils/left_angle", v.left_angle, -1.0);
+  nh.param("perception_utils/right_angle", v.right_angle, -1.0);
+  nh.param("perception_utils/max_dist", v.max_dist, -1.0);
+  min_candidate_dist_ = v.min_candidate_dist;
+  have_viewpoints_ = c.split && dev_ && v.candidate_rnum > 0 && v.candidate_dphi > 0.0 && v.max_dist > 0.0;
+  if (have_viewpoints_) warn("fuelmi_frontier_set_viewpoint_cfg", fuelmi_frontier_set_viewpoint_cfg(dev_, &v));
 }
 FrontierFinder::~FrontierFinder() {
   if (dev_) fuelmi_frontier_destroy(dev_);
@@ -272,6 +289,18 @@ void FrontierFinder::pull(int which, list<Frontier>& out) {
       f.filtered_cells_.resize(nf);
       for (int i = 0; i < nf; ++i) f.filtered_cells_[i] = Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     }
+    const int nvp = fuelmi_frontier_viewpoint_count(dev_, which, k);
+    if (nvp > 0) {
+      std::vector<double> py(4 * (size_t)nvp);
+      std::vector<int> vis(nvp);
+      fuelmi_frontier_viewpoints(dev_, which, k, py.data(), vis.data());
+      f.viewpoints_.resize(nvp);
+      for (int i = 0; i < nvp; ++i) {
+        f.viewpoints_[i].pos_ = Vector3d(py[4 * i], py[4 * i + 1], py[4 * i + 2]);
+        f.viewpoints_[i].yaw_ = py[4 * i + 3];
+        f.viewpoints_[i].visib_num_ = vis[i];
+      }
+    }
     f.id_ = k;
     out.push_back(f);
   }
@@ -288,12 +317,75 @@ void FrontierFinder::searchFrontiers() {
 }
 
 void FrontierFinder::computeFrontiersToVisit() {
-  // reference (:392-423) samples viewpoints and sends clusters without any to dormant_frontiers_;
-  // viewpoint sampling is a "next" row, so every new cluster becomes an active frontier here
+  if (have_viewpoints_) {
+    // reference (:392-423): sampleViewpoints per new cluster on the device; clusters with viewpoints
+    // join frontiers_ (viewpoints sorted by coverage), the others dormant_frontiers_
+    int na = 0, nd = 0;
+    warn("fuelmi_frontier_compute_to_visit", fuelmi_frontier_compute_to_visit(dev_, &na, &nd));
+    pull(1, frontiers_);
+    pull(2, dormant_frontiers_);
+    return;
+  }
+  // without the viewpoint parameters every new cluster becomes an active frontier
   warn("fuelmi_frontier_commit", fuelmi_frontier_commit(dev_, 0));
   frontiers_.insert(frontiers_.end(), tmp_frontiers_.begin(), tmp_frontiers_.end());
   int id = 0;
   for (auto& f : frontiers_) f.id_ = id++;
+}
+
+void FrontierFinder::getTopViewpointsInfo(const Vector3d& cur_pos, vector<Vector3d>& points, vector<double>& yaws,
+                                          vector<Vector3d>& averages) {  // :425-450
+  points.clear();
+  yaws.clear();
+  averages.clear();
+  for (auto& frontier : frontiers_) {
+    if (frontier.viewpoints_.empty()) continue;
+    const Viewpoint* pick = &frontier.viewpoints_.front();  // all close: the best one
+    for (auto& view : frontier.viewpoints_) {
+      if ((view.pos_ - cur_pos).norm() < min_candidate_dist_) continue;
+      pick = &view;
+      break;
+    }
+    points.push_back(pick->pos_);
+    yaws.push_back(pick->yaw_);
+    averages.push_back(frontier.average_);
+  }
+}
+
+void FrontierFinder::getViewpointsInfo(const Vector3d& cur_pos, const vector<int>& ids, const int& view_num,
+                                       const double& max_decay, vector<vector<Vector3d>>& points,
+                                       vector<vector<double>>& yaws) {  // :452-487
+  points.clear();
+  yaws.clear();
+  for (auto id : ids) {
+    for (auto& frontier : frontiers_) {
+      if (frontier.id_ != id || frontier.viewpoints_.empty()) continue;
+      vector<Vector3d> pts;
+      vector<double> ys;
+      const int visib_thresh = frontier.viewpoints_.front().visib_num_ * max_decay;
+      for (auto& view : frontier.viewpoints_) {
+        if ((int)pts.size() >= view_num || view.visib_num_ <= visib_thresh) break;
+        if ((view.pos_ - cur_pos).norm() < min_candidate_dist_) continue;
+        pts.push_back(view.pos_);
+        ys.push_back(view.yaw_);
+      }
+      if (pts.empty()) {  // all viewpoints are very close: take them regardless of the distance
+        for (auto& view : frontier.viewpoints_) {
+          if ((int)pts.size() >= view_num || view.visib_num_ <= visib_thresh) break;
+          pts.push_back(view.pos_);
+          ys.push_back(view.yaw_);
+        }
+      }
+      points.push_back(pts);
+      yaws.push_back(ys);
+    }
+  }
+}
+
+bool FrontierFinder::isFrontierCovered() {  // :697-719
+  int covered = 0;
+  warn("fuelmi_frontier_is_covered", fuelmi_frontier_is_covered(dev_, &covered));
+  return covered != 0;
 }
 
 void FrontierFinder::getFrontiers(vector<vector<Vector3d>>& clusters) {

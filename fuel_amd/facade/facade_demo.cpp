@@ -107,6 +107,8 @@ int main(int argc, char** argv) {
   wr(out, infl.data(), N);
   wr(out, dist.data(), N);
 
+  Eigen::Vector3d ub_min, ub_max;
+  map->getUpdatedBox(ub_min, ub_max, false);  // kept for the second finder below
   FrontierFinder ff(edt, nh);
   ff.searchFrontiers();
   ff.computeFrontiersToVisit();
@@ -188,6 +190,44 @@ int main(int argc, char** argv) {
   int ng = (int)g0.size();
   wr(out, &ng, 1);
   wr(out, g0.data(), g0.size());
+  // the complete exploration front end as FastExplorationManager::planExploreMotion drives it
+  // (fast_exploration_manager.cpp:97-118): searchFrontiers (with splitLargeFrontiers) ->
+  // computeFrontiersToVisit -> getTopViewpointsInfo, plus the FSM's isFrontierCovered check
+  {
+    ros::NodeHandle nh2 = nh;
+    auto& Q = nh2.num;
+    Q["frontier/cluster_size_xy"] = 1.0;
+    Q["frontier/down_sample"] = 3;
+    Q["frontier/candidate_rmin"] = 1.5;
+    Q["frontier/candidate_rmax"] = 2.5;
+    Q["frontier/candidate_rnum"] = 3;
+    Q["frontier/candidate_dphi"] = 15 * 3.1415926 / 180.0;
+    Q["frontier/min_candidate_clearance"] = 0.21;
+    Q["frontier/min_visib_num"] = 3;
+    Q["frontier/min_candidate_dist"] = 0.75;
+    Q["frontier/min_view_finish_fraction"] = 0.2;
+    Q["perception_utils/top_angle"] = 0.56125;
+    Q["perception_utils/left_angle"] = 0.69222;
+    Q["perception_utils/right_angle"] = 0.68901;
+    Q["perception_utils/max_dist"] = 4.5;
+    double lo[3] = {ub_min(0), ub_min(1), ub_min(2)}, hi[3] = {ub_max(0), ub_max(1), ub_max(2)};
+    fuelmi_map_set_updated_box(map->device(), lo, hi);
+    FrontierFinder ff2(edt, nh2);
+    ff2.searchFrontiers();
+    ff2.computeFrontiersToVisit();
+    std::vector<std::vector<Eigen::Vector3d>> act, dor;
+    ff2.getFrontiers(act);
+    ff2.getDormantFrontiers(dor);
+    std::vector<Eigen::Vector3d> pts, avgs;
+    std::vector<double> yaws;
+    ff2.getTopViewpointsInfo(Eigen::Vector3d(0.0, 0.0, 1.0), pts, yaws, avgs);
+    int hdr2[4] = {(int)act.size(), (int)dor.size(), (int)pts.size(), ff2.isFrontierCovered() ? 1 : 0};
+    wr(out, hdr2, 4);
+    for (size_t i = 0; i < pts.size(); ++i) {
+      double q[7] = {pts[i](0), pts[i](1), pts[i](2), yaws[i], avgs[i](0), avgs[i](1), avgs[i](2)};
+      wr(out, q, 7);
+    }
+  }
   fclose(in);
   fclose(out);
   std::printf("facade_demo ok: %d voxels, %d frontier clusters, cost %.6f -> %.6f\n", N, nc, f0, f1);

@@ -74,6 +74,7 @@ def test_facade_cycle_matches_oracle(tmp_path):
     assert np.array_equal(occ, state)
     assert np.array_equal(infl, om.infl)
     assert np.abs(np.minimum(dist, 1e6) - np.minimum(om.dist, 1e6)).max() <= 1e-4
+    ub = om.get_updated_box(reset=False)
     of = fo.OracleFrontier(om, cmin)
     n_o = of.search()
     (nc,) = struct.unpack_from("i", raw, off)
@@ -98,3 +99,26 @@ def test_facade_cycle_matches_oracle(tmp_path):
     assert abs(f0 - co) <= 1e-6 * max(1.0, abs(co))
     assert np.abs(g0 - go).max() <= 1e-4
     assert f1 < f0  # the facade's solver loop decreases the reference objective
+    off += 8 * ng
+    # second finder: split + viewpoints + top-viewpoint query, against the (canonical-order) oracle
+    na, nd, ntop, covered = struct.unpack_from("4i", raw, off)
+    off += 16
+    top = np.frombuffer(raw, np.float64, 7 * ntop, off).reshape(ntop, 7)
+    of2 = fo.OracleFrontier(om, cmin, cluster_size_xy=1.0, down_sample=3, split=True, canonical_order=True)
+    of2.set_viewpoint_cfg(fo.viewpoint_cfg(min_visib_num=3))
+    om.set_updated_box(*ub)
+    assert of2.search() > 0
+    of2.compute_to_visit()
+    assert na == len(of2.clusters(1)) > 0 and nd == len(of2.clusters(2)) and ntop == na
+    cur = np.array([0.0, 0.0, 1.0])
+    for k in range(na):
+        py, vis = of2.viewpoints(1, k)
+        pick = py[0]
+        for v in py:
+            if np.linalg.norm(v[:3] - cur) < 0.75:
+                continue
+            pick = v
+            break
+        assert np.array_equal(top[k, :3], pick[:3]) and abs(top[k, 3] - pick[3]) <= 1e-9
+        assert np.array_equal(top[k, 4:], of2.cluster_info(1, k)[0])
+    assert covered == int(of2.is_covered())
