@@ -69,11 +69,12 @@ struct SArgs {
   u32* node;     // current node of every cell
   SNode* nodes;
   u32 cap_nodes;
-  u32* ctr;      // [0] n_nodes [1] splits of this level [2] n_filtered [3] overflow [4] n_final
+  u32* ctr;      // [0] n_nodes [1] splits of this level [2] n_filtered [3] overflow [4] n_final [5] used slots
   u64* hkeys;
   LeafAcc* hvals;
   u32* hmemb;    // [table size][memb_cap] voxel addresses of the members of every (node, leaf)
   u32 memb_cap;
+  u32* used;     // slots occupied at this level (ctr[5] of them): the per-slot kernels walk this list
   u32 hmask;
   // filtered-cell output
   u32* f_node;
@@ -111,7 +112,7 @@ k_sp_init(SArgs S, const u32* __restrict__ cells_in, const u32* __restrict__ ran
   }
   if (i == 0) {
     S.ctr[0] = nkept;
-    S.ctr[1] = S.ctr[2] = S.ctr[3] = S.ctr[4] = 0u;
+    S.ctr[1] = S.ctr[2] = S.ctr[3] = S.ctr[4] = S.ctr[5] = 0u;
   }
 }
 
@@ -165,6 +166,15 @@ __global__ void __launch_bounds__(256) k_sp_sums(Geo g, SArgs S, u32 level) {
   }
 }
 
+// between levels only the slots of the previous level need resetting
+__global__ void k_sp_clear_used(SArgs S) {
+  const u32 n = S.ctr[5];
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 h = S.used[i];
+    S.hkeys[h] = SP_EMPTY;
+    S.hvals[h] = LeafAcc{0u, {0.f, 0.f, 0.f}};
+  }
+}
 __global__ void k_sp_clear(u64* keys, LeafAcc* vals, u32 n) {
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     keys[i] = SP_EMPTY;
@@ -200,6 +210,7 @@ __global__ void __launch_bounds__(256) k_sp_leaf(Geo g, SArgs S, u32 level) {
     u32 h = (u32)sp_mix(key) & S.hmask;
     while (true) {
       const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&S.hkeys[h]), SP_EMPTY, key);
+      if (old == SP_EMPTY) S.used[atomicAdd(&S.ctr[5], 1u)] = h;  // first cell of this (node, leaf)
       if (old == SP_EMPTY || old == key) break;
       h = (h + 1) & S.hmask;
     }
@@ -217,9 +228,9 @@ __global__ void __launch_bounds__(256) k_sp_leaf(Geo g, SArgs S, u32 level) {
 // are symmetric, so the last float bit decides in which voxel a visibility ray starts: the sum must
 // be reproducible, not merely accurate.
 __global__ void __launch_bounds__(256) k_sp_centroid(Geo g, SArgs S) {
-  const u32 tsize = S.hmask + 1u;
-  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < tsize; h += gridDim.x * blockDim.x) {
-    if (S.hkeys[h] == SP_EMPTY) continue;
+  const u32 nused = S.ctr[5];
+  for (u32 ui = blockIdx.x * blockDim.x + threadIdx.x; ui < nused; ui += gridDim.x * blockDim.x) {
+    const u32 h = S.used[ui];
     const u32 n = min(S.hvals[h].cnt, S.memb_cap);
     u32* mb = S.hmemb + (size_t)h * S.memb_cap;
     for (u32 i = 1; i < n; ++i) {  // insertion sort in place (n <= (down_sample + 1)^3)
@@ -266,7 +277,7 @@ __global__ void __launch_bounds__(256) k_sp_stats(Geo g, SArgs S) {
   __shared__ u32 t_cnt[256];
   __shared__ u32 t_far[256];
   const int lane = threadIdx.x & 63;
-  const u32 tsize = S.hmask + 1u;
+  const u32 tsize = S.ctr[5];  // walks the list of occupied slots
   t_far[threadIdx.x] = 0u;
   // few, long-lived blocks: the flush is one set of same-address global atomics per node and block
   t_key[threadIdx.x] = 0xFFFFFFFFu;
@@ -275,8 +286,9 @@ __global__ void __launch_bounds__(256) k_sp_stats(Geo g, SArgs S) {
   __syncthreads();
   for (u32 base = blockIdx.x * 1024u; base < tsize; base += gridDim.x * 1024u) {
     for (int k = 0; k < 4; ++k) {
-      const u32 h = base + (u32)k * 256u + threadIdx.x;
-      const u64 key = h < tsize ? S.hkeys[h] : SP_EMPTY;
+      const u32 ui = base + (u32)k * 256u + threadIdx.x;
+      const u32 h = ui < tsize ? S.used[ui] : 0u;
+      const u64 key = ui < tsize ? S.hkeys[h] : SP_EMPTY;
       const bool active = key != SP_EMPTY;
       u32 nd = 0u;
       double dx = 0.0, dy = 0.0;
@@ -407,10 +419,10 @@ __global__ void __launch_bounds__(256) k_sp_decide(SArgs S, u32 level, u32 n_nod
 
 // centroids of the nodes that became FINAL at this level = their filtered_cells_
 __global__ void __launch_bounds__(256) k_sp_emit(Geo g, SArgs S, u32 level) {
-  const u32 tsize = S.hmask + 1u;
-  for (u32 h = blockIdx.x * blockDim.x + threadIdx.x; h < tsize; h += gridDim.x * blockDim.x) {
+  const u32 nused = S.ctr[5];
+  for (u32 ui = blockIdx.x * blockDim.x + threadIdx.x; ui < nused; ui += gridDim.x * blockDim.x) {
+    const u32 h = S.used[ui];
     const u64 key = S.hkeys[h];
-    if (key == SP_EMPTY) continue;
     const u32 nd = (u32)(key >> (3 * SP_LBITS));
     const SNode& N = S.nodes[nd];
     if (N.state != N_FINAL || N.level != level) continue;
@@ -443,8 +455,8 @@ __global__ void __launch_bounds__(256) k_sp_part(Geo g, SArgs S, u32 level) {
   }
 }
 
-__global__ void k_sp_next_level(SArgs S) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) S.ctr[1] = 0u;
+__global__ void k_sp_next_level(SArgs S) {  // after k_sp_clear_used
+  if (threadIdx.x == 0 && blockIdx.x == 0) S.ctr[1] = S.ctr[5] = 0u;
 }
 
 // depth-first order of the FINAL nodes: key = (orig, path left-aligned); rank + cell offsets, and
@@ -511,6 +523,7 @@ struct SplitScratch {
   u64* hkeys = nullptr;
   LeafAcc* hvals = nullptr;
   u32* hmemb = nullptr;
+  u32* used = nullptr;
   u32 memb_cap = 0;
   u32* f_node = nullptr;
   u64* f_leaf = nullptr;
@@ -522,7 +535,7 @@ void frontier_split_free(fuelmi_frontier* f) {
   SplitScratch* s = f->split;
   if (!s) return;
   void* dev[] = {s->cells, s->node,  s->ctr,    s->seeds,  s->counts, s->nodes,
-                 s->hkeys, s->hvals, s->hmemb, s->f_node, s->f_leaf, s->f_xyz};
+                 s->hkeys, s->hvals, s->hmemb, s->used,   s->f_node, s->f_leaf, s->f_xyz};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (s->h_ctr) (void)hipHostFree(s->h_ctr);
@@ -553,13 +566,14 @@ static int split_ensure(fuelmi_frontier* f, u32 n) {
     s->cap_cells = 0;  // force (re)allocation of the table with the new member capacity
   }
   if (n > s->cap_cells) {
-    void* old[] = {s->cells, s->node, s->hkeys, s->hvals, s->hmemb, s->f_node, s->f_leaf, s->f_xyz};
+    void* old[] = {s->cells, s->node, s->hkeys, s->hvals, s->hmemb, s->used, s->f_node, s->f_leaf, s->f_xyz};
     for (void* p : old)
       if (p) HIPCHK(hipFree(p));
     s->cells = s->node = s->f_node = nullptr;
     s->hkeys = s->f_leaf = nullptr;
     s->hvals = nullptr;
     s->hmemb = nullptr;
+    s->used = nullptr;
     s->f_xyz = nullptr;
     s->cap_cells = 0;
     const u32 cap = n + n / 4 + 4096;
@@ -567,7 +581,7 @@ static int split_ensure(fuelmi_frontier* f, u32 n) {
     while (t < 2u * cap) t <<= 1;
     if ((rc = sp_alloc(&s->cells, cap)) || (rc = sp_alloc(&s->node, cap)) || (rc = sp_alloc(&s->hkeys, t)) ||
         (rc = sp_alloc(&s->hvals, t)) || (rc = sp_alloc(&s->hmemb, (size_t)t * s->memb_cap)) ||
-        (rc = sp_alloc(&s->f_node, cap)) || (rc = sp_alloc(&s->f_leaf, cap)) ||
+        (rc = sp_alloc(&s->used, cap)) || (rc = sp_alloc(&s->f_node, cap)) || (rc = sp_alloc(&s->f_leaf, cap)) ||
         (rc = sp_alloc(&s->f_xyz, 3 * (size_t)cap)))
       return rc;
     s->cap_cells = cap;
@@ -612,7 +626,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   SArgs S;
   S.n = n;
   S.cells = s->cells, S.node = s->node, S.nodes = s->nodes, S.cap_nodes = s->cap_nodes, S.ctr = s->ctr;
-  S.hkeys = s->hkeys, S.hvals = s->hvals, S.hmemb = s->hmemb, S.memb_cap = s->memb_cap;
+  S.hkeys = s->hkeys, S.hvals = s->hvals, S.hmemb = s->hmemb, S.memb_cap = s->memb_cap, S.used = s->used;
   u32 t = 1024;  // table sized to this search (cleared every level)
   while (t < 2u * n) t <<= 1;
   S.hmask = t - 1u;
@@ -623,20 +637,21 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
 
   const int gb = (int)std::min<u32>(2048u, (n + 255u) / 256u);
   const int gb4 = (int)std::min<u32>(2048u, (n + 1023u) / 1024u);
-  const int gt = (int)std::min<u32>(2048u, (t + 255u) / 256u);
+  const int gt = (int)std::min<u32>(2048u, (t + 255u) / 256u);  // full-table clear (once)
   k_sp_init<<<(std::max(n, nkept) + 255) / 256, 256, 0, st>>>(S, F.ms_val[fin], F.ms_key[fin], n_out, s->seeds, nseeds,
                                                                 nkept);
   u32 n_nodes = nkept;
+  k_sp_clear<<<gt, 256, 0, st>>>(S.hkeys, S.hvals, t);
   for (u32 level = 0; level < 40u; ++level) {
     k_sp_sums<<<gb4, 256, 0, st>>>(g, S, level);
-    k_sp_clear<<<gt, 256, 0, st>>>(S.hkeys, S.hvals, t);
     k_sp_leaf<<<gb, 256, 0, st>>>(g, S, level);
-    k_sp_centroid<<<gt, 256, 0, st>>>(g, S);
-    k_sp_stats<<<(int)std::min<u32>(64u, (t + 1023u) / 1024u), 256, 0, st>>>(g, S);
+    k_sp_centroid<<<256, 256, 0, st>>>(g, S);
+    k_sp_stats<<<128, 256, 0, st>>>(g, S);
     k_sp_decide<<<(n_nodes + 255) / 256, 256, 0, st>>>(S, level, n_nodes);
-    k_sp_emit<<<gt, 256, 0, st>>>(g, S, level);
+    k_sp_emit<<<256, 256, 0, st>>>(g, S, level);
     k_sp_part<<<gb, 256, 0, st>>>(g, S, level);
     HIPCHK(hipMemcpyAsync(s->h_ctr, s->ctr, 16 * sizeof(u32), hipMemcpyDeviceToHost, st));
+    k_sp_clear_used<<<256, 256, 0, st>>>(S);
     k_sp_next_level<<<1, 64, 0, st>>>(S);
     HIPCHK(hipStreamSynchronize(st));
     if (s->h_ctr[3]) {
@@ -673,20 +688,26 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   }
   HIPCHK(hipStreamSynchronize(st));
 
-  // filtered cells per piece, ascending leaf index (z-major like PCL's idx = i + j*dx + k*dx*dy)
-  std::vector<u32> order(nfilt);
-  for (u32 i = 0; i < nfilt; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-    return fn[a] != fn[b] ? fn[a] < fn[b] : fl[a] < fl[b];
-  });
+  // filtered cells per piece, ascending leaf index (z-major like PCL's idx = i + j*dx + k*dx*dy):
+  // bucket by piece, then order the ~100 entries of each bucket
+  std::vector<u32> start(nfinal + 1, 0u);
+  for (u32 i = 0; i < nfilt; ++i)
+    if (fn[i] < nfinal) ++start[fn[i] + 1];
+  for (u32 r = 0; r < nfinal; ++r) start[r + 1] += start[r];
+  std::vector<u32> order(start[nfinal]), fill(start.begin(), start.end() - 1);
+  for (u32 i = 0; i < nfilt; ++i)
+    if (fn[i] < nfinal) order[fill[fn[i]]++] = i;
   filtered->assign(nfinal, std::vector<float>());
-  for (u32 k = 0; k < nfilt; ++k) {
-    const u32 i = order[k];
-    if (fn[i] >= nfinal) continue;
-    std::vector<float>& v = (*filtered)[fn[i]];
-    v.push_back(fx[3 * (size_t)i]);
-    v.push_back(fx[3 * (size_t)i + 1]);
-    v.push_back(fx[3 * (size_t)i + 2]);
+  for (u32 r = 0; r < nfinal; ++r) {
+    std::sort(order.begin() + start[r], order.begin() + start[r + 1], [&](u32 a, u32 b) { return fl[a] < fl[b]; });
+    std::vector<float>& v = (*filtered)[r];
+    v.reserve(3 * (size_t)(start[r + 1] - start[r]));
+    for (u32 k = start[r]; k < start[r + 1]; ++k) {
+      const u32 i = order[k];
+      v.push_back(fx[3 * (size_t)i]);
+      v.push_back(fx[3 * (size_t)i + 1]);
+      v.push_back(fx[3 * (size_t)i + 2]);
+    }
   }
   *n_final = nfinal;
   *n_cells = n;

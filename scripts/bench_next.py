@@ -25,13 +25,32 @@ for it in range(12):
 gpu_ms = float(np.median(ts[2:]) * 1e3)
 om = fo.OracleMap(map_size, box[0], box[1])
 om.occ[:] = occ
-of = fo.OracleFrontier(om, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True)
+of = fo.OracleFrontier(om, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True, canonical_order=True)
 om.set_updated_box(box[0], box[1])
 t0 = time.perf_counter()
 n_o = of.search()
 cpu_ms = (time.perf_counter() - t0) * 1e3
 out["frontier_search_with_split"] = {"gpu_ms": gpu_ms, "cpu_oracle_ms": cpu_ms, "pieces_gpu": n, "pieces_cpu": n_o,
                                      "cells": int(sum(len(c) for c in gf.clusters(0)))}
+
+# ---- rank 1: viewpoint sampling for every piece (computeFrontiersToVisit) -----------------------------
+gm.setLocalBound((0, 0, 0), tuple(v - 1 for v in gm.nvox))
+gm.clearAndInflateLocalMap()
+gf.setViewpointConfig(gf.viewpointConfig())
+gm.synchronize()
+t0 = time.perf_counter()
+na, nd = gf.computeFrontiersToVisit()
+gpu_vp_ms = (time.perf_counter() - t0) * 1e3
+nvp = sum(len(gf.viewpoints(1, k)[1]) for k in range(na))
+om.set_local_bound((0, 0, 0), tuple(v - 1 for v in om.nvox))
+om.inflate_local()
+of.set_viewpoint_cfg(fo.viewpoint_cfg())
+t0 = time.perf_counter()
+of.compute_to_visit()
+cpu_vp_ms = (time.perf_counter() - t0) * 1e3
+out["compute_frontiers_to_visit"] = {"gpu_ms": gpu_vp_ms, "cpu_oracle_ms": cpu_vp_ms, "active": na, "dormant": nd,
+                                     "active_cpu": len(of.clusters(1)), "viewpoints": int(nvp),
+                                     "candidates": int(n * 100)}
 
 # ---- rank 3: depth frame -> fused map ----------------------------------------------------------------
 w = synth.World.for_map_size(map_size)
