@@ -159,6 +159,7 @@ SYMBOLS = {
     "fuelmi_bspline_dev_create": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), _PP]),
     "fuelmi_bspline_dev_eval": (C.c_int, [_P]),
     "fuelmi_bspline_dev_download": (C.c_int, [_P, _dp, _dp]),
+    "fuelmi_bspline_dev_optimize": (C.c_int, [_P, C.c_int, _dp, _dp, C.POINTER(C.c_int)]),
     "fuelmi_bspline_dev_destroy": (None, [_P]),
     "fuelmi_timer_begin": (C.c_int, [_P]),
     "fuelmi_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -36,6 +36,8 @@ struct fuelmi_bspline_dev {
   BsplineArgs a;
   std::vector<void*> allocs;
   size_t lds;
+  double *opt_x = nullptr, *opt_cost = nullptr;  // fuelmi_bspline_dev_optimize outputs
+  int* opt_evals = nullptr;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -47,18 +49,17 @@ __device__ __forceinline__ double dot3(const double* a, const double* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
-__global__ void __launch_bounds__(64)
-k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// combineCost for candidate c at the variables x (NLopt layout); writes grad[nvar], returns the
+// cost in every lane.  One wavefront; smem_raw = 5*3*N doubles of LDS.
+__device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, const BsplineArgs& A, int c,
+                               const double* x, double* grad, unsigned char* smem_raw) {
   const int N = A.N, dim = A.dim;
   double* q = reinterpret_cast<double*>(smem_raw);  // [N][3]
   double* tj = q + 3 * N;                            // [N][3] 2*jerk/pt_dist      (j <= N-4)
   double* tv = tj + 3 * N;                           // [N][3] vel hinge factor    (j <= N-2)
   double* ta = tv + 3 * N;                           // [N][3] acc hinge factor    (j <= N-3)
   double* gw = ta + 3 * N;                           // [N][3] waypoint gradient scratch
-  const int c = blockIdx.x;
   const int lane = threadIdx.x;
-  const double* x = A.x + (size_t)c * A.nvar;
   const bool opt_time = (A.cost_function & FUELMI_COST_MINTIME) != 0;
   const double dt = opt_time ? x[A.nvar - 1] : A.knot_span[c];
   const double pt_dist = A.pt_dist[c];
@@ -136,7 +137,6 @@ k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
   __syncthreads();
 
   // ---- pass 2: per-point gradient (gather) ----
-  double* grad = A.grad + (size_t)c * A.nvar;
   for (int i = lane; i < N; i += 64) {
     double gq[3] = {0.0, 0.0, 0.0};
     if (A.cost_function & FUELMI_COST_SMOOTHNESS) {
@@ -275,9 +275,180 @@ k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
   }
   cost = wave_sum(cost);
   gt = wave_sum(gt);
+  if (lane == 0 && opt_time) grad[A.nvar - 1] = gt;
+  __syncthreads();  // grad[] complete and visible to every lane
+  return cost;
+}
+
+__global__ void __launch_bounds__(64)
+k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int c = blockIdx.x;
+  const double cost = bspline_eval(g, dist, A, c, A.x + (size_t)c * A.nvar, A.grad + (size_t)c * A.nvar, smem_raw);
+  if (threadIdx.x == 0) A.cost[c] = cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BsplineOptimizer::optimize() (bspline_optimizer.cpp:165-253) for a whole batch on the device: one
+// wavefront per candidate runs the complete solve -- variable clamping and bounds exactly as the
+// reference sets them up (:177-214: box shrunk by 0.1, +-10 around the start, knot span in [0,5]),
+// best-so-far tracking like costFunction (:693-707), evaluation cap like set_maxeval, xtol_rel 1e-5.
+// The reference hands the iteration to NLopt (LD_LBFGS / LD_TNEWTON, third party); here it is a
+// box-projected L-BFGS (memory 8, Armijo backtracking) -- the same algorithm as the oracle's
+// fo_bspline_optimize, so results agree with it up to reduction order; against NLopt only the final
+// cost is comparable.  All work vectors (6 + 2*8 of n ~ 100 doubles) live in LDS behind the
+// evaluation scratch: the solve is a chain of ~200 dependent evaluations and dot products, so its
+// speed is the latency of every step, not bandwidth.
+// ---------------------------------------------------------------------------------------------
+struct LbfgsArgs {
+  int max_eval;
+  double box_lo[3], box_hi[3];  // exploration box shrunk by 0.1 (:174-178)
+  double* x_out;                // [C][nvar] best variables
+  double* cost_out;             // [C]
+  int* evals_out;               // [C]
+};
+#define LBFGS_MEM 8
+
+__device__ __forceinline__ double wdot(const double* a, const double* b, int n) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += a[i] * b[i];
+  return wave_sum(s);
+}
+
+__global__ void __launch_bounds__(64)
+k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsArgs L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int c = blockIdx.x, lane = threadIdx.x, n = A.nvar;
+  double* w = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N;  // behind bspline_eval's 5 x [N][3]
+  double *q = w, *gq = q + n, *xn = gq + n, *gn = xn + n, *d = gn + n, *best = d + n;
+  double* S = best + n;             // [MEM][n]
+  double* Y = S + LBFGS_MEM * n;    // [MEM][n]
+  double* rho = Y + LBFGS_MEM * n;  // [MEM]
+  double* al = rho + LBFGS_MEM;     // [MEM]
+  const double* x0 = A.x + (size_t)c * n;
+  const int npt = A.dim * A.N;
+  auto lb_of = [&](int i, double q0) {
+    if (A.dim == 1) return -1e300;
+    if (i >= npt) return 0.0;
+    return fmax(q0 - 10.0, L.box_lo[i % 3]);
+  };
+  auto ub_of = [&](int i, double q0) {
+    if (A.dim == 1) return 1e300;
+    if (i >= npt) return 5.0;
+    return fmin(q0 + 10.0, L.box_hi[i % 3]);
+  };
+  // start point: control points clamped into the shrunk box (:194-199); d[] keeps it for the bounds
+  for (int i = lane; i < n; i += 64) {
+    double v = x0[i];
+    if (A.dim != 1 && i < npt) v = fmax(fmin(v, L.box_hi[i % 3]), L.box_lo[i % 3]);
+    q[i] = v;
+    best[i] = v;
+  }
+  __syncthreads();
+  // the bounds refer to the (clamped) START values: recomputed from x0 where needed
+  auto start_val = [&](int i) {
+    double v = x0[i];
+    if (A.dim != 1 && i < npt) v = fmax(fmin(v, L.box_hi[i % 3]), L.box_lo[i % 3]);
+    return v;
+  };
+  int evals = 0;
+  double f = bspline_eval(g, dist, A, c, q, gq, smem_raw);
+  ++evals;
+  double fbest = f;
+  int hist = 0, head = 0;  // number of stored pairs, slot of the oldest
+  while (evals < L.max_eval) {
+    // projected steepest-descent seed, then the two-loop recursion
+    for (int i = lane; i < n; i += 64) {
+      const double sv = start_val(i), lo = lb_of(i, sv), hi = ub_of(i, sv);
+      const bool at_lb = q[i] <= lo && gq[i] > 0, at_ub = q[i] >= hi && gq[i] < 0;
+      d[i] = (at_lb || at_ub) ? 0.0 : -gq[i];
+    }
+    __syncthreads();
+    for (int k = hist - 1; k >= 0; --k) {
+      const int sl = (head + k) % LBFGS_MEM;
+      const double a = wdot(S + sl * n, d, n) * rho[sl];
+      if (lane == 0) al[sl] = a;
+      for (int i = lane; i < n; i += 64) d[i] -= a * Y[sl * n + i];
+      __syncthreads();
+    }
+    if (hist > 0) {
+      const int sl = (head + hist - 1) % LBFGS_MEM;
+      const double yy = wdot(Y + sl * n, Y + sl * n, n), sy = 1.0 / rho[sl];
+      const double gamma = yy > 0 ? sy / yy : 1.0;
+      for (int i = lane; i < n; i += 64) d[i] *= gamma;
+      __syncthreads();
+    }
+    for (int k = 0; k < hist; ++k) {
+      const int sl = (head + k) % LBFGS_MEM;
+      const double b = wdot(Y + sl * n, d, n) * rho[sl];
+      const double a = al[sl];
+      for (int i = lane; i < n; i += 64) d[i] += S[sl * n + i] * (a - b);
+      __syncthreads();
+    }
+    double gd = wdot(gq, d, n);
+    if (!(gd < 0)) {  // not a descent direction: restart with steepest descent
+      hist = 0, head = 0;
+      for (int i = lane; i < n; i += 64) d[i] = -gq[i];
+      __syncthreads();
+      gd = -wdot(gq, gq, n);
+      if (gd == 0) break;
+    }
+    double step = hist == 0 ? 1.0 / fmax(1.0, sqrt(-gd)) : 1.0, fn = f;
+    bool ok = false;
+    for (int ls = 0; ls < 20 && evals < L.max_eval; ++ls) {
+      for (int i = lane; i < n; i += 64) {
+        const double sv = start_val(i);
+        xn[i] = fmin(fmax(q[i] + step * d[i], lb_of(i, sv)), ub_of(i, sv));
+      }
+      __syncthreads();
+      fn = bspline_eval(g, dist, A, c, xn, gn, smem_raw);
+      ++evals;
+      if (fn < fbest) {  // costFunction's best_variable_ (:699-703)
+        fbest = fn;
+        for (int i = lane; i < n; i += 64) best[i] = xn[i];
+      }
+      double dec = 0.0;
+      for (int i = lane; i < n; i += 64) dec += gq[i] * (xn[i] - q[i]);
+      dec = wave_sum(dec);
+      if (fn <= f + 1e-4 * dec) {
+        ok = true;
+        break;
+      }
+      step *= 0.5;
+    }
+    if (!ok) break;
+    // curvature pair into the ring buffer
+    double sy = 0.0, ss = 0.0, xx = 0.0;
+    const int slot = hist < LBFGS_MEM ? (head + hist) % LBFGS_MEM : head;
+    for (int i = lane; i < n; i += 64) {
+      const double si = xn[i] - q[i], yi = gn[i] - gq[i];
+      sy += si * yi, ss += si * si, xx += xn[i] * xn[i];
+    }
+    sy = wave_sum(sy), ss = wave_sum(ss), xx = wave_sum(xx);
+    if (sy > 1e-12) {
+      for (int i = lane; i < n; i += 64) {
+        S[slot * n + i] = xn[i] - q[i];
+        Y[slot * n + i] = gn[i] - gq[i];
+      }
+      if (lane == 0) rho[slot] = 1.0 / sy;
+      if (hist < LBFGS_MEM)
+        ++hist;
+      else
+        head = (head + 1) % LBFGS_MEM;
+    }
+    for (int i = lane; i < n; i += 64) {
+      q[i] = xn[i];
+      gq[i] = gn[i];
+    }
+    f = fn;
+    __syncthreads();
+    if (sqrt(ss) <= 1e-5 * sqrt(xx)) break;  // xtol_rel 1e-5
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) L.x_out[(size_t)c * n + i] = best[i];
   if (lane == 0) {
-    A.cost[c] = cost;
-    if (opt_time) grad[A.nvar - 1] = gt;
+    L.cost_out[c] = fbest;
+    L.evals_out[c] = evals;
   }
 }
 
@@ -375,9 +546,10 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
     fuelmi_bspline_dev_destroy(b);
     return rc;
   }
-  if (b->lds > 64 * 1024)
+  if (b->lds > 64 * 1024) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_cost_grad),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds));
+  }
   *out = b;
   return FUELMI_OK;
 }
@@ -388,6 +560,56 @@ extern "C" int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b) {
   StageScope sc(b->map, FUELMI_K_BSPLINE);
   k_bspline_cost_grad<<<b->a.C, 64, b->lds, b->map->stream>>>(b->map->g, b->map->dist, b->a);
   HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+// whole solves on the device; synchronous: returns the best variables, their cost and the number of
+// objective evaluations per candidate
+extern "C" int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, double* x_out, double* cost_out,
+                                           int* evals_out) {
+  ARGCHK(b && max_eval >= 1 && x_out && cost_out);
+  fuelmi_map* m = b->map;
+  HIPCHK(hipSetDevice(m->device));
+  const BsplineArgs& A = b->a;
+  const size_t C = (size_t)A.C, n = (size_t)A.nvar;
+  const size_t lds_opt = b->lds + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
+  if (lds_opt > 160 * 1024) {
+    fuelmi_set_error("%d variables exceed the LDS budget of the device optimiser", (int)n);
+    return FUELMI_ELIMIT;
+  }
+  if (!b->opt_x) {
+    void* d = nullptr;
+    if (lds_opt > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_optimize),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_opt));
+    HIPCHK(hipMalloc(&d, C * n * sizeof(double)));
+    b->allocs.push_back(d);
+    b->opt_x = (double*)d;
+    HIPCHK(hipMalloc(&d, C * sizeof(double)));
+    b->allocs.push_back(d);
+    b->opt_cost = (double*)d;
+    HIPCHK(hipMalloc(&d, C * sizeof(int)));
+    b->allocs.push_back(d);
+    b->opt_evals = (int*)d;
+  }
+  LbfgsArgs L;
+  L.max_eval = max_eval;
+  for (int k = 0; k < 3; ++k) {  // getBox(bmin, bmax); bmin += 0.1; bmax -= 0.1  (:174-178)
+    L.box_lo[k] = m->cfg.box_min[k] + 0.1;
+    L.box_hi[k] = m->cfg.box_max[k] - 0.1;
+  }
+  L.x_out = b->opt_x, L.cost_out = b->opt_cost, L.evals_out = b->opt_evals;
+  {
+    StageScope sc(m, FUELMI_K_BSPLINE);
+    k_bspline_optimize<<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(x_out, b->opt_x, C * n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(cost_out, b->opt_cost, C * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  std::vector<int> ev(C);
+  HIPCHK(hipMemcpyAsync(ev.data(), b->opt_evals, C * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  if (evals_out) memcpy(evals_out, ev.data(), C * sizeof(int));
   return FUELMI_OK;
 }
 

@@ -473,38 +473,49 @@ void BsplineOptimizer::setBoundaryStates(const vector<Eigen::Vector3d>& start, c
 }
 void BsplineOptimizer::setTimeLowerBound(const double& lb) { time_lb_ = lb; }
 
+namespace {
+struct BatchStore {  // keeps the arrays a one-candidate fuelmi_bspline_batch points to
+  std::vector<double> st, en, guide, wp, vpt, vdir;
+  double tlb;
+};
+}  // namespace
+// one-candidate batch from the optimiser's members (what combineCost reads, :518-691)
+#define FUELMI_FILL_BATCH(b, S, XV)                                                                      \
+  S.st.assign(9, 0.0), S.en.assign(9, 0.0), S.vpt.assign(3, 0.0), S.vdir.assign(3, 0.0);                 \
+  for (size_t i = 0; i < start_state_.size() && i < 3; ++i)                                              \
+    for (int k = 0; k < 3; ++k) S.st[3 * i + k] = start_state_[i](k);                                    \
+  for (size_t i = 0; i < end_state_.size() && i < 3; ++i)                                                \
+    for (int k = 0; k < 3; ++k) S.en[3 * i + k] = end_state_[i](k);                                      \
+  for (auto& g : guide_pts_)                                                                             \
+    for (int k = 0; k < 3; ++k) S.guide.push_back(g(k));                                                 \
+  for (auto& w : waypoints_)                                                                             \
+    for (int k = 0; k < 3; ++k) S.wp.push_back(w(k));                                                    \
+  for (int k = 0; k < 3; ++k) S.vpt[k] = view_cons_.pt_(k), S.vdir[k] = view_cons_.dir_(k);              \
+  S.tlb = time_lb_;                                                                                      \
+  b.cost_function = cost_function_;                                                                      \
+  b.dim = dim_;                                                                                          \
+  b.point_num = point_num_;                                                                              \
+  b.n_traj = 1;                                                                                          \
+  b.x = (XV).data();                                                                                     \
+  b.pt_dist = &pt_dist_;                                                                                 \
+  b.knot_span = &knot_span_;                                                                             \
+  b.time_lb = &S.tlb;                                                                                    \
+  b.start_state = S.st.data();                                                                           \
+  b.end_state = S.en.data();                                                                             \
+  b.end_n = (int)std::max<size_t>(1, std::min<size_t>(3, end_state_.size()));                            \
+  b.guide_pts = S.guide.empty() ? nullptr : S.guide.data();                                              \
+  b.waypoints = S.wp.empty() ? nullptr : S.wp.data();                                                    \
+  b.waypt_idx = waypt_idx_.empty() ? nullptr : waypt_idx_.data();                                        \
+  b.n_waypt = (int)waypoints_.size();                                                                    \
+  b.view_pt = S.vpt.data();                                                                              \
+  b.view_dir = S.vdir.data();                                                                            \
+  b.view_idx = &view_cons_.idx_;
+
 void BsplineOptimizer::combineCost(const std::vector<double>& x, std::vector<double>& grad, double& cost) {
   auto t1 = std::chrono::steady_clock::now();
   fuelmi_bspline_batch b;
-  std::vector<double> st(9, 0.0), en(9, 0.0), guide, wp, vpt(3), vdir(3);
-  for (size_t i = 0; i < start_state_.size() && i < 3; ++i)
-    for (int k = 0; k < 3; ++k) st[3 * i + k] = start_state_[i](k);
-  for (size_t i = 0; i < end_state_.size() && i < 3; ++i)
-    for (int k = 0; k < 3; ++k) en[3 * i + k] = end_state_[i](k);
-  for (auto& g : guide_pts_)
-    for (int k = 0; k < 3; ++k) guide.push_back(g(k));
-  for (auto& w : waypoints_)
-    for (int k = 0; k < 3; ++k) wp.push_back(w(k));
-  for (int k = 0; k < 3; ++k) vpt[k] = view_cons_.pt_(k), vdir[k] = view_cons_.dir_(k);
-  const double tlb = time_lb_;
-  b.cost_function = cost_function_;
-  b.dim = dim_;
-  b.point_num = point_num_;
-  b.n_traj = 1;
-  b.x = x.data();
-  b.pt_dist = &pt_dist_;
-  b.knot_span = &knot_span_;
-  b.time_lb = &tlb;
-  b.start_state = st.data();
-  b.end_state = en.data();
-  b.end_n = (int)std::max<size_t>(1, std::min<size_t>(3, end_state_.size()));
-  b.guide_pts = guide.empty() ? nullptr : guide.data();
-  b.waypoints = wp.empty() ? nullptr : wp.data();
-  b.waypt_idx = waypt_idx_.empty() ? nullptr : waypt_idx_.data();
-  b.n_waypt = (int)waypoints_.size();
-  b.view_pt = vpt.data();
-  b.view_dir = vdir.data();
-  b.view_idx = &view_cons_.idx_;
+  BatchStore S;
+  FUELMI_FILL_BATCH(b, S, x)
   grad.assign(variable_num_, 0.0);
   warn("fuelmi_bspline_cost_grad",
        fuelmi_bspline_cost_grad(edt_environment_->sdf_map_->device(), &cfg_, &b, &cost, grad.data()));
@@ -554,108 +565,35 @@ void BsplineOptimizer::optimize(Eigen::MatrixXd& points, double& dt, const int& 
 // Box-projected L-BFGS (memory 8, Armijo backtracking) under the reference's stopping criteria.
 // Replaces nlopt::opt (bspline_optimizer.cpp:165-229); iterates are NOT NLopt's.
 void BsplineOptimizer::optimize() {
+  // The reference hands the variables to NLopt (:165-253).  Here the whole solve runs in one kernel
+  // launch on the device (fuelmi_bspline_dev_optimize: start clamping, bounds, best-variable tracking,
+  // evaluation cap and xtol_rel as the reference configures them; box-projected L-BFGS in place of
+  // NLopt's LD_LBFGS / LD_TNEWTON).  max_iteration_time_ is not enforced: a capped solve takes well
+  // under a millisecond.
   const int n = variable_num_;
-  Eigen::Vector3d bmin, bmax;
-  edt_environment_->sdf_map_->getBox(bmin, bmax);
-  std::vector<double> q(n), lb(n, -1e300), ub(n, 1e300);
+  std::vector<double> q(n);
   for (int i = 0; i < point_num_; ++i)
-    for (int j = 0; j < dim_; ++j) {
-      double cij = control_points_(i, j);
-      if (dim_ != 1) cij = std::max(std::min(cij, bmax(j % 3) - 0.1), bmin(j % 3) + 0.1);
-      q[dim_ * i + j] = cij;
-    }
+    for (int j = 0; j < dim_; ++j) q[dim_ * i + j] = control_points_(i, j);
   if (optimize_time_) q[n - 1] = knot_span_;
-  if (dim_ != 1) {
-    for (int i = 0; i < 3 * point_num_; ++i) {
-      lb[i] = std::max(q[i] - 10.0, bmin(i % 3) + 0.1);
-      ub[i] = std::min(q[i] + 10.0, bmax(i % 3) - 0.1);
-    }
-    if (optimize_time_) lb[n - 1] = 0.0, ub[n - 1] = 5.0;
-  }
-  const int max_eval = max_iteration_num_[max_num_id_];
-  const double max_time = max_iteration_time_[max_time_id_];
-  const auto t0 = std::chrono::steady_clock::now();
-  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-  auto eval = [&](const std::vector<double>& x, std::vector<double>& g) {
-    double f;
-    combineCost(x, g, f);
-    ++iter_num_;
-    if (f < min_cost_) {
-      min_cost_ = f;
-      best_variable_ = x;
-    }
-    return f;
-  };
-  auto project = [&](std::vector<double>& x) {
-    for (int i = 0; i < n; ++i) x[i] = std::min(std::max(x[i], lb[i]), ub[i]);
-  };
-  std::vector<double> g(n), xn(n), gn(n), d(n);
-  double f = eval(q, g);
-  std::deque<std::vector<double>> S, Y;
-  std::deque<double> R;
-  const size_t mem = 8;
-  while (iter_num_ < max_eval && elapsed() < max_time) {
-    // two-loop recursion on the projected gradient
-    for (int i = 0; i < n; ++i) {
-      const bool at_lb = q[i] <= lb[i] && g[i] > 0, at_ub = q[i] >= ub[i] && g[i] < 0;
-      d[i] = (at_lb || at_ub) ? 0.0 : -g[i];
-    }
-    std::vector<double> al(S.size());
-    for (int k = (int)S.size() - 1; k >= 0; --k) {
-      double a = 0;
-      for (int i = 0; i < n; ++i) a += S[k][i] * d[i];
-      a *= R[k];
-      al[k] = a;
-      for (int i = 0; i < n; ++i) d[i] -= a * Y[k][i];
-    }
-    if (!S.empty()) {
-      double yy = 0, sy = 1.0 / R.back();
-      for (int i = 0; i < n; ++i) yy += Y.back()[i] * Y.back()[i];
-      const double gamma = yy > 0 ? sy / yy : 1.0;
-      for (int i = 0; i < n; ++i) d[i] *= gamma;
-    }
-    for (size_t k = 0; k < S.size(); ++k) {
-      double b = 0;
-      for (int i = 0; i < n; ++i) b += Y[k][i] * d[i];
-      b *= R[k];
-      for (int i = 0; i < n; ++i) d[i] += S[k][i] * (al[k] - b);
-    }
-    double gd = 0;
-    for (int i = 0; i < n; ++i) gd += g[i] * d[i];
-    if (!(gd < 0)) {  // not a descent direction: restart with steepest descent
-      S.clear(), Y.clear(), R.clear();
-      gd = 0;
-      for (int i = 0; i < n; ++i) d[i] = -g[i], gd -= g[i] * g[i];
-      if (gd == 0) break;
-    }
-    double step = S.empty() ? 1.0 / std::max(1.0, std::sqrt(-gd)) : 1.0, fn = f;
-    bool ok = false;
-    for (int ls = 0; ls < 20 && iter_num_ < max_eval && elapsed() < max_time; ++ls) {
-      for (int i = 0; i < n; ++i) xn[i] = q[i] + step * d[i];
-      project(xn);
-      fn = eval(xn, gn);
-      double dec = 0;
-      for (int i = 0; i < n; ++i) dec += g[i] * (xn[i] - q[i]);
-      if (fn <= f + 1e-4 * dec) {
-        ok = true;
-        break;
-      }
-      step *= 0.5;
-    }
-    if (!ok) break;
-    std::vector<double> s(n), y(n);
-    double sy = 0, xs = 0, xx = 0;
-    for (int i = 0; i < n; ++i) {
-      s[i] = xn[i] - q[i], y[i] = gn[i] - g[i];
-      sy += s[i] * y[i], xs += s[i] * s[i], xx += xn[i] * xn[i];
-    }
-    q = xn, g = gn, f = fn;
-    if (sy > 1e-12) {
-      S.push_back(s), Y.push_back(y), R.push_back(1.0 / sy);
-      if (S.size() > mem) S.pop_front(), Y.pop_front(), R.pop_front();
-    }
-    if (std::sqrt(xs) <= 1e-5 * std::sqrt(xx)) break;  // xtol_rel 1e-5
-  }
+  auto t1 = std::chrono::steady_clock::now();
+  fuelmi_bspline_batch b;
+  BatchStore S;
+  FUELMI_FILL_BATCH(b, S, q)
+  fuelmi_bspline_dev* dev = nullptr;
+  int rc = fuelmi_bspline_dev_create(edt_environment_->sdf_map_->device(), &cfg_, &b, &dev);
+  warn("fuelmi_bspline_dev_create", rc);
+  if (rc) return;
+  best_variable_.assign(n, 0.0);
+  double cost = 0.0;
+  int evals = 0;
+  rc = fuelmi_bspline_dev_optimize(dev, std::max(1, max_iteration_num_[max_num_id_]), best_variable_.data(), &cost,
+                                   &evals);
+  warn("fuelmi_bspline_dev_optimize", rc);
+  fuelmi_bspline_dev_destroy(dev);
+  comb_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+  if (rc) return;
+  iter_num_ = evals;
+  min_cost_ = cost;
   for (int i = 0; i < point_num_; ++i)
     for (int j = 0; j < dim_; ++j) control_points_(i, j) = best_variable_[dim_ * i + j];
   if (optimize_time_) knot_span_ = best_variable_[n - 1];

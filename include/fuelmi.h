@@ -279,6 +279,14 @@ int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
                               const fuelmi_bspline_batch* batch, fuelmi_bspline_dev** out);
 int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b);             /* async on the map's stream */
 int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, double* grad);
+/* BsplineOptimizer::optimize() (bspline_optimizer.cpp:165-253) for every candidate of the batch on the
+ * device: start point and bounds as the reference sets them up (control points clamped into the
+ * exploration box shrunk by 0.1, +-10 around the start, knot span in [0,5]), at most max_eval objective
+ * evaluations (set_maxeval), xtol_rel 1e-5, the best variables seen are returned (best_variable_).  The
+ * iteration itself is a box-projected L-BFGS instead of NLopt's (third party): final costs are
+ * comparable, iterates are not.  x_out [C][nvar], cost_out [C], evals_out [C] or NULL; synchronous. */
+int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, double* x_out, double* cost_out,
+                                int* evals_out);
 void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b);
 
 /* ------------------------------------------------------------------------------------------

@@ -1401,3 +1401,105 @@ extern "C" int fo_project_depth(const unsigned short* img, int rows, int cols, c
   }
   return cnt;
 }
+
+// ---------------------------------------------------------------------------------------------
+// BsplineOptimizer::optimize() around a box-projected L-BFGS (see fuel_oracle.h).  Sequential f64.
+// ---------------------------------------------------------------------------------------------
+extern "C" double fo_bspline_optimize(const fo_map* m, const fo_bspline_cfg* cfg, const fo_bspline_problem* pb,
+                                      double* x_io, int max_eval, int* evals_out) {
+  const int N = pb->point_num, dim = pb->dim;
+  const bool opt_time = (pb->cost_function & (1 << 8)) != 0;
+  const int n = opt_time ? dim * N + 1 : dim * N, npt = dim * N;
+  const int MEM = 8;
+  double blo[3], bhi[3];
+  for (int k = 0; k < 3; ++k) blo[k] = m->box_mind[k] + 0.1, bhi[k] = m->box_maxd[k] - 0.1;  // :174-178
+  std::vector<double> q(n), lb(n, -1e300), ub(n, 1e300);
+  for (int i = 0; i < n; ++i) {
+    double v = x_io[i];
+    if (dim != 1 && i < npt) v = std::max(std::min(v, bhi[i % 3]), blo[i % 3]);  // :194-199
+    q[i] = v;
+  }
+  if (dim != 1) {
+    for (int i = 0; i < npt; ++i) lb[i] = std::max(q[i] - 10.0, blo[i % 3]), ub[i] = std::min(q[i] + 10.0, bhi[i % 3]);
+    if (opt_time) lb[n - 1] = 0.0, ub[n - 1] = 5.0;
+  }
+  int evals = 0;
+  std::vector<double> best = q, g(n), xn(n), gn(n), d(n);
+  double f, fbest;
+  fo_bspline_cost_grad(m, cfg, pb, q.data(), &f, g.data());
+  ++evals;
+  fbest = f;
+  std::vector<std::vector<double>> S(MEM, std::vector<double>(n)), Y(MEM, std::vector<double>(n));
+  double rho[8], al[8];
+  int hist = 0, head = 0;
+  auto dot = [&](const double* a, const double* b) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+  };
+  while (evals < max_eval) {
+    for (int i = 0; i < n; ++i) {
+      const bool at_lb = q[i] <= lb[i] && g[i] > 0, at_ub = q[i] >= ub[i] && g[i] < 0;
+      d[i] = (at_lb || at_ub) ? 0.0 : -g[i];
+    }
+    for (int k = hist - 1; k >= 0; --k) {
+      const int sl = (head + k) % MEM;
+      const double a = dot(S[sl].data(), d.data()) * rho[sl];
+      al[sl] = a;
+      for (int i = 0; i < n; ++i) d[i] -= a * Y[sl][i];
+    }
+    if (hist > 0) {
+      const int sl = (head + hist - 1) % MEM;
+      const double yy = dot(Y[sl].data(), Y[sl].data()), sy = 1.0 / rho[sl];
+      const double gamma = yy > 0 ? sy / yy : 1.0;
+      for (int i = 0; i < n; ++i) d[i] *= gamma;
+    }
+    for (int k = 0; k < hist; ++k) {
+      const int sl = (head + k) % MEM;
+      const double b = dot(Y[sl].data(), d.data()) * rho[sl];
+      for (int i = 0; i < n; ++i) d[i] += S[sl][i] * (al[sl] - b);
+    }
+    double gd = dot(g.data(), d.data());
+    if (!(gd < 0)) {
+      hist = 0, head = 0;
+      for (int i = 0; i < n; ++i) d[i] = -g[i];
+      gd = -dot(g.data(), g.data());
+      if (gd == 0) break;
+    }
+    double step = hist == 0 ? 1.0 / std::max(1.0, std::sqrt(-gd)) : 1.0, fn = f;
+    bool ok = false;
+    for (int ls = 0; ls < 20 && evals < max_eval; ++ls) {
+      for (int i = 0; i < n; ++i) xn[i] = std::min(std::max(q[i] + step * d[i], lb[i]), ub[i]);
+      fo_bspline_cost_grad(m, cfg, pb, xn.data(), &fn, gn.data());
+      ++evals;
+      if (fn < fbest) fbest = fn, best = xn;
+      double dec = 0;
+      for (int i = 0; i < n; ++i) dec += g[i] * (xn[i] - q[i]);
+      if (fn <= f + 1e-4 * dec) {
+        ok = true;
+        break;
+      }
+      step *= 0.5;
+    }
+    if (!ok) break;
+    double sy = 0, ss = 0, xx = 0;
+    const int slot = hist < MEM ? (head + hist) % MEM : head;
+    for (int i = 0; i < n; ++i) {
+      const double si = xn[i] - q[i], yi = gn[i] - g[i];
+      sy += si * yi, ss += si * si, xx += xn[i] * xn[i];
+    }
+    if (sy > 1e-12) {
+      for (int i = 0; i < n; ++i) S[slot][i] = xn[i] - q[i], Y[slot][i] = gn[i] - g[i];
+      rho[slot] = 1.0 / sy;
+      if (hist < MEM)
+        ++hist;
+      else
+        head = (head + 1) % MEM;
+    }
+    q = xn, g = gn, f = fn;
+    if (std::sqrt(ss) <= 1e-5 * std::sqrt(xx)) break;
+  }
+  for (int i = 0; i < n; ++i) x_io[i] = best[i];
+  if (evals_out) *evals_out = evals;
+  return fbest;
+}

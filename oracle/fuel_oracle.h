@@ -192,6 +192,14 @@ double fo_bspline_pt_dist(const double* ctrl_pts, int n, int dim);
 void fo_bspline_cost_grad(const fo_map* m, const fo_bspline_cfg* cfg, const fo_bspline_problem* pb,
                           const double* x, double* cost, double* grad);
 
+/* BsplineOptimizer::optimize() (bspline_optimizer.cpp:165-253): start point / bounds / best-variable
+   tracking / evaluation cap as the reference sets them up around NLopt; the iteration itself (NLopt
+   LD_LBFGS, third party, absent) is replaced by a box-projected L-BFGS (memory 8, Armijo backtracking,
+   xtol_rel 1e-5) -- PARITY UNPINNED against NLopt, the reference for libfuelmi's device optimiser.
+   x_io: start variables in, best variables out; returns the best cost; *evals = objective evaluations. */
+double fo_bspline_optimize(const fo_map* m, const fo_bspline_cfg* cfg, const fo_bspline_problem* pb, double* x_io,
+                           int max_eval, int* evals);
+
 /* MapROS::proessDepthImage (plan_env/src/map_ros.cpp:176-215); parameters map_ros.cpp:22-30 */
 typedef struct {
   double fx, fy, cx, cy;

@@ -419,10 +419,10 @@ def bspline_pt_dist(ctrl):
     return lib().fo_bspline_pt_dist(_dp(ctrl), n, dim)
 
 
-def bspline_cost_grad(omap, x, point_num, cost_function, pt_dist, start_state, end_state, end_n=3,
+def _bspline_setup(x, point_num, cost_function, pt_dist, start_state, end_state, end_n=3,
                       dim=3, knot_span=0.0, time_lb=-1.0, guide_pts=None, waypoints=None,
                       waypt_idx=None, view=None, **cfgkw):
-    """One combineCost evaluation.  Returns (cost, grad)."""
+    """(lib, cfg, problem, x, keep-alive list) shared by the evaluation and the optimiser."""
     L = lib()
     p = dict(DEFAULT_BSPLINE)
     p.update(cfgkw)
@@ -454,7 +454,31 @@ def bspline_cost_grad(omap, x, point_num, cost_function, pt_dist, start_state, e
         pb.view_pt = ptr(view[0])
         pb.view_dir = ptr(view[1])
         pb.view_idx = int(view[2])
+    return L, cfg, pb, x, keep
+
+
+def bspline_cost_grad(omap, x, point_num, cost_function, pt_dist, start_state, end_state, end_n=3,
+                      dim=3, knot_span=0.0, time_lb=-1.0, guide_pts=None, waypoints=None,
+                      waypt_idx=None, view=None, **cfgkw):
+    """One combineCost evaluation.  Returns (cost, grad)."""
+    L, cfg, pb, x, keep = _bspline_setup(x, point_num, cost_function, pt_dist, start_state, end_state, end_n, dim,
+                                         knot_span, time_lb, guide_pts, waypoints, waypt_idx, view, **cfgkw)
     cost = C.c_double()
     grad = np.zeros(len(x))
     L.fo_bspline_cost_grad(omap.h, C.byref(cfg), C.byref(pb), _dp(x), C.byref(cost), _dp(grad))
     return cost.value, grad
+
+
+def bspline_optimize(omap, x, point_num, cost_function, pt_dist, start_state, end_state, end_n=3, dim=3,
+                     knot_span=0.0, time_lb=-1.0, guide_pts=None, waypoints=None, waypt_idx=None, view=None,
+                     max_eval=300, **cfgkw):
+    """BsplineOptimizer::optimize() with the in-house L-BFGS: returns (best_x, best_cost, evaluations)."""
+    L, cfg, pb, x, keep = _bspline_setup(x, point_num, cost_function, pt_dist, start_state, end_state, end_n, dim,
+                                         knot_span, time_lb, guide_pts, waypoints, waypt_idx, view, **cfgkw)
+    L.fo_bspline_optimize.restype = C.c_double
+    L.fo_bspline_optimize.argtypes = [C.c_void_p, C.POINTER(BsplineCfg), C.POINTER(BsplineProblem),
+                                      C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+    xo = x.copy()
+    ev = C.c_int()
+    f = L.fo_bspline_optimize(omap.h, C.byref(cfg), C.byref(pb), _dp(xo), int(max_eval), C.byref(ev))
+    return xo, f, ev.value

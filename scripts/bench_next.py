@@ -52,6 +52,42 @@ out["compute_frontiers_to_visit"] = {"gpu_ms": gpu_vp_ms, "cpu_oracle_ms": cpu_v
                                      "active_cpu": len(of.clusters(1)), "viewpoints": int(nvp),
                                      "candidates": int(n * 100)}
 
+# ---- rank 4: whole trajectory solves (BsplineOptimizer::optimize) for the 64 bench candidates ----------
+gm.updateESDF3d()
+om.update_esdf()
+x, ptd, st, en = bench.bspline_problem(ctrl, 0.175)
+cf = fuel_amd.NORMAL_PHASE | fuel_amd.MINTIME
+opt = fuel_amd.BsplineOptimizer()
+opt.setEnvironment(gm)
+pb = fuel_amd.BsplineBatchProblem(x, ctrl.shape[1], cf, ptd, st, en, 3, 3, 0.175)
+dev = opt.deviceProblem(pb)
+dev.optimize(max_eval=300)
+gm.synchronize()
+t0 = time.perf_counter()
+xg, cg, eg = dev.optimize(max_eval=300)
+gpu_opt_ms = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter()
+co, eo = [], []
+for c in range(8):  # bounded CPU sample: 8 of the 64 solves
+    xo, f, e = fo.bspline_optimize(om, x[c], ctrl.shape[1], cf, ptd[c], st[c], en[c], 3, 3, 0.175, max_eval=300)
+    co.append(f)
+    eo.append(e)
+cpu_opt_ms = (time.perf_counter() - t0) * 1e3 * (len(x) / 8.0)
+# the solve is latency-bound per candidate (one wavefront each): a larger batch costs almost nothing more
+rng = np.random.default_rng(5)
+ctrl_big = np.concatenate([ctrl + rng.normal(scale=0.05, size=ctrl.shape) for _ in range(16)], axis=0)
+xb, ptdb, stb, enb = bench.bspline_problem(ctrl_big, 0.175)
+devb = opt.deviceProblem(fuel_amd.BsplineBatchProblem(xb, ctrl.shape[1], cf, ptdb, stb, enb, 3, 3, 0.175))
+devb.optimize(max_eval=300)
+t0 = time.perf_counter()
+_, _, egb = devb.optimize(max_eval=300)
+gpu_big_ms = (time.perf_counter() - t0) * 1e3
+out["bspline_optimize_1024_candidates"] = {"gpu_ms": gpu_big_ms, "evals_gpu_mean": float(egb.mean()),
+                                            "cpu_oracle_ms_extrapolated": cpu_opt_ms * 16}
+out["bspline_optimize_64_candidates"] = {"gpu_ms": gpu_opt_ms, "cpu_oracle_ms_extrapolated_from_8": cpu_opt_ms,
+                                          "evals_gpu_mean": float(eg.mean()), "evals_cpu_mean": float(np.mean(eo)),
+                                          "final_cost_ratio_gpu_over_cpu_first8": float(np.mean(cg[:8] / np.array(co)))}
+
 # ---- rank 3: depth frame -> fused map ----------------------------------------------------------------
 w = synth.World.for_map_size(map_size)
 truth = w.world(42, bench.WORKLOADS["G400"][1])
