@@ -105,6 +105,9 @@ __device__ __forceinline__ bool f1_cell(const Geo& g, const u64* __restrict__ oc
   return false;
 }
 
+// (Folding the one-block tails -- k_scan_sums, k_ms_scan, k_pack -- into their producers with a "last
+// block done" ticket was tried and is 10x slower: the agent-scope fence every block needs before its
+// ticket writes back and invalidates the whole XCD L2, 977 times in k_pred.  They stay ~5 us launches.)
 // ---- kernels ----------------------------------------------------------------------------------
 // isFrontierChanged (:365-372) for the cells of several clusters: changed[cl] |= !F1(cell)
 __global__ void k_check_clusters(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk,
@@ -124,45 +127,10 @@ __global__ void k_clear_flags(u64* flag, const int* __restrict__ cells, const in
   }
 }
 
-// predicate planes + in-block packed prefix of their popcounts
-__global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
-  __shared__ u64 wsum[4];
-  const FVar& V = *F.var;
-  if ((int)blockIdx.x >= V.nblocks) return;
-  const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = V.w0 + rel;
-  u64 q = 0ull, s = 0ull;
-  if (w < g.W) {
-    u64 z0, zl, y0, yl, mq, ms;
-    word_masks(g, w, F.qbox, V.sbox, z0, zl, y0, yl, mq, ms);
-    if ((mq | ms) != 0ull) {
-      u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~F.flag[w];
-      q = f1 & mq;
-      s = f1 & ms & ~mq;
-    }
-    F.qb[w] = q;
-    F.sb[w] = s;
-  }
-  u64 packed = (u64)__popcll(q) | ((u64)__popcll(s) << 32);
-  u64 v = packed;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    u64 t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
-  if (lane == 63) wsum[wave] = v;
-  __syncthreads();
-  u64 woff = 0;
-  for (int k = 0; k < wave; ++k) woff += wsum[k];
-  u64 excl = v - packed + woff;
-  F.pref[rel] = excl;
-  if (threadIdx.x == 255) F.blocksum[blockIdx.x] = excl + packed;
-}
-
-// exclusive scan of the block sums (single block) + totals
-__global__ void __launch_bounds__(256) k_scan_sums(FArgs F) {
-  const int nblocks = F.var->nblocks;
+// exclusive scan of the block sums + totals (one block)
+__device__ void scan_sums_tail(const FArgs& F) {
   __shared__ u64 part[256];
+  const int nblocks = F.var->nblocks;
   const int per = (nblocks + 255) / 256;
   const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
   u64 s = 0;
@@ -200,6 +168,42 @@ __global__ void __launch_bounds__(256) k_scan_sums(FArgs F) {
     run += v;
   }
 }
+
+// predicate planes + in-block packed prefix of their popcounts
+__global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
+  __shared__ u64 wsum[4];
+  const FVar& V = *F.var;
+  if ((int)blockIdx.x >= V.nblocks) return;
+  const int rel = blockIdx.x * 256 + threadIdx.x;
+  const int w = V.w0 + rel;
+  u64 q = 0ull, s = 0ull;
+  if (w < g.W) {
+    u64 z0, zl, y0, yl, mq, ms;
+    word_masks(g, w, F.qbox, V.sbox, z0, zl, y0, yl, mq, ms);
+    if ((mq | ms) != 0ull) {
+      u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~F.flag[w];
+      q = f1 & mq;
+      s = f1 & ms & ~mq;
+    }
+    F.qb[w] = q;
+    F.sb[w] = s;
+  }
+  u64 packed = (u64)__popcll(q) | ((u64)__popcll(s) << 32);
+  u64 v = packed;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    u64 t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  u64 woff = 0;
+  for (int k = 0; k < wave; ++k) woff += wsum[k];
+  u64 excl = v - packed + woff;
+  F.pref[rel] = excl;
+  if (threadIdx.x == 255) F.blocksum[blockIdx.x] = excl + packed;
+}
+__global__ void __launch_bounds__(256) k_scan_sums(FArgs F) { scan_sums_tail(F); }
 
 __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
   int w = (int)(a >> 6);
@@ -489,10 +493,14 @@ __global__ void __launch_bounds__(256) k_union(Geo g, FArgs F, int TX, int TY) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_flatten(Geo g, FArgs F) {
-  const u32 nq = F.counts[0];
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x)
-    F.parent[i] = uf_find(F.parent, i);
+// root of a cell without writing (k_claim: k_union has finished, parents are final and chains short)
+__device__ __forceinline__ u32 uf_root(const u32* parent, u32 i) {
+  u32 p = parent[i];
+  while (p != i) {
+    i = p;
+    p = parent[i];
+  }
+  return i;
 }
 
 __device__ __forceinline__ bool in_box(const Geo& g, const Box3& b, long a) {
@@ -540,9 +548,13 @@ __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
       ad[k] = 0u;
       if (i < nq) {
         ad[k] = F.cell_adr[i];
+        // flatten on the way: every cell ends with parent = root (k_sizes / the seed claims read it);
+        // a plain store is safe here, nothing issues atomics on parent[] in this kernel
+        const u32 root = uf_root(F.parent, i);
+        F.parent[i] = root;
         if (in_box(g, sbox, ad[k])) {
           act[k] = true;
-          rt[k] = F.parent[i];
+          rt[k] = root;
         }
       }
       const u64 m = __ballot(act[k]);
@@ -602,9 +614,9 @@ __global__ void __launch_bounds__(256) k_claim(Geo g, FArgs F) {
         const u32 j = rank_q(F, a + (long)dx * g.nyz + (long)dy * g.nz - 1 + __builtin_ctz(p));
         active = j < F.cap_q;
         if (active) {
-          r = F.parent[j];
+          r = uf_root(F.parent, j);
           if (p == 5u && j + 1 < F.cap_q) {
-            r2 = F.parent[j + 1];
+            r2 = uf_root(F.parent, j + 1);
             two = r2 != r;
           }
           if (r == last) active = false;  // this seed already claimed that component
@@ -765,14 +777,6 @@ __global__ void __launch_bounds__(256) k_rank_kept(FArgs F) {
     if (rank == nkept - 1) F.counts[5] = off + zi - (si >= nq ? 1u : 0u);
   }
 }
-__global__ void __launch_bounds__(256) k_ms_keys(FArgs F) {
-  const u32 nq = F.counts[0];
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
-    int s = F.cell_slot[i];
-    F.ms_key[0][i] = s >= 0 ? (u32)F.slot2rank[s] : NOKEY;
-    F.ms_val[0][i] = F.cell_adr[i];
-  }
-}
 struct MsPass {
   bool on;
   u32 n;
@@ -792,32 +796,21 @@ __device__ __forceinline__ MsPass ms_pass(const FArgs& F, int pass) {
   p.key_out = F.ms_key[1 - pass], p.val_out = F.ms_val[1 - pass];
   return p;
 }
-// histogram of the current 8-bit digit per block, digit-major: hist[d * nb + block]
-__global__ void __launch_bounds__(256) k_ms_hist(FArgs F, int pass) {
-  __shared__ u32 h[256];
-  const MsPass P = ms_pass(F, pass);
-  if (!P.on) return;
-  for (int chunk = blockIdx.x; chunk < P.nb; chunk += gridDim.x) {  // any grid size covers all chunks
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const u32 base = (u32)chunk * MS_CH;
-    for (int k = 0; k < MS_CH / 256; ++k) {
-      u32 i = base + k * 256 + threadIdx.x;
-      if (i < P.n) {
-        u32 kk = P.key[i];
-        if (kk != NOKEY) atomicAdd(&h[(kk >> P.shift) & 255u], 1u);
-      }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < P.ndig) F.ms_hist[threadIdx.x * P.nb + chunk] = h[threadIdx.x];
-    __syncthreads();
+// (key, value) of input item i: pass 0 of the clustering chain derives them from the per-cell slot
+// (what a separate k_ms_keys launch used to materialise); otherwise they are read from the buffers
+__device__ __forceinline__ u32 ms_key_at(const FArgs& F, const MsPass& P, int pass, u32 i) {
+  if (pass == 0 && F.keys_from_slots) {
+    const int s = F.cell_slot[i];
+    return s >= 0 ? (u32)F.slot2rank[s] : NOKEY;
   }
+  return P.key[i];
 }
-// in-place exclusive scan of the ndig*nb histogram entries by one block
-__global__ void __launch_bounds__(256) k_ms_scan(FArgs F, int pass) {
+__device__ __forceinline__ u32 ms_val_at(const FArgs& F, const MsPass& P, int pass, u32 i) {
+  return (pass == 0 && F.keys_from_slots) ? F.cell_adr[i] : P.val[i];
+}
+// in-place exclusive scan of the ndig*nb histogram entries (one block)
+__device__ void ms_scan_tail(const FArgs& F, const MsPass& P) {
   __shared__ u32 part[256];
-  const MsPass P = ms_pass(F, pass);
-  if (!P.on) return;
   u32* v = F.ms_hist;
   const int cnt = P.ndig * P.nb;
   const int per = (cnt + 255) / 256;
@@ -842,6 +835,31 @@ __global__ void __launch_bounds__(256) k_ms_scan(FArgs F, int pass) {
     run += x;
   }
 }
+// histogram of the current 8-bit digit per block, digit-major: hist[d * nb + block]
+__global__ void __launch_bounds__(256) k_ms_hist(FArgs F, int pass) {
+  __shared__ u32 h[256];
+  const MsPass P = ms_pass(F, pass);
+  if (!P.on) return;
+  for (int chunk = blockIdx.x; chunk < P.nb; chunk += gridDim.x) {  // any grid size covers all chunks
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 base = (u32)chunk * MS_CH;
+    for (int k = 0; k < MS_CH / 256; ++k) {
+      u32 i = base + k * 256 + threadIdx.x;
+      if (i < P.n) {
+        u32 kk = ms_key_at(F, P, pass, i);
+        if (kk != NOKEY) atomicAdd(&h[(kk >> P.shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < P.ndig) F.ms_hist[threadIdx.x * P.nb + chunk] = h[threadIdx.x];
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_ms_scan(FArgs F, int pass) {
+  const MsPass P = ms_pass(F, pass);
+  if (P.on) ms_scan_tail(F, P);
+}
 // stable scatter: position = scanned[d][block] + (# earlier elements of this block with digit d)
 __global__ void __launch_bounds__(256) k_ms_scatter(FArgs F, int pass) {
   __shared__ u32 running[256];
@@ -856,7 +874,7 @@ __global__ void __launch_bounds__(256) k_ms_scatter(FArgs F, int pass) {
     for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
     const u32 i = base + k * 256 + threadIdx.x;
-    u32 kk = (i < P.n) ? P.key[i] : NOKEY;
+    u32 kk = (i < P.n) ? ms_key_at(F, P, pass, i) : NOKEY;
     const bool active = kk != NOKEY;
     const u32 d = (kk >> P.shift) & 255u;
     u32 lane_rank = 0;
@@ -874,7 +892,7 @@ __global__ void __launch_bounds__(256) k_ms_scatter(FArgs F, int pass) {
       u32 pos = running[d] + lane_rank;
       for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
       P.key_out[pos] = kk;
-      P.val_out[pos] = P.val[i];
+      P.val_out[pos] = ms_val_at(F, P, pass, i);
     }
     __syncthreads();
     running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
@@ -898,6 +916,15 @@ __device__ __forceinline__ void info_atomics(FArgs& F, u32 k, u32 sx, u32 sy, u3
   atomicMax(&r.box[3], mx);
   atomicMax(&r.box[4], my);
   atomicMax(&r.box[5], mz);
+}
+// counts + cluster records -> pinned host memory (one block, after k_ms_info's atomics on the records)
+__device__ void pack_tail(const FArgs& F) {
+  const u32 nkept = min(F.counts[3], F.cap_kept);
+  const u32 words = nkept * (u32)(sizeof(KeptRec) / 4);
+  const u32* src = reinterpret_cast<const u32*>(F.krec);
+  u32* dst = reinterpret_cast<u32*>(F.h_rec);
+  for (u32 i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x < 16) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
 }
 __global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
   __shared__ u32 s_red[4][9];
@@ -979,16 +1006,7 @@ __global__ void __launch_bounds__(256) k_ms_info(Geo g, FArgs F) {
     __syncthreads();
   }
 }
-
-// counts + cluster records -> pinned host memory (after k_ms_info's atomics on the records)
-__global__ void __launch_bounds__(256) k_pack(FArgs F) {
-  const u32 nkept = min(F.counts[3], F.cap_kept);
-  const u32 words = nkept * (u32)(sizeof(KeptRec) / 4);
-  const u32* src = reinterpret_cast<const u32*>(F.krec);
-  u32* dst = reinterpret_cast<u32*>(F.h_rec);
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src[i];
-  if (blockIdx.x == 0 && threadIdx.x < 16) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
-}
+__global__ void __launch_bounds__(256) k_pack(FArgs F) { pack_tail(F); }
 
 __global__ void k_load_var(const FVar* __restrict__ h, FVar* __restrict__ d) {
   const int n = (int)(sizeof(FVar) / 4);
@@ -1131,6 +1149,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     return rc;
   }
   F.kept = F.counts + 16;
+  F.keys_from_slots = 1;
   F.occ = m->occ_bits.p;
   F.unk = m->unk_bits.p;
   F.flag = f->flag.p;
@@ -1263,7 +1282,7 @@ int frontier_regroup(fuelmi_frontier* f, const FArgs& F2, int npass) {
     k_ms_scatter<<<256, 256, 0, f->stream>>>(F2, p);
   }
   k_ms_info<<<256, 256, 0, f->stream>>>(g, F2);
-  k_pack<<<8, 256, 0, f->stream>>>(F2);
+  k_pack<<<1, 256, 0, f->stream>>>(F2);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -1288,8 +1307,6 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
     k_union<<<cgrid, 256, 0, f->stream>>>(g, F, f->TX, f->TY);
     FDBG("k_union");
   }
-  k_flatten<<<cgrid, 256, 0, f->stream>>>(g, F);
-  FDBG("k_flatten");
   k_claim<<<cgrid, 256, 0, f->stream>>>(g, F);
   FDBG("k_claim");
   k_sizes<<<cgrid, 256, 0, f->stream>>>(g, F);
@@ -1299,8 +1316,6 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   // ---- grouping + cluster info, still without touching the host ----
   k_rank_kept<<<16, 256, 0, f->stream>>>(F);
   FDBG("k_rank_kept");
-  k_ms_keys<<<cgrid, 256, 0, f->stream>>>(F);
-  FDBG("k_ms_keys");
   for (int p = 0; p < npass; ++p) {
     k_ms_hist<<<f->nb_launch, 256, 0, f->stream>>>(F, p);
     FDBG("k_ms_hist");
@@ -1311,7 +1326,7 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   }
   k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
   FDBG("k_ms_info");
-  k_pack<<<8, 256, 0, f->stream>>>(F);
+  k_pack<<<1, 256, 0, f->stream>>>(F);
   FDBG("k_pack");
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
@@ -1454,7 +1469,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     FDBG("k_rank_kept");
     k_ms_info<<<256, 256, 0, f->stream>>>(g, F);
     FDBG("k_ms_info");
-    k_pack<<<8, 256, 0, f->stream>>>(F);
+    k_pack<<<1, 256, 0, f->stream>>>(F);
     FDBG("k_pack");
     HIPCHK(hipStreamSynchronize(f->stream));
   }

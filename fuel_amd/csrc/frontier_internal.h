@@ -66,6 +66,7 @@ struct FArgs {
   struct KeptRec* h_rec;  // [cap_kept]
   u32* h_part;            // like info_part
   u32* h_cells;           // [cap_q] grouped cell addresses
+  int keys_from_slots;    // multisplit pass 0 derives (key, value) from cell_slot / slot2rank / cell_adr
 };
 
 #define MS_CH 2048  // cells per multisplit block (256 threads x 8)

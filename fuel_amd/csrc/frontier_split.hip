@@ -671,6 +671,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   // regroup the cells by depth-first rank and refill the result buffers
   FArgs F2 = F;
   F2.counts = s->counts;
+  F2.keys_from_slots = 0;  // keys/values come from k_sp_keys
   HIPCHK(hipMemsetAsync(s->counts, 0, 16 * sizeof(u32), st));
   k_sp_rank<<<(n_nodes + 255) / 256, 256, 0, st>>>(S, n_nodes, F.krec, s->counts);
   k_sp_keys<<<gb, 256, 0, st>>>(S, F.ms_key[0], F.ms_val[0]);
