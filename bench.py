@@ -31,6 +31,10 @@ WORKLOADS = {
     "G400": ((40.0, 40.0, 10.0), 400, 120),
     "G800": ((80.0, 80.0, 20.0), 3200, 960),
     "G100": ((10.0, 10.0, 5.0), 25, 8),  # smoke-sized
+    # streaming variants (BASELINE config #4): the map starts unknown, one 640x480 depth frame per step
+    # (sparser worlds than the full-box recipe, so that a frame sees several metres of free space)
+    "G800S": ((80.0, 80.0, 20.0), 600, 0),
+    "G400S": ((40.0, 40.0, 10.0), 150, 0),
 }
 
 
@@ -70,7 +74,7 @@ def bspline_problem(ctrl, dt):
     return np.ascontiguousarray(x), pt_dist, start, end
 
 
-def build_inputs(workload, seed):
+def build_inputs(workload, seed, n_traj=64):
     """Synthetic map state (host) for one agent: occupancy log-odds + candidate trajectories."""
     from fuel_amd import synth
     map_size, n_obs, n_sph = WORKLOADS[workload]
@@ -79,7 +83,7 @@ def build_inputs(workload, seed):
     occ, n_known = w.known_state(truth, seed, n_sph)
     lo, hi = exploration_box(map_size)
     rng = np.random.default_rng(1000 + seed)
-    ctrl = make_trajectories(rng, 64, 32, np.array(lo) + 0.5, np.array(hi) - 0.5)
+    ctrl = make_trajectories(rng, n_traj, 32, np.array(lo) + 0.5, np.array(hi) - 0.5)
     return map_size, (lo, hi), occ, ctrl, n_known
 
 
@@ -128,6 +132,96 @@ class GpuCycle:
 
     def finish(self):
         self.map.synchronize()
+
+
+def streaming_frames(map_size, n_obs, n_frames, seed):
+    """Depth frames (16UC1, 640x480) along a seeded camera path through a fresh synthetic world."""
+    from fuel_amd import synth
+    w = synth.World.for_map_size(map_size)
+    truth = w.world(seed, n_obs)
+    frames = []
+    n_try = 6 * n_frames
+    for k in range(n_try):  # keep the poses of the seeded path that look into open space
+        pose = w.camera(truth, 7 + seed, k, n_try, 0.7)
+        img = w.depth_image(truth, pose, 640, 480)
+        if np.median(np.where(img == 0, 7000, img)) < 2000:  # staring at a wall: skip
+            continue
+        frames.append((img, pose[:3].copy(), synth.World.pose_quaternion(pose)))
+        if len(frames) == n_frames:
+            break
+    if not frames:
+        raise SystemExit("no usable camera pose in the synthetic world")
+    return frames
+
+
+class GpuStreamCycle:
+    """BASELINE config #4: streaming depth inserts + incremental (box-local) ESDF + incremental frontier
+    search on a map that starts unknown, plus the B-spline batch.  One step = one depth frame."""
+
+    def __init__(self, map_size, box, frames, ctrl, device, dt=0.175):
+        import fuel_amd
+        self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device)
+        self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100)
+        self.frames = frames
+        self.k = 0
+        self.opt = fuel_amd.BsplineOptimizer()
+        self.opt.setEnvironment(self.map)
+        x, ptd, st, en = bspline_problem(ctrl, dt)
+        cf = fuel_amd.NORMAL_PHASE | fuel_amd.MINTIME
+        self.problem = fuel_amd.BsplineBatchProblem(x, ctrl.shape[1], cf, ptd, st, en, 3, 3, dt)
+        self.dev_problem = self.opt.deviceProblem(self.problem)
+        self.n_clusters = 0
+        self.box_vox = []  # voxels of the local bound of every frame (the ESDF / inflation box)
+
+    def step(self):
+        img, pos, q = self.frames[self.k % len(self.frames)]
+        self.k += 1
+        m = self.map
+        if m.inputDepthImage(img, pos, q) > 0:      # MapROS::depthPoseCallback
+            lo, hi = m.getLocalBound()
+            self.box_vox.append(float(np.prod(np.array(hi) - np.array(lo) + 1)))
+            m.clearAndInflateLocalMap()
+            m.updateESDF3d()                          # (the reference defers this to a 50 ms timer)
+        self.dev_problem.eval()
+        self.n_clusters = self.ff.searchFrontiers()  # consumes the accumulated updated box
+        self.ff.commit()
+
+    step_serial = step
+
+    def finish(self):
+        self.map.synchronize()
+
+
+def cpu_baseline_stream(map_size, box, frames, ctrl, budget_s=12.0, dt=0.175):
+    """The CPU oracle on the streaming cycle (projection + fusion + local ESDF + incremental frontiers +
+    B-spline batch), bounded sample of consecutive frames."""
+    from oracle import fuel_oracle as fo
+    om = fo.OracleMap(map_size, box[0], box[1])
+    of = fo.OracleFrontier(om, 100)
+    x, ptd, st, en = bspline_problem(ctrl, dt)
+    cf = fo.COST["NORMAL_PHASE"] | fo.COST["MINTIME"]
+    times = []
+    t_all = time.perf_counter()
+    k = 0
+    while True:
+        img, pos, q = frames[k % len(frames)]
+        k += 1
+        t0 = time.perf_counter()
+        pts = fo.project_depth(img, pos, q)
+        if len(pts):
+            om.input_points(pts, pos)
+            om.inflate_local()
+            om.update_esdf()
+        for c in range(ctrl.shape[0]):
+            fo.bspline_cost_grad(om, x[c], ctrl.shape[1], cf, ptd[c], st[c], en[c], 3, 3, dt)
+        of.search()
+        of.commit()
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 4 and time.perf_counter() - t_all > budget_s:
+            break
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "cycles/s", "cores": 1, "kind": "port",
+            "sample": "%d consecutive streaming cycles (median), 1 thread, g++ -O3" % len(times)}
 
 
 def cpu_baseline(map_size, box, occ, ctrl, budget_s=12.0, dt=0.175):
@@ -203,6 +297,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="G400", choices=sorted(WORKLOADS))
+    ap.add_argument("--candidates", type=int, default=64,
+                    help="B-spline candidates per cycle (BASELINE configs: 1, 64 = headline, 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--serial-stages", action="store_true",
@@ -225,8 +321,18 @@ def main():
 
     import fuel_amd
     from fuel_amd import _lib
-    map_size, box, occ, ctrl, n_known = build_inputs(args.workload, seed=42 + rank)
-    cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank)
+    streaming = args.workload.endswith("S")
+    if streaming:
+        map_size, n_obs, _ = WORKLOADS[args.workload]
+        box = exploration_box(map_size)
+        frames = streaming_frames(map_size, n_obs, 24, seed=42 + rank)
+        rng = np.random.default_rng(1000 + 42 + rank)
+        ctrl = make_trajectories(rng, args.candidates, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
+        occ, n_known = None, 0
+        cyc = GpuStreamCycle(map_size, box, frames, ctrl, device=local_rank)
+    else:
+        map_size, box, occ, ctrl, n_known = build_inputs(args.workload, seed=42 + rank, n_traj=args.candidates)
+        cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank)
     if args.serial_stages:
         cyc.step = cyc.step_serial
 
@@ -234,6 +340,8 @@ def main():
     # (on the map's own stream) to find the dominant kernel
     stages = {"inflate": _lib.K_INFLATE, "esdf_zy": _lib.K_ESDF_ZY, "esdf_x": _lib.K_ESDF_X,
               "frontier": _lib.K_FRONTIER, "bspline": _lib.K_BSPLINE}
+    if streaming:
+        stages["insert"] = _lib.K_INSERT  # upload + projection + fusion (+ one host sync): reported, not ranked
     for _ in range(args.warmup):
         cyc.step()
     cyc.finish()
@@ -255,7 +363,7 @@ def main():
     for name, sid in stages.items():
         n, tot = cyc.map.profileGet(sid)
         iso_ms_all[name] = tot / max(n, 1)
-    kernel_stages = {k: v for k, v in iso_ms_all.items() if k != "frontier"}  # frontier = many kernels + host
+    kernel_stages = {k: v for k, v in iso_ms_all.items() if k not in ("frontier", "insert")}  # multi-kernel stages
     dominant = max(kernel_stages, key=kernel_stages.get)
     # timed region: only the dominant kernel stays bracketed (two event records per step)
     cyc.map.profileEnable(1 << stages[dominant])
@@ -266,7 +374,9 @@ def main():
     if rank == 0:
         nv = cyc.map.nvox
         nvox = nv[0] * nv[1] * nv[2]
-        # algorithmic HBM bytes per launch of each stage, full box = nvox
+        if streaming:  # box-local stages: mean voxel count of the frames' local bounds
+            nvox = float(np.mean(cyc.box_vox[-args.steps:])) if cyc.box_vox else 0.0
+        # algorithmic HBM bytes per launch of each stage, box = nvox voxels
         alg_bytes = {
             "inflate": nvox * (3 / 8.0),          # occupied plane in, scratch plane out+in, inflated plane out
             "esdf_zy": nvox * (2 / 8.0 + 4.0),    # inflated+unknown planes in, u32 y-pass result out
@@ -303,9 +413,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 bit-planes / u32 squared distances / f32 ESDF / f64 log-odds and B-spline",
             "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%d @0.1m map per GPU, full-box inflate+ESDF, full "
-                                   "exploration-box frontier search, 64 B-spline candidates x 32 ctrl pts"
-                                   % (args.workload, nv[0], nv[1], nv[2]),
+            "config": {"workload": ("%s: %dx%dx%d @0.1m map per GPU, streaming 640x480 depth frames from an unknown "
+                                    "map: device projection + fusion, box-local inflate+ESDF (mean box %.2f M voxels), "
+                                    "incremental frontier search, %d B-spline candidates x 32 ctrl pts"
+                                    % (args.workload, nv[0], nv[1], nv[2], nvox / 1e6, ctrl.shape[0])) if streaming else
+                                   ("%s: %dx%dx%d @0.1m map per GPU, full-box inflate+ESDF, full "
+                                    "exploration-box frontier search, %d B-spline candidates x 32 ctrl pts"
+                                    % (args.workload, nv[0], nv[1], nv[2], ctrl.shape[0])),
                        "known_voxels": int(n_known), "frontier_clusters": int(cyc.n_clusters),
                        "parallelism": "independent map per GPU (no collective)"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -314,11 +428,19 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes[dominant]},
         }
+        # whole-cycle figure: compulsory bytes of all stages (frontier: 4 planes of the search box in, 3 out,
+        # plus ~40 B per frontier cell) x cycles/s against the HBM peak
+        cyc_bytes = alg_bytes["inflate"] + alg_bytes["esdf_zy"] + alg_bytes["esdf_x"] + alg_bytes["bspline"] + \
+            (nvox if streaming else nv[0] * nv[1] * nv[2]) * (7 / 8.0)
+        cps_per_gpu = out["value"] / n_gpus
+        out["cycle_hbm"] = {"algorithmic_bytes_per_cycle": cyc_bytes, "achieved": cyc_bytes * cps_per_gpu / 1e9,
+                            "unit": "GB/s", "frac": cyc_bytes * cps_per_gpu / 1e9 / HBM_PEAK_GBS}
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms
             out["roofline"]["isolated_frac"] = alg_bytes[dominant] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(map_size, box, occ, ctrl, args.cpu_budget)
+            out["cpu_baseline"] = (cpu_baseline_stream(map_size, box, frames, ctrl, args.cpu_budget) if streaming
+                                   else cpu_baseline(map_size, box, occ, ctrl, args.cpu_budget))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
