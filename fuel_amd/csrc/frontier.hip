@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
   u64 q = 0ull, s = 0ull;
   if (w < g.W) {
     u64 z0, zl, y0, yl, mq, ms;
-    word_masks(g, w, F.qbox, V.sbox, z0, zl, y0, yl, mq, ms);
+    word_masks(g, w, V.qreg, V.sbox, z0, zl, y0, yl, mq, ms);
     if ((mq | ms) != 0ull) {
       u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~F.flag[w];
       q = f1 & mq;
@@ -313,12 +313,15 @@ __device__ __forceinline__ void lds_union(u32* lab, u32 a, u32 b) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_ccl_local(Geo g, FArgs F, int TX, int TY, int nty) {
+__global__ void __launch_bounds__(256) k_ccl_local(Geo g, FArgs F, int TX, int TY) {
+  if ((int)blockIdx.x >= F.var->ntiles) return;
+  const Box3& QR = F.var->qreg;
+  const int nty = F.var->nty;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32* lab = reinterpret_cast<u32*>(smem_raw);  // [TX*TY lines][nz]
   const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
-  const int x0 = F.qbox.lo[0] + tx * TX, y0 = F.qbox.lo[1] + ty * TY;
-  const int nxl = min(TX, F.qbox.hi[0] - x0 + 1), nyl = min(TY, F.qbox.hi[1] - y0 + 1);
+  const int x0 = QR.lo[0] + tx * TX, y0 = QR.lo[1] + ty * TY;
+  const int nxl = min(TX, QR.hi[0] - x0 + 1), nyl = min(TY, QR.hi[1] - y0 + 1);
   const int nz = g.nz, nseg = (nz + 31) >> 5;
   const int items = TX * TY * nseg;
   u32* segb = lab + TX * TY * nz;  // [TX*TY][nseg] Q0 bits of each 32-voxel segment
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(256) k_union(Geo g, FArgs F, int TX, int TY) {
       int x = (int)(a / g.nyz);
       int r = (int)(a - (long)x * g.nyz);
       int y = r / g.nz, z = r - y * g.nz;
-      const int lx = (x - F.qbox.lo[0]) % TX, ly = (y - F.qbox.lo[1]) % TY;
+      const int lx = (x - F.var->qreg.lo[0]) % TX, ly = (y - F.var->qreg.lo[1]) % TY;
       const bool zlo = z > 0, zhi = z < g.nz - 1;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
@@ -1268,6 +1271,14 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
   for (size_t k = 0; k < cand.size(); ++k)
     if (changed[k]) {
       if (removed_ids) removed_ids->push_back(cand_pos[k] - erased);
+      for (int q = 0; q < 3; ++q) {  // its cells lost their flags: they may be re-grown from the scan box
+        const int lo = (int)std::floor((cand[k]->bmin[q] - m->g.org[q]) * m->g.res_inv);
+        const int hi = (int)std::floor((cand[k]->bmax[q] - m->g.org[q]) * m->g.res_inv);
+        if (f->rm_lo[q] > f->rm_hi[q])
+          f->rm_lo[q] = lo, f->rm_hi[q] = hi;
+        else
+          f->rm_lo[q] = std::min(f->rm_lo[q], lo), f->rm_hi[q] = std::max(f->rm_hi[q], hi);
+      }
       L.erase(cand[k]);
       ++erased;
     }
@@ -1302,7 +1313,7 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   k_compact<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_compact");
   if (f->ccl_tiles > 0) {
-    k_ccl_local<<<f->ccl_tiles, 256, f->ccl_lds, f->stream>>>(g, F, f->TX, f->TY, f->ccl_nty);
+    k_ccl_local<<<f->ccl_tiles, 256, f->ccl_lds, f->stream>>>(g, F, f->TX, f->TY);
     FDBG("k_ccl_local");
     k_union<<<cgrid, 256, 0, f->stream>>>(g, F, f->TX, f->TY);
     FDBG("k_union");
@@ -1352,6 +1363,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   HIPCHK(hipStreamWaitEvent(f->stream, m->ev_planes, 0));
   f->scope.reset(new StageScope(m, FUELMI_K_FRONTIER, f->stream));
   f->removed_ids.clear();
+  for (int q = 0; q < 3; ++q) f->rm_lo[q] = 1, f->rm_hi[q] = 0;
   int rc = remove_changed(f, f->frontiers, umin, umax, &f->removed_ids);
   if (rc) return rc;
   rc = remove_changed(f, f->dormant, umin, umax, nullptr);
@@ -1378,13 +1390,42 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->search_empty = empty;
   if (empty) return FUELMI_OK;
 
-  // words to process: everything the BFS could reach = Q box, plus the scan box
+  // Region that can hold Q0 cells: the scan box, the boxes of the clusters just dropped (their flags were
+  // cleared), or the whole exploration box when flags / occupancy changed behind the updated-box
+  // bookkeeping (fresh finder, reset, uploadOccupancy, resetBuffer).  Everything a previous search
+  // could reach is flagged, and every later change of the occupancy lies inside this search's updated
+  // box, so nothing outside the region can be grown into.
+  int rlo[3], rhi[3];
+  const bool all = f->dirty_all || f->seen_epoch != m->occ_epoch;
+  for (int k = 0; k < 3; ++k) {
+    rlo[k] = hv.sbox.lo[k], rhi[k] = hv.sbox.hi[k];
+    if (f->rm_lo[0] <= f->rm_hi[0]) rlo[k] = std::min(rlo[k], f->rm_lo[k]), rhi[k] = std::max(rhi[k], f->rm_hi[k]);
+    if (all) rlo[k] = 0, rhi[k] = nv[k] - 1;
+    hv.qreg.lo[k] = std::max(F.qbox.lo[k], rlo[k]);
+    hv.qreg.hi[k] = std::min(F.qbox.hi[k], rhi[k]);
+  }
+  f->dirty_all = true;  // until this search has completed
+  bool have_q = true;
+  for (int k = 0; k < 3; ++k)
+    if (hv.qreg.lo[k] > hv.qreg.hi[k]) have_q = false;
+  if (!have_q)
+    for (int k = 0; k < 3; ++k) hv.qreg.lo[k] = 1, hv.qreg.hi[k] = 0;
+  hv.nty = hv.ntiles = 0;
+  if (have_q) {
+    const int qx = hv.qreg.hi[0] - hv.qreg.lo[0] + 1, qy = hv.qreg.hi[1] - hv.qreg.lo[1] + 1;
+    hv.nty = (qy + f->TY - 1) / f->TY;
+    hv.ntiles = ((qx + f->TX - 1) / f->TX) * hv.nty;  // <= f->ccl_tiles (tiles of the whole Q box)
+  }
+  // words to process: the x-slabs of the region plus one slab either side (neighbour look-ups of the
+  // claims / unions read the Q0 plane there: it must not hold bits of an earlier search)
   auto adr = [&](const int* id) { return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2]; };
   long a_lo = adr(hv.sbox.lo), a_hi = adr(hv.sbox.hi);
-  if (F.qbox.lo[0] <= F.qbox.hi[0] && F.qbox.lo[1] <= F.qbox.hi[1] && F.qbox.lo[2] <= F.qbox.hi[2]) {
-    a_lo = std::min(a_lo, adr(F.qbox.lo));
-    a_hi = std::max(a_hi, adr(F.qbox.hi));
+  if (have_q) {
+    a_lo = std::min(a_lo, adr(hv.qreg.lo));
+    a_hi = std::max(a_hi, adr(hv.qreg.hi));
   }
+  a_lo = std::max(0L, a_lo - 2L * g.nyz);
+  a_hi = std::min((long)g.N - 1, a_hi + 2L * g.nyz);
   hv.w0 = (int)((a_lo >> 6) & ~255L);
   const int w_hi = (int)(a_hi >> 6);
   hv.nblocks = (w_hi - hv.w0) / 256 + 1;
@@ -1473,7 +1514,11 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     FDBG("k_pack");
     HIPCHK(hipStreamSynchronize(f->stream));
   }
-  if (nkept == 0) return FUELMI_OK;
+  if (nkept == 0) {
+    f->dirty_all = false;
+    f->seen_epoch = m->occ_epoch;
+    return FUELMI_OK;
+  }
   u32 ncl = nkept, ncells = n_out;
   std::vector<std::vector<float>> filtered;
   const bool split_mode = f->cfg.split != 0;
@@ -1534,6 +1579,8 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     }
   }
   *n_new = (int)f->tmp.size();
+  f->dirty_all = false;
+  f->seen_epoch = m->occ_epoch;
   return FUELMI_OK;
 }
 
@@ -1553,6 +1600,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   f->dormant.clear();
   f->tmp.clear();
   f->removed_ids.clear();
+  f->dirty_all = true;
   k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
   FDBG("k_zero_words");
   return FUELMI_OK;

@@ -29,6 +29,11 @@ struct FVar {
   int nwords;  // words processed (multiple of 256)
   int nblocks; // nwords / 256
   int pad;
+  // Q0 cells can only exist inside the region touched since the last search (scan box, boxes of the
+  // clusters just dropped; the whole exploration box after untracked changes): the CCL tiles cover
+  // this part of F.qbox only
+  Box3 qreg;
+  int nty, ntiles;
 };
 
 struct FArgs {
@@ -142,6 +147,9 @@ struct fuelmi_frontier {
   bool pending = false, search_empty = false;
   std::unique_ptr<StageScope> scope;
   std::vector<int> slot2rank;
+  bool dirty_all = true;    // flags / occupancy changed outside the updated-box bookkeeping
+  unsigned seen_epoch = 0;  // map->occ_epoch at the last completed search
+  int rm_lo[3], rm_hi[3];   // index box of the clusters removed by the current search (rm_lo > rm_hi: none)
   fuelmi_viewpoint_cfg vcfg;
   bool have_vcfg = false;
   struct SplitScratch* split = nullptr;  // device buffers of the split stage (frontier_split.hip)

@@ -83,7 +83,10 @@ struct fuelmi_map {
   unsigned char* flag_rayend = nullptr;  // flag_rayend_                      1 B/voxel
   u32* ray_owner = nullptr;     // per-frame end-voxel owner (point index)     4 B/voxel
   Plane hit_bits, miss_bits;    // per-frame touched voxels
+  u64* ins_partial = nullptr;   // per-block end-point boxes of the fusion's classify kernel
+  size_t ins_partial_cap = 0;
   signed char raycast_num = 0;
+  unsigned occ_epoch = 0;  // bumped by occupancy changes that bypass the updated box (upload, resetBuffer)
 
   // host-side bookkeeping the reference keeps in MapData
   Box3 local_bound;

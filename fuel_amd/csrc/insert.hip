@@ -26,7 +26,9 @@ struct InsertArgs {
   u64* miss;
   u32* owner;
   unsigned char* flag_rayend;
-  u64* bbox;  // [6] sortable-encoded min xyz, max xyz
+  u64* bbox;     // [6] sortable-encoded min xyz, max xyz
+  u64* partial;  // [classify blocks][6] per-block boxes, folded by block 0 of k_insert_raycast
+  int nblk;      // classify blocks
 };
 
 __device__ __forceinline__ u64 enc_f64(double d) {
@@ -104,7 +106,7 @@ __device__ __forceinline__ long pos_adr(const Geo& g, const double p[3]) {
   return (long)id[0] * g.nyz + (long)id[1] * g.nz + id[2];
 }
 
-__global__ void __launch_bounds__(1024) k_insert_classify(Geo g, InsertArgs A) {
+__global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   double pt[3];
   int flag = 0;
@@ -122,8 +124,8 @@ __global__ void __launch_bounds__(1024) k_insert_classify(Geo g, InsertArgs A) {
       ok = false;
   }
   // bounding box of the kept end points (update_min/max, :303-306): wave reduce, block reduce in LDS,
-  // then one set of atomics per 1024-point block (per-wave atomics on these six words were the
-  // kernel: ~1200 same-address operations per frame)
+  // one record per block; the next kernel folds the records (per-wave atomics on six words were
+  // ~1200 same-address operations per frame and made this the longest kernel of the fusion)
   __shared__ u64 s_lo[16][3], s_hi[16][3];
   u64 lo[3], hi[3];
   for (int k = 0; k < 3; ++k) {
@@ -144,10 +146,8 @@ __global__ void __launch_bounds__(1024) k_insert_classify(Geo g, InsertArgs A) {
     const int k = threadIdx.x;
     u64 l = ~0ull, h = 0ull;
     for (int w = 0; w < nwave; ++w) l = min(l, s_lo[w][k]), h = max(h, s_hi[w][k]);
-    if (l != ~0ull) {
-      atomicMin(&A.bbox[k], l);
-      atomicMax(&A.bbox[3 + k], h);
-    }
+    A.partial[(size_t)blockIdx.x * 6 + k] = l;
+    A.partial[(size_t)blockIdx.x * 6 + 3 + k] = h;
   }
 }
 
@@ -165,17 +165,58 @@ __device__ __forceinline__ double rc_intbound(double s, double ds) {
 }
 
 __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= A.n) return;
-  double pt[3];
-  int flag = 0;
-  if (!classify(g, A, i, pt, flag)) return;
-  long a = pos_adr(g, pt);
-  if (a < 0 || a >= g.N) return;
-  if (A.owner[a] != (u32)i) return;  // not the first point of this end voxel
-  A.owner[a] = 0xFFFFFFFFu;          // leave the owner table clean for the next frame
-  if ((signed char)A.flag_rayend[a] == A.num) return;
-  A.flag_rayend[a] = (unsigned char)A.num;
+  if (blockIdx.x == 0) {  // fold the per-block boxes of k_insert_classify (all 256 threads: a serial
+                          // loop over ~300 records by six threads cost 40 us of dependent loads)
+    __shared__ u64 s_red[4][6];
+    u64 v[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+    for (int b = threadIdx.x; b < A.nblk; b += 256)
+      for (int k = 0; k < 6; ++k) {
+        const u64 p = A.partial[(size_t)b * 6 + k];
+        v[k] = k < 3 ? min(v[k], p) : max(v[k], p);
+      }
+    for (int k = 0; k < 6; ++k)
+      for (int off = 32; off > 0; off >>= 1) {
+        const u64 t = __shfl_down(v[k], off, 64);
+        v[k] = k < 3 ? min(v[k], t) : max(v[k], t);
+      }
+    if ((threadIdx.x & 63) == 0)
+      for (int k = 0; k < 6; ++k) s_red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int k = threadIdx.x;
+      u64 r = A.bbox[k];
+      for (int w = 0; w < 4; ++w) r = k < 3 ? min(r, s_red[w][k]) : max(r, s_red[w][k]);
+      A.bbox[k] = r;
+    }
+  }
+  // Only the first point of every end voxel casts a ray (~1 point in 4): compact the casters of the
+  // block into LDS first, so that the walk runs with full waves and the other waves retire at once
+  __shared__ double s_pt[256][3];
+  __shared__ u32 s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0u;
+  __syncthreads();
+  {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double p0[3];
+    int flag = 0;
+    bool cast = i < A.n && classify(g, A, i, p0, flag);
+    if (cast) {
+      const long a = pos_adr(g, p0);
+      cast = a >= 0 && a < g.N && A.owner[a] == (u32)i;  // the first point of this end voxel
+      if (cast) {
+        A.owner[a] = 0xFFFFFFFFu;  // leave the owner table clean for the next frame
+        cast = (signed char)A.flag_rayend[a] != A.num;
+        if (cast) A.flag_rayend[a] = (unsigned char)A.num;
+      }
+    }
+    if (cast) {
+      const u32 slot = atomicAdd(&s_cnt, 1u);
+      s_pt[slot][0] = p0[0], s_pt[slot][1] = p0[1], s_pt[slot][2] = p0[2];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= s_cnt) return;
+  const double pt[3] = {s_pt[threadIdx.x][0], s_pt[threadIdx.x][1], s_pt[threadIdx.x][2]};
 
   // RayCaster::input(pt_w, camera_pos) (raycast.cpp:329-372)
   double s[3], e[3];
@@ -273,6 +314,16 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
     h_bbox[3 + k] = h_bbox[k];
   }
   HIPCHK(hipMemcpyAsync(d_bbox, h_bbox, 6 * sizeof(u64), hipMemcpyHostToDevice, m->stream));
+  {
+    const size_t need = (size_t)((n + 255) / 256) * 6;
+    if (need > m->ins_partial_cap) {
+      if (m->ins_partial) HIPCHK(hipFree(m->ins_partial));
+      m->ins_partial = nullptr;
+      m->ins_partial_cap = 0;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->ins_partial), (need + 64) * sizeof(u64)));
+      m->ins_partial_cap = need + 64;
+    }
+  }
   InsertArgs A;
   A.pts = d_pts;
   A.stride = stride;
@@ -286,7 +337,9 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   A.flag_rayend = m->flag_rayend;
   A.bbox = d_bbox;
   int nb = (n + 255) / 256;
-  k_insert_classify<<<(n + 1023) / 1024, 1024, 0, m->stream>>>(g, A);
+  A.nblk = nb;
+  A.partial = m->ins_partial;
+  k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
   k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, m->stream));
@@ -413,7 +466,9 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   const int nslots = nu * nvv;
   *nslots_out = nslots;
   const size_t img_bytes = ((size_t)rows * cols * 2 + 255) & ~(size_t)255;
-  int rc = map_ensure_stage(m, 64 + img_bytes + (size_t)nslots * 16 + 256, 0);
+  // the caller's image is ordinary pageable memory (a cv::Mat): stage it through the map's pinned
+  // buffer so the upload is one DMA instead of the runtime's chunked pageable path
+  int rc = map_ensure_stage(m, 64 + img_bytes + (size_t)nslots * 16 + 256, (size_t)rows * cols * 2);
   if (rc) return rc;
   u64* d_head = reinterpret_cast<u64*>(m->d_stage);
   unsigned short* d_img = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(m->d_stage) + 256);
@@ -422,7 +477,9 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   *d_head_out = d_head;
   HIPCHK(hipMemsetAsync(d_head, 0, 64, m->stream));
   if (nslots == 0) return FUELMI_OK;
-  HIPCHK(hipMemcpyAsync(d_img, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
+  // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
+  memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
+  HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
   DepthArgs D;
   D.img = d_img;
   D.rows = rows, D.cols = cols, D.margin = margin, D.skip = skip, D.nu = nu, D.nslots = nslots;

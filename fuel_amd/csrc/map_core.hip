@@ -379,7 +379,7 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   Plane* planes[] = {&m->occ_bits, &m->unk_bits, &m->infl_bits, &m->tmp_bits, &m->hit_bits, &m->miss_bits};
   for (Plane* p : planes)
     if (p->base) (void)hipFree(p->base);
-  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage};
+  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -399,6 +399,7 @@ extern "C" int fuelmi_map_get_info(const fuelmi_map* m, fuelmi_map_info* info) {
 }
 
 extern "C" int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ) {
+  if (m) ++m->occ_epoch;
   ARGCHK(m && occ);
   HIPCHK(hipSetDevice(m->device));
   const Geo& g = m->g;
@@ -452,6 +453,7 @@ extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
 }
 
 extern "C" int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]) {
+  if (m) ++m->occ_epoch;
   ARGCHK(m && min_pos && max_pos);
   HIPCHK(hipSetDevice(m->device));
   const Geo& g = m->g;
