@@ -730,3 +730,53 @@ def test_bspline_device_optimizer_against_oracle_lbfgs(fa):
     x1, c1, e1 = opt.deviceProblem(pb1).optimize(max_eval=300)
     assert np.array_equal(x1[0], xg[3]) and c1[0] == cg[3] and e1[0] == eg[3]
     gm.close()
+
+
+@pytest.mark.gpu
+def test_frontier_regrows_dropped_clusters_beyond_the_scan_box(fa):
+    """The search only processes the region that can hold new cells (scan box + boxes of the clusters it
+    just dropped).  A large cluster clipped by a small update is dropped as a whole and must be re-grown
+    over its full extent, far outside the scan box; untracked changes (uploadOccupancy) reopen the whole
+    box.  Frame-by-frame against the oracle, flags included."""
+    map_size = (24.0, 24.0, 4.0)
+    box = ((-11.0, -11.0, 0.0), (11.0, 11.0, 2.2))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    truth = om.fixture_world(9, 40)
+    of = fo.OracleFrontier(om, 40)
+    gf = fa.FrontierFinder(gm, cluster_min=40)
+    outside = 0
+    for k in range(40):
+        pose = om.fixture_camera(truth, 3, k, 40, 0.75)
+        pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+        om.input_points(pts, pose[:3])
+        gm.inputPointCloud(pts, pose[:3])
+        ub = om.get_updated_box(reset=False)
+        before = [(of.cluster_info(1, c)[1], of.cluster_info(1, c)[2]) for c in range(len(of.clusters(1)))]
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g
+        for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+            assert np.array_equal(a, b)
+        assert np.array_equal(of.flags, gf.flags())
+        rid = list(of.removed_ids())
+        assert rid == list(gf.removedIds())
+        # did a dropped cluster reach more than 1.5 m beyond the scan box (updated box +- 1 m)?
+        alive = list(range(len(before)))
+        for r in rid:
+            lo, hi = before[alive.pop(r)]
+            if (lo < np.array(ub[0]) - 2.5).any() or (hi > np.array(ub[1]) + 2.5).any():
+                outside += 1
+        of.commit()
+        gf.commit()
+    assert outside >= 3
+    # untracked change: the whole occupancy is replaced behind the finder's back
+    gm.uploadOccupancy(om.occ)
+    of2 = fo.OracleFrontier(om, 40)
+    gf.reset()
+    om.set_updated_box((-1.0, -1.0, 0.5), (1.0, 1.0, 1.5))
+    gm.setUpdatedBox((-1.0, -1.0, 0.5), (1.0, 1.0, 1.5))
+    assert of2.search() == gf.searchFrontiers()
+    for a, b in zip(sorted_clusters(of2.clusters(0)), gf.clusters(0)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(of2.flags, gf.flags())
+    gm.close()
