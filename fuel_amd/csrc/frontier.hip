@@ -1031,28 +1031,6 @@ static inline int fblocks(long n, int t, int cap = 1 << 16) {
   return (int)std::max(1L, std::min((long)cap, b));
 }
 
-[[maybe_unused]] static void cluster_info(const fuelmi_map* m, HCluster& c) {
-  // computeFrontierInfo (:374-390): mean and AABB of the voxel centres
-  const Geo& g = m->g;
-  for (int k = 0; k < 3; ++k) c.avg[k] = 0.0;
-  bool first = true;
-  for (int a : c.cells) {
-    int x = a / g.nyz, r = a - x * g.nyz, y = r / g.nz, z = r - y * g.nz;
-    const int id[3] = {x, y, z};
-    for (int k = 0; k < 3; ++k) {
-      double p = (id[k] + 0.5) * g.res + g.org[k];
-      c.avg[k] += p;
-      if (first) {
-        c.bmin[k] = c.bmax[k] = p;
-      } else {
-        c.bmin[k] = std::min(c.bmin[k], p);
-        c.bmax[k] = std::max(c.bmax[k], p);
-      }
-    }
-    first = false;
-  }
-  for (int k = 0; k < 3; ++k) c.avg[k] /= double(c.cells.size());
-}
 
 static bool have_overlap(const double* min1, const double* max1, const double* min2, const double* max2) {
   // haveOverlap (:353-363)
@@ -1132,7 +1110,6 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   FArgs& F = f->F;
   memset(&F, 0, sizeof(F));
   size_t nwords = ((size_t)g.W + 255) / 256 * 256 + 256;
-  f->nwords_alloc = nwords;
   F.cap_q = (u32)std::max<size_t>(1u << 20, (size_t)g.N / 8);
   F.cap_s = (u32)std::max<size_t>(1u << 18, (size_t)g.N / 32);
   F.cap_kept = 1u << 16;
@@ -1209,7 +1186,6 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   if (qx > 0 && qy > 0 && F.qbox.lo[2] <= F.qbox.hi[2]) {
     const int TX = f->TX, TY = f->TY;
     const int ntx = (qx + TX - 1) / TX, nty = (qy + TY - 1) / TY;
-    f->ccl_nty = nty;
     f->ccl_tiles = ntx * nty;
     f->ccl_lds = ((size_t)TX * TY * g.nz + 2 * (size_t)TX * TY * ((g.nz + 31) / 32) + 2 * (size_t)TX) * sizeof(u32);
     if (f->ccl_lds > 160 * 1024) {
@@ -1493,7 +1469,6 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     return FUELMI_ELIMIT;
   }
   const u32 nq = counts[0], nkept = counts[3], n_out = counts[5];
-  f->last_nb = (int)((nq + MS_CH - 1) / MS_CH);
   f->last_nkept = (int)nkept;
   if (nkept > 256 && f->npass < 2) {
     // more than 256 clusters but only one radix pass was enqueued: run the high-digit pass now

@@ -127,7 +127,6 @@ struct fuelmi_frontier {
   int iz_min = 0;
   Plane flag, qb, sb;
   FArgs F;
-  size_t nwords_alloc = 0;
   std::vector<void*> allocs;
   std::list<HCluster> frontiers, dormant, tmp;
   std::vector<int> removed_ids;
@@ -137,16 +136,14 @@ struct fuelmi_frontier {
   size_t d_stage_bytes = 0;
   void* h_pin = nullptr;  // pinned result staging
   size_t pin_bytes = 0;
-  int last_nb = 0;  // multisplit blocks the previous search needed (launch estimate)
   int last_nkept = 0, nb_launch = 0, npass = 1;
   FVar* h_var = nullptr;  // pinned per-search arguments
   FVar* d_var = nullptr;
-  int TX = 1, TY = 16, ccl_tiles = 0, ccl_nty = 0;
+  int TX = 1, TY = 16, ccl_tiles = 0;
   size_t ccl_lds = 0;
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
   bool pending = false, search_empty = false;
   std::unique_ptr<StageScope> scope;
-  std::vector<int> slot2rank;
   bool dirty_all = true;    // flags / occupancy changed outside the updated-box bookkeeping
   unsigned seen_epoch = 0;  // map->occ_epoch at the last completed search
   int rm_lo[3], rm_hi[3];   // index box of the clusters removed by the current search (rm_lo > rm_hi: none)
