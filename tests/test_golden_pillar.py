@@ -1,0 +1,92 @@
+"""BASELINE config #1 ("plumbing"): the reference's own pillar.pcd world pushed through the REAL reference
+code (tests/golden/make_pillar_golden.py, run where /root/reference exists) and stored as
+tests/golden/pillar_plumbing.npz.  Replayed here by the CPU oracle (everywhere) and by libfuelmi through
+the C-ABI (GPU): depth projection -> fusion -> inflation -> ESDF -> frontier search with splitting ->
+viewpoints -> B-spline cost/gradient."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_pillar_golden as mk  # noqa: E402
+from oracle import fuel_oracle as fo  # noqa: E402
+
+FIX = os.path.join(HERE, "golden", "pillar_plumbing.npz")
+
+
+def load():
+    z = np.load(FIX)
+    frames = [(z["depth%d" % i], z["pos%d" % i], z["quat%d" % i]) for i in range(len(mk.POSES))]
+    return z, frames, z["ctrl"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_oracle_reproduces_the_reference_fixture():
+    z, frames, ctrl = load()
+    out = mk.run("oracle", frames, ctrl)
+    for k, b in out.items():
+        a = z[k]
+        if a.dtype.kind in "US":
+            assert str(a) == str(b), k
+        elif k in ("bspline_cost", "bspline_grad"):
+            assert np.allclose(a, b, rtol=1e-12, atol=1e-12), k
+        else:
+            assert np.array_equal(a, b), k
+    assert int(z["n_clusters"]) == 18 and int(z["known_voxels"]) > 100000
+
+
+@pytest.mark.gpu
+def test_device_reproduces_the_reference_fixture():
+    import fuel_amd as fa
+    z, frames, ctrl = load()
+    gm = fa.SDFMap(mk.MAP_SIZE, *mk.BOX)
+    dcfg = mk.depth_cfg(gm.depthConfig)
+    for k, (img, pos, q) in enumerate(frames):
+        assert gm.inputDepthImage(img, pos, q, dcfg) == int(z["points_per_frame"][k])
+        gm.clearAndInflateLocalMap()
+    assert np.array_equal(np.concatenate(gm.getUpdatedBox()), z["updated_box"])
+    nv = gm.nvox
+    gm.setLocalBound((0, 0, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1))
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    h = gm.syncHost(occupancy=True, inflate=True, distance=True)
+    assert sha(h["occupancy"]) == str(z["occupancy_sha256"])  # f64 log-odds, bit for bit
+    assert sha(h["inflate"]) == str(z["inflate_sha256"])
+    assert np.abs(np.minimum(h["distance"].reshape(-1)[::97], 1e6) - z["distance_sample"]).max() <= 1e-4
+    ff = fa.FrontierFinder(gm, cluster_min=mk.CLUSTER_MIN, cluster_size_xy=mk.CLUSTER_XY, down_sample=3, split=True)
+    ff.setViewpointConfig(ff.viewpointConfig())
+    assert ff.searchFrontiers() == int(z["n_clusters"])
+    off = z["cluster_offsets"]
+    for k, c in enumerate(ff.clusters(0)):  # the reference's pieces, in its order (cells as sorted addresses)
+        assert np.array_equal(c, z["cluster_cells"][off[k]:off[k + 1]])
+    na, nd = ff.computeFrontiersToVisit()
+    assert (na, nd) == (int(z["n_active"]), int(z["n_dormant"]))
+    # viewpoints: the reference feeds PCL its cells in BFS order, the device in address order -- the last
+    # float bit of a leaf centroid can move a ray's start voxel, so coverage counts may differ
+    # by a cell or two; the best viewpoint of every cluster is the same sample position
+    cnt = np.array([len(ff.viewpoints(1, k)[1]) for k in range(na)])
+    assert np.abs(cnt - z["viewpoint_counts"]).max() <= 2
+    best = np.array([ff.viewpoints(1, k)[1][0] for k in range(na)])
+    assert np.abs(best - z["best_visib"]).max() <= 3
+    dt = 0.25
+    st = np.zeros((1, 3, 3))
+    en = np.zeros((1, 3, 3))
+    st[0, 0] = (ctrl[0] + 4 * ctrl[1] + ctrl[2]) / 6
+    en[0, 0] = (ctrl[-1] + 4 * ctrl[-2] + ctrl[-3]) / 6
+    x = np.concatenate([ctrl.reshape(-1), [dt]])[None, :]
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    pb = fa.BsplineBatchProblem(x, len(ctrl), fa.NORMAL_PHASE | fa.MINTIME, np.array([fo.bspline_pt_dist(ctrl)]), st, en,
+                                3, 3, dt)
+    c, g = opt.combineCost(pb)
+    assert abs(c[0] - float(z["bspline_cost"])) <= 1e-6 * max(1.0, abs(float(z["bspline_cost"])))
+    assert np.abs(g[0] - z["bspline_grad"]).max() <= 1e-4
+    ff.close()
+    gm.close()
