@@ -1,10 +1,12 @@
-// active_perception/frontier_finder.h -- drop-in replacement of the grid part of the reference's
-// FrontierFinder (fuel_planner/active_perception/include/active_perception/frontier_finder.h:25-80).
-// searchFrontiers() runs the scan + clustering on the GPU (libfuelmi) and fills the same
-// Frontier records (cells_, average_, box_min_, box_max_).  Viewpoint sampling, the cost matrix and
-// splitLargeFrontiers are SURVEY 8(f) "next" rows: computeFrontiersToVisit() here promotes every
-// new cluster to frontiers_ without sampling viewpoints, and the viewpoint/tour queries are not
-// provided by this header.
+// active_perception/frontier_finder.h -- drop-in for the reference header of the same name
+// (fuel_planner/active_perception/include/active_perception/frontier_finder.h:25-80).
+//
+// Behind the same records (Frontier, Viewpoint) and calls: searchFrontiers() runs scan, clustering,
+// splitLargeFrontiers and the down-sampling on the device; computeFrontiersToVisit() samples and scores
+// the viewpoints there; isFrontierCovered() checks coverage there.  The cost-matrix / tour group
+// (updateFrontierCostMatrix, getFullCostMatrix, getPathForTour, setNextFrontier: A* searches through
+// ViewNode) is not part of this library -- a maintainer keeps the reference's code for it on top of
+// frontiers_ / viewpoints_.
 #ifndef _FRONTIER_FINDER_H_
 #define _FRONTIER_FINDER_H_
 
@@ -27,59 +29,63 @@ using std::vector;
 namespace fast_planner {
 class EDTEnvironment;
 
+// one sampled viewpoint of a frontier cluster: where to hover, where to look, how many of the cluster's
+// down-sampled cells it sees
 struct Viewpoint {
   Vector3d pos_;
   double yaw_;
   int visib_num_;
 };
 
+// a frontier cluster as the exploration planner consumes it
 struct Frontier {
-  vector<Vector3d> cells_;           // voxel centres, ascending voxel address (reference: BFS order)
-  vector<Vector3d> filtered_cells_;  // VoxelGrid centroids (filled when frontier/cluster_size_xy and down_sample are set)
-  Vector3d average_;
   int id_;
-  vector<Viewpoint> viewpoints_;
-  Vector3d box_min_, box_max_;
-  list<vector<Vector3d>> paths_;
+  Vector3d average_, box_min_, box_max_;  // mean and AABB of the cells (voxel centres)
+  vector<Vector3d> cells_;                // voxel centres, ascending voxel address (reference: BFS order)
+  vector<Vector3d> filtered_cells_;       // VoxelGrid centroids (needs frontier/cluster_size_xy + down_sample)
+  vector<Viewpoint> viewpoints_;          // best coverage first (needs the candidate_* / perception_utils params)
+  list<vector<Vector3d>> paths_;          // filled by the cost-matrix code (not part of this library)
   list<double> costs_;
 };
 
 class FrontierFinder {
 public:
-  FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& nh);
+  FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& node);
   ~FrontierFinder();
 
+  // per plan cycle: find / update the clusters, then sample viewpoints for the new ones
   void searchFrontiers();
   void computeFrontiersToVisit();
+  bool isFrontierCovered();
 
+  // cluster queries
   void getFrontiers(vector<vector<Vector3d>>& clusters);
   void getDormantFrontiers(vector<vector<Vector3d>>& clusters);
   void getFrontierBoxes(vector<pair<Vector3d, Vector3d>>& boxes);
-  // Get viewpoint with highest coverage for each frontier
+
+  // viewpoint queries: the best viewpoint of every active cluster that is not too close to cur_pos, and
+  // the few best of selected clusters
   void getTopViewpointsInfo(const Vector3d& cur_pos, vector<Vector3d>& points, vector<double>& yaws,
                             vector<Vector3d>& averages);
-  // Get several viewpoints for a subset of frontiers
   void getViewpointsInfo(const Vector3d& cur_pos, const vector<int>& ids, const int& view_num,
                          const double& max_decay, vector<vector<Vector3d>>& points,
                          vector<vector<double>>& yaws);
-  bool isFrontierCovered();
   void wrapYaw(double& yaw);
 
-  // additions: clusters found by the last searchFrontiers() and ids removed by it
+  // additions: clusters found by the last searchFrontiers() and the list positions it removed
   const list<Frontier>& newFrontiers() const { return tmp_frontiers_; }
   const vector<int>& removedIds() const { return removed_ids_; }
 
 private:
   void pull(int which, list<Frontier>& out);
 
-  shared_ptr<EDTEnvironment> edt_env_;
   fuelmi_frontier* dev_;
-  list<Frontier> frontiers_, dormant_frontiers_, tmp_frontiers_;
-  vector<int> removed_ids_;
+  shared_ptr<EDTEnvironment> edt_env_;
   int cluster_min_;
-  double resolution_;
-  double min_candidate_dist_;
+  double resolution_, min_candidate_dist_;
   bool have_viewpoints_;  // frontier/candidate_* and perception_utils/* were all given
+  vector<int> removed_ids_;
+  list<Frontier> frontiers_, dormant_frontiers_, tmp_frontiers_;
 };
 }  // namespace fast_planner
 #endif

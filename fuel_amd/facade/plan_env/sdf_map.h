@@ -35,175 +35,179 @@ class Mat;
 class RayCaster;
 
 namespace fast_planner {
-struct MapParam;
 struct MapData;
+struct MapParam;
 class MapROS;
+
+// shorthand for the Eigen types of the reference's signatures (aliases: the mangled names are unchanged)
+typedef Eigen::Vector3d V3d;
+typedef Eigen::Vector3i V3i;
 
 class SDFMap {
 public:
+  typedef std::shared_ptr<SDFMap> Ptr;
+  enum OCCUPANCY { UNKNOWN, FREE, OCCUPIED };
+
   SDFMap();
   ~SDFMap();
 
-  enum OCCUPANCY { UNKNOWN, FREE, OCCUPIED };
-
-  void initMap(ros::NodeHandle& nh);
-  void inputPointCloud(const pcl::PointCloud<pcl::PointXYZ>& points, const int& point_num,
-                       const Eigen::Vector3d& camera_pos);
-
-  void posToIndex(const Eigen::Vector3d& pos, Eigen::Vector3i& id);
-  void indexToPos(const Eigen::Vector3i& id, Eigen::Vector3d& pos);
-  void boundIndex(Eigen::Vector3i& id);
-  int toAddress(const Eigen::Vector3i& id);
-  int toAddress(const int& x, const int& y, const int& z);
-  bool isInMap(const Eigen::Vector3d& pos);
-  bool isInMap(const Eigen::Vector3i& idx);
-  bool isInBox(const Eigen::Vector3i& id);
-  bool isInBox(const Eigen::Vector3d& pos);
-  void boundBox(Eigen::Vector3d& low, Eigen::Vector3d& up);
-  int getOccupancy(const Eigen::Vector3d& pos);
-  int getOccupancy(const Eigen::Vector3i& id);
-  void setOccupied(const Eigen::Vector3d& pos, const int& occ = 1);
-  int getInflateOccupancy(const Eigen::Vector3d& pos);
-  int getInflateOccupancy(const Eigen::Vector3i& id);
-  double getDistance(const Eigen::Vector3d& pos);
-  double getDistance(const Eigen::Vector3i& id);
-  double getDistWithGrad(const Eigen::Vector3d& pos, Eigen::Vector3d& grad);
+  // -- life cycle and the mutators MapROS / the planners call (device work) --
+  void initMap(ros::NodeHandle& node);
+  void inputPointCloud(const pcl::PointCloud<pcl::PointXYZ>& cloud, const int& n_points, const V3d& cam);
   void updateESDF3d();
   void resetBuffer();
-  void resetBuffer(const Eigen::Vector3d& min, const Eigen::Vector3d& max);
+  void resetBuffer(const V3d& lo, const V3d& hi);
+  void setOccupied(const V3d& where, const int& value = 1);
 
-  void getRegion(Eigen::Vector3d& ori, Eigen::Vector3d& size);
-  void getBox(Eigen::Vector3d& bmin, Eigen::Vector3d& bmax);
-  void getUpdatedBox(Eigen::Vector3d& bmin, Eigen::Vector3d& bmax, bool reset = false);
+  // -- queries answered by the device --
+  double getDistWithGrad(const V3d& where, V3d& gradient);
+
+  // -- map geometry --
   double getResolution();
   int getVoxelNum();
+  void getRegion(V3d& origin, V3d& extent);
+  void getBox(V3d& lo, V3d& hi);
+  void getUpdatedBox(V3d& lo, V3d& hi, bool reset = false);
 
-  // ---- additions of this implementation (not in the reference) ----
+  // -- inline helpers compiled into the callers (they read the host mirrors in MapData) --
+  int toAddress(const int& ix, const int& iy, const int& iz);
+  int toAddress(const V3i& cell);
+  void posToIndex(const V3d& where, V3i& cell);
+  void indexToPos(const V3i& cell, V3d& centre);
+  void boundIndex(V3i& cell);
+  void boundBox(V3d& lo, V3d& hi);
+  bool isInMap(const V3i& cell);
+  bool isInMap(const V3d& where);
+  bool isInBox(const V3i& cell);
+  bool isInBox(const V3d& where);
+  int getOccupancy(const V3i& cell);
+  int getOccupancy(const V3d& where);
+  int getInflateOccupancy(const V3i& cell);
+  int getInflateOccupancy(const V3d& where);
+  double getDistance(const V3i& cell);
+  double getDistance(const V3d& where);
+
+  // -- additions of this implementation (not in the reference) --
   // device handle for the FrontierFinder / BsplineOptimizer facades
   fuelmi_map* device() const { return dev_; }
   // which host mirrors the mutators keep coherent (default: all, as the reference's getters need)
   void setHostMirror(bool occupancy, bool inflate, bool distance);
-  // batched SDFMap::getDistWithGrad for n positions (xyz packed), one kernel launch
+  // batched getDistWithGrad for n positions (xyz packed), one kernel launch
   void getDistWithGradBatch(const double* pos_xyz, int n, double* dist, double* grad_xyz);
 
-private:
-  void clearAndInflateLocalMap();
-  void syncMirrors(const Eigen::Vector3i& bmin, const Eigen::Vector3i& bmax, bool occ, bool infl, bool dist);
-  void pullBounds();
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 
-  unique_ptr<MapParam> mp_;
-  unique_ptr<MapData> md_;
+private:
+  friend MapROS;  // calls clearAndInflateLocalMap() and reads mp_ / md_ like in the reference
+
+  void clearAndInflateLocalMap();
+  void pullBounds();
+  void syncMirrors(const V3i& lo, const V3i& hi, bool occ, bool infl, bool dist);
+
   fuelmi_map* dev_;
   bool mirror_occ_, mirror_infl_, mirror_dist_;
+  unique_ptr<MapData> md_;
+  unique_ptr<MapParam> mp_;
+};
 
-  friend MapROS;
+// Host copies of what the callers' inline getters and MapROS read.  Field NAMES and element types are
+// the reference's (sdf_map.h:86-125); everything else of its MapData lives on the device.
+struct MapData {
+  std::vector<char> occupancy_buffer_inflate_;
+  std::vector<double> occupancy_buffer_;
+  std::vector<double> distance_buffer_;
+  bool reset_updated_box_;
+  V3d update_min_, update_max_;
+  V3i local_bound_min_, local_bound_max_;
 
-public:
-  typedef std::shared_ptr<SDFMap> Ptr;
   EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 };
 
 struct MapParam {
-  // map properties
-  Eigen::Vector3d map_origin_, map_size_;
-  Eigen::Vector3d map_min_boundary_, map_max_boundary_;
-  Eigen::Vector3i map_voxel_num_;
+  // grid geometry
   double resolution_, resolution_inv_;
-  double obstacles_inflation_;
-  double virtual_ceil_height_, ground_height_;
-  Eigen::Vector3i box_min_, box_max_;
-  Eigen::Vector3d box_mind_, box_maxd_;
-  double default_dist_;
-  bool optimistic_, signed_dist_;
-  // map fusion
+  V3i map_voxel_num_;
+  V3d map_origin_, map_size_, map_min_boundary_, map_max_boundary_;
+  double ground_height_, virtual_ceil_height_;
+  // exploration box, as indices and as positions
+  V3i box_min_, box_max_;
+  V3d box_mind_, box_maxd_;
+  // fusion
   double p_hit_, p_miss_, p_min_, p_max_, p_occ_;
   double prob_hit_log_, prob_miss_log_, clamp_min_log_, clamp_max_log_, min_occupancy_log_;
-  double max_ray_length_;
-  double local_bound_inflate_;
+  double max_ray_length_, local_bound_inflate_, unknown_flag_;
   int local_map_margin_;
-  double unknown_flag_;
+  // inflation / distance field
+  double obstacles_inflation_, default_dist_;
+  bool optimistic_, signed_dist_;
 };
 
-struct MapData {
-  // host mirrors of the device grid (same names and element types as the reference)
-  std::vector<double> occupancy_buffer_;
-  std::vector<char> occupancy_buffer_inflate_;
-  std::vector<double> distance_buffer_;
-  Eigen::Vector3i local_bound_min_, local_bound_max_;
-  Eigen::Vector3d update_min_, update_max_;
-  bool reset_updated_box_;
-
-  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
-};
-
-// ---- inline helpers: same arithmetic as the reference (sdf_map.h:127-237), own wording ----
-inline void SDFMap::posToIndex(const Eigen::Vector3d& pos, Eigen::Vector3i& id) {
-  for (int k = 0; k < 3; ++k) id(k) = (int)floor((pos(k) - mp_->map_origin_(k)) * mp_->resolution_inv_);
+// ---- inline helpers.  The arithmetic is the reference's (sdf_map.h:127-237: floor((p - origin) *
+// res_inv), centre = (i + 0.5) * res + origin, 1e-4 margins of isInMap, half-open index box, open
+// position box, the three-way occupancy thresholds); they read the host mirrors above. ----
+inline int SDFMap::toAddress(const int& ix, const int& iy, const int& iz) {
+  const V3i& n = mp_->map_voxel_num_;
+  return (ix * n(1) + iy) * n(2) + iz;
 }
-inline void SDFMap::indexToPos(const Eigen::Vector3i& id, Eigen::Vector3d& pos) {
-  for (int k = 0; k < 3; ++k) pos(k) = (id(k) + 0.5) * mp_->resolution_ + mp_->map_origin_(k);
+inline int SDFMap::toAddress(const V3i& cell) { return toAddress(cell(0), cell(1), cell(2)); }
+inline void SDFMap::posToIndex(const V3d& where, V3i& cell) {
+  for (int a = 0; a < 3; ++a) cell(a) = (int)floor((where(a) - mp_->map_origin_(a)) * mp_->resolution_inv_);
 }
-inline void SDFMap::boundIndex(Eigen::Vector3i& id) {
-  for (int k = 0; k < 3; ++k) id(k) = std::max(std::min(id(k), mp_->map_voxel_num_(k) - 1), 0);
+inline void SDFMap::indexToPos(const V3i& cell, V3d& centre) {
+  for (int a = 0; a < 3; ++a) centre(a) = (cell(a) + 0.5) * mp_->resolution_ + mp_->map_origin_(a);
 }
-inline int SDFMap::toAddress(const int& x, const int& y, const int& z) {
-  return (x * mp_->map_voxel_num_(1) + y) * mp_->map_voxel_num_(2) + z;
+inline void SDFMap::boundIndex(V3i& cell) {
+  for (int a = 0; a < 3; ++a) cell(a) = std::max(std::min(cell(a), mp_->map_voxel_num_(a) - 1), 0);
 }
-inline int SDFMap::toAddress(const Eigen::Vector3i& id) { return toAddress(id(0), id(1), id(2)); }
-inline bool SDFMap::isInMap(const Eigen::Vector3d& pos) {
-  for (int k = 0; k < 3; ++k)
-    if (pos(k) < mp_->map_min_boundary_(k) + 1e-4 || pos(k) > mp_->map_max_boundary_(k) - 1e-4) return false;
-  return true;
-}
-inline bool SDFMap::isInMap(const Eigen::Vector3i& idx) {
-  for (int k = 0; k < 3; ++k)
-    if (idx(k) < 0 || idx(k) > mp_->map_voxel_num_(k) - 1) return false;
-  return true;
-}
-inline bool SDFMap::isInBox(const Eigen::Vector3i& id) {
-  for (int k = 0; k < 3; ++k)
-    if (id(k) < mp_->box_min_(k) || id(k) >= mp_->box_max_(k)) return false;
-  return true;
-}
-inline bool SDFMap::isInBox(const Eigen::Vector3d& pos) {
-  for (int k = 0; k < 3; ++k)
-    if (pos(k) <= mp_->box_mind_(k) || pos(k) >= mp_->box_maxd_(k)) return false;
-  return true;
-}
-inline void SDFMap::boundBox(Eigen::Vector3d& low, Eigen::Vector3d& up) {
-  for (int k = 0; k < 3; ++k) {
-    low(k) = std::max(low(k), mp_->box_mind_(k));
-    up(k) = std::min(up(k), mp_->box_maxd_(k));
+inline void SDFMap::boundBox(V3d& lo, V3d& hi) {
+  for (int a = 0; a < 3; ++a) {
+    lo(a) = std::max(lo(a), mp_->box_mind_(a));
+    hi(a) = std::min(hi(a), mp_->box_maxd_(a));
   }
 }
-inline int SDFMap::getOccupancy(const Eigen::Vector3i& id) {
-  if (!isInMap(id)) return -1;
-  const double o = md_->occupancy_buffer_[toAddress(id)];
-  if (o < mp_->clamp_min_log_ - 1e-3) return UNKNOWN;
-  return o > mp_->min_occupancy_log_ ? OCCUPIED : FREE;
+inline bool SDFMap::isInMap(const V3i& cell) {
+  bool inside = true;
+  for (int a = 0; a < 3; ++a) inside = inside && cell(a) >= 0 && cell(a) <= mp_->map_voxel_num_(a) - 1;
+  return inside;
 }
-inline int SDFMap::getOccupancy(const Eigen::Vector3d& pos) {
-  Eigen::Vector3i id;
-  posToIndex(pos, id);
-  return getOccupancy(id);
+inline bool SDFMap::isInMap(const V3d& where) {
+  bool inside = true;
+  for (int a = 0; a < 3; ++a)
+    inside = inside && !(where(a) < mp_->map_min_boundary_(a) + 1e-4) && !(where(a) > mp_->map_max_boundary_(a) - 1e-4);
+  return inside;
 }
-inline int SDFMap::getInflateOccupancy(const Eigen::Vector3i& id) {
-  if (!isInMap(id)) return -1;
-  return int(md_->occupancy_buffer_inflate_[toAddress(id)]);
+inline bool SDFMap::isInBox(const V3i& cell) {
+  bool inside = true;
+  for (int a = 0; a < 3; ++a) inside = inside && cell(a) >= mp_->box_min_(a) && cell(a) < mp_->box_max_(a);
+  return inside;
 }
-inline int SDFMap::getInflateOccupancy(const Eigen::Vector3d& pos) {
-  Eigen::Vector3i id;
-  posToIndex(pos, id);
-  return getInflateOccupancy(id);
+inline bool SDFMap::isInBox(const V3d& where) {
+  bool inside = true;
+  for (int a = 0; a < 3; ++a) inside = inside && where(a) > mp_->box_mind_(a) && where(a) < mp_->box_maxd_(a);
+  return inside;
 }
-inline double SDFMap::getDistance(const Eigen::Vector3i& id) {
-  if (!isInMap(id)) return -1;
-  return md_->distance_buffer_[toAddress(id)];
+inline int SDFMap::getOccupancy(const V3i& cell) {
+  if (!isInMap(cell)) return -1;
+  const double logodds = md_->occupancy_buffer_[toAddress(cell)];
+  if (logodds < mp_->clamp_min_log_ - 1e-3) return UNKNOWN;
+  return logodds > mp_->min_occupancy_log_ ? OCCUPIED : FREE;
 }
-inline double SDFMap::getDistance(const Eigen::Vector3d& pos) {
-  Eigen::Vector3i id;
-  posToIndex(pos, id);
-  return getDistance(id);
+inline int SDFMap::getInflateOccupancy(const V3i& cell) {
+  return isInMap(cell) ? int(md_->occupancy_buffer_inflate_[toAddress(cell)]) : -1;
 }
+inline double SDFMap::getDistance(const V3i& cell) {
+  return isInMap(cell) ? md_->distance_buffer_[toAddress(cell)] : -1.0;
+}
+// position overloads: index of the voxel containing the position, then the cell version
+#define FUELMI_BY_POSITION(RET, NAME)          \
+  inline RET SDFMap::NAME(const V3d& where) {  \
+    V3i cell;                                  \
+    posToIndex(where, cell);                   \
+    return NAME(cell);                         \
+  }
+FUELMI_BY_POSITION(int, getOccupancy)
+FUELMI_BY_POSITION(int, getInflateOccupancy)
+FUELMI_BY_POSITION(double, getDistance)
+#undef FUELMI_BY_POSITION
 }  // namespace fast_planner
 #endif
