@@ -109,4 +109,40 @@ for img, pose, q in frames:
     tc.append(time.perf_counter() - t0)
 out["depth_frame_640x480_project_and_fuse"] = {"gpu_ms": float(np.median(tg[2:]) * 1e3),
                                                "cpu_oracle_ms": float(np.median(tc[2:]) * 1e3), "points": int(npts)}
+# ---- the complete exploration front end per planning cycle, as the facade drives it -----------------------
+# depth frame -> fusion -> inflation -> ESDF -> search incl. splitting -> viewpoints -> 64 full solves
+gm3 = fuel_amd.SDFMap(map_size, box[0], box[1], device=0)
+om3 = fo.OracleMap(map_size, box[0], box[1])
+gf3 = fuel_amd.FrontierFinder(gm3, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True)
+gf3.setViewpointConfig(gf3.viewpointConfig())
+of3 = fo.OracleFrontier(om3, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True, canonical_order=True)
+of3.set_viewpoint_cfg(fo.viewpoint_cfg())
+opt3 = fuel_amd.BsplineOptimizer()
+opt3.setEnvironment(gm3)
+dev3 = opt3.deviceProblem(fuel_amd.BsplineBatchProblem(x, ctrl.shape[1], cf, ptd, st, en, 3, 3, 0.175))
+tg3, tc3 = [], []
+for img, pose, q in frames:
+    t0 = time.perf_counter()
+    if gm3.inputDepthImage(img, pose[:3], q) > 0:
+        gm3.clearAndInflateLocalMap()
+        gm3.updateESDF3d()
+    gf3.searchFrontiers()
+    gf3.computeFrontiersToVisit()
+    dev3.optimize(max_eval=100)
+    gm3.synchronize()
+    tg3.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    pts = fo.project_depth(img, pose[:3], q)
+    if len(pts):
+        om3.input_points(pts, pose[:3])
+        om3.inflate_local()
+        om3.update_esdf()
+    of3.search()
+    of3.compute_to_visit()
+    for c in range(4):  # bounded sample of the 64 solves
+        fo.bspline_optimize(om3, x[c], ctrl.shape[1], cf, ptd[c], st[c], en[c], 3, 3, 0.175, max_eval=100)
+    tc3.append(time.perf_counter() - t0)
+out["full_front_end_cycle"] = {"gpu_ms": float(np.median(tg3[2:]) * 1e3),
+                               "cpu_oracle_ms_with_4_of_64_solves": float(np.median(tc3[2:]) * 1e3),
+                               "active_frontiers_gpu": len(gf3.clusters(1)), "active_frontiers_cpu": len(of3.clusters(1))}
 print(json.dumps(out))
