@@ -780,3 +780,38 @@ def test_frontier_regrows_dropped_clusters_beyond_the_scan_box(fa):
         assert np.array_equal(a, b)
     assert np.array_equal(of2.flags, gf.flags())
     gm.close()
+
+
+@pytest.mark.gpu
+def test_error_paths_of_the_front_end_calls(fa):
+    """Misuse is reported through the status code / FuelmiError, never by a crash or a silent fallback."""
+    from fuel_amd._lib import FuelmiError
+    gm = fa.SDFMap((6.0, 6.0, 3.0))
+    gf = fa.FrontierFinder(gm, cluster_min=10)                      # split off: no filtered cells
+    with pytest.raises(FuelmiError):
+        gf.computeFrontiersToVisit()                                # no viewpoint configuration yet
+    with pytest.raises(FuelmiError):
+        gf.setViewpointConfig(gf.viewpointConfig(rnum=0))           # invalid configuration
+    gf.setViewpointConfig(gf.viewpointConfig())
+    with pytest.raises(FuelmiError):
+        gf.searchFrontiersEnd()                                     # no matching _begin
+    assert gf.isFrontierCovered() is False                          # nothing to cover yet
+    with pytest.raises(FuelmiError):
+        gm.inputDepthImage(np.zeros((8, 8), np.uint16), (0, 0, 1), (1, 0, 0, 0), gm.depthConfig(skip=0))
+    # a frame from outside the map and an all-too-near frame are ignored, not errors
+    assert gm.inputDepthImage(np.full((48, 64), 1500, np.uint16), (100.0, 0.0, 1.0), (1, 0, 0, 0)) == 0
+    assert gm.inputDepthImage(np.full((48, 64), 50, np.uint16), (0.0, 0.0, 1.0), (1, 0, 0, 0)) == 0
+    ctrl = np.zeros((1, 8, 3))
+    ctrl[0, :, 0] = np.linspace(-1, 1, 8)
+    x = np.concatenate([ctrl.reshape(1, -1), [[0.2]]], axis=1)
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    pb = fa.BsplineBatchProblem(x, 8, fa.NORMAL_PHASE | fa.MINTIME, np.array([0.25]), np.zeros((1, 3, 3)),
+                                np.zeros((1, 3, 3)), 3, 3, 0.2)
+    dev = opt.deviceProblem(pb)
+    with pytest.raises(FuelmiError):
+        dev.optimize(max_eval=0)
+    xo, co, ev = dev.optimize(max_eval=1)  # the cap is honoured down to a single evaluation
+    assert ev[0] == 1 and np.isfinite(co[0])
+    gf.close()
+    gm.close()
