@@ -389,7 +389,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
-            key = {"esdf_zy": "k_esdf_zy4<0>", "esdf_x": "k_esdf_x4<0>", "inflate": "k_inflate",
+            key = {"esdf_zy": "k_esdf_zy4<0>", "esdf_x": "k_esdf_x4<0>", "inflate": "k_inflate_yz",
                    "bspline": "k_bspline_cost_grad"}[dominant]
             if args.workload == "G400":
                 hit = [v for k, v in pmc.items() if k.endswith(key)]

@@ -78,6 +78,7 @@ struct fuelmi_map {
   Plane unk_bits;               // occ < clamp_min_log - 1e-3
   Plane infl_bits;              // occupancy_buffer_inflate_ == 1
   Plane tmp_bits;               // scratch plane (occ & box)
+  Plane tmp2_bits;              // scratch plane (y/z-dilated sources of the inflation)
   float* dist = nullptr;        // distance_buffer_ as f32                     4 B/voxel
   u32* esdf_tmp = nullptr;      // y-pass result (squared voxel units)         4 B/voxel
   unsigned char* flag_rayend = nullptr;  // flag_rayend_                      1 B/voxel

@@ -117,24 +117,33 @@ k_box_and(Geo g, Box3 b, const u64* __restrict__ src, u64* __restrict__ dst, int
 
 // SDFMap::clearAndInflateLocalMap (sdf_map.cpp:434-462) on bit-planes:
 //   infl = (infl & ~box) | OR_{dx,dy,dz in [-s,s]} shift(S, dx*ny*nz + dy*nz + dz), clipped to [0,N)
+// The stamp is a cube, and shifts of the linear bit string compose, so the (2s+1)^3 shifted copies
+// factor into a y/z dilation followed by an x dilation (5 + 5 window pairs per word instead of 25;
+// the intermediate plane keeps the bits that leave [0,N) in its margins, so the reference's
+// "only the final address is range-checked" wrap quirk is preserved exactly).
 // One thread per output word; the dz loop is a funnel-shifted OR over a 128-bit window.
 __global__ void __launch_bounds__(256)
-k_inflate(Geo g, Box3 b, int step, const u64* __restrict__ S, u64* __restrict__ infl, int w_lo,
-          int w_hi) {
+k_inflate_yz(Geo g, int step, const u64* __restrict__ S, u64* __restrict__ T, int w_lo, int w_hi) {
   int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (w > w_hi) return;
   u64 acc = 0ull;
-  for (int dx = -step; dx <= step; ++dx)
-    for (int dy = -step; dy <= step; ++dy) {
-      long off = (long)dx * g.nyz + (long)dy * g.nz;
-      long start = 64L * w - off - step;
-      u64 lo = plane_window(S, start);
-      u64 hi = plane_window(S, start + 64);
-      if ((lo | hi) == 0ull) continue;
-      u64 r = lo;
-      for (int k = 1; k <= 2 * step; ++k) r |= (lo >> k) | (hi << (64 - k));
-      acc |= r;
-    }
+  for (int dy = -step; dy <= step; ++dy) {
+    long start = 64L * w - (long)dy * g.nz - step;
+    u64 lo = plane_window(S, start);
+    u64 hi = plane_window(S, start + 64);
+    if ((lo | hi) == 0ull) continue;
+    u64 r = lo;
+    for (int k = 1; k <= 2 * step; ++k) r |= (lo >> k) | (hi << (64 - k));
+    acc |= r;
+  }
+  T[w] = acc;
+}
+__global__ void __launch_bounds__(256)
+k_inflate_x(Geo g, Box3 b, int step, const u64* __restrict__ T, u64* __restrict__ infl, int w_lo, int w_hi) {
+  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > w_hi) return;
+  u64 acc = 0ull;
+  for (int dx = -step; dx <= step; ++dx) acc |= plane_window(T, 64L * w - (long)dx * g.nyz);
   long a0 = 64L * w;
   if (a0 + 64 > g.N) acc &= bit_range(0, (int)(g.N - a0));
   infl[w] = (infl[w] & ~box_mask_word(g, w, b)) | acc;
@@ -342,7 +351,7 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
     return fail(FUELMI_EHIP);
   }
   if ((rc = plane_alloc(m, m->occ_bits)) || (rc = plane_alloc(m, m->unk_bits)) ||
-      (rc = plane_alloc(m, m->infl_bits)) || (rc = plane_alloc(m, m->tmp_bits)) ||
+      (rc = plane_alloc(m, m->infl_bits)) || (rc = plane_alloc(m, m->tmp_bits)) || (rc = plane_alloc(m, m->tmp2_bits)) ||
       (rc = plane_alloc(m, m->hit_bits)) || (rc = plane_alloc(m, m->miss_bits)))
     return fail(rc);
   size_t Npad = (size_t)g.W * 64;
@@ -376,7 +385,8 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  Plane* planes[] = {&m->occ_bits, &m->unk_bits, &m->infl_bits, &m->tmp_bits, &m->hit_bits, &m->miss_bits};
+  Plane* planes[] = {&m->occ_bits, &m->unk_bits,  &m->infl_bits, &m->tmp_bits,
+                     &m->tmp2_bits, &m->hit_bits, &m->miss_bits};
   for (Plane* p : planes)
     if (p->base) (void)hipFree(p->base);
   void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial};
@@ -422,15 +432,19 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
   long reach = (long)step * ((long)g.nyz + g.nz + 1);
   long a_lo = adr_of(g, b.lo) - reach, a_hi = adr_of(g, b.hi) + reach;
   int out_lo = (int)std::max(0L, a_lo >> 6), out_hi = (int)std::min((long)g.W - 1, a_hi >> 6);
-  // S must be valid wherever k_inflate reads: output range +- (reach + step + 64) bits
-  int rd = (int)((reach + step + 127) / 64) + 1;
-  int s_lo = std::max(out_lo - rd, -m->margin_words), s_hi = std::min(out_hi + rd, g.W - 1 + m->margin_words);
+  // T (y/z-dilated sources) must be valid wherever the x pass reads, S wherever the y/z pass reads
+  const int rx = (int)(((long)step * g.nyz + 127) / 64) + 1;
+  const int ryz = (int)(((long)step * (g.nz + 1) + step + 127) / 64) + 1;
+  const int t_lo = std::max(out_lo - rx, -m->margin_words), t_hi = std::min(out_hi + rx, g.W - 1 + m->margin_words);
+  const int s_lo = std::max(t_lo - ryz, -m->margin_words), s_hi = std::min(t_hi + ryz, g.W - 1 + m->margin_words);
   {
     StageScope sc(m, FUELMI_K_INFLATE);
     k_box_and<<<blocks_for(s_hi - s_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->occ_bits.p, m->tmp_bits.p,
                                                                         s_lo, s_hi);
-    k_inflate<<<blocks_for(out_hi - out_lo + 1, 256), 256, 0, m->stream>>>(g, b, step, m->tmp_bits.p,
-                                                                           m->infl_bits.p, out_lo, out_hi);
+    k_inflate_yz<<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, m->tmp_bits.p, m->tmp2_bits.p,
+                                                                          t_lo, t_hi);
+    k_inflate_x<<<blocks_for(out_hi - out_lo + 1, 256), 256, 0, m->stream>>>(g, b, step, m->tmp2_bits.p,
+                                                                             m->infl_bits.p, out_lo, out_hi);
   }
   if (m->cfg.virtual_ceil_height > -0.5) {
     int ceil_id = (int)std::floor((m->cfg.virtual_ceil_height - g.org[2]) * g.res_inv);
