@@ -341,19 +341,21 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   }
 }
 
-// x pass, 32 columns (8 lanes x 4) per tile row; a wave covers 8 x-rows x 32 columns
-template <int OUT>
+// x pass, 4*SEGS columns (SEGS lanes x 4) per tile row; SEGS = 8: a wave covers 8 x-rows x 32 columns
+// (128 B per row); SEGS = 4 halves the LDS tile for long x lines so that several workgroups still
+// share a CU
+template <int OUT, int SEGS>
 __global__ void __launch_bounds__(1024)
 k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][8] of uint4
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4
   const int xlen = b.hi[0] - b.lo[0] + 1;
   const int ylen = b.hi[1] - b.lo[1] + 1;
   const int ncol = ylen * zlen_a;
-  const int seg = threadIdx.x & 7;
-  const int row0 = threadIdx.x >> 3;  // 0..rows-1
-  const int rows = blockDim.x >> 3;
-  const int col = blockIdx.x * 32 + seg * 4;
+  const int seg = threadIdx.x & (SEGS - 1);
+  const int row0 = threadIdx.x / SEGS;  // 0..rows-1
+  const int rows = blockDim.x / SEGS;
+  const int col = blockIdx.x * (4 * SEGS) + seg * 4;
   const bool valid = col < ncol;
   const int yy = valid ? col / zlen_a : 0;
   const int z = z0a + (valid ? col - yy * zlen_a : 0);
@@ -362,18 +364,18 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   const float resf = (float)g.res;
 #pragma unroll 4
   for (int xi = row0; xi < xlen; xi += rows)
-    tile[xi * 8 + seg] = valid ? *reinterpret_cast<const uint4*>(tmp + (long)(b.lo[0] + xi) * g.nyz + coloff) : inf4;
+    tile[xi * SEGS + seg] = valid ? *reinterpret_cast<const uint4*>(tmp + (long)(b.lo[0] + xi) * g.nyz + coloff) : inf4;
   __syncthreads();
   if (!valid) return;
   const bool full = z >= b.lo[2] && z + 3 <= b.hi[2];
   for (int xi = row0; xi < xlen; xi += rows) {
-    uint4 bb = tile[xi * 8 + seg];
+    uint4 bb = tile[xi * SEGS + seg];
     u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
     const int rmax = max(xi, xlen - 1 - xi);
     for (int r = 1; r <= rmax && (u32)(r * r) < mx; ++r) {
       const u32 rr = (u32)(r * r);
-      const uint4 va = tile[max(xi - r, 0) * 8 + seg];
-      const uint4 vb = tile[min(xi + r, xlen - 1) * 8 + seg];
+      const uint4 va = tile[max(xi - r, 0) * SEGS + seg];
+      const uint4 vb = tile[min(xi + r, xlen - 1) * SEGS + seg];
       bb.x = min(bb.x, min(va.x, vb.x) + rr);
       bb.y = min(bb.y, min(va.y, vb.y) + rr);
       bb.z = min(bb.z, min(va.z, vb.z) + rr);
@@ -408,7 +410,12 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
-  int zc_max = std::max(4, ((32 * 1024) / (4 * ylen)) & ~3);
+  // ~20 z per chunk amortises the per-row bit fetches (measured: 400 rows x 20 z = 32 KB on G400,
+  // 800 rows x 20 z = 64 KB on G800 are the optima; bigger tiles lose occupancy, smaller ones repeat the
+  // row prologue); FUELMI_ZY_TILE_KB overrides for tuning
+  static const char* zy_kb = getenv("FUELMI_ZY_TILE_KB");
+  const int budget = zy_kb ? atoi(zy_kb) * 1024 : std::min(std::max(32 * 1024, ylen * 4 * 20), 80 * 1024);
+  int zc_max = std::max(4, (budget / (4 * ylen)) & ~3);
   zc_max = std::min(zc_max, std::min(zlen_a, 64));
   int nzc = (zlen_a + zc_max - 1) / zc_max;
   int ZC = (((zlen_a + nzc - 1) / nzc) + 3) & ~3;
@@ -427,20 +434,28 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   return FUELMI_OK;
 }
 
-template <int OUT>
-static int launch_x4(fuelmi_map* m, const Box3& b) {
+template <int OUT, int SEGS>
+static int launch_x4s(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
-  size_t lds = (size_t)xlen * 32 * sizeof(u32);
+  size_t lds = (size_t)xlen * SEGS * 4 * sizeof(u32);
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int ncol = ylen * zlen_a;
-  k_esdf_x4<OUT><<<(ncol + 31) / 32, 1024, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a, zlen_a);
+  k_esdf_x4<OUT, SEGS><<<(ncol + 4 * SEGS - 1) / (4 * SEGS), 1024, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a,
+                                                                                    zlen_a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
+}
+template <int OUT>
+static int launch_x4(fuelmi_map* m, const Box3& b) {
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  static const char* force = getenv("FUELMI_X_SEGS");  // tuning hook: "4" or "8"
+  const bool narrow = force ? atoi(force) == 4 : (size_t)xlen * 128 > 80 * 1024;
+  return narrow ? launch_x4s<OUT, 4>(m, b) : launch_x4s<OUT, 8>(m, b);
 }
 
 template <int MODE>
