@@ -445,8 +445,10 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int ncol = ylen * zlen_a;
-  k_esdf_x4<OUT, SEGS><<<(ncol + 4 * SEGS - 1) / (4 * SEGS), 1024, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a,
-                                                                                    zlen_a);
+  static const char* xt = getenv("FUELMI_X_THREADS");  // tuning hook
+  const int threads = xt ? atoi(xt) : 1024;
+  k_esdf_x4<OUT, SEGS><<<(ncol + 4 * SEGS - 1) / (4 * SEGS), threads, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a,
+                                                                                       zlen_a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }

@@ -675,6 +675,7 @@ extern "C" int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, doubl
   double tot = 0.0;
   for (size_t i = 0; i + 1 < s.used; i += 2) {
     float ms = 0.f;
+    HIPCHK(hipEventSynchronize(s.ev[i + 1]));  // stages of the frontier finder are recorded on ITS stream
     HIPCHK(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
     tot += ms;
   }
