@@ -402,7 +402,7 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   }
 }
 
-static inline bool use_vec4(const Geo& g, int xlen) { return (g.nz % 4) == 0 && (size_t)xlen * 128 <= 160 * 1024; }
+static inline bool use_vec4(const Geo& g, int xlen) { return (g.nz % 4) == 0 && (size_t)xlen * 64 <= 150 * 1024; }
 
 template <int MODE>
 static int launch_zy4(fuelmi_map* m, const Box3& b) {
@@ -456,7 +456,9 @@ template <int OUT>
 static int launch_x4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
   static const char* force = getenv("FUELMI_X_SEGS");  // tuning hook: "4" or "8"
-  const bool narrow = force ? atoi(force) == 4 : (size_t)xlen * 128 > 80 * 1024;
+  // the 32-column tile is faster whenever it fits (measured on 800-voxel lines: 0.32 vs 0.37 ms), the
+  // 16-column one extends the vector path to x lines of up to 2400 voxels
+  const bool narrow = force ? atoi(force) == 4 : (size_t)xlen * 128 > 150 * 1024;
   return narrow ? launch_x4s<OUT, 4>(m, b) : launch_x4s<OUT, 8>(m, b);
 }
 

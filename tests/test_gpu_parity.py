@@ -815,3 +815,28 @@ def test_error_paths_of_the_front_end_calls(fa):
     assert ev[0] == 1 and np.isfinite(co[0])
     gf.close()
     gm.close()
+
+
+@pytest.mark.gpu
+def test_esdf_on_a_very_long_x_line(fa):
+    """x lines of 1300 voxels: the x pass switches to its 16-column tile (the 32-column one would not fit
+    the LDS); result against the oracle."""
+    map_size = (130.0, 4.0, 4.0)
+    om = fo.OracleMap(map_size)
+    rng = np.random.default_rng(21)
+    occ = om.occ.reshape(om.nvox)
+    occ[:] = om.l_min                                            # everything known free
+    idx = rng.integers(0, [om.nvox[0], om.nvox[1], om.nvox[2]], size=(60, 3))
+    occ[idx[:, 0], idx[:, 1], idx[:, 2]] = om.l_occ + 0.5         # a few obstacles far apart along x
+    occ[900:, :, :] = om.unknown_value                            # and an unknown end
+    gm = fa.SDFMap(map_size)
+    gm.uploadOccupancy(om.occ)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    assert_map_equal(om, gm)
+    gm.close()
