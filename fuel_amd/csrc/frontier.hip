@@ -129,21 +129,25 @@ __global__ void k_clear_flags(u64* flag, const int* __restrict__ cells, const in
 
 // exclusive scan of the block sums + totals (one block)
 __device__ void scan_sums_tail(const FArgs& F) {
-  __shared__ u64 part[256];
+  // one block of 1024 threads: contiguous slices of the block sums per thread, then a Hillis-Steele scan
+  // of the 1024 partials in LDS (a 256-thread version with a serial middle cost 18 us on an 800^2 x 200 map)
+  __shared__ u64 part[1024];
   const int nblocks = F.var->nblocks;
-  const int per = (nblocks + 255) / 256;
+  const int T = blockDim.x;
+  const int per = (nblocks + T - 1) / T;
   const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
   u64 s = 0;
   for (int b = b0; b < b1; ++b) s += F.blocksum[b];
   part[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 run = 0;
-    for (int t = 0; t < 256; ++t) {
-      u64 v = part[t];
-      part[t] = run;
-      run += v;
-    }
+  for (int off = 1; off < T; off <<= 1) {
+    const u64 v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  if (threadIdx.x == T - 1) {
+    const u64 run = part[T - 1];
     u32 nq = (u32)run, ns = (u32)(run >> 32);
     u32 ovf = 0;
     if (nq > F.cap_q) {
@@ -160,8 +164,7 @@ __device__ void scan_sums_tail(const FArgs& F) {
     F.counts[3] = 0;
     F.counts[5] = 0;
   }
-  __syncthreads();
-  u64 run = part[threadIdx.x];
+  u64 run = part[threadIdx.x] - s;  // exclusive prefix of this thread's slice
   for (int b = b0; b < b1; ++b) {
     u64 v = F.blocksum[b];
     F.blockscan[b] = run;
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
   F.pref[rel] = excl;
   if (threadIdx.x == 255) F.blocksum[blockIdx.x] = excl + packed;
 }
-__global__ void __launch_bounds__(256) k_scan_sums(FArgs F) { scan_sums_tail(F); }
+__global__ void __launch_bounds__(1024) k_scan_sums(FArgs F) { scan_sums_tail(F); }
 
 __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
   int w = (int)(a >> 6);
@@ -813,25 +816,23 @@ __device__ __forceinline__ u32 ms_val_at(const FArgs& F, const MsPass& P, int pa
 }
 // in-place exclusive scan of the ndig*nb histogram entries (one block)
 __device__ void ms_scan_tail(const FArgs& F, const MsPass& P) {
-  __shared__ u32 part[256];
+  __shared__ u32 part[1024];
   u32* v = F.ms_hist;
+  const int T = blockDim.x;
   const int cnt = P.ndig * P.nb;
-  const int per = (cnt + 255) / 256;
+  const int per = (cnt + T - 1) / T;
   const int b0 = threadIdx.x * per, b1 = min(cnt, b0 + per);
   u32 s = 0;
   for (int b = b0; b < b1; ++b) s += v[b];
   part[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 run = 0;
-    for (int t = 0; t < 256; ++t) {
-      u32 x = part[t];
-      part[t] = run;
-      run += x;
-    }
+  for (int off = 1; off < T; off <<= 1) {  // Hillis-Steele over the per-thread partials
+    const u32 x = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += x;
+    __syncthreads();
   }
-  __syncthreads();
-  u32 run = part[threadIdx.x];
+  u32 run = part[threadIdx.x] - s;
   for (int b = b0; b < b1; ++b) {
     u32 x = v[b];
     v[b] = run;
@@ -859,7 +860,7 @@ __global__ void __launch_bounds__(256) k_ms_hist(FArgs F, int pass) {
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) k_ms_scan(FArgs F, int pass) {
+__global__ void __launch_bounds__(1024) k_ms_scan(FArgs F, int pass) {
   const MsPass P = ms_pass(F, pass);
   if (P.on) ms_scan_tail(F, P);
 }
@@ -1265,7 +1266,7 @@ int frontier_regroup(fuelmi_frontier* f, const FArgs& F2, int npass) {
   const Geo& g = f->map->g;
   for (int p = 0; p < npass; ++p) {
     k_ms_hist<<<256, 256, 0, f->stream>>>(F2, p);
-    k_ms_scan<<<1, 256, 0, f->stream>>>(F2, p);
+    k_ms_scan<<<1, 1024, 0, f->stream>>>(F2, p);
     k_ms_scatter<<<256, 256, 0, f->stream>>>(F2, p);
   }
   k_ms_info<<<256, 256, 0, f->stream>>>(g, F2);
@@ -1284,7 +1285,7 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   FDBG("k_load_var");
   k_pred<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_pred");
-  k_scan_sums<<<1, 256, 0, f->stream>>>(F);
+  k_scan_sums<<<1, 1024, 0, f->stream>>>(F);
   FDBG("k_scan_sums");
   k_compact<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_compact");
@@ -1306,7 +1307,7 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   for (int p = 0; p < npass; ++p) {
     k_ms_hist<<<f->nb_launch, 256, 0, f->stream>>>(F, p);
     FDBG("k_ms_hist");
-    k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
+    k_ms_scan<<<1, 1024, 0, f->stream>>>(F, p);
     FDBG("k_ms_scan");
     k_ms_scatter<<<f->nb_launch, 256, 0, f->stream>>>(F, p);
     FDBG("k_ms_scatter");
@@ -1475,7 +1476,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     for (int p = 1; p < 2; ++p) {
       k_ms_hist<<<nb_launch, 256, 0, f->stream>>>(F, p);
       FDBG("k_ms_hist");
-      k_ms_scan<<<1, 256, 0, f->stream>>>(F, p);
+      k_ms_scan<<<1, 1024, 0, f->stream>>>(F, p);
       FDBG("k_ms_scan");
       k_ms_scatter<<<nb_launch, 256, 0, f->stream>>>(F, p);
       FDBG("k_ms_scatter");
