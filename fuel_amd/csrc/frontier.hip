@@ -117,6 +117,42 @@ __global__ void k_check_clusters(Geo g, const u64* __restrict__ occ, const u64* 
   if (i >= n) return;
   if (!f1_cell(g, occ, unk, cells[i])) changed[cell_cluster[i]] = 1;
 }
+// the same two tests over clusters whose cells sit in the device pool: cand[k] = (pool offset, first
+// flat index); a thread finds its cluster by bisection over the (few) candidates
+__device__ __forceinline__ int pool_cluster_of(const u32* __restrict__ cand_start, int ncand, u32 i) {
+  int lo = 0, hi = ncand - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cand_start[mid] <= i)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo;
+}
+__global__ void k_check_pool(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk,
+                             const u32* __restrict__ pool, const u64* __restrict__ cand_off,
+                             const u32* __restrict__ cand_start, int ncand, u32 total, int* __restrict__ changed) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = pool_cluster_of(cand_start, ncand, i);
+  const u32 a = pool[cand_off[k] + (i - cand_start[k])];
+  if (!f1_cell(g, occ, unk, a)) changed[k] = 1;
+}
+__global__ void k_clear_pool(u64* flag, const u32* __restrict__ pool, const u64* __restrict__ cand_off,
+                             const u32* __restrict__ cand_start, int ncand, u32 total,
+                             const int* __restrict__ changed) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = pool_cluster_of(cand_start, ncand, i);
+  if (!changed[k]) return;
+  const long a = pool[cand_off[k] + (i - cand_start[k])];
+  atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
+}
+__global__ void k_pool_put(u32* __restrict__ dst, const u32* __restrict__ src, u32 n, int seed) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+  if (seed >= 0 && blockIdx.x == 0 && threadIdx.x == 0) dst[n] = (u32)seed;  // order is irrelevant on the device
+}
 __global__ void k_clear_flags(u64* flag, const int* __restrict__ cells, const int* __restrict__ cell_cluster,
                               const int* __restrict__ changed, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1077,6 +1113,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   for (void* p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   if (f->h_var) (void)hipHostFree(f->h_var);
+  if (f->pool) (void)hipFree(f->pool);
   frontier_split_free(f);
   for (hipGraphExec_t e : f->graph_exec)
     if (e) (void)hipGraphExecDestroy(e);
@@ -1202,6 +1239,58 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   return FUELMI_OK;
 }
 
+// ---- device pool of committed clusters' cells ---------------------------------------------------
+static int pool_upload(fuelmi_frontier* f, HCluster& c) {  // from the host list (rebuilds)
+  c.pool_off = f->pool_used;
+  if (!c.cells.empty())
+    HIPCHK(hipMemcpyAsync(f->pool + f->pool_used, c.cells.data(), c.cells.size() * sizeof(int), hipMemcpyHostToDevice,
+                          f->stream));
+  f->pool_used += c.cells.size();
+  return FUELMI_OK;
+}
+static int pool_reserve(fuelmi_frontier* f, size_t need) {
+  if (f->pool_used + need <= f->pool_cap) return FUELMI_OK;
+  // compact (erased clusters leave holes) and grow: re-upload the live clusters from their host lists
+  size_t live = need;
+  for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
+    for (HCluster& c : *L) live += c.cells.size();
+  HIPCHK(hipStreamSynchronize(f->stream));
+  if (live > f->pool_cap / 2 || !f->pool) {
+    size_t cap = std::max<size_t>(1u << 20, f->pool_cap);
+    while (cap / 2 < live) cap *= 2;
+    if (f->pool) HIPCHK(hipFree(f->pool));
+    f->pool = nullptr;
+    f->pool_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&f->pool), cap * sizeof(u32)));
+    f->pool_cap = cap;
+  }
+  f->pool_used = 0;
+  for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
+    for (HCluster& c : *L) {
+      int rc = pool_upload(f, c);
+      if (rc) return rc;
+    }
+  HIPCHK(hipStreamSynchronize(f->stream));  // the host lists may be freed by the caller afterwards
+  return FUELMI_OK;
+}
+int frontier_keep_cluster(fuelmi_frontier* f, HCluster& c) {
+  const size_t n = c.size();
+  int rc = pool_reserve(f, n);
+  if (rc) return rc;
+  if (c.lazy) {  // this search's result still sits grouped on the device: device-to-device
+    const size_t src_off = (size_t)(c.lazy - reinterpret_cast<const int*>(f->F.h_cells));
+    k_pool_put<<<fblocks((long)c.lazy_n, 256, 256), 256, 0, f->stream>>>(f->pool + f->pool_used,
+                                                                        f->F.ms_val[f->last_fin] + src_off, c.lazy_n,
+                                                                        c.lazy_seed);
+    HIPCHK(hipGetLastError());
+    c.pool_off = f->pool_used;
+    f->pool_used += n;
+    c.materialize();
+    return FUELMI_OK;
+  }
+  return pool_upload(f, c);
+}
+
 // drop clusters of `L` that overlap the updated box and contain a cell that is no longer a
 // frontier (searchFrontiers :62-93); flags of dropped clusters are cleared on the device
 static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const double* umin, const double* umax,
@@ -1218,31 +1307,35 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
       ncell += it->cells.size();
     }
   if (cand.empty()) return FUELMI_OK;
-  std::vector<int> cells, cl;
-  cells.reserve(ncell);
-  cl.reserve(ncell);
-  for (size_t k = 0; k < cand.size(); ++k)
-    for (int a : cand[k]->cells) {
-      cells.push_back(a);
-      cl.push_back((int)k);
-    }
-  size_t bytes = ncell * sizeof(int);
-  int rc = frontier_ensure_stage(f, 2 * bytes + cand.size() * sizeof(int) + 64);
+  // candidates' cells are already on the device (pool): upload only (pool offset, first flat index)
+  const size_t nc = cand.size();
+  std::vector<u64> off(nc);
+  std::vector<u32> start(nc);
+  u32 total = 0;
+  for (size_t k = 0; k < nc; ++k) {
+    off[k] = cand[k]->pool_off;
+    start[k] = total;
+    total += (u32)cand[k]->cells.size();
+  }
+  const size_t b_off = nc * sizeof(u64), b_start = ((nc * sizeof(u32) + 7) / 8) * 8;
+  int rc = frontier_ensure_stage(f, b_off + b_start + nc * sizeof(int) + 64);
   if (rc) return rc;
-  int* d_cells = (int*)f->d_stage;
-  int* d_cl = d_cells + ncell;
-  int* d_changed = d_cl + ncell;
-  HIPCHK(hipMemcpyAsync(d_cells, cells.data(), bytes, hipMemcpyHostToDevice, f->stream));
-  HIPCHK(hipMemcpyAsync(d_cl, cl.data(), bytes, hipMemcpyHostToDevice, f->stream));
-  HIPCHK(hipMemsetAsync(d_changed, 0, cand.size() * sizeof(int), f->stream));
-  k_check_clusters<<<fblocks((long)ncell, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, d_cells,
-                                                                    d_cl, (int)ncell, d_changed);
-  FDBG("k_check_clusters");
-  k_clear_flags<<<fblocks((long)ncell, 256), 256, 0, f->stream>>>(f->flag.p, d_cells, d_cl, d_changed, (int)ncell);
-  FDBG("k_clear_flags");
-  std::vector<int> changed(cand.size());
-  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, cand.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  u64* d_off = reinterpret_cast<u64*>(f->d_stage);
+  u32* d_start = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(f->d_stage) + b_off);
+  int* d_changed = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(f->d_stage) + b_off + b_start);
+  HIPCHK(hipMemcpyAsync(d_off, off.data(), b_off, hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(d_start, start.data(), nc * sizeof(u32), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemsetAsync(d_changed, 0, nc * sizeof(int), f->stream));
+  k_check_pool<<<fblocks((long)total, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->pool, d_off,
+                                                                d_start, (int)nc, total, d_changed);
+  FDBG("k_check_pool");
+  k_clear_pool<<<fblocks((long)total, 256), 256, 0, f->stream>>>(f->flag.p, f->pool, d_off, d_start, (int)nc, total,
+                                                                d_changed);
+  FDBG("k_clear_pool");
+  std::vector<int> changed(nc);
+  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, nc * sizeof(int), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
+  (void)ncell;
   // removed_ids_ semantics (:74-85): index in the list as it shrinks
   int erased = 0;
   for (size_t k = 0; k < cand.size(); ++k)
@@ -1502,6 +1595,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     int rc = frontier_split_run(f, nq, nkept, n_out, nkept <= 256 ? 1 : 0, &ncl, &ncells, &filtered);
     if (rc) return rc;
   }
+  f->last_fin = ncl <= 256 ? 1 : 0;  // buffer holding the grouped cells the lazy clusters point into
   const u32 nchunk = (ncells + SZ_CH - 1) / SZ_CH;
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
@@ -1577,6 +1671,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   f->tmp.clear();
   f->removed_ids.clear();
   f->dirty_all = true;
+  f->pool_used = 0;
   k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
   FDBG("k_zero_words");
   return FUELMI_OK;
@@ -1585,8 +1680,12 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
 extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
   ARGCHK(f);
   auto& dst = dormant ? f->dormant : f->frontiers;
-  for (HCluster& c : f->tmp) c.materialize();
-  dst.splice(dst.end(), f->tmp);
+  HIPCHK(hipSetDevice(f->map->device));
+  while (!f->tmp.empty()) {
+    int rc = frontier_keep_cluster(f, f->tmp.front());
+    if (rc) return rc;
+    dst.splice(dst.end(), f->tmp, f->tmp.begin());
+  }
   return FUELMI_OK;
 }
 

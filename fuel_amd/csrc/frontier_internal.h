@@ -94,6 +94,9 @@ struct HCluster {
   // copied out only when somebody keeps it (commit) -- a 140 k-cell surface costs ~25 us to copy,
   // 10 % of a plan cycle, and the buffer stays valid until the next search.
   std::vector<float> filtered;  // filtered_cells_ (xyz triples), only for clusters found with cfg.split
+  // committed clusters also keep their cells in the finder's device pool (remove_changed and
+  // isFrontierCovered test them there instead of re-uploading them on every search)
+  size_t pool_off = (size_t)-1;
   const int* lazy = nullptr;
   u32 lazy_n = 0;
   int lazy_seed = -1;  // NQ seed address to merge in, or -1
@@ -149,9 +152,14 @@ struct fuelmi_frontier {
   int rm_lo[3], rm_hi[3];   // index box of the clusters removed by the current search (rm_lo > rm_hi: none)
   fuelmi_viewpoint_cfg vcfg;
   bool have_vcfg = false;
+  u32* pool = nullptr;  // device copies of the cells of frontiers_ / dormant_frontiers_
+  size_t pool_cap = 0, pool_used = 0;
+  int last_fin = 1;     // which multisplit buffer holds the grouped cells of the last search
   struct SplitScratch* split = nullptr;  // device buffers of the split stage (frontier_split.hip)
 };
 void frontier_split_free(fuelmi_frontier* f);
+// tmp cluster -> committed: materialises the host list and copies the cells into the device pool
+int frontier_keep_cluster(fuelmi_frontier* f, HCluster& c);
 
 
 // runs the stable radix multisplit of F2.ms_key[0]/ms_val[0] (F2.counts[0] items, F2.counts[3] keys,

@@ -194,13 +194,23 @@ __global__ void __launch_bounds__(64) k_vp_sample(Geo g, VArgs V) {
   }
 }
 
-// isFrontierCovered's per-cluster count of cells that stopped being frontier cells
+// isFrontierCovered's per-cluster count of cells that stopped being frontier cells; the cells are read
+// from the finder's device pool (cand_off[k] = pool offset of candidate k, cand_start[k] = its first flat
+// index)
 __global__ void k_vp_changed(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk,
-                             const int* __restrict__ cells, const int* __restrict__ cell_cluster, int n,
-                             u32* __restrict__ changed) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const long a = cells[i];
+                             const u32* __restrict__ pool, const u64* __restrict__ cand_off,
+                             const u32* __restrict__ cand_start, int ncand, u32 total, u32* __restrict__ changed) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = ncand - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cand_start[mid] <= i)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const long a = pool[cand_off[lo] + (i - cand_start[lo])];
   auto bit = [&](const u64* p, long q) { return (p[q >> 6] >> (q & 63)) & 1ull; };
   bool f1 = !(bit(occ, a) || bit(unk, a));
   if (f1) {
@@ -208,7 +218,7 @@ __global__ void k_vp_changed(Geo g, const u64* __restrict__ occ, const u64* __re
     f1 = (x > 0 && bit(unk, a - g.nyz)) || (x < g.nx - 1 && bit(unk, a + g.nyz)) || (y > 0 && bit(unk, a - g.nz)) ||
          (y < g.ny - 1 && bit(unk, a + g.nz)) || (z > 0 && bit(unk, a - 1)) || (z < g.nz - 1 && bit(unk, a + 1));
   }
-  if (!f1) atomicAdd(&changed[cell_cluster[i]], 1u);
+  if (!f1) atomicAdd(&changed[lo], 1u);
 }
 
 }  // namespace
@@ -336,7 +346,8 @@ extern "C" int fuelmi_frontier_compute_to_visit(fuelmi_frontier* f, int* n_activ
   int na = 0, nd = 0;
   while (!f->tmp.empty()) {
     HCluster& c = f->tmp.front();
-    c.materialize();
+    rc = frontier_keep_cluster(f, c);
+    if (rc) return rc;
     if (!c.viewpoints.empty()) {
       // sort by coverage, best first -- std::sort with the reference's comparator (:403-405)
       std::sort(c.viewpoints.begin(), c.viewpoints.end(),
@@ -402,30 +413,33 @@ extern "C" int fuelmi_frontier_is_covered(fuelmi_frontier* f, int* covered) {
       ncell += c.cells.size();
     }
   if (cand.empty()) return FUELMI_OK;
-  std::vector<int> cells(ncell), cl(ncell);
-  size_t at = 0;
-  for (size_t k = 0; k < cand.size(); ++k)
-    for (int a : cand[k]->cells) {
-      cells[at] = a;
-      cl[at++] = (int)k;
-    }
+  const size_t nc = cand.size();
+  std::vector<u64> off(nc);
+  std::vector<u32> start(nc);
+  u32 total = 0;
+  for (size_t k = 0; k < nc; ++k) {
+    off[k] = cand[k]->pool_off;
+    start[k] = total;
+    total += (u32)cand[k]->cells.size();
+  }
+  (void)ncell;
   unsigned char* d;
-  const size_t bc = ncell * 4, bk = ((cand.size() * 4 + 7) / 8) * 8;
-  int rc = view_stage(f, 2 * bc + bk, &d);
+  const size_t b_off = nc * sizeof(u64), b_start = ((nc * sizeof(u32) + 7) / 8) * 8;
+  int rc = view_stage(f, b_off + b_start + nc * sizeof(u32) + 64, &d);
   if (rc) return rc;
   hipStream_t st = f->stream;
   HIPCHK(hipStreamWaitEvent(st, m->ev_planes, 0));
-  int* d_cells = reinterpret_cast<int*>(d);
-  int* d_cl = reinterpret_cast<int*>(d + bc);
-  u32* d_changed = reinterpret_cast<u32*>(d + 2 * bc);
-  HIPCHK(hipMemcpyAsync(d_cells, cells.data(), bc, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(d_cl, cl.data(), bc, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(d_changed, 0, bk, st));
-  k_vp_changed<<<(int)((ncell + 255) / 256), 256, 0, st>>>(m->g, m->occ_bits.p, m->unk_bits.p, d_cells, d_cl, (int)ncell,
-                                                           d_changed);
+  u64* d_off = reinterpret_cast<u64*>(d);
+  u32* d_start = reinterpret_cast<u32*>(d + b_off);
+  u32* d_changed = reinterpret_cast<u32*>(d + b_off + b_start);
+  HIPCHK(hipMemcpyAsync(d_off, off.data(), b_off, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_start, start.data(), nc * sizeof(u32), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_changed, 0, nc * sizeof(u32), st));
+  k_vp_changed<<<(int)((total + 255) / 256), 256, 0, st>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->pool, d_off, d_start,
+                                                           (int)nc, total, d_changed);
   HIPCHK(hipGetLastError());
-  std::vector<u32> changed(cand.size());
-  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, cand.size() * 4, hipMemcpyDeviceToHost, st));
+  std::vector<u32> changed(nc);
+  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, nc * sizeof(u32), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   for (size_t k = 0; k < cand.size(); ++k) {
     // "++change_num >= change_thresh" inside the loop over changed cells: true iff at least one cell
