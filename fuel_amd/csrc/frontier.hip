@@ -1114,6 +1114,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   if (f->h_var) (void)hipHostFree(f->h_var);
   if (f->pool) (void)hipFree(f->pool);
+  if (f->h_changed) (void)hipHostFree(f->h_changed);
   frontier_split_free(f);
   for (hipGraphExec_t e : f->graph_exec)
     if (e) (void)hipGraphExecDestroy(e);
@@ -1291,31 +1292,45 @@ int frontier_keep_cluster(fuelmi_frontier* f, HCluster& c) {
   return pool_upload(f, c);
 }
 
-// drop clusters of `L` that overlap the updated box and contain a cell that is no longer a
-// frontier (searchFrontiers :62-93); flags of dropped clusters are cleared on the device
-static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const double* umin, const double* umax,
-                          std::vector<int>* removed_ids) {
+// Drop the clusters that overlap the updated box and contain a cell that is no longer a frontier cell
+// (searchFrontiers :62-93).  The test and the clearing of the flags run on the device ahead of the
+// scan; the host learns the verdicts together with the search result (no round trip of its own) and
+// updates frontiers_ / dormant_frontiers_ / removed_ids_ in _search_end.  The search region therefore
+// includes the boxes of ALL candidates, not only of the ones that turn out to be dropped.
+static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const double* umax) {
   fuelmi_map* m = f->map;
-  std::vector<std::list<HCluster>::iterator> cand;
-  std::vector<int> cand_pos;
-  int pos = 0;
-  size_t ncell = 0;
-  for (auto it = L.begin(); it != L.end(); ++it, ++pos)
-    if (have_overlap(it->bmin, it->bmax, umin, umax)) {
-      cand.push_back(it);
-      cand_pos.push_back(pos);
-      ncell += it->cells.size();
-    }
-  if (cand.empty()) return FUELMI_OK;
-  // candidates' cells are already on the device (pool): upload only (pool offset, first flat index)
-  const size_t nc = cand.size();
+  f->pend_rm.clear();
+  for (std::list<HCluster>* L : {&f->frontiers, &f->dormant}) {
+    int pos = 0;
+    for (auto it = L->begin(); it != L->end(); ++it, ++pos)
+      if (have_overlap(it->bmin, it->bmax, umin, umax)) f->pend_rm.push_back({L, it, pos});
+  }
+  const size_t nc = f->pend_rm.size();
+  if (nc == 0) return FUELMI_OK;
   std::vector<u64> off(nc);
   std::vector<u32> start(nc);
   u32 total = 0;
   for (size_t k = 0; k < nc; ++k) {
-    off[k] = cand[k]->pool_off;
+    const HCluster& c = *f->pend_rm[k].it;
+    off[k] = c.pool_off;
     start[k] = total;
-    total += (u32)cand[k]->cells.size();
+    total += (u32)c.cells.size();
+    for (int q = 0; q < 3; ++q) {  // if dropped, its cells lose their flags and may be re-grown from the scan box
+      const int lo = (int)std::floor((c.bmin[q] - m->g.org[q]) * m->g.res_inv);
+      const int hi = (int)std::floor((c.bmax[q] - m->g.org[q]) * m->g.res_inv);
+      if (f->rm_lo[q] > f->rm_hi[q])
+        f->rm_lo[q] = lo, f->rm_hi[q] = hi;
+      else
+        f->rm_lo[q] = std::min(f->rm_lo[q], lo), f->rm_hi[q] = std::max(f->rm_hi[q], hi);
+    }
+  }
+  if (nc > f->h_changed_cap) {
+    if (f->h_changed) HIPCHK(hipHostFree(f->h_changed));
+    f->h_changed = nullptr;
+    f->h_changed_cap = 0;
+    const size_t cap = nc + nc / 2 + 64;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_changed), cap * sizeof(int), hipHostMallocDefault));
+    f->h_changed_cap = cap;
   }
   const size_t b_off = nc * sizeof(u64), b_start = ((nc * sizeof(u32) + 7) / 8) * 8;
   int rc = frontier_ensure_stage(f, b_off + b_start + nc * sizeof(int) + 64);
@@ -1332,27 +1347,24 @@ static int remove_changed(fuelmi_frontier* f, std::list<HCluster>& L, const doub
   k_clear_pool<<<fblocks((long)total, 256), 256, 0, f->stream>>>(f->flag.p, f->pool, d_off, d_start, (int)nc, total,
                                                                 d_changed);
   FDBG("k_clear_pool");
-  std::vector<int> changed(nc);
-  HIPCHK(hipMemcpyAsync(changed.data(), d_changed, nc * sizeof(int), hipMemcpyDeviceToHost, f->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
-  (void)ncell;
-  // removed_ids_ semantics (:74-85): index in the list as it shrinks
-  int erased = 0;
-  for (size_t k = 0; k < cand.size(); ++k)
-    if (changed[k]) {
-      if (removed_ids) removed_ids->push_back(cand_pos[k] - erased);
-      for (int q = 0; q < 3; ++q) {  // its cells lost their flags: they may be re-grown from the scan box
-        const int lo = (int)std::floor((cand[k]->bmin[q] - m->g.org[q]) * m->g.res_inv);
-        const int hi = (int)std::floor((cand[k]->bmax[q] - m->g.org[q]) * m->g.res_inv);
-        if (f->rm_lo[q] > f->rm_hi[q])
-          f->rm_lo[q] = lo, f->rm_hi[q] = hi;
-        else
-          f->rm_lo[q] = std::min(f->rm_lo[q], lo), f->rm_hi[q] = std::max(f->rm_hi[q], hi);
-      }
-      L.erase(cand[k]);
-      ++erased;
-    }
+  HIPCHK(hipMemcpyAsync(f->h_changed, d_changed, nc * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  // (off / start are pageable: their uploads were staged by the runtime before hipMemcpyAsync returned)
   return FUELMI_OK;
+}
+// after the stream has drained: apply the verdicts.  removed_ids_ semantics (:74-85): index in
+// frontiers_ as the list shrinks; dormant clusters are dropped silently.
+static void remove_changed_end(fuelmi_frontier* f) {
+  int erased_active = 0;
+  for (size_t k = 0; k < f->pend_rm.size(); ++k) {
+    if (!f->h_changed[k]) continue;
+    const fuelmi_frontier::PendingRm& p = f->pend_rm[k];
+    if (p.list == &f->frontiers) {
+      f->removed_ids.push_back(p.pos - erased_active);
+      ++erased_active;
+    }
+    p.list->erase(p.it);
+  }
+  f->pend_rm.clear();
 }
 
 int frontier_regroup(fuelmi_frontier* f, const FArgs& F2, int npass) {
@@ -1434,9 +1446,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->scope.reset(new StageScope(m, FUELMI_K_FRONTIER, f->stream));
   f->removed_ids.clear();
   for (int q = 0; q < 3; ++q) f->rm_lo[q] = 1, f->rm_hi[q] = 0;
-  int rc = remove_changed(f, f->frontiers, umin, umax, &f->removed_ids);
-  if (rc) return rc;
-  rc = remove_changed(f, f->dormant, umin, umax, nullptr);
+  int rc = remove_changed_begin(f, umin, umax);
   if (rc) return rc;
 
   // scan box (:95-106): updated box +- (1,1,0.5) clipped to the exploration box, as indices
@@ -1539,9 +1549,15 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     fuelmi_frontier* f;
     ~ScopeEnd() { f->scope.reset(); }
   } scope_end{f};
-  if (f->search_empty) return FUELMI_OK;
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
+  if (f->search_empty) {
+    if (!f->pend_rm.empty()) {
+      HIPCHK(hipStreamSynchronize(f->stream));
+      remove_changed_end(f);
+    }
+    return FUELMI_OK;
+  }
   const Geo& g = m->g;
   FArgs& F = f->F;
   const int nb_launch = f->nb_launch;
@@ -1557,6 +1573,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     }
     HIPCHK(q);
   }
+  remove_changed_end(f);
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
                      counts[1], F.cap_s, counts[3], F.cap_kept);

@@ -152,6 +152,16 @@ struct fuelmi_frontier {
   int rm_lo[3], rm_hi[3];   // index box of the clusters removed by the current search (rm_lo > rm_hi: none)
   fuelmi_viewpoint_cfg vcfg;
   bool have_vcfg = false;
+  // clusters being tested by the running search ("did a cell stop being a frontier cell?"): the verdicts
+  // arrive with the search result, the lists are updated in _search_end
+  struct PendingRm {
+    std::list<HCluster>* list;
+    std::list<HCluster>::iterator it;
+    int pos;  // position in its list when the search began
+  };
+  std::vector<PendingRm> pend_rm;
+  int* h_changed = nullptr;  // pinned verdicts
+  size_t h_changed_cap = 0;
   u32* pool = nullptr;  // device copies of the cells of frontiers_ / dormant_frontiers_
   size_t pool_cap = 0, pool_used = 0;
   int last_fin = 1;     // which multisplit buffer holds the grouped cells of the last search
