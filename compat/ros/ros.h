@@ -38,6 +38,7 @@ public:
 #define ROS_ERROR(...) do { std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)
 #define ROS_WARN(...) do { } while (0)
 #define ROS_INFO(...) do { } while (0)
+#define ROS_ERROR_COND(c, ...) do { } while (0)
 #define ROS_WARN_THROTTLE(p, ...) do { } while (0)
 #define ROS_INFO_STREAM(x) do { } while (0)
 #define ROS_WARN_STREAM(x) do { } while (0)

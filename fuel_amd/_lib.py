@@ -161,6 +161,9 @@ SYMBOLS = {
     "fuelmi_bspline_dev_download": (C.c_int, [_P, _dp, _dp]),
     "fuelmi_bspline_dev_optimize": (C.c_int, [_P, C.c_int, _dp, _dp, C.POINTER(C.c_int)]),
     "fuelmi_bspline_dev_destroy": (None, [_P]),
+    "fuelmi_bspline_parameterize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
+    "fuelmi_bspline_boundary_states": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
+    "fuelmi_bspline_dev_load_samples": (C.c_int, [_P, C.c_int, _dp, _dp, _dp]),
     "fuelmi_timer_begin": (C.c_int, [_P]),
     "fuelmi_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "fuelmi_profile_enable": (C.c_int, [_P, C.c_uint]),

@@ -38,6 +38,8 @@ struct fuelmi_bspline_dev {
   size_t lds;
   double *opt_x = nullptr, *opt_cost = nullptr;  // fuelmi_bspline_dev_optimize outputs
   int* opt_evals = nullptr;
+  double* fit_in = nullptr;  // fuelmi_bspline_dev_load_samples staging: ts | points | derivs
+  size_t fit_cap = 0;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -453,6 +455,230 @@ k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Spline glue around the solve (NonUniformBspline, bspline/src/non_uniform_bspline.cpp): the planners
+// turn path samples into control points (parameterizeToBspline :178-265), read the boundary states
+// back off the spline (getBoundaryStates :107-122) and hand both to optimize().  One wavefront per
+// candidate does all of it out of LDS, so a batch of candidates goes samples -> solve without a host
+// round trip.
+//
+// parameterizeToBspline solves the (K+4) x (K+degree-1) system "spline passes through the samples,
+// start/end velocity and acceleration match" in the least-squares sense (Eigen's ColPivHouseholderQR).
+// Every row touches `degree` consecutive unknowns, so the normal matrix is banded (half-bandwidth
+// degree-1): banded Cholesky plus one step of iterative refinement against the original rows, which
+// brings the solution back to QR accuracy (cond(A) < 1e3).
+struct FitArgs {
+  int C, K, degree;
+  const double* ts;      // [C]
+  const double* points;  // [C][K][3]
+  const double* derivs;  // [C][4][3]  start vel, end vel, start acc, end acc
+  double* ctrl;          // candidate c: ctrl + c * stride, (K + degree - 1) rows of 3
+  long stride;
+  // planner glue (all optional): what setBoundaryStates / optimize() derive from the fitted spline
+  int write_dt;          // ctrl[c * stride + 3 n] = ts[c]   (trailing knot-span variable)
+  double* knot_span;     // [C]
+  double* pt_dist;       // [C]      optimize() :136-140
+  double* start_state;   // [C][3][3]  getBoundaryStates(2, 0).start
+  double* end_state;     // [C][3][3]  row 0 = getBoundaryStates(2, 0).end[0]
+};
+
+// value at t = 0 (at_end = false) or t = duration of the d-th derivative of the uniform B-spline with
+// control points q[n][3], degree p, knots u[n + p + 1]  (evaluateDeBoorT of computeDerivatives()[d-1];
+// the derivative's knot vector is the parent's without its first and last knot, :99-103)
+__device__ void spline_boundary_value(const double* q, int n, int p, const double* u, int d, bool at_end,
+                                      double* out) {
+  const int pd = p - d, nd = n - d;
+  const double duration = u[n] - u[p];  // getTimeSum() of the position spline
+  const double uu = (at_end ? duration : 0.0) + u[pd + d];
+  const double ub = fmin(fmax(u[pd + d], uu), u[nd + d]);
+  int k = pd;
+  while (u[k + 1 + d] < ub) ++k;
+  const int i0 = k - pd;
+  double w[6][3];
+  for (int i = 0; i <= p; ++i)
+    for (int a = 0; a < 3; ++a) w[i][a] = q[3 * (i0 + i) + a];
+  for (int l = 1; l <= d; ++l) {  // getDerivativeControlPoints of level l-1, window only
+    const int pl = p - (l - 1);
+    for (int i = 0; i + l <= p; ++i) {
+      const int gi = i0 + i;
+      const double den = u[gi + pl + 1 + (l - 1)] - u[gi + 1 + (l - 1)];
+      for (int a = 0; a < 3; ++a) w[i][a] = pl * (w[i + 1][a] - w[i][a]) / den;
+    }
+  }
+  for (int r = 1; r <= pd; ++r)  // de Boor (:51-71), knots of the derivative = u[. + d]
+    for (int i = pd; i >= r; --i) {
+      const double alpha = (ub - u[i + k - pd + d]) / (u[i + 1 + k - r + d] - u[i + k - pd + d]);
+      for (int a = 0; a < 3; ++a) w[i][a] = (1 - alpha) * w[i - 1][a] + alpha * w[i][a];
+    }
+  for (int a = 0; a < 3; ++a) out[a] = w[pd][a];
+}
+
+// setUniformBspline's knot vector (:15-32): cumulative sums from -p * ts
+__device__ void spline_uniform_knots(double* u, int n, int p, double ts) {
+  const int m = n + p;
+  for (int i = 0; i <= m; ++i) u[i] = (i <= p) ? double(-p + i) * ts : u[i - 1] + ts;
+}
+
+struct FitRow {
+  int c0;           // first unknown the row touches
+  const double* w;  // `degree` coefficients
+};
+__device__ __forceinline__ FitRow fit_row(int r, int K, int degree, const double* wts) {
+  if (r < K) return {r, wts};
+  const int s = r - K;  // 0 start vel, 1 end vel, 2 start acc, 3 end acc
+  return {(s & 1) ? K - 1 : 0, wts + ((s < 2) ? 5 : 10)};
+}
+
+// banded Cholesky solve of M x = g for three right-hand sides (lanes 0..2); M holds L afterwards
+__device__ void fit_solve(const double* L, int n, int hb, double* g, int lane) {
+  if (lane < 3) {
+    for (int j = 0; j < n; ++j) {
+      double s = g[3 * j + lane];
+      for (int d = 1; d <= hb && d <= j; ++d) s -= L[5 * j + d] * g[3 * (j - d) + lane];
+      g[3 * j + lane] = s / L[5 * j];
+    }
+    for (int j = n - 1; j >= 0; --j) {
+      double s = g[3 * j + lane];
+      for (int d = 1; d <= hb && j + d < n; ++d) s -= L[5 * (j + d) + d] * g[3 * (j + d) + lane];
+      g[3 * j + lane] = s / L[5 * j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bspline_fit(FitArgs F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int K = F.K, p = F.degree, n = K + p - 1, hb = p - 1, R = K + 4;
+  double* wts = reinterpret_cast<double*>(smem_raw);  // pos / vel / acc coefficients, 5 each
+  double* M = wts + 16;                               // [n][5]  M(j, j-d) at [j][d]
+  double* g = M + 5 * n;                              // [n][3]
+  double* x = g + 3 * n;                              // [n][3]
+  double* res = x + 3 * n;                            // [R][3]
+  double* u = res + 3 * R;                            // [n + p + 1]
+  const double ts = F.ts[c];
+  const double* pts = F.points + (size_t)c * K * 3;
+  const double* der = F.derivs + (size_t)c * 12;
+  if (lane == 0) {  // coefficient rows as the reference writes them (:199-236)
+    for (int i = 0; i < 15; ++i) wts[i] = 0.0;
+    if (p == 3) {
+      const double a = 1 / 6.0, b = 1 / (2 * ts), e = 1 / (ts * ts);
+      wts[0] = a * 1, wts[1] = a * 4, wts[2] = a * 1;
+      wts[5] = b * -1, wts[6] = b * 0, wts[7] = b * 1;
+      wts[10] = e * 1, wts[11] = e * -2, wts[12] = e * 1;
+    } else if (p == 4) {
+      const double a = 1 / 24.0, b = 1 / (6 * ts), e = 1 / (2 * ts * ts);
+      wts[0] = a * 1, wts[1] = a * 11, wts[2] = a * 11, wts[3] = a * 1;
+      wts[5] = b * -1, wts[6] = b * -3, wts[7] = b * 3, wts[8] = b * 1;
+      wts[10] = e * 1, wts[11] = e * -1, wts[12] = e * -1, wts[13] = e * 1;
+    } else {
+      const double cp[5] = {1, 26, 66, 26, 1}, cv[5] = {-1, -10, 0, 10, 1}, ca[5] = {1, 2, -6, 2, 1};
+      for (int i = 0; i < 5; ++i) wts[i] = cp[i] / 120.0, wts[5 + i] = cv[i] / (24 * ts), wts[10 + i] = ca[i] / (6 * ts * ts);
+    }
+  }
+  __syncthreads();
+  auto rhs = [&](int r, int a) { return r < K ? pts[3 * r + a] : der[3 * (r - K) + a]; };
+  // normal matrix and right-hand side, one unknown per lane
+  for (int j = lane; j < n; j += 64) {
+    double m[5] = {0, 0, 0, 0, 0}, gj[3] = {0, 0, 0};
+    auto add = [&](int r) {
+      const FitRow fr = fit_row(r, K, p, wts);
+      const int o = j - fr.c0;
+      if (o < 0 || o >= p) return;
+      const double wj = fr.w[o];
+      for (int d = 0; d <= hb && d <= o; ++d) m[d] += wj * fr.w[o - d];
+      for (int a = 0; a < 3; ++a) gj[a] += wj * rhs(r, a);
+    };
+    for (int r = max(0, j - p + 1); r <= min(K - 1, j); ++r) add(r);
+    for (int r = K; r < R; ++r) add(r);
+    for (int d = 0; d < 5; ++d) M[5 * j + d] = m[d];
+    for (int a = 0; a < 3; ++a) g[3 * j + a] = gj[a];
+  }
+  __syncthreads();
+  if (lane == 0) {  // banded Cholesky, in place
+    for (int j = 0; j < n; ++j) {
+      double s = M[5 * j];
+      for (int d = 1; d <= hb && d <= j; ++d) s -= M[5 * j + d] * M[5 * j + d];
+      const double ljj = sqrt(s);
+      M[5 * j] = ljj;
+      for (int i = j + 1; i <= j + hb && i < n; ++i) {
+        double t = M[5 * i + (i - j)];
+        for (int k = max(0, i - hb); k < j; ++k) t -= M[5 * i + (i - k)] * M[5 * j + (j - k)];
+        M[5 * i + (i - j)] = t / ljj;
+      }
+    }
+  }
+  __syncthreads();
+  fit_solve(M, n, hb, g, lane);
+  __syncthreads();
+  for (int i = lane; i < 3 * n; i += 64) x[i] = g[i];
+  __syncthreads();
+  // one refinement step: residual of the original rows, normal right-hand side, solve, add
+  for (int r = lane; r < R; r += 64) {
+    const FitRow fr = fit_row(r, K, p, wts);
+    for (int a = 0; a < 3; ++a) {
+      double s = rhs(r, a);
+      for (int k = 0; k < p; ++k) s -= fr.w[k] * x[3 * (fr.c0 + k) + a];
+      res[3 * r + a] = s;
+    }
+  }
+  __syncthreads();
+  for (int j = lane; j < n; j += 64) {
+    double gj[3] = {0, 0, 0};
+    auto add = [&](int r) {
+      const FitRow fr = fit_row(r, K, p, wts);
+      const int o = j - fr.c0;
+      if (o < 0 || o >= p) return;
+      for (int a = 0; a < 3; ++a) gj[a] += fr.w[o] * res[3 * r + a];
+    };
+    for (int r = max(0, j - p + 1); r <= min(K - 1, j); ++r) add(r);
+    for (int r = K; r < R; ++r) add(r);
+    for (int a = 0; a < 3; ++a) g[3 * j + a] = gj[a];
+  }
+  __syncthreads();
+  fit_solve(M, n, hb, g, lane);
+  __syncthreads();
+  for (int i = lane; i < 3 * n; i += 64) x[i] += g[i];
+  __syncthreads();
+  double* out = F.ctrl + (size_t)c * F.stride;
+  for (int i = lane; i < 3 * n; i += 64) out[i] = x[i];
+  if (F.write_dt && lane == 0) out[3 * n] = ts;
+  if (F.knot_span && lane == 0) F.knot_span[c] = ts;
+  if (!F.start_state && !F.end_state && !F.pt_dist) return;
+  if (lane == 0) spline_uniform_knots(u, n, p, ts);
+  __syncthreads();
+  if (lane < 3 && F.start_state) spline_boundary_value(x, n, p, u, lane, false, F.start_state + (size_t)c * 9 + 3 * lane);
+  if (lane == 3 && F.end_state) spline_boundary_value(x, n, p, u, 0, true, F.end_state + (size_t)c * 9);
+  if (lane == 4 && F.pt_dist) {
+    double s = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+      const double dx = x[3 * i + 3] - x[3 * i], dy = x[3 * i + 4] - x[3 * i + 1], dz = x[3 * i + 5] - x[3 * i + 2];
+      s += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    F.pt_dist[c] = s / double(n);
+  }
+}
+static size_t fit_lds(int K, int degree) {
+  const int n = K + degree - 1;
+  return (size_t)(16 + 5 * n + 3 * n + 3 * n + 3 * (K + 4) + n + degree + 1) * sizeof(double);
+}
+
+// getBoundaryStates(ks, ke) of C uniform B-splines: lanes 0..ks evaluate the start states, the next
+// ke+1 lanes the end states
+__global__ __launch_bounds__(64) void k_bspline_boundary(int n, int p, const double* __restrict__ ts,
+                                                         const double* __restrict__ ctrl, int ks, int ke,
+                                                         double* __restrict__ start, double* __restrict__ end) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* q = reinterpret_cast<double*>(smem_raw);
+  double* u = q + 3 * n;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < 3 * n; i += 64) q[i] = ctrl[(size_t)c * 3 * n + i];
+  if (lane == 0) spline_uniform_knots(u, n, p, ts[c]);
+  __syncthreads();
+  if (lane <= ks) spline_boundary_value(q, n, p, u, lane, false, start + ((size_t)c * (ks + 1) + lane) * 3);
+  else if (lane <= ks + 1 + ke)
+    spline_boundary_value(q, n, p, u, lane - ks - 1, true, end + ((size_t)c * (ke + 1) + (lane - ks - 1)) * 3);
+}
+
+// ---------------------------------------------------------------------------------------------
 static int upload(fuelmi_bspline_dev* b, const void* src, size_t bytes, const void** dst) {
   *dst = nullptr;
   if (!src || bytes == 0) return FUELMI_OK;
@@ -632,4 +858,132 @@ extern "C" int fuelmi_bspline_cost_grad(fuelmi_map* m, const fuelmi_bspline_cfg*
   if (rc == FUELMI_OK) rc = fuelmi_bspline_dev_download(b, cost, grad);
   fuelmi_bspline_dev_destroy(b);
   return rc;
+}
+
+// ---- spline glue entry points ----
+namespace {
+struct DevBuf {  // scoped device scratch of the one-shot calls
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+int fit_launch(fuelmi_map* m, const FitArgs& F) {
+  const size_t lds = fit_lds(F.K, F.degree);
+  if (lds > 160 * 1024) {
+    fuelmi_set_error("%d samples exceed the LDS budget of the spline fit", F.K);
+    return FUELMI_ELIMIT;
+  }
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_fit), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  k_bspline_fit<<<F.C, 64, lds, m->stream>>>(F);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+}  // namespace
+
+extern "C" int fuelmi_bspline_parameterize(fuelmi_map* m, int n_traj, int n_points, int degree, const double* ts,
+                                           const double* points, const double* derivs, double* ctrl) {
+  ARGCHK(m && ts && points && derivs && ctrl);
+  ARGCHK(n_traj >= 1 && n_points >= 2 && degree >= 3 && degree <= 5);
+  for (int c = 0; c < n_traj; ++c)
+    if (!(ts[c] > 0)) {  // "[B-spline]:time step error." (:181-184)
+      fuelmi_set_error("fuelmi_bspline_parameterize: time step of candidate %d is not positive", c);
+      return FUELMI_EINVAL;
+    }
+  HIPCHK(hipSetDevice(m->device));
+  const size_t C = (size_t)n_traj, K = (size_t)n_points, n = K + degree - 1;
+  const size_t b_ts = C * sizeof(double), b_pts = C * K * 3 * sizeof(double), b_der = C * 12 * sizeof(double),
+               b_ctrl = C * n * 3 * sizeof(double);
+  DevBuf buf;
+  HIPCHK(hipMalloc(&buf.p, b_ts + b_pts + b_der + b_ctrl));
+  unsigned char* d = static_cast<unsigned char*>(buf.p);
+  HIPCHK(hipMemcpyAsync(d, ts, b_ts, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d + b_ts, points, b_pts, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d + b_ts + b_pts, derivs, b_der, hipMemcpyHostToDevice, m->stream));
+  FitArgs F;
+  memset(&F, 0, sizeof(F));
+  F.C = n_traj, F.K = n_points, F.degree = degree;
+  F.ts = reinterpret_cast<double*>(d);
+  F.points = reinterpret_cast<double*>(d + b_ts);
+  F.derivs = reinterpret_cast<double*>(d + b_ts + b_pts);
+  F.ctrl = reinterpret_cast<double*>(d + b_ts + b_pts + b_der);
+  F.stride = (long)(n * 3);
+  const int rc = fit_launch(m, F);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctrl, F.ctrl, b_ctrl, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_bspline_boundary_states(fuelmi_map* m, int n_traj, int n_ctrl, int degree, const double* ts,
+                                              const double* ctrl, int ks, int ke, double* start, double* end) {
+  ARGCHK(m && ts && ctrl && start && end);
+  ARGCHK(n_traj >= 1 && degree >= 1 && degree <= 5 && n_ctrl > degree);
+  ARGCHK(ks >= 0 && ke >= 0 && ks <= degree && ke <= degree);
+  HIPCHK(hipSetDevice(m->device));
+  const size_t C = (size_t)n_traj, n = (size_t)n_ctrl;
+  const size_t b_ts = C * sizeof(double), b_ctrl = C * n * 3 * sizeof(double), b_s = C * (ks + 1) * 3 * sizeof(double),
+               b_e = C * (ke + 1) * 3 * sizeof(double);
+  const size_t lds = (3 * n + n + degree + 1) * sizeof(double);
+  if (lds > 64 * 1024) {
+    fuelmi_set_error("%d control points exceed the LDS budget", n_ctrl);
+    return FUELMI_ELIMIT;
+  }
+  DevBuf buf;
+  HIPCHK(hipMalloc(&buf.p, b_ts + b_ctrl + b_s + b_e));
+  unsigned char* d = static_cast<unsigned char*>(buf.p);
+  HIPCHK(hipMemcpyAsync(d, ts, b_ts, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d + b_ts, ctrl, b_ctrl, hipMemcpyHostToDevice, m->stream));
+  double* d_s = reinterpret_cast<double*>(d + b_ts + b_ctrl);
+  double* d_e = reinterpret_cast<double*>(d + b_ts + b_ctrl + b_s);
+  k_bspline_boundary<<<n_traj, 64, lds, m->stream>>>(n_ctrl, degree, reinterpret_cast<double*>(d),
+                                                      reinterpret_cast<double*>(d + b_ts), ks, ke, d_s, d_e);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(start, d_s, b_s, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(end, d_e, b_e, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return FUELMI_OK;
+}
+
+// planner glue on the device: samples -> control points + knot span -> getBoundaryStates(2, 0) ->
+// setBoundaryStates + pt_dist_, written into the batch's own device state (asynchronous; the next
+// _eval / _optimize sees it)
+extern "C" int fuelmi_bspline_dev_load_samples(fuelmi_bspline_dev* b, int n_points, const double* ts,
+                                               const double* points, const double* derivs) {
+  ARGCHK(b && ts && points && derivs);
+  BsplineArgs& A = b->a;
+  const int degree = A.cfg.bspline_degree;
+  ARGCHK(A.dim == 3 && degree >= 3 && degree <= 5 && n_points >= 2 && n_points + degree - 1 == A.N);
+  fuelmi_map* m = b->map;
+  HIPCHK(hipSetDevice(m->device));
+  const size_t C = (size_t)A.C, K = (size_t)n_points;
+  const size_t b_ts = C * sizeof(double), b_pts = C * K * 3 * sizeof(double), b_der = C * 12 * sizeof(double);
+  if (b_ts + b_pts + b_der > b->fit_cap) {
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, b_ts + b_pts + b_der));
+    b->allocs.push_back(d);
+    b->fit_in = static_cast<double*>(d);
+    b->fit_cap = b_ts + b_pts + b_der;
+  }
+  unsigned char* d = reinterpret_cast<unsigned char*>(b->fit_in);
+  HIPCHK(hipMemcpyAsync(d, ts, b_ts, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d + b_ts, points, b_pts, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(d + b_ts + b_pts, derivs, b_der, hipMemcpyHostToDevice, m->stream));
+  FitArgs F;
+  memset(&F, 0, sizeof(F));
+  F.C = A.C, F.K = n_points, F.degree = degree;
+  F.ts = reinterpret_cast<double*>(d);
+  F.points = reinterpret_cast<double*>(d + b_ts);
+  F.derivs = reinterpret_cast<double*>(d + b_ts + b_pts);
+  F.ctrl = const_cast<double*>(A.x);
+  F.stride = A.nvar;
+  F.write_dt = (A.cost_function & FUELMI_COST_MINTIME) ? 1 : 0;
+  F.knot_span = const_cast<double*>(A.knot_span);
+  F.pt_dist = const_cast<double*>(A.pt_dist);
+  F.start_state = const_cast<double*>(A.start_state);
+  F.end_state = const_cast<double*>(A.end_state);
+  StageScope sc(m, FUELMI_K_BSPLINE);
+  return fit_launch(m, F);
 }

@@ -455,6 +455,40 @@ class BsplineOptimizer:
         return BsplineDeviceProblem(self, problem)
 
 
+class NonUniformBspline:
+    """The two NonUniformBspline calls the planners wrap around optimize() (bspline/src/non_uniform_bspline.cpp),
+    batched over candidates on the map's device."""
+
+    @staticmethod
+    def parameterizeToBspline(sdf_map, ts, points, derivs, degree=3):
+        """ts [C], points [C][K][3], derivs [C][4][3] -> control points [C][K+degree-1][3] (:178-265)."""
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        derivs = np.ascontiguousarray(derivs, dtype=np.float64)
+        if points.ndim != 3 or points.shape[2] != 3 or ts.shape != (points.shape[0],) or \
+                derivs.shape != (points.shape[0], 4, 3):
+            raise ValueError("parameterizeToBspline: ts [C], points [C][K][3], derivs [C][4][3]")
+        cn, k = points.shape[0], points.shape[1]
+        ctrl = np.empty((cn, k + degree - 1, 3))
+        check(lib().fuelmi_bspline_parameterize(sdf_map.h, cn, k, int(degree), _dp(ts), _dp(points), _dp(derivs),
+                                                _dp(ctrl)))
+        return ctrl
+
+    @staticmethod
+    def getBoundaryStates(sdf_map, ctrl, ts, degree=3, ks=2, ke=0):
+        """ctrl [C][N][3], ts [C] -> (start [C][ks+1][3], end [C][ke+1][3]) (:107-122)."""
+        ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        if ctrl.ndim != 3 or ctrl.shape[2] != 3 or ts.shape != (ctrl.shape[0],):
+            raise ValueError("getBoundaryStates: ctrl [C][N][3], ts [C]")
+        cn = ctrl.shape[0]
+        start = np.empty((cn, ks + 1, 3))
+        end = np.empty((cn, ke + 1, 3))
+        check(lib().fuelmi_bspline_boundary_states(sdf_map.h, cn, ctrl.shape[1], int(degree), _dp(ts), _dp(ctrl),
+                                                   int(ks), int(ke), _dp(start), _dp(end)))
+        return start, end
+
+
 class BsplineDeviceProblem:
     def __init__(self, opt, problem):
         self.L = opt.L
@@ -483,6 +517,18 @@ class BsplineDeviceProblem:
         ev = np.empty(c.n_traj, dtype=np.int32)
         check(self.L.fuelmi_bspline_dev_optimize(self.h, int(max_eval), _dp(x), _dp(cost), _ip(ev)))
         return x, cost, ev
+
+    def loadSamples(self, ts, points, derivs):
+        """samples -> parameterizeToBspline -> getBoundaryStates(2, 0) -> setBoundaryStates + pt_dist_ on the
+        device (planner_manager.cpp:161-184): ts [C], points [C][K][3], derivs [C][4][3]."""
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        derivs = np.ascontiguousarray(derivs, dtype=np.float64)
+        c = self.problem.c
+        if ts.shape != (c.n_traj,) or points.ndim != 3 or points.shape[0] != c.n_traj or points.shape[2] != 3 \
+                or derivs.shape != (c.n_traj, 4, 3):
+            raise ValueError("loadSamples: ts [C], points [C][K][3], derivs [C][4][3]")
+        check(self.L.fuelmi_bspline_dev_load_samples(self.h, points.shape[1], _dp(ts), _dp(points), _dp(derivs)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -289,6 +289,31 @@ int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, double* x_o
                                 int* evals_out);
 void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b);
 
+/* Spline glue around the solve, batched (NonUniformBspline, bspline/src/non_uniform_bspline.cpp).
+ *
+ * fuelmi_bspline_parameterize = parameterizeToBspline (:178-265) for n_traj sample sets at once: the
+ * least-squares control points of a uniform B-spline (degree 3..5, knot span ts) through n_points
+ * samples whose start/end velocity and acceleration match `derivs` (the reference solves the
+ * (K+4) x (K+degree-1) system with Eigen's ColPivHouseholderQR; results agree to ~1e-12).
+ *   ts [C], points [C][K][3], derivs [C][4][3] (start vel, end vel, start acc, end acc)
+ *   -> ctrl [C][K+degree-1][3].  ts <= 0 is rejected ("time step error", :181-184).
+ * fuelmi_bspline_boundary_states = getBoundaryStates(ks, ke) (:107-122) of n_traj uniform B-splines
+ * (setUniformBspline :15-32): position and the first ks / ke derivatives at t = 0 / t = duration.
+ *   ctrl [C][n_ctrl][3] -> start [C][ks+1][3], end [C][ke+1][3].
+ * Host arrays, synchronous. */
+int fuelmi_bspline_parameterize(fuelmi_map* m, int n_traj, int n_points, int degree, const double* ts,
+                                const double* points, const double* derivs, double* ctrl);
+int fuelmi_bspline_boundary_states(fuelmi_map* m, int n_traj, int n_ctrl, int degree, const double* ts,
+                                   const double* ctrl, int ks, int ke, double* start, double* end);
+/* The planners' sequence "samples -> parameterizeToBspline -> getBoundaryStates(2, 0) ->
+ * setBoundaryStates -> optimize" (plan_manage/src/planner_manager.cpp:161-184, 296-314) without leaving
+ * the device: refills the batch `b` (dim 3, point_num = n_points + bspline_degree - 1) with the fitted
+ * control points, knot span ts, pt_dist_, start state (pos, vel, acc) and end position; asynchronous on
+ * the map's stream, the next _dev_eval / _dev_optimize uses them.  Rows 1..2 of end_state keep what
+ * the batch was created with (the planners pass end_n = 1). */
+int fuelmi_bspline_dev_load_samples(fuelmi_bspline_dev* b, int n_points, const double* ts, const double* points,
+                                    const double* derivs);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): HIP events recorded on the map's own stream.
  * ---------------------------------------------------------------------------------------- */

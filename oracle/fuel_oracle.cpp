@@ -5,6 +5,7 @@
 #include "fuel_oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -1502,4 +1503,160 @@ extern "C" double fo_bspline_optimize(const fo_map* m, const fo_bspline_cfg* cfg
   for (int i = 0; i < n; ++i) x_io[i] = best[i];
   if (evals_out) *evals_out = evals;
   return fbest;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NonUniformBspline glue (fuel_planner/bspline/src/non_uniform_bspline.cpp)
+// ---------------------------------------------------------------------------------------------
+namespace {
+// Least squares by Householder QR with column pivoting -- the published algorithm behind Eigen's
+// ColPivHouseholderQR::solve (Eigen is third party and absent; Golub & Van Loan, Alg. 5.4.1): at every
+// step the remaining column of largest norm is moved to the front, a reflector zeroes it below the
+// diagonal and is applied to the rest and to b; then R x = Q^T b by back substitution, un-permuted.
+std::vector<double> lstsq_colpiv_qr(std::vector<double> A, int rows, int cols, std::vector<double> b) {
+  std::vector<int> perm(cols);
+  for (int j = 0; j < cols; ++j) perm[j] = j;
+  auto at = [&](int i, int j) -> double& { return A[(size_t)i * cols + j]; };
+  for (int k = 0; k < cols; ++k) {
+    int best = k;
+    double bestn = -1.0;
+    for (int j = k; j < cols; ++j) {
+      double s = 0.0;
+      for (int i = k; i < rows; ++i) s += at(i, j) * at(i, j);
+      if (s > bestn) bestn = s, best = j;
+    }
+    if (best != k) {
+      for (int i = 0; i < rows; ++i) std::swap(at(i, k), at(i, best));
+      std::swap(perm[k], perm[best]);
+    }
+    double norm = std::sqrt(bestn);
+    if (norm == 0.0) continue;
+    const double alpha = at(k, k) > 0 ? -norm : norm;
+    std::vector<double> v(rows - k);
+    for (int i = k; i < rows; ++i) v[i - k] = at(i, k);
+    v[0] -= alpha;
+    double vv = 0.0;
+    for (double e : v) vv += e * e;
+    if (vv == 0.0) continue;
+    for (int j = k; j < cols; ++j) {
+      double dot = 0.0;
+      for (int i = k; i < rows; ++i) dot += v[i - k] * at(i, j);
+      const double f = 2.0 * dot / vv;
+      for (int i = k; i < rows; ++i) at(i, j) -= f * v[i - k];
+    }
+    double dot = 0.0;
+    for (int i = k; i < rows; ++i) dot += v[i - k] * b[i];
+    const double f = 2.0 * dot / vv;
+    for (int i = k; i < rows; ++i) b[i] -= f * v[i - k];
+  }
+  std::vector<double> y(cols), x(cols);
+  for (int j = cols - 1; j >= 0; --j) {
+    double s = b[j];
+    for (int k = j + 1; k < cols; ++k) s -= at(j, k) * y[k];
+    y[j] = s / at(j, j);
+  }
+  for (int j = 0; j < cols; ++j) x[perm[j]] = y[j];
+  return x;
+}
+
+// a spline as NonUniformBspline holds it: control points (rows), degree p_, knots u_
+struct OSpline {
+  std::vector<std::array<double, 3>> cp;
+  int p = 0;
+  std::vector<double> u;
+  int n_() const { return (int)cp.size() - 1; }
+  int m_() const { return n_() + p + 1; }
+};
+// setUniformBspline (:15-32)
+OSpline spline_uniform(const double* ctrl, int n, int degree, double interval) {
+  OSpline s;
+  s.cp.resize(n);
+  for (int i = 0; i < n; ++i) s.cp[i] = {ctrl[3 * i], ctrl[3 * i + 1], ctrl[3 * i + 2]};
+  s.p = degree;
+  const int m = s.m_();
+  s.u.assign(m + 1, 0.0);
+  for (int i = 0; i <= m; ++i) s.u[i] = i <= degree ? double(-degree + i) * interval : s.u[i - 1] + interval;
+  return s;
+}
+// evaluateDeBoor (:51-71)
+std::array<double, 3> spline_deboor(const OSpline& s, double uu) {
+  const int p = s.p;
+  const double ub = std::min(std::max(s.u[p], uu), s.u[s.m_() - p]);
+  int k = p;
+  while (s.u[k + 1] < ub) ++k;
+  std::vector<std::array<double, 3>> d;
+  for (int i = 0; i <= p; ++i) d.push_back(s.cp[k - p + i]);
+  for (int r = 1; r <= p; ++r)
+    for (int i = p; i >= r; --i) {
+      const double alpha = (ub - s.u[i + k - p]) / (s.u[i + 1 + k - r] - s.u[i + k - p]);
+      for (int a = 0; a < 3; ++a) d[i][a] = (1 - alpha) * d[i - 1][a] + alpha * d[i][a];
+    }
+  return d[p];
+}
+// getDerivative (:89-104) with getDerivativeControlPoints (:77-87)
+OSpline spline_derivative(const OSpline& s) {
+  OSpline d;
+  d.p = s.p - 1;
+  d.cp.resize(s.cp.size() - 1);
+  for (size_t i = 0; i < d.cp.size(); ++i)
+    for (int a = 0; a < 3; ++a)
+      d.cp[i][a] = s.p * (s.cp[i + 1][a] - s.cp[i][a]) / (s.u[i + s.p + 1] - s.u[i + 1]);
+  d.u.assign(s.u.begin() + 1, s.u.end() - 1);
+  return d;
+}
+}  // namespace
+
+// parameterizeToBspline (:178-265); ctrl: (K + degree - 1) x 3.  Returns 0, or -1 on the inputs the
+// reference refuses (ts <= 0, fewer than 2 points).
+extern "C" int fo_spline_parameterize(double ts, const double* pts, int K, const double* derivs4, int degree,
+                                      double* ctrl) {
+  if (ts <= 0 || K < 2 || degree < 3 || degree > 5) return -1;
+  const int rows = K + 4, cols = K + degree - 1;
+  std::vector<double> A((size_t)rows * cols, 0.0);
+  double pp[5], pv[5], pa[5];
+  if (degree == 3) {
+    const double c3[3] = {1, 4, 1}, v3[3] = {-1, 0, 1}, a3[3] = {1, -2, 1};
+    for (int i = 0; i < 3; ++i) pp[i] = 1 / 6.0 * c3[i], pv[i] = 1 / (2 * ts) * v3[i], pa[i] = 1 / (ts * ts) * a3[i];
+  } else if (degree == 4) {
+    const double c4[4] = {1, 11, 11, 1}, v4[4] = {-1, -3, 3, 1}, a4[4] = {1, -1, -1, 1};
+    for (int i = 0; i < 4; ++i)
+      pp[i] = 1 / 24.0 * c4[i], pv[i] = 1 / (6 * ts) * v4[i], pa[i] = 1 / (2 * ts * ts) * a4[i];
+  } else {
+    const double c5[5] = {1, 26, 66, 26, 1}, v5[5] = {-1, -10, 0, 10, 1}, a5[5] = {1, 2, -6, 2, 1};
+    for (int i = 0; i < 5; ++i) pp[i] = c5[i] / 120.0, pv[i] = v5[i] / (24 * ts), pa[i] = a5[i] / (6 * ts * ts);
+  }
+  for (int i = 0; i < K; ++i)
+    for (int k = 0; k < degree; ++k) A[(size_t)i * cols + i + k] = pp[k];
+  for (int k = 0; k < degree; ++k) {
+    A[(size_t)K * cols + k] = pv[k];
+    A[(size_t)(K + 1) * cols + K - 1 + k] = pv[k];
+    A[(size_t)(K + 2) * cols + k] = pa[k];
+    A[(size_t)(K + 3) * cols + K - 1 + k] = pa[k];
+  }
+  for (int a = 0; a < 3; ++a) {
+    std::vector<double> b(rows);
+    for (int i = 0; i < K; ++i) b[i] = pts[3 * i + a];
+    for (int i = 0; i < 4; ++i) b[K + i] = derivs4[3 * i + a];
+    const std::vector<double> x = lstsq_colpiv_qr(A, rows, cols, b);
+    for (int j = 0; j < cols; ++j) ctrl[3 * j + a] = x[j];
+  }
+  return 0;
+}
+
+// getBoundaryStates(ks, ke) (:107-122) of the uniform spline (ctrl, degree, ts);
+// start: (ks + 1) x 3, end: (ke + 1) x 3
+extern "C" void fo_spline_boundary_states(const double* ctrl, int n, int degree, double ts, int ks, int ke,
+                                          double* start, double* end) {
+  const OSpline s = spline_uniform(ctrl, n, degree, ts);
+  std::vector<OSpline> ders;  // computeDerivatives(max(ks, ke)) (:89-97)
+  const int kd = std::max(ks, ke);
+  if (kd >= 1) ders.push_back(spline_derivative(s));
+  for (int i = 2; i <= kd; ++i) ders.push_back(spline_derivative(ders.back()));
+  const double duration = s.u[s.m_() - s.p] - s.u[s.p];  // getTimeSum (:267-269)
+  auto at = [](const OSpline& sp, double t) { return spline_deboor(sp, t + sp.u[sp.p]); };  // evaluateDeBoorT
+  auto put = [](double* dst, const std::array<double, 3>& v) { dst[0] = v[0], dst[1] = v[1], dst[2] = v[2]; };
+  put(start, at(s, 0.0));
+  for (int i = 0; i < ks; ++i) put(start + 3 * (i + 1), at(ders[i], 0.0));
+  put(end, at(s, duration));
+  for (int i = 0; i < ke; ++i) put(end + 3 * (i + 1), at(ders[i], duration));
 }

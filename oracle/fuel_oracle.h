@@ -200,6 +200,15 @@ void fo_bspline_cost_grad(const fo_map* m, const fo_bspline_cfg* cfg, const fo_b
 double fo_bspline_optimize(const fo_map* m, const fo_bspline_cfg* cfg, const fo_bspline_problem* pb, double* x_io,
                            int max_eval, int* evals);
 
+/* NonUniformBspline::parameterizeToBspline (bspline/src/non_uniform_bspline.cpp:178-265): least-squares
+   control points [(K+degree-1) x 3] through K samples with start/end velocity and acceleration
+   (derivs4: start vel, end vel, start acc, end acc); the solver is a restatement of column-pivoted
+   Householder QR (Eigen, third party).  Returns -1 on the inputs the reference refuses. */
+int fo_spline_parameterize(double ts, const double* pts, int K, const double* derivs4, int degree, double* ctrl);
+/* setUniformBspline (:15-32) + getBoundaryStates(ks, ke) (:107-122): start [(ks+1) x 3], end [(ke+1) x 3] */
+void fo_spline_boundary_states(const double* ctrl, int n, int degree, double ts, int ks, int ke, double* start,
+                               double* end);
+
 /* MapROS::proessDepthImage (plan_env/src/map_ros.cpp:176-215); parameters map_ros.cpp:22-30 */
 typedef struct {
   double fx, fy, cx, cy;

@@ -419,6 +419,33 @@ def bspline_pt_dist(ctrl):
     return lib().fo_bspline_pt_dist(_dp(ctrl), n, dim)
 
 
+def spline_parameterize(ts, points, derivs, degree=3):
+    """parameterizeToBspline (non_uniform_bspline.cpp:178-265): points [K][3], derivs [4][3] -> ctrl [K+degree-1][3]."""
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    derivs = np.ascontiguousarray(derivs, dtype=np.float64)
+    L = lib()
+    L.fo_spline_parameterize.restype = C.c_int
+    L.fo_spline_parameterize.argtypes = [C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                         C.POINTER(C.c_double)]
+    ctrl = np.zeros((len(points) + degree - 1, 3))
+    if L.fo_spline_parameterize(float(ts), _dp(points), len(points), _dp(derivs), int(degree), _dp(ctrl)):
+        raise ValueError("parameterizeToBspline: refused inputs")
+    return ctrl
+
+
+def spline_boundary_states(ctrl, ts, degree=3, ks=2, ke=0):
+    """getBoundaryStates(ks, ke) (non_uniform_bspline.cpp:107-122) -> (start [ks+1][3], end [ke+1][3])."""
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+    L = lib()
+    L.fo_spline_boundary_states.restype = None
+    L.fo_spline_boundary_states.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    start = np.zeros((ks + 1, 3))
+    end = np.zeros((ke + 1, 3))
+    L.fo_spline_boundary_states(_dp(ctrl), len(ctrl), int(degree), float(ts), int(ks), int(ke), _dp(start), _dp(end))
+    return start, end
+
+
 def _bspline_setup(x, point_num, cost_function, pt_dist, start_state, end_state, end_n=3,
                       dim=3, knot_span=0.0, time_lb=-1.0, guide_pts=None, waypoints=None,
                       waypt_idx=None, view=None, **cfgkw):

@@ -280,3 +280,31 @@ def project_depth(img, pos, quat_wxyz, cfg=None):
                                   (C.c_double * 3)(*[float(v) for v in pos]),
                                   (C.c_double * 4)(*[float(v) for v in quat_wxyz]), out.ctypes.data, cap)
     return out[:n].copy()
+
+
+def spline_parameterize(ts, points, derivs, degree=3):
+    """The real NonUniformBspline::parameterizeToBspline."""
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    derivs = np.ascontiguousarray(derivs, dtype=np.float64)
+    L = lib()
+    D = C.POINTER(C.c_double)
+    L.ref_spline_parameterize.restype = None
+    L.ref_spline_parameterize.argtypes = [C.c_double, D, C.c_int, D, C.c_int, D]
+    ctrl = np.zeros((len(points) + degree - 1, 3))
+    L.ref_spline_parameterize(float(ts), points.ctypes.data_as(D), len(points), derivs.ctypes.data_as(D), int(degree),
+                              ctrl.ctypes.data_as(D))
+    return ctrl
+
+
+def spline_boundary_states(ctrl, ts, degree=3, ks=2, ke=0):
+    """The real NonUniformBspline::getBoundaryStates on setUniformBspline(ctrl, degree, ts)."""
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+    L = lib()
+    D = C.POINTER(C.c_double)
+    L.ref_spline_boundary_states.restype = None
+    L.ref_spline_boundary_states.argtypes = [D, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, D, D]
+    start = np.zeros((ks + 1, 3))
+    end = np.zeros((ke + 1, 3))
+    L.ref_spline_boundary_states(ctrl.ctypes.data_as(D), len(ctrl), int(degree), float(ts), int(ks), int(ke),
+                                 start.ctypes.data_as(D), end.ctypes.data_as(D))
+    return start, end

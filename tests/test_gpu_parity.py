@@ -732,6 +732,102 @@ def test_bspline_device_optimizer_against_oracle_lbfgs(fa):
     gm.close()
 
 
+def _sample_paths(rng, cn, k, lo, hi):
+    """cn smooth sample sets inside [lo, hi] + start/end velocity and acceleration, as getSamples() hands them over."""
+    pts = np.empty((cn, k, 3))
+    for c in range(cn):
+        a = lo + (hi - lo) * rng.random(3)
+        b = lo + (hi - lo) * rng.random(3)
+        s = np.linspace(0, 1, k)[:, None]
+        pts[c] = a + (b - a) * s + 0.4 * np.sin(np.pi * s * rng.integers(1, 4)) * rng.normal(size=3)
+    pts = np.clip(pts, lo, hi)
+    der = rng.normal(scale=0.7, size=(cn, 4, 3))
+    return pts, der
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_spline_parameterize_and_boundary_states_match_oracle(fa, degree):
+    """fuelmi_bspline_parameterize / _boundary_states vs the oracle's restatement of NonUniformBspline
+    (itself pinned on the real class): control points within 1e-9 (the reference solves by QR, the device by
+    banded normal equations + one refinement step), boundary states within 1e-10 (same arithmetic, FMA
+    contraction aside).  K = 2 (the smallest the reference accepts), ragged knot spans, 150 samples."""
+    gm = fa.SDFMap((8.0, 8.0, 3.0))
+    rng = np.random.default_rng(40 + degree)
+    for cn, k in [(1, 2), (5, 3), (33, 17), (3, 150)]:
+        ts = 0.1 + 0.4 * rng.random(cn)
+        pts, der = _sample_paths(rng, cn, k, np.array([-3.0, -3.0, 0.2]), np.array([3.0, 3.0, 1.8]))
+        got = fa.NonUniformBspline.parameterizeToBspline(gm, ts, pts, der, degree)
+        assert got.shape == (cn, k + degree - 1, 3)
+        for c in range(cn):
+            want = fo.spline_parameterize(ts[c], pts[c], der[c], degree)
+            assert np.abs(got[c] - want).max() <= 1e-9, (cn, k, c)
+        for ks, ke in [(2, 0), (2, 2), (degree, 1), (0, 0)]:
+            s, e = fa.NonUniformBspline.getBoundaryStates(gm, got, ts, degree, ks, ke)
+            for c in range(cn):
+                s0, e0 = fo.spline_boundary_states(got[c], ts[c], degree, ks, ke)
+                scale = max(1.0, np.abs(s0).max(), np.abs(e0).max())
+                assert np.abs(s[c] - s0).max() <= 1e-10 * scale and np.abs(e[c] - e0).max() <= 1e-10 * scale
+    with pytest.raises(fa.FuelmiError):  # "[B-spline]:time step error."
+        fa.NonUniformBspline.parameterizeToBspline(gm, np.array([0.0]), pts[:1], der[:1], degree)
+    with pytest.raises(fa.FuelmiError):  # "point set have only 1 points"
+        fa.NonUniformBspline.parameterizeToBspline(gm, np.array([0.2]), pts[:1, :1], der[:1], degree)
+    with pytest.raises(fa.FuelmiError):
+        fa.NonUniformBspline.parameterizeToBspline(gm, np.array([0.2]), pts[:1], der[:1], 6)
+    gm.close()
+
+
+@pytest.mark.gpu
+def test_samples_to_solve_on_the_device_matches_the_stepwise_oracle(fa):
+    """planner_manager.cpp:161-184 as one device sequence (loadSamples -> eval / optimize) against the same
+    steps done one by one with the oracle: parameterizeToBspline -> getBoundaryStates(2,0) -> pt_dist_ ->
+    combineCost.  Cost rel 1e-6, gradient 1e-4 (the §8d bar); the solve then improves every candidate."""
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    gm = gpu_twin(fa, om, box)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    cf = fa.NORMAL_PHASE | fa.MINTIME
+    rng = np.random.default_rng(77)
+    cn, k, degree = 20, 30, 3
+    n = k + degree - 1
+    ts = 0.15 + 0.1 * rng.random(cn)
+    pts, der = _sample_paths(rng, cn, k, np.array(box[0]) + 0.6, np.array(box[1]) - 0.6)
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    # the batch is created with placeholders; loadSamples replaces x, knot span, pt_dist and the boundary states
+    x0 = np.zeros((cn, 3 * n + 1))
+    x0[:, -1] = 1.0
+    pb = fa.BsplineBatchProblem(x0, n, cf, np.ones(cn), np.zeros((cn, 3, 3)), np.zeros((cn, 3, 3)), 1, 3, 1.0)
+    dev = opt.deviceProblem(pb)
+    dev.loadSamples(ts, pts, der)
+    dev.eval()
+    cost, grad = dev.download()
+    f0 = np.empty(cn)
+    for c in range(cn):
+        ctrl = fo.spline_parameterize(ts[c], pts[c], der[c], degree)
+        st, en = fo.spline_boundary_states(ctrl, ts[c], degree, 2, 0)
+        en3 = np.zeros((3, 3))
+        en3[0] = en[0]
+        x = np.concatenate([ctrl.reshape(-1), [ts[c]]])
+        f, g = fo.bspline_cost_grad(om, x, n, cf, fo.bspline_pt_dist(ctrl), st, en3, 1, 3, ts[c])
+        f0[c] = f
+        assert abs(cost[c] - f) <= 1e-6 * max(1.0, abs(f)), c
+        assert np.abs(grad[c] - g).max() <= GRAD_TOL * max(1.0, np.abs(g).max()), c
+    xg, cg, eg = dev.optimize(max_eval=200)
+    assert (cg <= f0 + 1e-9).all() and (cg < 0.9 * f0).sum() >= cn // 2
+    # a second load into the same batch (the next replan) starts from the new samples, not the old solution
+    dev.loadSamples(ts[::-1].copy(), pts[::-1].copy(), der[::-1].copy())
+    dev.eval()
+    cost2, _ = dev.download()
+    assert np.allclose(cost2, cost[::-1], rtol=1e-9, atol=1e-12)
+    gm.close()
+
+
 @pytest.mark.gpu
 def test_frontier_regrows_dropped_clusters_beyond_the_scan_box(fa):
     """The search only processes the region that can hold new cells (scan box + boxes of the clusters it
