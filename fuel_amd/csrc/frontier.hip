@@ -149,9 +149,12 @@ __global__ void k_clear_pool(u64* flag, const u32* __restrict__ pool, const u64*
   const long a = pool[cand_off[k] + (i - cand_start[k])];
   atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
 }
-__global__ void k_pool_put(u32* __restrict__ dst, const u32* __restrict__ src, u32 n, int seed) {
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
-  if (seed >= 0 && blockIdx.x == 0 && threadIdx.x == 0) dst[n] = (u32)seed;  // order is irrelevant on the device
+__global__ void k_pool_put(u32* __restrict__ pool, const u32* __restrict__ cells, const PoolPut* __restrict__ table) {
+  const PoolPut e = table[blockIdx.x];  // one workgroup per cluster
+  u32* dst = pool + e.dst;
+  const u32* src = cells + e.src;
+  for (u32 i = threadIdx.x; i < e.n; i += blockDim.x) dst[i] = src[i];
+  if (e.seed >= 0 && threadIdx.x == 0) dst[e.n] = (u32)e.seed;  // order is irrelevant on the device
 }
 __global__ void k_clear_flags(u64* flag, const int* __restrict__ cells, const int* __restrict__ cell_cluster,
                               const int* __restrict__ changed, int n) {
@@ -1274,22 +1277,37 @@ static int pool_reserve(fuelmi_frontier* f, size_t need) {
   HIPCHK(hipStreamSynchronize(f->stream));  // the host lists may be freed by the caller afterwards
   return FUELMI_OK;
 }
-int frontier_keep_cluster(fuelmi_frontier* f, HCluster& c) {
-  const size_t n = c.size();
-  int rc = pool_reserve(f, n);
+// commit this search's clusters to the pool: the ones whose cells still sit grouped on the device are
+// copied there by ONE launch (a table of {destination, source, count, seed} per cluster)
+int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
+  size_t need = 0, nlazy = 0;
+  for (HCluster& c : clusters) need += c.size(), nlazy += c.lazy ? 1 : 0;
+  int rc = pool_reserve(f, need);
   if (rc) return rc;
-  if (c.lazy) {  // this search's result still sits grouped on the device: device-to-device
-    const size_t src_off = (size_t)(c.lazy - reinterpret_cast<const int*>(f->F.h_cells));
-    k_pool_put<<<fblocks((long)c.lazy_n, 256, 256), 256, 0, f->stream>>>(f->pool + f->pool_used,
-                                                                        f->F.ms_val[f->last_fin] + src_off, c.lazy_n,
-                                                                        c.lazy_seed);
-    HIPCHK(hipGetLastError());
+  std::vector<PoolPut> table;
+  table.reserve(nlazy);
+  for (HCluster& c : clusters) {
+    if (!c.lazy) {
+      if ((rc = pool_upload(f, c))) return rc;
+      continue;
+    }
+    PoolPut e;
+    e.dst = f->pool_used;
+    e.src = (u32)(c.lazy - reinterpret_cast<const int*>(f->F.h_cells));
+    e.n = (u32)c.lazy_n;
+    e.seed = c.lazy_seed;
+    table.push_back(e);
     c.pool_off = f->pool_used;
-    f->pool_used += n;
+    f->pool_used += c.size();
     c.materialize();
-    return FUELMI_OK;
   }
-  return pool_upload(f, c);
+  if (table.empty()) return FUELMI_OK;
+  if ((rc = frontier_ensure_stage(f, table.size() * sizeof(PoolPut)))) return rc;
+  HIPCHK(hipMemcpyAsync(f->d_stage, table.data(), table.size() * sizeof(PoolPut), hipMemcpyHostToDevice, f->stream));
+  k_pool_put<<<(unsigned)table.size(), 256, 0, f->stream>>>(f->pool, f->F.ms_val[f->last_fin],
+                                                             reinterpret_cast<const PoolPut*>(f->d_stage));
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
 }
 
 // Drop the clusters that overlap the updated box and contain a cell that is no longer a frontier cell
@@ -1698,11 +1716,9 @@ extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
   ARGCHK(f);
   auto& dst = dormant ? f->dormant : f->frontiers;
   HIPCHK(hipSetDevice(f->map->device));
-  while (!f->tmp.empty()) {
-    int rc = frontier_keep_cluster(f, f->tmp.front());
-    if (rc) return rc;
-    dst.splice(dst.end(), f->tmp, f->tmp.begin());
-  }
+  const int rc = frontier_keep_clusters(f, f->tmp);
+  if (rc) return rc;
+  dst.splice(dst.end(), f->tmp);
   return FUELMI_OK;
 }
 

@@ -169,7 +169,12 @@ struct fuelmi_frontier {
 };
 void frontier_split_free(fuelmi_frontier* f);
 // tmp cluster -> committed: materialises the host list and copies the cells into the device pool
-int frontier_keep_cluster(fuelmi_frontier* f, HCluster& c);
+struct PoolPut {  // one cluster's copy into the cell pool
+  u64 dst;
+  u32 src, n;
+  int seed, pad;
+};
+int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters);
 
 
 // runs the stable radix multisplit of F2.ms_key[0]/ms_val[0] (F2.counts[0] items, F2.counts[3] keys,

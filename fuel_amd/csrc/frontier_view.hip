@@ -344,10 +344,10 @@ extern "C" int fuelmi_frontier_compute_to_visit(fuelmi_frontier* f, int* n_activ
   int rc = sample_viewpoints(f, f->tmp);
   if (rc) return rc;
   int na = 0, nd = 0;
+  rc = frontier_keep_clusters(f, f->tmp);
+  if (rc) return rc;
   while (!f->tmp.empty()) {
     HCluster& c = f->tmp.front();
-    rc = frontier_keep_cluster(f, c);
-    if (rc) return rc;
     if (!c.viewpoints.empty()) {
       // sort by coverage, best first -- std::sort with the reference's comparator (:403-405)
       std::sort(c.viewpoints.begin(), c.viewpoints.end(),

@@ -88,6 +88,35 @@ out["bspline_optimize_64_candidates"] = {"gpu_ms": gpu_opt_ms, "cpu_oracle_ms_ex
                                           "evals_gpu_mean": float(eg.mean()), "evals_cpu_mean": float(np.mean(eo)),
                                           "final_cost_ratio_gpu_over_cpu_first8": float(np.mean(cg[:8] / np.array(co)))}
 
+# ---- rank 4 glue: samples -> parameterizeToBspline -> getBoundaryStates -> optimize, 1024 candidates -------
+K = ctrl.shape[1] - 2
+smp = np.stack([(c[:-2] + 4 * c[1:-1] + c[2:]) / 6.0 for c in ctrl_big])  # the splines' own knot points
+der = np.zeros((len(smp), 4, 3))
+tsb = np.full(len(smp), 0.175)
+x0 = np.zeros((len(smp), 3 * ctrl.shape[1] + 1))
+x0[:, -1] = 1.0
+devs = opt.deviceProblem(fuel_amd.BsplineBatchProblem(x0, ctrl.shape[1], cf, np.ones(len(smp)),
+                                                      np.zeros((len(smp), 3, 3)), np.zeros((len(smp), 3, 3)), 1, 3, 1.0))
+devs.loadSamples(tsb, smp, der)
+devs.optimize(max_eval=300)
+t0 = time.perf_counter()
+devs.loadSamples(tsb, smp, der)
+gm.synchronize()
+gpu_fit_ms = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter()
+devs.loadSamples(tsb, smp, der)
+devs.optimize(max_eval=300)
+gpu_fit_solve_ms = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter()
+for c in range(64):  # bounded CPU sample
+    cp = fo.spline_parameterize(tsb[c], smp[c], der[c], 3)
+    fo.spline_boundary_states(cp, tsb[c], 3, 2, 0)
+    fo.bspline_pt_dist(cp)
+cpu_fit_ms = (time.perf_counter() - t0) * 1e3 * (len(smp) / 64.0)
+out["samples_to_control_points_1024_candidates"] = {"gpu_ms": gpu_fit_ms, "cpu_oracle_ms_extrapolated_from_64": cpu_fit_ms,
+                                                     "samples_per_candidate": int(K)}
+out["samples_to_solved_trajectory_1024_candidates"] = {"gpu_ms": gpu_fit_solve_ms}
+
 # ---- rank 3: depth frame -> fused map ----------------------------------------------------------------
 w = synth.World.for_map_size(map_size)
 truth = w.world(42, bench.WORKLOADS["G400"][1])
