@@ -140,13 +140,16 @@ k_esdf_zy(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ u
 // distance_buffer_ value of a squared voxel distance.  f32 arithmetic: best < 2^24 is exact in f32,
 // sqrtf is correctly rounded, so the result is within ~1.2 ulp (< 5e-6 m at 40 m) of the reference's
 // f64 res*sqrt(D) -- the f64 sqrt sequence made the x pass VALU-bound.
+// v_sqrt_f32 directly (1 ulp: <= 1e-5 m at 100 m, the parity bar is 1e-4): the correctly rounded sqrtf
+// expands to ~15 instructions per value, more than the envelope scan of a typical voxel
+__device__ __forceinline__ float esdf_sqrt(u32 best) { return __builtin_amdgcn_sqrtf((float)best); }
 __device__ __forceinline__ float esdf_out(u32 best, float res) {
-  return (best >= INF32) ? INFINITY : res * sqrtf((float)best);
+  return (best >= INF32) ? INFINITY : res * esdf_sqrt(best);
 }
 __device__ __forceinline__ float esdf_merge_neg(float cur, u32 best, float res) {
   if (best >= INF32) return -INFINITY;  // reference: += -(res*sqrt(DBL_MAX)) + res
   if (best == 0u) return cur;
-  return cur - res * sqrtf((float)best) + res;
+  return cur - res * esdf_sqrt(best) + res;
 }
 
 // x pass.  The (y,z) columns of the box are enumerated j = yy*zlen + zz; a block stages S
@@ -300,20 +303,31 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
     }
   }
   __syncthreads();
-  // y pass: one lane per 4 z-adjacent outputs
+  // y pass: one lane per 4 z-adjacent outputs.  The scan walks outwards one row per step with byte
+  // offsets and r^2 advanced by additions (32-bit multiplies are quarter rate) and a single exit test
+  // r^2 < min(mx, (rmax+1)^2).
   const int G = ZC >> 2;
   const int total = ylen * G;
   const int dyi = T / G, dgi = T - dyi * G;
+  const int stride = ZC * 4;                   // bytes per tile row
+  const int last_row = (ylen - 1) * stride;
   int yi = threadIdx.x / G, gi = threadIdx.x - yi * G;
   for (int o = threadIdx.x; o < total; o += T) {
-    const uint4 v0 = *reinterpret_cast<const uint4*>(tile + yi * ZC + 4 * gi);
+    const int col = 16 * gi;
+    const int base = __mul24(yi, stride) + col;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(smem_raw + base);
     u32 b0 = v0.x, b1 = v0.y, b2 = v0.z, b3 = v0.w;
     u32 mx = max(max(b0, b1), max(b2, b3));
     const int rmax = max(yi, ylen - 1 - yi);
-    for (int r = 1; r <= rmax && (u32)(r * r) < mx; ++r) {
-      const u32 rr = (u32)(r * r);
-      const uint4 va = *reinterpret_cast<const uint4*>(tile + max(yi - r, 0) * ZC + 4 * gi);
-      const uint4 vb = *reinterpret_cast<const uint4*>(tile + min(yi + r, ylen - 1) * ZC + 4 * gi);
+    const u32 lim = (u32)__mul24(rmax + 1, rmax + 1);
+    const int hi_off = last_row + col;
+    int oa = base, ob = base;
+    u32 rr = 1u, inc = 3u;
+    while (rr < min(mx, lim)) {
+      oa = max(oa - stride, col);
+      ob = min(ob + stride, hi_off);
+      const uint4 va = *reinterpret_cast<const uint4*>(smem_raw + oa);
+      const uint4 vb = *reinterpret_cast<const uint4*>(smem_raw + ob);
       // a clamped row repeats a candidate already seen with a smaller r: harmless; INF32 + r^2 stays
       // above every finite value and below 2^31
       b0 = min(b0, min(va.x, vb.x) + rr);
@@ -321,6 +335,8 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
       b2 = min(b2, min(va.z, vb.z) + rr);
       b3 = min(b3, min(va.w, vb.w) + rr);
       mx = max(max(b0, b1), max(b2, b3));
+      rr += inc;
+      inc += 2u;
     }
     const int z = zc0 + 4 * gi;
     u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz + z;
