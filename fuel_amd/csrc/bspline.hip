@@ -42,9 +42,24 @@ struct fuelmi_bspline_dev {
   size_t fit_cap = 0;
 };
 
+// 64-lane sum on the DPP data path (no LDS crossbar round trips): quads, half rows, rows, then the two
+// row broadcasts of GFX9; lane 63 ends with the total.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return __shfl(v, 0, 64);
+  v += dpp_take<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_take<0x140, 0xF>(v);  // row_mirror: every lane of a row holds the row's sum
+  v += dpp_take<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_take<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double dot3(const double* a, const double* b) {
@@ -53,8 +68,25 @@ __device__ __forceinline__ double dot3(const double* a, const double* b) {
 
 // combineCost for candidate c at the variables x (NLopt layout); writes grad[nvar], returns the
 // cost in every lane.  One wavefront; smem_raw = 5*3*N doubles of LDS.
+// per-candidate constants of the objective, staged once per kernel in LDS behind the 5 x [N][3] scratch
+// (a solve evaluates ~200 times: re-reading them from global memory was a dependent load per use)
+#define EVAL_CONST 24  // [0] pt_dist [1] knot_span [2] time_lb [3..11] start state [12..20] end state
+__device__ __forceinline__ double* eval_const(const BsplineArgs& A, unsigned char* smem_raw) {
+  return reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N;
+}
+__device__ void load_eval_const(const BsplineArgs& A, int c, unsigned char* smem_raw) {
+  double* K = eval_const(A, smem_raw);
+  const int l = threadIdx.x;
+  if (l == 0) K[0] = A.pt_dist[c];
+  if (l == 1) K[1] = A.knot_span ? A.knot_span[c] : 0.0;
+  if (l == 2) K[2] = A.time_lb ? A.time_lb[c] : -1.0;
+  if (l >= 3 && l < 12) K[l] = ((A.cost_function & FUELMI_COST_START) && A.start_state) ? A.start_state[(size_t)c * 9 + (l - 3)] : 0.0;
+  if (l >= 12 && l < 21) K[l] = ((A.cost_function & FUELMI_COST_END) && A.end_state) ? A.end_state[(size_t)c * 9 + (l - 12)] : 0.0;
+  __syncthreads();
+}
 __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, const BsplineArgs& A, int c,
                                const double* x, double* grad, unsigned char* smem_raw) {
+  const double* K = eval_const(A, smem_raw);
   const int N = A.N, dim = A.dim;
   double* q = reinterpret_cast<double*>(smem_raw);  // [N][3]
   double* tj = q + 3 * N;                            // [N][3] 2*jerk/pt_dist      (j <= N-4)
@@ -63,8 +95,8 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
   double* gw = ta + 3 * N;                           // [N][3] waypoint gradient scratch
   const int lane = threadIdx.x;
   const bool opt_time = (A.cost_function & FUELMI_COST_MINTIME) != 0;
-  const double dt = opt_time ? x[A.nvar - 1] : A.knot_span[c];
-  const double pt_dist = A.pt_dist[c];
+  const double dt = opt_time ? x[A.nvar - 1] : K[1];
+  const double pt_dist = K[0];
   const fuelmi_bspline_cfg& P = A.cfg;
 
   for (int i = lane; i < N; i += 64)
@@ -73,6 +105,16 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
 
   double cost = 0.0, gt = 0.0;  // lane-partial weighted cost and knot-span gradient
   const double dt_inv = 1 / dt, dt_inv2 = dt_inv * dt_inv;
+  // Divisions by per-evaluation constants are multiplications by their reciprocals (one f64 division is a
+  // dependent chain of ~11 instructions and a solve is latency-bound): each affected term moves by <= 1 ulp
+  // against the reference's quotient, 10 orders of magnitude inside the parity bar.
+  const double pt_inv = 1 / pt_dist;
+  const double r_2dt = 1 / (2 * dt), r_dt2 = 1 / (dt * dt), r_ndt2 = 1 / (-dt * dt), r_ndt3 = 1 / (-dt * dt * dt);
+  // the ESDF corners of this lane's first control point: loads start here and are consumed in pass 2,
+  // behind the arithmetic of pass 1
+  DistGather G0;
+  const bool gather0 = (A.cost_function & FUELMI_COST_DISTANCE) && lane < N;
+  if (gather0) dist_gather_issue(g, dist, &q[3 * lane], G0);
 
   // ---- pass 1: per-stencil quantities ----
   for (int i = lane; i < N; i += 64) {
@@ -85,9 +127,9 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
     if ((A.cost_function & FUELMI_COST_SMOOTHNESS) && i + 3 < N) {
       double s = 0.0;
       for (int k = 0; k < 3; ++k) {
-        double ji = (q[3 * (i + 3) + k] - 3 * q[3 * (i + 2) + k] + 3 * q[3 * (i + 1) + k] - q[3 * i + k]) / pt_dist;
+        double ji = (q[3 * (i + 3) + k] - 3 * q[3 * (i + 2) + k] + 3 * q[3 * (i + 1) + k] - q[3 * i + k]) * pt_inv;
         s += ji * ji;
-        tj[3 * i + k] = 2 * ji / pt_dist;
+        tj[3 * i + k] = 2 * ji * pt_inv;
       }
       cost += P.ld_smooth * s;
     }
@@ -152,10 +194,12 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
     }
     if (A.cost_function & FUELMI_COST_DISTANCE) {
       double dg[3];
-      double d = dist_with_grad_dev(g, dist, &q[3 * i], dg);
+      double d = (i == lane && gather0) ? dist_gather_finish(g, G0, dg) : dist_with_grad_dev(g, dist, &q[3 * i], dg);
       double nrm = sqrt(dot3(dg, dg));
-      if (nrm > 1e-4)
-        for (int k = 0; k < 3; ++k) dg[k] /= nrm;
+      if (nrm > 1e-4) {
+        const double nrm_inv = 1 / nrm;
+        for (int k = 0; k < 3; ++k) dg[k] *= nrm_inv;
+      }
       if (d < P.dist0) {
         cost += P.ld_dist * ((d - P.dist0) * (d - P.dist0));
         for (int k = 0; k < 3; ++k) gq[k] += P.ld_dist * (2.0 * (d - P.dist0) * dg[k]);
@@ -172,58 +216,47 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
         gq[k] += P.ld_feasi * s;
       }
     }
-    if ((A.cost_function & FUELMI_COST_START) && i < 3) {
-      const double* ss = A.start_state + (size_t)c * 9;
-      const double w_pos = 10.0;
-      double c_start = 0.0, gt_start = 0.0;
-      for (int k = 0; k < 3; ++k) {
-        double q1 = q[k], q2 = q[3 + k], q3 = q[6 + k];
-        double dq = 1 / 6.0 * (q1 + 4 * q2 + q3) - ss[k];
-        c_start += w_pos * dq * dq;
-        double gk = w_pos * 2 * dq * ((i == 1) ? (4 / 6.0) : (1 / 6.0));
-        dq = 1 / (2 * dt) * (q3 - q1) - ss[3 + k];
-        c_start += dq * dq;
-        if (i == 0) gk += 2 * dq * (-1.0) / (2 * dt);
-        if (i == 2) gk += 2 * dq * 1.0 / (2 * dt);
-        gt_start += dq * (q3 - q1) / (-dt * dt);
-        dq = 1 / (dt * dt) * (q1 - 2 * q2 + q3) - ss[6 + k];
-        c_start += dq * dq;
-        gk += 2 * dq * ((i == 1) ? -2.0 : 1.0) / (dt * dt);
-        gt_start += dq * (q1 - 2 * q2 + q3) / (-dt * dt * dt);
-        gq[k] += P.ld_start * gk;
-      }
-      if (i == 0) {
-        cost += P.ld_start * c_start;
-        if (opt_time) gt += P.ld_start * gt_start;
-      }
-    }
-    if ((A.cost_function & FUELMI_COST_END) && i >= N - 3) {
-      const double* es = A.end_state + (size_t)c * 9;
-      const int r = i - (N - 3);  // 0: q_3, 1: q_2, 2: q_1
-      double c_end = 0.0, gt_end = 0.0;
-      for (int k = 0; k < 3; ++k) {
-        double q_3 = q[3 * (N - 3) + k], q_2 = q[3 * (N - 2) + k], q_1 = q[3 * (N - 1) + k];
-        double dq = 1 / 6.0 * (q_1 + 4 * q_2 + q_3) - es[k];
-        c_end += dq * dq;
-        double gk = 2 * dq * ((r == 1) ? (4 / 6.0) : (1 / 6.0));
-        if (A.end_n >= 2) {
-          dq = 1 / (2 * dt) * (q_1 - q_3) - es[3 + k];
-          c_end += dq * dq;
-          if (r == 2) gk += 2 * dq * 1.0 / (2 * dt);
-          if (r == 0) gk += 2 * dq * (-1.0) / (2 * dt);
-          gt_end += dq * (q_1 - q_3) / (-dt * dt);
+    // calcStartCost (:355-391) and calcEndCost (:393-431) share their algebra: position (1,4,1)/6,
+    // velocity (-1,0,1)/2dt, acceleration (1,-2,1)/dt^2 of three consecutive points against a target
+    // state.  The three START lanes and the three END lanes run it together (one pass through the ~12
+    // f64 divisions instead of two); the summation order of each term is the reference's ("first" is
+    // q1 for START and q_1 for END).  A lane holding both roles (N < 6) takes a second pass.
+    {
+      const bool is_start = (A.cost_function & FUELMI_COST_START) && i < 3;
+      const bool is_end = (A.cost_function & FUELMI_COST_END) && i >= N - 3;
+      for (int pass = 0; pass < 2; ++pass) {
+        const bool as_end = (pass == 0) ? (!is_start && is_end) : (is_start && is_end);
+        if (!(pass == 0 ? (is_start || is_end) : as_end)) continue;
+        const int b0 = as_end ? N - 3 : 0, r = i - b0;  // r: position of this lane's point among the three
+        const double* tgt = K + (as_end ? 12 : 3);
+        const double w_pos = as_end ? 1.0 : 10.0, lam = as_end ? P.ld_end : P.ld_start;
+        const bool have_vel = !as_end || A.end_n >= 2, have_acc = !as_end || A.end_n == 3;
+        double c_b = 0.0, gt_b = 0.0;
+        for (int k = 0; k < 3; ++k) {
+          const double qa = q[3 * b0 + k], qb = q[3 * (b0 + 1) + k], qc = q[3 * (b0 + 2) + k];
+          const double first = as_end ? qc : qa, last = as_end ? qa : qc;
+          double dq = 1 / 6.0 * (first + 4 * qb + last) - tgt[k];
+          c_b += w_pos * dq * dq;
+          double gk = w_pos * 2 * dq * ((r == 1) ? (4 / 6.0) : (1 / 6.0));
+          if (have_vel) {
+            dq = r_2dt * (qc - qa) - tgt[3 + k];
+            c_b += dq * dq;
+            if (r == 0) gk += 2 * dq * (-1.0) * r_2dt;
+            if (r == 2) gk += 2 * dq * 1.0 * r_2dt;
+            gt_b += dq * (qc - qa) * r_ndt2;
+          }
+          if (have_acc) {
+            dq = r_dt2 * (first - 2 * qb + last) - tgt[6 + k];
+            c_b += dq * dq;
+            gk += 2 * dq * ((r == 1) ? -2.0 : 1.0) * r_dt2;
+            gt_b += dq * (first - 2 * qb + last) * r_ndt3;
+          }
+          gq[k] += lam * gk;
         }
-        if (A.end_n == 3) {
-          dq = 1 / (dt * dt) * (q_1 - 2 * q_2 + q_3) - es[6 + k];
-          c_end += dq * dq;
-          gk += 2 * dq * ((r == 1) ? -2.0 : 1.0) / (dt * dt);
-          gt_end += dq * (q_1 - 2 * q_2 + q_3) / (-dt * dt * dt);
+        if (r == (as_end ? 2 : 0)) {
+          cost += lam * c_b;
+          if (opt_time) gt += lam * gt_b;
         }
-        gq[k] += P.ld_end * gk;
-      }
-      if (r == 2) {
-        cost += P.ld_end * c_end;
-        if (opt_time) gt += P.ld_end * gt_end;
       }
     }
     if ((A.cost_function & FUELMI_COST_GUIDE) && i >= A.order && i < N - A.order) {
@@ -266,7 +299,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
     // calcTimeCost (:504-516)
     double duration = (N - A.order) * dt;
     double cst = duration, g_t = double(N - A.order);
-    double lb = A.time_lb ? A.time_lb[c] : -1.0;
+    double lb = K[2];
     if (lb > 0 && duration < lb) {
       const double w_lb = 10;
       cst += w_lb * (duration - lb) * (duration - lb);
@@ -286,6 +319,7 @@ __global__ void __launch_bounds__(64)
 k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int c = blockIdx.x;
+  load_eval_const(A, c, smem_raw);
   const double cost = bspline_eval(g, dist, A, c, A.x + (size_t)c * A.nvar, A.grad + (size_t)c * A.nvar, smem_raw);
   if (threadIdx.x == 0) A.cost[c] = cost;
 }
@@ -321,7 +355,8 @@ __global__ void __launch_bounds__(64)
 k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsArgs L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int c = blockIdx.x, lane = threadIdx.x, n = A.nvar;
-  double* w = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N;  // behind bspline_eval's 5 x [N][3]
+  double* w = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N + EVAL_CONST;  // behind bspline_eval's scratch
+  load_eval_const(A, blockIdx.x, smem_raw);
   double *q = w, *gq = q + n, *xn = gq + n, *gn = xn + n, *d = gn + n, *best = d + n;
   double* S = best + n;             // [MEM][n]
   double* Y = S + LBFGS_MEM * n;    // [MEM][n]
@@ -448,6 +483,178 @@ k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsAr
   }
   __syncthreads();
   for (int i = lane; i < n; i += 64) L.x_out[(size_t)c * n + i] = best[i];
+  if (lane == 0) {
+    L.cost_out[c] = fbest;
+    L.evals_out[c] = evals;
+  }
+}
+
+template <int NPL>
+__device__ __forceinline__ double reg_dot(const double (&a)[NPL], const double (&b)[NPL]) {
+  double s2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < NPL; ++e) s2 += a[e] * b[e];
+  return wave_sum(s2);
+}
+// objective at register-resident variables: staged through LDS (xs in, gs out) around bspline_eval
+template <int NPL>
+__device__ __forceinline__ double reg_objective(const Geo& g, const float* __restrict__ dist, const BsplineArgs& A, int c,
+                                                double* xs, double* gs, unsigned char* smem_raw, const bool (&on)[NPL],
+                                                const double (&xv)[NPL], double (&gv)[NPL]) {
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < NPL; ++e)
+    if (on[e]) xs[lane + 64 * e] = xv[e];
+  __syncthreads();
+  const double fv = bspline_eval(g, dist, A, c, xs, gs, smem_raw);  // ends with a barrier
+#pragma unroll
+  for (int e = 0; e < NPL; ++e) gv[e] = on[e] ? gs[lane + 64 * e] : 0.0;
+  return fv;
+}
+
+// The same solve with the whole L-BFGS state in registers: lane l owns the variables l, l+64, ...
+// (NPL per lane, n <= 64*NPL), the 2 x 8 history vectors included (ordered oldest -> newest, shifted
+// when full, so every index is static).  The workgroup is ONE wavefront: dot products are a multiply-add
+// per owned variable plus a DPP reduction, updates are register arithmetic, nothing but the objective
+// touches LDS (variables in, gradient out).  Same operations in the same order as the LDS version above
+// (which stays as the path for n > 256): identical results, ~1/3 of the time per iteration.
+template <int NPL>
+__global__ void __launch_bounds__(64)
+k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsArgs L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int c = blockIdx.x, lane = threadIdx.x, n = A.nvar;
+  double* xs = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N + EVAL_CONST;  // variables handed to the objective
+  load_eval_const(A, blockIdx.x, smem_raw);
+  double* gs = xs + n;                                                  // its gradient
+  const double* x0 = A.x + (size_t)c * n;
+  const int npt = A.dim * A.N;
+  bool on[NPL];
+  double lo[NPL], hi[NPL], q[NPL], gq[NPL], xn[NPL], gn[NPL], d[NPL], best[NPL];
+  double S[LBFGS_MEM][NPL], Y[LBFGS_MEM][NPL], rho[LBFGS_MEM], al[LBFGS_MEM];
+#pragma unroll
+  for (int e = 0; e < NPL; ++e) {
+    const int i = lane + 64 * e;
+    on[e] = i < n;
+    double v = on[e] ? x0[i] : 0.0;
+    // start point: control points clamped into the shrunk box (:194-199); the bounds refer to it
+    if (on[e] && A.dim != 1 && i < npt) v = fmax(fmin(v, L.box_hi[i % 3]), L.box_lo[i % 3]);
+    q[e] = best[e] = v;
+    lo[e] = hi[e] = 0.0;
+    if (on[e]) {
+      if (A.dim == 1) {
+        lo[e] = -1e300, hi[e] = 1e300;
+      } else if (i >= npt) {
+        lo[e] = 0.0, hi[e] = 5.0;
+      } else {
+        lo[e] = fmax(v - 10.0, L.box_lo[i % 3]), hi[e] = fmin(v + 10.0, L.box_hi[i % 3]);
+      }
+    }
+    gq[e] = xn[e] = gn[e] = d[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < LBFGS_MEM; ++k) S[k][e] = Y[k][e] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < LBFGS_MEM; ++k) rho[k] = al[k] = 0.0;
+  int evals = 0;
+  double f = reg_objective<NPL>(g, dist, A, c, xs, gs, smem_raw, on, q, gq);
+  ++evals;
+  double fbest = f;
+  int hist = 0;  // stored pairs, slot 0 the oldest
+  while (evals < L.max_eval) {
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) {
+      const bool at_lb = q[e] <= lo[e] && gq[e] > 0, at_ub = q[e] >= hi[e] && gq[e] < 0;
+      d[e] = (at_lb || at_ub) ? 0.0 : -gq[e];
+    }
+#pragma unroll
+    for (int k = LBFGS_MEM - 1; k >= 0; --k)
+      if (k < hist) {
+        const double a = reg_dot<NPL>(S[k], d) * rho[k];
+        al[k] = a;
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) d[e] -= a * Y[k][e];
+      }
+#pragma unroll
+    for (int k = 0; k < LBFGS_MEM; ++k)
+      if (k == hist - 1) {
+        const double yy = reg_dot<NPL>(Y[k], Y[k]), sy = 1.0 / rho[k];
+        const double gamma = yy > 0 ? sy / yy : 1.0;
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) d[e] *= gamma;
+      }
+#pragma unroll
+    for (int k = 0; k < LBFGS_MEM; ++k)
+      if (k < hist) {
+        const double b = reg_dot<NPL>(Y[k], d) * rho[k];
+        const double a = al[k];
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) d[e] += S[k][e] * (a - b);
+      }
+    double gd = reg_dot<NPL>(gq, d);
+    if (!(gd < 0)) {  // not a descent direction: restart with steepest descent
+      hist = 0;
+#pragma unroll
+      for (int e = 0; e < NPL; ++e) d[e] = -gq[e];
+      gd = -reg_dot<NPL>(gq, gq);
+      if (gd == 0) break;
+    }
+    double step = hist == 0 ? 1.0 / fmax(1.0, sqrt(-gd)) : 1.0, fn = f;
+    bool ok = false;
+    for (int ls = 0; ls < 20 && evals < L.max_eval; ++ls) {
+#pragma unroll
+      for (int e = 0; e < NPL; ++e) xn[e] = on[e] ? fmin(fmax(q[e] + step * d[e], lo[e]), hi[e]) : 0.0;
+      fn = reg_objective<NPL>(g, dist, A, c, xs, gs, smem_raw, on, xn, gn);
+      ++evals;
+      if (fn < fbest) {  // costFunction's best_variable_ (:699-703)
+        fbest = fn;
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) best[e] = xn[e];
+      }
+      double dec = 0.0;
+#pragma unroll
+      for (int e = 0; e < NPL; ++e) dec += gq[e] * (xn[e] - q[e]);
+      dec = wave_sum(dec);
+      if (fn <= f + 1e-4 * dec) {
+        ok = true;
+        break;
+      }
+      step *= 0.5;
+    }
+    if (!ok) break;
+    double sy = 0.0, ss = 0.0, xx = 0.0, sn[NPL], yn[NPL];
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) {
+      sn[e] = xn[e] - q[e], yn[e] = gn[e] - gq[e];
+      sy += sn[e] * yn[e], ss += sn[e] * sn[e], xx += xn[e] * xn[e];
+    }
+    sy = wave_sum(sy), ss = wave_sum(ss), xx = wave_sum(xx);
+    if (sy > 1e-12) {
+      if (hist == LBFGS_MEM) {  // drop the oldest pair
+#pragma unroll
+        for (int k = 0; k + 1 < LBFGS_MEM; ++k) {
+          rho[k] = rho[k + 1];
+#pragma unroll
+          for (int e = 0; e < NPL; ++e) S[k][e] = S[k + 1][e], Y[k][e] = Y[k + 1][e];
+        }
+        hist = LBFGS_MEM - 1;
+      }
+#pragma unroll
+      for (int k = 0; k < LBFGS_MEM; ++k)
+        if (k == hist) {
+          rho[k] = 1.0 / sy;
+#pragma unroll
+          for (int e = 0; e < NPL; ++e) S[k][e] = sn[e], Y[k][e] = yn[e];
+        }
+      ++hist;
+    }
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) q[e] = xn[e], gq[e] = gn[e];
+    f = fn;
+    if (sqrt(ss) <= 1e-5 * sqrt(xx)) break;  // xtol_rel 1e-5
+  }
+#pragma unroll
+  for (int e = 0; e < NPL; ++e)
+    if (on[e]) L.x_out[(size_t)c * n + lane + 64 * e] = best[e];
   if (lane == 0) {
     L.cost_out[c] = fbest;
     L.evals_out[c] = evals;
@@ -727,7 +934,7 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
   A.nvar = opt_time ? A.dim * A.N + 1 : A.dim * A.N;
   A.order = (A.dim == 1) ? 3 : cfg->bspline_degree;  // optimize() :123-127
   A.n_guide = A.N - 2 * A.order;
-  b->lds = (size_t)A.N * 3 * 5 * sizeof(double);
+  b->lds = ((size_t)A.N * 3 * 5 + EVAL_CONST) * sizeof(double);
   if (b->lds > 160 * 1024) {
     fuelmi_set_error("%d control points exceed the LDS budget", A.N);
     delete b;
@@ -798,7 +1005,10 @@ extern "C" int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, 
   HIPCHK(hipSetDevice(m->device));
   const BsplineArgs& A = b->a;
   const size_t C = (size_t)A.C, n = (size_t)A.nvar;
-  const size_t lds_opt = b->lds + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
+  static const bool lds_path = getenv("FUELMI_OPT_LDS") != nullptr;  // tuning hook: force the LDS-state kernel
+  const int npl = lds_path ? 0 : (n <= 128 ? 2 : (n <= 256 ? 4 : 0));  // register-state kernel up to 256 variables
+  const size_t lds_opt = npl ? b->lds + 2 * n * sizeof(double)
+                             : b->lds + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
   if (lds_opt > 160 * 1024) {
     fuelmi_set_error("%d variables exceed the LDS budget of the device optimiser", (int)n);
     return FUELMI_ELIMIT;
@@ -827,7 +1037,12 @@ extern "C" int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, 
   L.x_out = b->opt_x, L.cost_out = b->opt_cost, L.evals_out = b->opt_evals;
   {
     StageScope sc(m, FUELMI_K_BSPLINE);
-    k_bspline_optimize<<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+    if (npl == 2)
+      k_bspline_optimize_r<2><<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+    else if (npl == 4)
+      k_bspline_optimize_r<4><<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+    else
+      k_bspline_optimize<<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(x_out, b->opt_x, C * n * sizeof(double), hipMemcpyDeviceToHost, m->stream));

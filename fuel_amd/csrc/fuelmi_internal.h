@@ -176,25 +176,48 @@ __device__ __forceinline__ double get_distance_idx(const Geo& g, const float* di
   if (x < 0 || y < 0 || z < 0 || x > g.nx - 1 || y > g.ny - 1 || z > g.nz - 1) return -1.0;
   return dist_to_f64(dist[(long)x * g.nyz + (long)y * g.nz + z], g.res);
 }
-__device__ __forceinline__ double dist_with_grad_dev(const Geo& g, const float* __restrict__ dist, const double pos[3],
-                                     double grad[3]) {
-  for (int k = 0; k < 3; ++k)
-    if (pos[k] < g.minb[k] + 1e-4 || pos[k] > g.maxb[k] - 1e-4) {
-      grad[0] = grad[1] = grad[2] = 0.0;
-      return 0.0;
-    }
-  int idx[3];
+// getDistWithGrad split in two so that a caller can put independent work between the eight loads and
+// their first use: _issue computes the cell and starts the loads, _finish interpolates.
+struct DistGather {
+  bool in_map;      // isInMap(pos) (:498-501)
+  unsigned oob;     // corner c = 4x+2y+z lies outside the map: value -1 (getDistance)
+  float raw[8];
   double diff[3];
+};
+__device__ __forceinline__ void dist_gather_issue(const Geo& g, const float* __restrict__ dist, const double pos[3],
+                                                  DistGather& G) {
+  G.in_map = true;
+  G.oob = 0u;
+  for (int k = 0; k < 3; ++k)
+    if (pos[k] < g.minb[k] + 1e-4 || pos[k] > g.maxb[k] - 1e-4) G.in_map = false;
+  if (!G.in_map) return;
+  int idx[3];
   for (int k = 0; k < 3; ++k) {
     double pm = pos[k] - 0.5 * g.res * 1.0;
     idx[k] = (int)floor((pm - g.org[k]) * g.res_inv);
     double ip = (idx[k] + 0.5) * g.res + g.org[k];
-    diff[k] = (pos[k] - ip) * g.res_inv;
+    G.diff[k] = (pos[k] - ip) * g.res_inv;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int x = idx[0] + (c >> 2), y = idx[1] + ((c >> 1) & 1), z = idx[2] + (c & 1);
+    const bool out = x < 0 || y < 0 || z < 0 || x > g.nx - 1 || y > g.ny - 1 || z > g.nz - 1;
+    G.raw[c] = 0.0f;
+    if (out)
+      G.oob |= 1u << c;
+    else
+      G.raw[c] = dist[(long)x * g.nyz + (long)y * g.nz + z];
+  }
+}
+__device__ __forceinline__ double dist_gather_finish(const Geo& g, const DistGather& G, double grad[3]) {
+  if (!G.in_map) {
+    grad[0] = grad[1] = grad[2] = 0.0;
+    return 0.0;
   }
   double v[2][2][2];
-  for (int x = 0; x < 2; x++)
-    for (int y = 0; y < 2; y++)
-      for (int z = 0; z < 2; z++) v[x][y][z] = get_distance_idx(g, dist, idx[0] + x, idx[1] + y, idx[2] + z);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c >> 2][(c >> 1) & 1][c & 1] = ((G.oob >> c) & 1u) ? -1.0 : dist_to_f64(G.raw[c], g.res);
+  const double* diff = G.diff;
   double v00 = (1 - diff[0]) * v[0][0][0] + diff[0] * v[1][0][0];
   double v01 = (1 - diff[0]) * v[0][0][1] + diff[0] * v[1][0][1];
   double v10 = (1 - diff[0]) * v[0][1][0] + diff[0] * v[1][1][0];
@@ -210,6 +233,12 @@ __device__ __forceinline__ double dist_with_grad_dev(const Geo& g, const float* 
   g0 += diff[2] * diff[1] * (v[1][1][1] - v[0][1][1]);
   grad[0] = g0 * g.res_inv;
   return d;
+}
+__device__ __forceinline__ double dist_with_grad_dev(const Geo& g, const float* __restrict__ dist, const double pos[3],
+                                     double grad[3]) {
+  DistGather G;
+  dist_gather_issue(g, dist, pos, G);
+  return dist_gather_finish(g, G, grad);
 }
 #endif  // __HIPCC__
 
