@@ -111,17 +111,25 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
   double pt[3];
   int flag = 0;
   bool ok = (i < A.n) && classify(g, A, i, pt, flag);
+  long a = -1;
   if (ok) {
-    long a = pos_adr(g, pt);
-    if (a >= 0 && a < g.N) {
+    a = pos_adr(g, pt);
+    if (!(a >= 0 && a < g.N)) ok = false;
+  }
+  {
+    // neighbouring pixels end in the same voxel more often than not: a lane whose predecessor holds the
+    // same (voxel, hit/miss) pair has nothing to add -- same bit, and the predecessor's index is lower
+    const int lane = threadIdx.x & 63;
+    const long key = ok ? 2 * a + flag : -1L - lane;
+    const long prev = __shfl_up(key, 1, 64);
+    if (ok && !(lane > 0 && prev == key)) {
       u64 bit = 1ull << (a & 63);
       if (flag)
         atomicOr(&A.hit[a >> 6], bit);
       else
         atomicOr(&A.miss[a >> 6], bit);
       atomicMin(&A.owner[a], (u32)i);
-    } else
-      ok = false;
+    }
   }
   // bounding box of the kept end points (update_min/max, :303-306): wave reduce, block reduce in LDS,
   // one record per block; the next kernel folds the records (per-wave atomics on six words were
