@@ -201,8 +201,15 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   // block into LDS first, so that the walk runs with full waves and the other waves retire at once
   __shared__ double s_pt[256][3];
   __shared__ u32 s_cnt;
+  // The rays of a workgroup (neighbouring pixels) converge on the camera and revisit the same voxels
+  // there: a bitmap of the 32^3 voxels around the camera voxel lets each workgroup send one atomic per
+  // voxel of that cube instead of one per ray (same-address memory-side atomics serialise).
+  __shared__ u32 s_seen[1024];
+  for (int t = threadIdx.x; t < 1024; t += 256) s_seen[t] = 0u;
   if (threadIdx.x == 0) s_cnt = 0u;
   __syncthreads();
+  int cv[3];
+  for (int k = 0; k < 3; ++k) cv[k] = (int)floor((A.cam[k] - g.org[k]) * g.res_inv) - 16;
   {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double p0[3];
@@ -252,7 +259,13 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     if (c[0] == ec[0] && c[1] == ec[1] && c[2] == ec[2]) break;
     if (!first) {  // the first reported cell (the end voxel itself) is discarded (:314)
       long av = (long)ix * g.nyz + (long)iy * g.nz + iz;
-      if (av >= 0 && av < g.N) atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
+      bool send = av >= 0 && av < g.N;
+      const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
+      if (send && (ux | uy | uz) < 32u) {
+        const u32 id = (ux << 10) | (uy << 5) | uz, bit = 1u << (id & 31);
+        send = !(atomicOr(&s_seen[id >> 5], bit) & bit);
+      }
+      if (send) atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
     }
     first = false;
     if (tmax[0] < tmax[1]) {
