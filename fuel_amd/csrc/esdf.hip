@@ -444,8 +444,8 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_esdf_zy4<MODE><<<xlen * nzc, 512, lds, m->stream>>>(g, b, m->infl_bits.p, m->unk_bits.p, m->esdf_tmp, ZC, nzc,
-                                                        z0a);
+  STAGE_LAUNCH(m, (k_esdf_zy4<MODE>), xlen * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
+               m->esdf_tmp, ZC, nzc, z0a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -463,8 +463,8 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
   int ncol = ylen * zlen_a;
   static const char* xt = getenv("FUELMI_X_THREADS");  // tuning hook
   const int threads = xt ? atoi(xt) : 1024;
-  k_esdf_x4<OUT, SEGS><<<(ncol + 4 * SEGS - 1) / (4 * SEGS), threads, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist, z0a,
-                                                                                       zlen_a);
+  STAGE_LAUNCH(m, (k_esdf_x4<OUT, SEGS>), (ncol + 4 * SEGS - 1) / (4 * SEGS), threads, lds, g, b, (const u32*)m->esdf_tmp,
+               m->dist, z0a, zlen_a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -497,8 +497,8 @@ static int launch_zy(fuelmi_map* m, const Box3& b) {
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy<MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_esdf_zy<MODE><<<xlen * nzc, 256, lds, m->stream>>>(g, b, m->infl_bits.p, m->unk_bits.p, m->esdf_tmp, ZC,
-                                                       nzc);
+  STAGE_LAUNCH(m, (k_esdf_zy<MODE>), xlen * nzc, 256, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
+               m->esdf_tmp, ZC, nzc);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -512,7 +512,7 @@ static int launch_x_s(fuelmi_map* m, const Box3& b) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x<S, OUT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int ncol = ylen * zlen;
-  k_esdf_x<S, OUT><<<(ncol + S - 1) / S, 256, lds, m->stream>>>(g, b, m->esdf_tmp, m->dist);
+  STAGE_LAUNCH(m, (k_esdf_x<S, OUT>), (ncol + S - 1) / S, 256, lds, g, b, (const u32*)m->esdf_tmp, m->dist);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -533,22 +533,22 @@ int esdf_update(fuelmi_map* m) {
   const Box3& b = m->local_bound;
   int rc;
   {
-    StageScope sc(m, FUELMI_K_ESDF_ZY);
+    StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
     rc = m->cfg.optimistic ? launch_zy<1>(m, b) : launch_zy<0>(m, b);
   }
   if (rc) return rc;
   {
-    StageScope sc(m, FUELMI_K_ESDF_X);
+    StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
     rc = launch_x<0>(m, b);
   }
   if (rc) return rc;
   if (m->cfg.signed_dist) {
     {
-      StageScope sc(m, FUELMI_K_ESDF_ZY);
+      StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
       rc = launch_zy<2>(m, b);
     }
     if (rc) return rc;
-    StageScope sc(m, FUELMI_K_ESDF_X);
+    StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
     rc = launch_x<1>(m, b);
   }
   return rc;

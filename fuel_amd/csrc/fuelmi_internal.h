@@ -3,6 +3,7 @@
 #define FUELMI_INTERNAL_H_
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -105,6 +106,10 @@ struct fuelmi_map {
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
   unsigned profile_mask = 0;
   ProfileSlot prof[FUELMI_K_COUNT];
+  // event pair of a single-kernel stage being profiled: the launch site attaches it to the kernel itself
+  // (hipExtLaunchKernelGGL), so the pair holds the kernel's own begin / end and not the times at which
+  // the command processor got round to two marker packets
+  hipEvent_t kev[2] = {nullptr, nullptr};
 };
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
@@ -116,9 +121,22 @@ struct StageScope {
   int stage;
   hipEvent_t e1 = nullptr;
   hipStream_t st = nullptr;
-  StageScope(fuelmi_map* m_, int stage_, hipStream_t stream = nullptr);
+  // kernel_timed: the scope covers exactly one kernel launched through STAGE_LAUNCH
+  StageScope(fuelmi_map* m_, int stage_, hipStream_t stream = nullptr, bool kernel_timed = false);
   ~StageScope();
 };
+
+// launch on the map's stream; inside a kernel-timed StageScope the profiling events ride on the kernel
+#define STAGE_LAUNCH(m, kern, grid, block, lds, ...)                                                            \
+  do {                                                                                                          \
+    if ((m)->kev[0]) {                                                                                          \
+      hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, (m)->stream, (m)->kev[0], (m)->kev[1], 0,       \
+                            __VA_ARGS__);                                                                       \
+      (m)->kev[0] = (m)->kev[1] = nullptr;                                                                      \
+    } else {                                                                                                    \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, (m)->stream, __VA_ARGS__);                         \
+    }                                                                                                           \
+  } while (0)
 
 // ---- device helpers ---------------------------------------------------------------------------
 #ifdef __HIPCC__

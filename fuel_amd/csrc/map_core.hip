@@ -37,7 +37,7 @@ static std::mutex g_query_mutex;  // serialises host-staged queries (staging buf
 // ---------------------------------------------------------------------------------------------
 // profiling scopes
 // ---------------------------------------------------------------------------------------------
-StageScope::StageScope(fuelmi_map* m_, int stage_, hipStream_t stream) : m(m_), stage(stage_) {
+StageScope::StageScope(fuelmi_map* m_, int stage_, hipStream_t stream, bool kernel_timed) : m(m_), stage(stage_) {
   st = stream ? stream : m->stream;
   if (!(m->profile_mask & (1u << stage))) return;
   ProfileSlot& s = m->prof[stage];
@@ -46,12 +46,21 @@ StageScope::StageScope(fuelmi_map* m_, int stage_, hipStream_t stream) : m(m_), 
     s.ev.resize(old + 64);
     for (size_t i = old; i < s.ev.size(); ++i) (void)hipEventCreate(&s.ev[i]);
   }
-  (void)hipEventRecord(s.ev[s.used], st);
-  e1 = s.ev[s.used + 1];
+  if (kernel_timed) {
+    m->kev[0] = s.ev[s.used], m->kev[1] = s.ev[s.used + 1];
+  } else {
+    (void)hipEventRecord(s.ev[s.used], st);
+    e1 = s.ev[s.used + 1];
+  }
   s.used += 2;
 }
 StageScope::~StageScope() {
   if (e1) (void)hipEventRecord(e1, st);
+  if (m->kev[0]) {  // a kernel-timed scope whose launch never happened (error path): keep the pair well-formed
+    (void)hipEventRecord(m->kev[0], st);
+    (void)hipEventRecord(m->kev[1], st);
+    m->kev[0] = m->kev[1] = nullptr;
+  }
 }
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes) {
