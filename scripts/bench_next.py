@@ -149,17 +149,22 @@ of3.set_viewpoint_cfg(fo.viewpoint_cfg())
 opt3 = fuel_amd.BsplineOptimizer()
 opt3.setEnvironment(gm3)
 dev3 = opt3.deviceProblem(fuel_amd.BsplineBatchProblem(x, ctrl.shape[1], cf, ptd, st, en, 3, 3, 0.175))
-tg3, tc3 = [], []
+tg3, tc3, parts3 = [], [], []
 for img, pose, q in frames:
     t0 = time.perf_counter()
     if gm3.inputDepthImage(img, pose[:3], q) > 0:
         gm3.clearAndInflateLocalMap()
         gm3.updateESDF3d()
+    t1 = time.perf_counter()
     gf3.searchFrontiers()
+    t2 = time.perf_counter()
     gf3.computeFrontiersToVisit()
+    t3 = time.perf_counter()
     dev3.optimize(max_eval=100)
     gm3.synchronize()
-    tg3.append(time.perf_counter() - t0)
+    t4 = time.perf_counter()
+    tg3.append(t4 - t0)
+    parts3.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
     t0 = time.perf_counter()
     pts = fo.project_depth(img, pose[:3], q)
     if len(pts):
@@ -173,5 +178,6 @@ for img, pose, q in frames:
     tc3.append(time.perf_counter() - t0)
 out["full_front_end_cycle"] = {"gpu_ms": float(np.median(tg3[2:]) * 1e3),
                                "cpu_oracle_ms_with_4_of_64_solves": float(np.median(tc3[2:]) * 1e3),
+                               "gpu_ms_map_search_viewpoints_solves": [round(float(v) * 1e3, 3) for v in np.median(np.array(parts3[2:]), axis=0)],
                                "active_frontiers_gpu": len(gf3.clusters(1)), "active_frontiers_cpu": len(of3.clusters(1))}
 print(json.dumps(out))
