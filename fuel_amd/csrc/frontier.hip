@@ -1484,8 +1484,8 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
 // ESDF, B-spline evaluation on the map's stream) before collecting the result with _search_end.
 extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   ARGCHK(f);
+  FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_search_begin");
   fuelmi_map* m = f->map;
-  f->pending = false;
   HIPCHK(hipSetDevice(m->device));
   const Geo& g = m->g;
   FArgs& F = f->F;
@@ -1735,6 +1735,7 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
 
 extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   ARGCHK(f);
+  FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_reset");
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
   f->frontiers.clear();
@@ -1750,6 +1751,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
 
 extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
   ARGCHK(f);
+  FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_commit");
   auto& dst = dormant ? f->dormant : f->frontiers;
   HIPCHK(hipSetDevice(f->map->device));
   const int rc = frontier_keep_clusters(f, f->tmp);

@@ -175,6 +175,15 @@ struct PoolPut {  // one cluster's copy into the cell pool
   int seed, pad;
 };
 int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters);
+// between _search_begin and _search_end the cluster lists belong to the running search (its verdicts on
+// changed clusters are applied in _search_end): calls that would modify them are refused
+#define FRONTIER_NOT_SEARCHING(f, what)                                                        \
+  do {                                                                                         \
+    if ((f)->pending) {                                                                        \
+      fuelmi_set_error(what ": a search is in flight (call fuelmi_frontier_search_end first)"); \
+      return FUELMI_EINVAL;                                                                    \
+    }                                                                                          \
+  } while (0)
 
 
 // runs the stable radix multisplit of F2.ms_key[0]/ms_val[0] (F2.counts[0] items, F2.counts[3] keys,

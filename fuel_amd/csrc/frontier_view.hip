@@ -336,6 +336,7 @@ static int sample_viewpoints(fuelmi_frontier* f, std::list<HCluster>& L) {
 // computeFrontiersToVisit (:392-423)
 extern "C" int fuelmi_frontier_compute_to_visit(fuelmi_frontier* f, int* n_active_new, int* n_dormant_new) {
   ARGCHK(f);
+  FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_compute_to_visit");
   if (!f->have_vcfg) {
     fuelmi_set_error("fuelmi_frontier_compute_to_visit: no viewpoint configuration set");
     return FUELMI_EINVAL;
@@ -392,6 +393,7 @@ extern "C" int fuelmi_frontier_viewpoints(const fuelmi_frontier* f, int which, i
 // isFrontierCovered (:697-719) against the map's accumulated updated box (not consumed)
 extern "C" int fuelmi_frontier_is_covered(fuelmi_frontier* f, int* covered) {
   ARGCHK(f && covered);
+  FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_is_covered");
   *covered = 0;
   if (!f->have_vcfg) {
     fuelmi_set_error("fuelmi_frontier_is_covered: no viewpoint configuration set");

@@ -892,6 +892,13 @@ def test_error_paths_of_the_front_end_calls(fa):
     with pytest.raises(FuelmiError):
         gf.searchFrontiersEnd()                                     # no matching _begin
     assert gf.isFrontierCovered() is False                          # nothing to cover yet
+    # between _begin and _end the cluster lists belong to the search: modifying calls are refused
+    gf.searchFrontiersBegin()
+    for call in (gf.searchFrontiersBegin, gf.commit, gf.reset, gf.computeFrontiersToVisit, gf.isFrontierCovered):
+        with pytest.raises(FuelmiError):
+            call()
+    gf.searchFrontiersEnd()
+    gf.commit()
     with pytest.raises(FuelmiError):
         gm.inputDepthImage(np.zeros((8, 8), np.uint16), (0, 0, 1), (1, 0, 0, 0), gm.depthConfig(skip=0))
     # a frame from outside the map and an all-too-near frame are ignored, not errors
