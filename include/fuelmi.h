@@ -194,10 +194,12 @@ int fuelmi_frontier_cluster_filtered(const fuelmi_frontier* f, int which, int k,
  * (getUpdatedBox(reset=true)), drops changed clusters, scans, clusters.  *n_new = number of new
  * clusters (tmp_frontiers_.size()). */
 int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new);
-/* The same search split in two: _begin drops changed clusters and enqueues the device pipeline on
- * the frontier's own HIP stream without waiting; _end waits and assembles the clusters.  Work
- * queued on the map between the two calls (inflation, ESDF, B-spline evaluation) overlaps the
- * scan, which only reads the occupancy state.  Do not fuse points between _begin and _end. */
+/* The same search split in two: _begin queues the test for changed clusters and the device pipeline on
+ * the frontier's own HIP stream without waiting; _end waits, drops the changed clusters from
+ * frontiers_ / dormant_frontiers_ (removed_ids_) and assembles the new ones.  Work queued on the map
+ * between the two calls (inflation, ESDF, B-spline evaluation) overlaps the scan, which only reads the
+ * occupancy state.  Do not fuse points between _begin and _end; _commit, _reset, _compute_to_visit,
+ * _is_covered and a second _begin return FUELMI_EINVAL until _end has been called. */
 int fuelmi_frontier_search_begin(fuelmi_frontier* f);
 int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new);
 /* move tmp_frontiers_ into frontiers_ (dormant=0) or dormant_frontiers_ (dormant=1) */
