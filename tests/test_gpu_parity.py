@@ -315,6 +315,18 @@ def test_bspline_one_dimensional_yaw_case(fa):
     for c in range(Cn):
         co, go = fo.bspline_cost_grad(om, x[c], N, cf, ptd[c], st[c], en[c], 3, 1, 0.3, -1.0, None, wp[c], wi[c])
         assert abs(cg[c] - co) <= 1e-9 * max(1.0, abs(co)) and np.abs(gg[c] - go).max() <= 1e-8 * max(1, np.abs(go).max())
+    # the whole yaw solve on the device (unbounded variables when dim = 1, :188-193) against the oracle's
+    dev = opt.deviceProblem(fa.BsplineBatchProblem(x, N, cf, ptd, st, en, 3, 1, 0.3, None, None, wp, wi))
+    # (run to convergence: the two runs agree to 5 digits for ~50 evaluations, then part ways with the
+    # reduction order and meet again at the minimum; a cap in between would compare two mid-descent points)
+    xs, cs, ev = dev.optimize(max_eval=2000)
+    assert ev.max() < 2000
+    for c in range(Cn):
+        xo, co, eo = fo.bspline_optimize(om, x[c], N, cf, ptd[c], st[c], en[c], 3, 1, 0.3, -1.0, None, wp[c], wi[c],
+                                         max_eval=2000)
+        assert cs[c] < 0.01 * cg[c] and abs(cs[c] - co) <= 1e-3 * co, (c, cs[c], co, cg[c])
+        chk, _ = fo.bspline_cost_grad(om, xs[c], N, cf, ptd[c], st[c], en[c], 3, 1, 0.3, -1.0, None, wp[c], wi[c])
+        assert abs(chk - cs[c]) <= 1e-9 * max(1.0, abs(chk))
     gm.close()
 
 
