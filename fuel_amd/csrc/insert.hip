@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   __syncthreads();
   int cv[3];
   for (int k = 0; k < 3; ++k) cv[k] = (int)floor((A.cam[k] - g.org[k]) * g.res_inv) - 16;
+  // one LDS word = the 32 z-neighbours cv[2] .. cv[2]+31 of the line (cv[0] + ux, cv[1] + uy)
   {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double p0[3];
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     }
   }
   __syncthreads();
-  if (threadIdx.x >= s_cnt) return;
+  if (threadIdx.x < s_cnt) {
   const double pt[3] = {s_pt[threadIdx.x][0], s_pt[threadIdx.x][1], s_pt[threadIdx.x][2]};
 
   // RayCaster::input(pt_w, camera_pos) (raycast.cpp:329-372)
@@ -259,13 +260,14 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     if (c[0] == ec[0] && c[1] == ec[1] && c[2] == ec[2]) break;
     if (!first) {  // the first reported cell (the end voxel itself) is discarded (:314)
       long av = (long)ix * g.nyz + (long)iy * g.nz + iz;
-      bool send = av >= 0 && av < g.N;
+      bool send = av >= 0 && av < g.N && ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz;
+      const bool raw = av >= 0 && av < g.N;  // what the reference's bounds test lets through (wrapped rows included)
       const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
       if (send && (ux | uy | uz) < 32u) {
-        const u32 id = (ux << 10) | (uy << 5) | uz, bit = 1u << (id & 31);
-        send = !(atomicOr(&s_seen[id >> 5], bit) & bit);
+        atomicOr(&s_seen[(ux << 5) | uy], 1u << uz);  // flushed as whole words when the block is done
+      } else if (raw) {
+        atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
       }
-      if (send) atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
     }
     first = false;
     if (tmax[0] < tmax[1]) {
@@ -286,6 +288,24 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
       }
     }
     if (--guard < 0) break;
+  }
+  }  // walkers
+  // flush the cube: every non-empty LDS word is 32 z-consecutive voxels of one line, i.e. one or two
+  // words of the miss plane
+  __syncthreads();
+  for (int t = threadIdx.x; t < 1024; t += 256) {
+    const u32 bits = s_seen[t];
+    if (!bits) continue;
+    const int x = cv[0] + (t >> 5), y = cv[1] + (t & 31);
+    const long a0 = (long)x * g.nyz + (long)y * g.nz + cv[2];  // address of bit 0 (its voxel may lie below z = 0:
+    const long w0 = a0 >> 6;                                    // then the low bits are clear, see the walk)
+    const int sh = (int)(a0 & 63);
+    const u64 lo = (u64)bits << sh;
+    if (lo) atomicOr(&A.miss[w0], lo);
+    if (sh > 32) {
+      const u64 hi = (u64)bits >> (64 - sh);
+      if (hi) atomicOr(&A.miss[w0 + 1], hi);
+    }
   }
 }
 
