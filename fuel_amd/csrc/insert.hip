@@ -172,6 +172,9 @@ __device__ __forceinline__ double rc_intbound(double s, double ds) {
   return (1 - s) / ds;
 }
 
+#ifndef CUBE_XY
+#define CUBE_XY 32  // lines per side of the near-camera cube (x 32 voxels in z); 64 measured slower (longer flush)
+#endif
 __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   if (blockIdx.x == 0) {  // fold the per-block boxes of k_insert_classify (all 256 threads: a serial
                           // loop over ~300 records by six threads cost 40 us of dependent loads)
@@ -202,14 +205,15 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   __shared__ double s_pt[256][3];
   __shared__ u32 s_cnt;
   // The rays of a workgroup (neighbouring pixels) converge on the camera and revisit the same voxels
-  // there: a bitmap of the 32^3 voxels around the camera voxel lets each workgroup send one atomic per
-  // voxel of that cube instead of one per ray (same-address memory-side atomics serialise).
-  __shared__ u32 s_seen[1024];
-  for (int t = threadIdx.x; t < 1024; t += 256) s_seen[t] = 0u;
+  // there: the miss marks of the 32^3 voxels around the camera voxel are collected in an LDS bitmap (one
+  // word = 32 z-neighbours of a line) and flushed once per workgroup as whole words -- a few hundred
+  // atomics instead of one per ray step, and far fewer same-address operations on the memory side.
+  __shared__ u32 s_seen[CUBE_XY * CUBE_XY];
+  for (int t = threadIdx.x; t < CUBE_XY * CUBE_XY; t += 256) s_seen[t] = 0u;
   if (threadIdx.x == 0) s_cnt = 0u;
   __syncthreads();
   int cv[3];
-  for (int k = 0; k < 3; ++k) cv[k] = (int)floor((A.cam[k] - g.org[k]) * g.res_inv) - 16;
+  for (int k = 0; k < 3; ++k) cv[k] = (int)floor((A.cam[k] - g.org[k]) * g.res_inv) - (k < 2 ? CUBE_XY / 2 : 16);
   // one LDS word = the 32 z-neighbours cv[2] .. cv[2]+31 of the line (cv[0] + ux, cv[1] + uy)
   {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,8 +267,8 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
       bool send = av >= 0 && av < g.N && ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz;
       const bool raw = av >= 0 && av < g.N;  // what the reference's bounds test lets through (wrapped rows included)
       const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
-      if (send && (ux | uy | uz) < 32u) {
-        atomicOr(&s_seen[(ux << 5) | uy], 1u << uz);  // flushed as whole words when the block is done
+      if (send && (ux | uy) < (u32)CUBE_XY && uz < 32u) {
+        atomicOr(&s_seen[ux * CUBE_XY + uy], 1u << uz);  // flushed as whole words when the block is done
       } else if (raw) {
         atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
       }
@@ -293,10 +297,10 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   // flush the cube: every non-empty LDS word is 32 z-consecutive voxels of one line, i.e. one or two
   // words of the miss plane
   __syncthreads();
-  for (int t = threadIdx.x; t < 1024; t += 256) {
+  for (int t = threadIdx.x; t < CUBE_XY * CUBE_XY; t += 256) {
     const u32 bits = s_seen[t];
     if (!bits) continue;
-    const int x = cv[0] + (t >> 5), y = cv[1] + (t & 31);
+    const int x = cv[0] + t / CUBE_XY, y = cv[1] + t % CUBE_XY;
     const long a0 = (long)x * g.nyz + (long)y * g.nz + cv[2];  // address of bit 0 (its voxel may lie below z = 0:
     const long w0 = a0 >> 6;                                    // then the low bits are clear, see the walk)
     const int sh = (int)(a0 & 63);
