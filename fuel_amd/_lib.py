@@ -168,6 +168,7 @@ SYMBOLS = {
     "fuelmi_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "fuelmi_profile_enable": (C.c_int, [_P, C.c_uint]),
     "fuelmi_profile_get": (C.c_int, [_P, C.c_int, _ip, _dp]),
+    "fuelmi_profile_get_samples": (C.c_int, [_P, C.c_int, _dp, C.c_int, _ip]),
 }
 
 

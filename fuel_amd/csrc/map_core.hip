@@ -692,3 +692,18 @@ extern "C" int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, doubl
   *total_ms = tot;
   return FUELMI_OK;
 }
+extern "C" int fuelmi_profile_get_samples(fuelmi_map* m, int stage, double* ms_out, int cap, int* n) {
+  ARGCHK(m && stage >= 0 && stage < FUELMI_K_COUNT && ms_out && cap >= 0 && n);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  ProfileSlot& s = m->prof[stage];
+  int k = 0;
+  for (size_t i = 0; i + 1 < s.used && k < cap; i += 2, ++k) {
+    float ms = 0.f;
+    HIPCHK(hipEventSynchronize(s.ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+    ms_out[k] = ms;
+  }
+  *n = k;
+  return FUELMI_OK;
+}

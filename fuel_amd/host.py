@@ -222,6 +222,13 @@ class SDFMap:
         check(self.L.fuelmi_profile_get(self.h, stage, C.byref(n), C.byref(t)))
         return n.value, t.value
 
+    def profileSamples(self, stage, cap=4096):
+        """Per-launch milliseconds of a stage since profileEnable."""
+        ms = np.empty(cap)
+        n = C.c_int()
+        check(self.L.fuelmi_profile_get_samples(self.h, stage, _dp(ms), cap, C.byref(n)))
+        return ms[:n.value].copy()
+
 
 class EDTEnvironment:
     """fast_planner::EDTEnvironment: distance/gradient query facade over SDFMap."""

@@ -334,6 +334,9 @@ int fuelmi_timer_end(fuelmi_map* m, float* elapsed_ms); /* synchronises the stre
 int fuelmi_profile_enable(fuelmi_map* m, unsigned stage_mask);
 /* synchronises, then returns launches and summed device milliseconds of a stage since enable */
 int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, double* total_ms);
+/* the same brackets one by one (up to cap values, milliseconds; *n = how many were written): lets the
+ * caller take a median, a single disturbed launch otherwise dominates a short sample */
+int fuelmi_profile_get_samples(fuelmi_map* m, int stage, double* ms, int cap, int* n);
 
 #ifdef __cplusplus
 }
