@@ -105,20 +105,8 @@ __device__ __forceinline__ bool f1_cell(const Geo& g, const u64* __restrict__ oc
   return false;
 }
 
-// (Folding the one-block tails -- k_scan_sums, k_ms_scan, k_pack -- into their producers with a "last
-// block done" ticket was tried and is 10x slower: the agent-scope fence every block needs before its
-// ticket writes back and invalidates the whole XCD L2, 977 times in k_pred.  They stay ~5 us launches.)
-// ---- kernels ----------------------------------------------------------------------------------
-// isFrontierChanged (:365-372) for the cells of several clusters: changed[cl] |= !F1(cell)
-__global__ void k_check_clusters(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk,
-                                 const int* __restrict__ cells, const int* __restrict__ cell_cluster, int n,
-                                 int* __restrict__ changed) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (!f1_cell(g, occ, unk, cells[i])) changed[cell_cluster[i]] = 1;
-}
-// the same two tests over clusters whose cells sit in the device pool: cand[k] = (pool offset, first
-// flat index); a thread finds its cluster by bisection over the (few) candidates
+// committed clusters' cells live in one device pool; candidate k of a changed-cluster test owns the
+// global indices [cand_start[k], cand_start[k+1])
 __device__ __forceinline__ int pool_cluster_of(const u32* __restrict__ cand_start, int ncand, u32 i) {
   int lo = 0, hi = ncand - 1;
   while (lo < hi) {
@@ -156,17 +144,6 @@ __global__ void k_pool_put(u32* __restrict__ pool, const u32* __restrict__ cells
   for (u32 i = threadIdx.x; i < e.n; i += blockDim.x) dst[i] = src[i];
   if (e.seed >= 0 && threadIdx.x == 0) dst[e.n] = (u32)e.seed;  // order is irrelevant on the device
 }
-__global__ void k_clear_flags(u64* flag, const int* __restrict__ cells, const int* __restrict__ cell_cluster,
-                              const int* __restrict__ changed, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (changed[cell_cluster[i]]) {
-    long a = cells[i];
-    atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
-  }
-}
-
-// exclusive scan of the block sums + totals (one block)
 __device__ void scan_sums_tail(const FArgs& F) {
   // one block of 1024 threads: contiguous slices of the block sums per thread, then a Hillis-Steele scan
   // of the 1024 partials in LDS (a 256-thread version with a serial middle cost 18 us on an 800^2 x 200 map)
