@@ -44,7 +44,7 @@ struct Frontier {
   vector<Vector3d> cells_;                // voxel centres, ascending voxel address (reference: BFS order)
   vector<Vector3d> filtered_cells_;       // VoxelGrid centroids (needs frontier/cluster_size_xy + down_sample)
   vector<Viewpoint> viewpoints_;          // best coverage first (needs the candidate_* / perception_utils params)
-  list<vector<Vector3d>> paths_;          // filled by the cost-matrix code (not part of this library)
+  list<vector<Vector3d>> paths_;          // to every frontier of frontiers_, in list order (updateFrontierCostMatrix)
   list<double> costs_;
 };
 
@@ -72,12 +72,21 @@ public:
                          vector<vector<double>>& yaws);
   void wrapYaw(double& yaw);
 
+  // tour planning (TSP input): pairwise costs between the best viewpoints of the active clusters, kept
+  // incrementally across searches; the full matrix with the current state in row 0; the stored paths
+  // along a tour
+  void updateFrontierCostMatrix();
+  void getFullCostMatrix(const Vector3d& cur_pos, const Vector3d& cur_vel, const Vector3d cur_yaw,
+                         Eigen::MatrixXd& mat);
+  void getPathForTour(const Vector3d& pos, const vector<int>& frontier_ids, vector<Vector3d>& path);
+  void setNextFrontier(const int& id);
+
   // additions: clusters found by the last searchFrontiers() and the list positions it removed
   const list<Frontier>& newFrontiers() const { return tmp_frontiers_; }
   const vector<int>& removedIds() const { return removed_ids_; }
 
 private:
-  void pull(int which, list<Frontier>& out);
+  void pull(int which, list<Frontier>& out, int from = 0);
 
   fuelmi_frontier* dev_;
   shared_ptr<EDTEnvironment> edt_env_;
@@ -86,6 +95,8 @@ private:
   bool have_viewpoints_;  // frontier/candidate_* and perception_utils/* were all given
   vector<int> removed_ids_;
   list<Frontier> frontiers_, dormant_frontiers_, tmp_frontiers_;
+  list<Frontier>::iterator first_new_ftr_;  // first cluster appended by the last computeFrontiersToVisit()
+  Frontier next_frontier_;
 };
 }  // namespace fast_planner
 #endif

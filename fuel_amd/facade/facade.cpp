@@ -10,6 +10,7 @@
 #include "plan_env/sdf_map.h"
 #include "plan_env/edt_environment.h"
 #include "active_perception/frontier_finder.h"
+#include "active_perception/graph_node.h"
 #include "bspline_opt/bspline_optimizer.h"
 
 namespace fast_planner {
@@ -262,11 +263,12 @@ FrontierFinder::~FrontierFinder() {
   if (dev_) fuelmi_frontier_destroy(dev_);
 }
 
-void FrontierFinder::pull(int which, list<Frontier>& out) {
-  out.clear();
+// host copies of the device list `which`, from position `from` on (from = 0 replaces `out`)
+void FrontierFinder::pull(int which, list<Frontier>& out, int from) {
+  if (from == 0) out.clear();
   const int n = fuelmi_frontier_count(dev_, which);
   std::vector<int> adr;
-  for (int k = 0; k < n; ++k) {
+  for (int k = from; k < n; ++k) {
     Frontier f;
     const int sz = fuelmi_frontier_cluster_size(dev_, which, k);
     adr.resize(sz);
@@ -312,25 +314,116 @@ void FrontierFinder::searchFrontiers() {
   pull(0, tmp_frontiers_);
   removed_ids_.resize(fuelmi_frontier_removed_count(dev_));
   if (!removed_ids_.empty()) fuelmi_frontier_removed_ids(dev_, removed_ids_.data());
-  pull(1, frontiers_);  // clusters dropped as "changed" disappear from the persistent lists
+  // clusters dropped as "changed" leave the persistent list; the survivors keep their records (and with
+  // them costs_ / paths_).  removed_ids_ are positions in the list as it shrinks (:74-85).
+  for (int id : removed_ids_) {
+    if (id < 0 || id >= (int)frontiers_.size()) break;
+    auto it = frontiers_.begin();
+    std::advance(it, id);
+    frontiers_.erase(it);
+  }
+  if ((int)frontiers_.size() != fuelmi_frontier_count(dev_, 1)) pull(1, frontiers_);  // lists out of step: start over
+  first_new_ftr_ = frontiers_.end();
   pull(2, dormant_frontiers_);
 }
 
 void FrontierFinder::computeFrontiersToVisit() {
+  const int before = (int)frontiers_.size();
   if (have_viewpoints_) {
     // reference (:392-423): sampleViewpoints per new cluster on the device; clusters with viewpoints
     // join frontiers_ (viewpoints sorted by coverage), the others dormant_frontiers_
     int na = 0, nd = 0;
     warn("fuelmi_frontier_compute_to_visit", fuelmi_frontier_compute_to_visit(dev_, &na, &nd));
-    pull(1, frontiers_);
+    pull(1, frontiers_, before);
     pull(2, dormant_frontiers_);
-    return;
+  } else {
+    // without the viewpoint parameters every new cluster becomes an active frontier
+    warn("fuelmi_frontier_commit", fuelmi_frontier_commit(dev_, 0));
+    frontiers_.insert(frontiers_.end(), tmp_frontiers_.begin(), tmp_frontiers_.end());
   }
-  // without the viewpoint parameters every new cluster becomes an active frontier
-  warn("fuelmi_frontier_commit", fuelmi_frontier_commit(dev_, 0));
-  frontiers_.insert(frontiers_.end(), tmp_frontiers_.begin(), tmp_frontiers_.end());
+  first_new_ftr_ = frontiers_.begin();
+  std::advance(first_new_ftr_, std::min(before, (int)frontiers_.size()));
   int id = 0;
-  for (auto& f : frontiers_) f.id_ = id++;
+  for (auto& f : frontiers_) f.id_ = id++;  // :417-419
+}
+
+// ---- tour planning: the reference's bookkeeping (frontier_finder.cpp:258-324, 507-589) on the host lists;
+// path costs come from the package's own ViewNode (A* through the map)
+void FrontierFinder::updateFrontierCostMatrix() {
+  if (!removed_ids_.empty()) {
+    // every surviving old cluster forgets its entries towards the removed ones
+    for (auto it = frontiers_.begin(); it != first_new_ftr_; ++it)
+      for (int id : removed_ids_) {
+        if (id < 0 || id >= (int)it->costs_.size()) break;
+        auto c = it->costs_.begin();
+        auto p = it->paths_.begin();
+        std::advance(c, id);
+        std::advance(p, id);
+        it->costs_.erase(c);
+        it->paths_.erase(p);
+      }
+    removed_ids_.clear();
+  }
+  // best viewpoint to best viewpoint, stored in both records (the way back is the same path reversed)
+  auto link = [](Frontier& a, Frontier& b) {
+    const Viewpoint& va = a.viewpoints_.front();
+    const Viewpoint& vb = b.viewpoints_.front();
+    vector<Vector3d> path;
+    const double cost = ViewNode::computeCost(va.pos_, vb.pos_, va.yaw_, vb.yaw_, Vector3d(0, 0, 0), 0, path);
+    a.costs_.push_back(cost);
+    a.paths_.push_back(path);
+    std::reverse(path.begin(), path.end());
+    b.costs_.push_back(cost);
+    b.paths_.push_back(path);
+  };
+  for (auto old = frontiers_.begin(); old != first_new_ftr_; ++old)
+    for (auto fresh = first_new_ftr_; fresh != frontiers_.end(); ++fresh) link(*old, *fresh);
+  for (auto a = first_new_ftr_; a != frontiers_.end(); ++a) {
+    a->costs_.push_back(0);  // itself
+    a->paths_.push_back({});
+    auto b = a;
+    for (++b; b != frontiers_.end(); ++b) link(*a, *b);
+  }
+  first_new_ftr_ = frontiers_.end();  // everything is linked now
+}
+
+void FrontierFinder::getFullCostMatrix(const Vector3d& cur_pos, const Vector3d& cur_vel, const Vector3d cur_yaw,
+                                       Eigen::MatrixXd& mat) {
+  // asymmetric TSP (:561-588): row/column 0 = the current state, nothing leads back to it
+  const int n = (int)frontiers_.size();
+  mat.resize(n + 1, n + 1);
+  int i = 1;
+  for (auto& ftr : frontiers_) {
+    int j = 1;
+    for (double cs : ftr.costs_) mat(i, j++) = cs;
+    ++i;
+  }
+  mat.leftCols<1>().setZero();
+  int j = 1;
+  for (auto& ftr : frontiers_) {
+    const Viewpoint& v = ftr.viewpoints_.front();
+    vector<Vector3d> path;
+    mat(0, j++) = ViewNode::computeCost(cur_pos, v.pos_, cur_yaw[0], v.yaw_, cur_vel, cur_yaw[1], path);
+  }
+}
+
+void FrontierFinder::getPathForTour(const Vector3d& pos, const vector<int>& frontier_ids, vector<Vector3d>& path) {
+  if (frontier_ids.empty()) return;
+  vector<list<Frontier>::iterator> at;
+  for (auto it = frontiers_.begin(); it != frontiers_.end(); ++it) at.push_back(it);
+  vector<Vector3d> segment;
+  ViewNode::searchPath(pos, at[frontier_ids[0]]->viewpoints_.front().pos_, segment);
+  path.insert(path.end(), segment.begin(), segment.end());
+  for (size_t k = 0; k + 1 < frontier_ids.size(); ++k) {  // stored path from tour stop k to stop k+1
+    auto p = at[frontier_ids[k]]->paths_.begin();
+    std::advance(p, frontier_ids[k + 1]);
+    path.insert(path.end(), p->begin(), p->end());
+  }
+}
+
+void FrontierFinder::setNextFrontier(const int& id) {  // declared by the reference, never defined there
+  for (auto& ftr : frontiers_)
+    if (ftr.id_ == id) next_frontier_ = ftr;
 }
 
 void FrontierFinder::getTopViewpointsInfo(const Vector3d& cur_pos, vector<Vector3d>& points, vector<double>& yaws,

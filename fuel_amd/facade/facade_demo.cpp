@@ -3,6 +3,7 @@
 // updateESDFCallback -> updateESDF3d; planExploreMotion -> searchFrontiers;
 // planExploreTraj -> BsplineOptimizer::optimize) and dumps results for tests/test_facade_gpu.py.
 //   facade_demo <scenario.bin> <result.bin>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -12,8 +13,21 @@
 #include <plan_env/edt_environment.h>
 #include <active_perception/frontier_finder.h>
 #include <bspline_opt/bspline_optimizer.h>
+#include <active_perception/graph_node.h>
 
 namespace fast_planner {
+// ViewNode belongs to the part of active_perception the facade does not replace (graph_node.cpp: A*
+// through the map).  For this demo: straight flight plus a yaw term, the path is its two end points
+// (tests/test_facade_gpu.py rebuilds the expected cost matrix with the same formula).
+double ViewNode::computeCost(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2, const double& y1, const double& y2,
+                             const Eigen::Vector3d&, const double&, std::vector<Eigen::Vector3d>& path) {
+  path = {p1, p2};
+  return (p2 - p1).norm() + 0.1 * std::fabs(y2 - y1);
+}
+double ViewNode::searchPath(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2, std::vector<Eigen::Vector3d>& path) {
+  path = {p1, p2};
+  return (p2 - p1).norm();
+}
 // the reference's MapROS is a friend of SDFMap and calls its private clearAndInflateLocalMap
 // (plan_env/src/map_ros.cpp:142,170); this stand-in does the same
 class MapROS {
@@ -226,6 +240,46 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < pts.size(); ++i) {
       double q[7] = {pts[i](0), pts[i](1), pts[i](2), yaws[i], avgs[i](0), avgs[i](1), avgs[i](2)};
       wr(out, q, 7);
+    }
+    // tour planning over two rounds (fast_exploration_manager.cpp:187,334-335,423): the cost matrix is
+    // kept incrementally -- after more frames some clusters are dropped (removed_ids_) and new ones linked
+    ff2.updateFrontierCostMatrix();
+    int n_extra = 0;
+    if (fread(&n_extra, sizeof(int), 1, in) != 1) n_extra = 0;
+    for (int k = 0; k < n_extra; ++k) {
+      int n;
+      double cam[3];
+      rd(in, &n, 1);
+      rd(in, cam, 3);
+      std::vector<float> xyz((size_t)n * 3);
+      rd(in, xyz.data(), xyz.size());
+      pcl::PointCloud<pcl::PointXYZ> cloud;
+      cloud.points.resize(n);
+      for (int i = 0; i < n; ++i) cloud.points[i] = pcl::PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+      map->inputPointCloud(cloud, n, Eigen::Vector3d(cam[0], cam[1], cam[2]));
+      MapROS::inflate(*map);
+    }
+    ff2.searchFrontiers();
+    const int n_removed = (int)ff2.removedIds().size();
+    ff2.computeFrontiersToVisit();
+    ff2.updateFrontierCostMatrix();
+    Eigen::MatrixXd mat;
+    const Eigen::Vector3d cur(0.0, 0.0, 1.0);
+    ff2.getFullCostMatrix(cur, Eigen::Vector3d(0, 0, 0), Eigen::Vector3d(0.3, 0, 0), mat);
+    std::vector<int> tour;
+    for (int k = 0; k < mat.rows() - 1 && k < 4; ++k) tour.push_back((k * 3) % (mat.rows() - 1));
+    std::vector<Eigen::Vector3d> tpath;
+    ff2.getPathForTour(cur, tour, tpath);
+    int hdr3[4] = {n_extra, n_removed, (int)mat.rows(), (int)tpath.size()};
+    wr(out, hdr3, 4);
+    for (int i = 0; i < mat.rows(); ++i)
+      for (int j = 0; j < mat.cols(); ++j) {
+        const double v = mat(i, j);
+        wr(out, &v, 1);
+      }
+    for (auto& q : tpath) {
+      double v[3] = {q(0), q(1), q(2)};
+      wr(out, v, 3);
     }
   }
   fclose(in);

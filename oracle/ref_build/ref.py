@@ -138,6 +138,33 @@ class RefFrontier:
             self.L.ref_frontier_cluster_filtered(self.h, which, k, fo._dp(o))
         return o
 
+    def update_cost_matrix(self):
+        self.L.ref_frontier_update_cost_matrix.restype = None
+        self.L.ref_frontier_update_cost_matrix.argtypes = [C.c_void_p]
+        self.L.ref_frontier_update_cost_matrix(self.h)
+
+    def full_cost_matrix(self, pos, vel=(0.0, 0.0, 0.0), yaw=(0.0, 0.0, 0.0)):
+        D = C.POINTER(C.c_double)
+        self.L.ref_frontier_full_cost_matrix.restype = C.c_int
+        self.L.ref_frontier_full_cost_matrix.argtypes = [C.c_void_p, D, D, D, D, C.c_int]
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (pos, vel, yaw)]
+        buf = np.zeros(1 << 16)
+        d = self.L.ref_frontier_full_cost_matrix(self.h, *[v.ctypes.data_as(D) for v in a], buf.ctypes.data_as(D), buf.size)
+        assert d > 0
+        return buf[:d * d].reshape(d, d).copy()
+
+    def path_for_tour(self, pos, ids):
+        D = C.POINTER(C.c_double)
+        self.L.ref_frontier_path_for_tour.restype = C.c_int
+        self.L.ref_frontier_path_for_tour.argtypes = [C.c_void_p, D, C.POINTER(C.c_int), C.c_int, D, C.c_int]
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        buf = np.zeros(3 * 4096)
+        n = self.L.ref_frontier_path_for_tour(self.h, p.ctypes.data_as(D), i.ctypes.data_as(C.POINTER(C.c_int)), len(i),
+                                              buf.ctypes.data_as(D), 4096)
+        assert n >= 0
+        return buf[:3 * n].reshape(n, 3).copy()
+
     def removed_ids(self):
         n = self.L.ref_frontier_removed_count(self.h)
         a = np.empty(n, dtype=np.int32)

@@ -266,6 +266,32 @@ void ref_frontier_viewpoints(ref_frontier* f, int which, int k, double* pos_yaw,
     visib[i] = it->viewpoints_[i].visib_num_;
   }
 }
+// tour planning (frontier_finder.cpp:258-324, 507-589) with the deterministic ViewNode of ref_frontier_stubs.cpp
+void ref_frontier_update_cost_matrix(ref_frontier* f) {
+  std::streambuf* keep = std::cout.rdbuf(nullptr);  // the function narrates every pair on stdout
+  f->ff->updateFrontierCostMatrix();
+  std::cout.rdbuf(keep);
+}
+int ref_frontier_full_cost_matrix(ref_frontier* f, const double pos[3], const double vel[3], const double yaw[3],
+                                  double* mat, int cap) {
+  Eigen::MatrixXd m;
+  f->ff->getFullCostMatrix(Eigen::Vector3d(pos[0], pos[1], pos[2]), Eigen::Vector3d(vel[0], vel[1], vel[2]),
+                           Eigen::Vector3d(yaw[0], yaw[1], yaw[2]), m);
+  const int d = m.rows();
+  if (d * d > cap) return -d;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j) mat[i * d + j] = m(i, j);
+  return d;
+}
+int ref_frontier_path_for_tour(ref_frontier* f, const double pos[3], const int* ids, int n, double* xyz, int cap) {
+  std::vector<int> v(ids, ids + n);
+  std::vector<Eigen::Vector3d> path;
+  f->ff->getPathForTour(Eigen::Vector3d(pos[0], pos[1], pos[2]), v, path);
+  if ((int)path.size() > cap) return -(int)path.size();
+  for (size_t i = 0; i < path.size(); ++i)
+    for (int k = 0; k < 3; ++k) xyz[3 * i + k] = path[i](k);
+  return (int)path.size();
+}
 int ref_frontier_removed_count(ref_frontier* f) { return (int)f->ff->removed_ids_.size(); }
 void ref_frontier_removed_ids(ref_frontier* f, int* ids) {
   for (size_t i = 0; i < f->ff->removed_ids_.size(); ++i) ids[i] = f->ff->removed_ids_[i];

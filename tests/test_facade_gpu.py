@@ -28,6 +28,10 @@ def test_facade_cycle_matches_oracle(tmp_path):
         pose = om.fixture_camera(truth, 5, k, 8, 0.6)
         pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
         frames.append((pts, pose[:3].copy()))
+    extra = []
+    for k in range(3):
+        pose = om.fixture_camera(truth, 24, k, 3, 0.6)  # round 2 drops four clusters (positions 1,7,7,7) and adds new ones
+        extra.append((om.fixture_render(truth, pose, 160, 120, 2, 2), pose[:3].copy()))
     rng = np.random.default_rng(2)
     N = 12
     a = np.array([-3.0, -2.0, 1.0])
@@ -51,6 +55,11 @@ def test_facade_cycle_matches_oracle(tmp_path):
         f.write(ctrl.astype(np.float64).tobytes())
         f.write(st.tobytes())
         f.write(en.tobytes())
+        f.write(struct.pack("i", len(extra)))  # second round of the tour-planning part
+        for pts, cam in extra:
+            f.write(struct.pack("i", len(pts)))
+            f.write(struct.pack("3d", *cam))
+            f.write(np.ascontiguousarray(pts, np.float32).tobytes())
     res = tmp_path / "res.bin"
     p = subprocess.run([DEMO, str(scen), str(res)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
@@ -122,3 +131,37 @@ def test_facade_cycle_matches_oracle(tmp_path):
         assert np.array_equal(top[k, :3], pick[:3]) and abs(top[k, 3] - pick[3]) <= 1e-9
         assert np.array_equal(top[k, 4:], of2.cluster_info(1, k)[0])
     assert covered == int(of2.is_covered())
+    off += 56 * ntop
+    # tour planning: cost matrix kept incrementally over a second round (clusters dropped and added);
+    # with the demo's ViewNode (straight flight + 0.1 |yaw difference|, path = the two end points) the
+    # matrix must equal that formula between the best viewpoints of the FINAL active list, in list order
+    n_extra, n_removed, dim, n_path = struct.unpack_from("4i", raw, off)
+    off += 16
+    mat = np.frombuffer(raw, np.float64, dim * dim, off).reshape(dim, dim)
+    off += 8 * dim * dim
+    tpath = np.frombuffer(raw, np.float64, 3 * n_path, off).reshape(n_path, 3)
+    for pts, cam in extra:
+        om.input_points(pts, cam)
+        om.inflate_local()
+    of2.search()
+    assert n_extra == len(extra) and n_removed == len(of2.removed_ids())
+    assert n_removed > 0, "scenario no longer drops a cluster in round 2: the incremental bookkeeping is not exercised"
+    of2.compute_to_visit()
+    tops = [of2.viewpoints(1, k)[0][0] for k in range(len(of2.clusters(1)))]
+    assert dim == len(tops) + 1 and dim > 2
+
+    def cost(p1, y1, p2, y2):
+        return np.linalg.norm(p2 - p1) + 0.1 * abs(y2 - y1)
+
+    want = np.zeros((dim, dim))
+    for i, a in enumerate(tops):
+        want[0, i + 1] = cost(cur, 0.3, a[:3], a[3])
+        for j, b in enumerate(tops):
+            if i != j:
+                want[i + 1, j + 1] = cost(a[:3], a[3], b[:3], b[3])
+    assert np.abs(mat - want).max() <= 1e-9
+    tour = [(k * 3) % (dim - 1) for k in range(min(4, dim - 1))]
+    wpath = [cur, tops[tour[0]][:3]]
+    for a, b in zip(tour[:-1], tour[1:]):
+        wpath += [tops[a][:3], tops[b][:3]] if a != b else []
+    assert n_path == len(wpath) and np.abs(tpath - np.array(wpath)).max() <= 1e-12

@@ -368,3 +368,56 @@ def test_spline_boundary_states_match_reference(degree, ks, ke):
         np.testing.assert_allclose(s1[0], pts[0], atol=1e-9)
         np.testing.assert_allclose(s1[1], der[0], atol=1e-9)
         np.testing.assert_allclose(e1[0], pts[-1], atol=1e-9)
+
+
+# ---- tour planning bookkeeping of the REAL FrontierFinder (updateFrontierCostMatrix & co.) ----
+def test_reference_cost_matrix_bookkeeping_equals_pairwise_costs():
+    """What the facade's updateFrontierCostMatrix / getFullCostMatrix / getPathForTour must reproduce
+    (tests/test_facade_gpu.py checks the facade against the same statement): with a deterministic
+    ViewNode (ref_frontier_stubs.cpp: straight flight + 0.1 |yaw difference|, path = the end points) the
+    incrementally kept matrix of the real class -- across a round that drops clusters (removed_ids_) and
+    adds new ones -- equals the pairwise costs between the best viewpoints of the final frontiers_."""
+    map_size = (10.0, 8.0, 4.0)
+    box = ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    rm = ref.RefMap(map_size, *box)
+    om = fo.OracleMap(map_size, *box)
+    truth = om.fixture_world(3, 14)
+    for k in range(8):
+        pose = om.fixture_camera(truth, 5, k, 8, 0.6)
+        rm.input_points(om.fixture_render(truth, pose, 160, 120, 2, 2), pose[:3])
+        rm.inflate_local()
+    rf = ref.RefFrontier(rm, 10, 1.0, fo.viewpoint_cfg(min_visib_num=3))
+    rf.search()
+    rf.compute_to_visit()
+    rf.update_cost_matrix()
+    n1 = len(rf.clusters(1))
+    for k in range(3):
+        pose = om.fixture_camera(truth, 24, k, 3, 0.6)
+        rm.input_points(om.fixture_render(truth, pose, 160, 120, 2, 2), pose[:3])
+        rm.inflate_local()
+    rf.search()
+    removed = list(rf.removed_ids())
+    assert len(removed) >= 2 and n1 > len(removed)
+    rf.compute_to_visit()
+    rf.update_cost_matrix()
+    cur = np.array([0.0, 0.0, 1.0])
+    mat = rf.full_cost_matrix(cur, (0, 0, 0), (0.3, 0, 0))
+    tops = [rf.viewpoints(1, k)[0][0] for k in range(len(rf.clusters(1)))]
+    assert mat.shape == (len(tops) + 1, len(tops) + 1)
+
+    def cost(p1, y1, p2, y2):
+        return np.linalg.norm(p2 - p1) + 0.1 * abs(y2 - y1)
+
+    want = np.zeros_like(mat)
+    for i, a in enumerate(tops):
+        want[0, i + 1] = cost(cur, 0.3, a[:3], a[3])
+        for j, b in enumerate(tops):
+            if i != j:
+                want[i + 1, j + 1] = cost(a[:3], a[3], b[:3], b[3])
+    assert np.abs(mat - want).max() <= 1e-12
+    tour = [0, 3, 1, 5]
+    path = rf.path_for_tour(cur, tour)
+    wpath = [cur, tops[0][:3]]
+    for a, b in zip(tour[:-1], tour[1:]):
+        wpath += [tops[a][:3], tops[b][:3]]
+    assert np.array_equal(path, np.array(wpath))
