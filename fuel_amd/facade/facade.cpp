@@ -225,7 +225,7 @@ double EDTEnvironment::evaluateCoarseEDT(Eigen::Vector3d& pos, double) { return 
 // ------------------------------------------------------------------------------------------------
 // FrontierFinder (grid part)
 // ------------------------------------------------------------------------------------------------
-FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& nh) : edt_env_(edt), dev_(nullptr) {
+FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& nh) : dev_(nullptr), edt_env_(edt) {
   nh.param("frontier/cluster_min", cluster_min_, -1);
   resolution_ = edt_env_->sdf_map_->getResolution();
   double cluster_size_xy = -1.0;
