@@ -294,8 +294,10 @@ def fleet_value(n_ranks, steps, elapsed_max):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed cycles (default 200 for the full-box workloads: 20 cycles are 4 ms, too short for "
+                         "a steady clock; 20 for the streaming ones, one distinct depth frame each)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed cycles first (default 20 / 3)")
     ap.add_argument("--workload", default="G400", choices=sorted(WORKLOADS))
     ap.add_argument("--candidates", type=int, default=64,
                     help="B-spline candidates per cycle (BASELINE configs: 1, 64 = headline, 256)")
@@ -304,6 +306,11 @@ def main():
     ap.add_argument("--serial-stages", action="store_true",
                     help="diagnostic: run the frontier scan after the ESDF chain instead of beside it")
     args = ap.parse_args()
+    stream_wl = args.workload.endswith("S")
+    if args.steps is None:
+        args.steps = 20 if stream_wl else 200
+    if args.warmup is None:
+        args.warmup = 3 if stream_wl else 20
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
