@@ -246,8 +246,14 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
            int ZC, int nzc, int z0a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32* tile = reinterpret_cast<u32*>(smem_raw);  // [ylen][ZC] dz^2 or INF32 (u32: the scan loop adds without sentinel tests), ZC % 4 == 0, ZC <= 64
-  const int x = b.lo[0] + blockIdx.x / nzc;
-  const int zc0 = z0a + (blockIdx.x % nzc) * ZC;
+  // XCD-aware order: workgroup i runs on XCD i % 8, and each XCD has its own L2.  The nzc chunk-blocks of
+  // one x-slab read the same bit-plane lines and write interleaved pieces of the same tmp lines, so they
+  // are given to the SAME XCD (slab x -> XCD x % 8) instead of being dealt round-robin over all eight.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xrel = xcd + 8 * (slot / nzc);
+  if (xrel > b.hi[0] - b.lo[0]) return;  // grid is padded to a multiple of 8 slabs
+  const int x = b.lo[0] + xrel;
+  const int zc0 = z0a + (slot % nzc) * ZC;
   const int ylen = b.hi[1] - b.lo[1] + 1;
   const int T = blockDim.x;
   // z pass: one lane per row of the chunk; chunk source bits live in one register
@@ -444,7 +450,7 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  STAGE_LAUNCH(m, (k_esdf_zy4<MODE>), xlen * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
+  STAGE_LAUNCH(m, (k_esdf_zy4<MODE>), ((xlen + 7) / 8) * 8 * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
                m->esdf_tmp, ZC, nzc, z0a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
