@@ -149,7 +149,11 @@ k_inflate_yz(Geo g, int step, const u64* __restrict__ S, u64* __restrict__ T, in
 }
 __global__ void __launch_bounds__(256)
 k_inflate_x(Geo g, Box3 b, int step, const u64* __restrict__ T, u64* __restrict__ infl, int w_lo, int w_hi) {
-  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  // every word is read by the 2*step+1 workgroups that hold its x-neighbours: give each XCD (workgroup i
+  // runs on XCD i % 8, own L2) one contiguous eighth of the word range instead of every eighth block
+  const int per_xcd = (gridDim.x + 7) >> 3;
+  const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  int w = w_lo + lb * blockDim.x + threadIdx.x;
   if (w > w_hi) return;
   u64 acc = 0ull;
   for (int dx = -step; dx <= step; ++dx) acc |= plane_window(T, 64L * w - (long)dx * g.nyz);
@@ -452,7 +456,7 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
                                                                         s_lo, s_hi);
     k_inflate_yz<<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, m->tmp_bits.p, m->tmp2_bits.p,
                                                                           t_lo, t_hi);
-    k_inflate_x<<<blocks_for(out_hi - out_lo + 1, 256), 256, 0, m->stream>>>(g, b, step, m->tmp2_bits.p,
+    k_inflate_x<<<((blocks_for(out_hi - out_lo + 1, 256) + 7) / 8) * 8, 256, 0, m->stream>>>(g, b, step, m->tmp2_bits.p,
                                                                              m->infl_bits.p, out_lo, out_hi);
   }
   if (m->cfg.virtual_ceil_height > -0.5) {
