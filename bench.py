@@ -177,16 +177,33 @@ class GpuStreamCycle:
         img, pos, q = self.frames[self.k % len(self.frames)]
         self.k += 1
         m = self.map
-        if m.inputDepthImage(img, pos, q) > 0:      # MapROS::depthPoseCallback
+        fused = m.inputDepthImage(img, pos, q) > 0  # MapROS::depthPoseCallback
+        # the scan only reads the occupancy planes the fusion just rewrote: queue it first (own stream), the
+        # inflation -> ESDF -> B-spline chain beside it, collect the clusters last (same order as GpuCycle)
+        self.ff.searchFrontiersBegin()                # consumes the accumulated updated box
+        if fused:
             lo, hi = m.getLocalBound()
             self.box_vox.append(float(np.prod(np.array(hi) - np.array(lo) + 1)))
             m.clearAndInflateLocalMap()
             m.updateESDF3d()                          # (the reference defers this to a 50 ms timer)
         self.dev_problem.eval()
-        self.n_clusters = self.ff.searchFrontiers()  # consumes the accumulated updated box
+        self.n_clusters = self.ff.searchFrontiersEnd()
         self.ff.commit()
 
-    step_serial = step
+    def step_serial(self):
+        """Diagnostic order: the frontier search after the map chain instead of beside it."""
+        img, pos, q = self.frames[self.k % len(self.frames)]
+        self.k += 1
+        m = self.map
+        if m.inputDepthImage(img, pos, q) > 0:
+            lo, hi = m.getLocalBound()
+            self.box_vox.append(float(np.prod(np.array(hi) - np.array(lo) + 1)))
+            m.clearAndInflateLocalMap()
+            m.updateESDF3d()
+        self.dev_problem.eval()
+        m.synchronize()
+        self.n_clusters = self.ff.searchFrontiers()
+        self.ff.commit()
 
     def finish(self):
         self.map.synchronize()
