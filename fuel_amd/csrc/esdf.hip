@@ -329,20 +329,27 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
     const int hi_off = last_row + col;
     int oa = base, ob = base;
     u32 rr = 1u, inc = 3u;
+    // two rows out per trip: four LDS reads in flight behind one wait and one exit test.  The second
+    // step may be one more than the exit test would have allowed -- every candidate f(y +- r) + r^2 is a
+    // true upper bound, so extra ones cannot change the minimum.
     while (rr < min(mx, lim)) {
-      oa = max(oa - stride, col);
-      ob = min(ob + stride, hi_off);
-      const uint4 va = *reinterpret_cast<const uint4*>(smem_raw + oa);
-      const uint4 vb = *reinterpret_cast<const uint4*>(smem_raw + ob);
+      const int oa1 = max(oa - stride, col), ob1 = min(ob + stride, hi_off);
+      oa = max(oa1 - stride, col);
+      ob = min(ob1 + stride, hi_off);
+      const uint4 va = *reinterpret_cast<const uint4*>(smem_raw + oa1);
+      const uint4 vb = *reinterpret_cast<const uint4*>(smem_raw + ob1);
+      const uint4 vc = *reinterpret_cast<const uint4*>(smem_raw + oa);
+      const uint4 vd = *reinterpret_cast<const uint4*>(smem_raw + ob);
+      const u32 rr2 = rr + inc;
       // a clamped row repeats a candidate already seen with a smaller r: harmless; INF32 + r^2 stays
       // above every finite value and below 2^31
-      b0 = min(b0, min(va.x, vb.x) + rr);
-      b1 = min(b1, min(va.y, vb.y) + rr);
-      b2 = min(b2, min(va.z, vb.z) + rr);
-      b3 = min(b3, min(va.w, vb.w) + rr);
+      b0 = min(b0, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
+      b1 = min(b1, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
+      b2 = min(b2, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
+      b3 = min(b3, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
       mx = max(max(b0, b1), max(b2, b3));
-      rr += inc;
-      inc += 2u;
+      rr = rr2 + inc + 2u;
+      inc += 4u;
     }
     const int z = zc0 + 4 * gi;
     u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz + z;
@@ -394,14 +401,18 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
     uint4 bb = tile[xi * SEGS + seg];
     u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
     const int rmax = max(xi, xlen - 1 - xi);
-    for (int r = 1; r <= rmax && (u32)(r * r) < mx; ++r) {
-      const u32 rr = (u32)(r * r);
+    // two rows out per trip (four LDS reads behind one wait, one exit test); extra candidates are true
+    // upper bounds, clamped rows repeat earlier ones: neither can change the minimum
+    for (int r = 1; r <= rmax && (u32)(r * r) < mx; r += 2) {
+      const u32 rr = (u32)(r * r), rr2 = (u32)((r + 1) * (r + 1));
       const uint4 va = tile[max(xi - r, 0) * SEGS + seg];
       const uint4 vb = tile[min(xi + r, xlen - 1) * SEGS + seg];
-      bb.x = min(bb.x, min(va.x, vb.x) + rr);
-      bb.y = min(bb.y, min(va.y, vb.y) + rr);
-      bb.z = min(bb.z, min(va.z, vb.z) + rr);
-      bb.w = min(bb.w, min(va.w, vb.w) + rr);
+      const uint4 vc = tile[max(xi - r - 1, 0) * SEGS + seg];
+      const uint4 vd = tile[min(xi + r + 1, xlen - 1) * SEGS + seg];
+      bb.x = min(bb.x, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
+      bb.y = min(bb.y, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
+      bb.z = min(bb.z, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
+      bb.w = min(bb.w, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
       mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
     }
     float* dst = dist + (long)(b.lo[0] + xi) * g.nyz + coloff;
