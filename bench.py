@@ -234,7 +234,8 @@ def cpu_baseline_stream(map_size, box, frames, ctrl, budget_s=12.0, dt=0.175):
         of.search()
         of.commit()
         times.append(time.perf_counter() - t0)
-        if len(times) >= 4 and time.perf_counter() - t_all > budget_s:
+        # one pass over the distinct frames at most: a frame seen again changes nothing and costs far less
+        if k >= len(frames) or (len(times) >= 4 and time.perf_counter() - t_all > budget_s):
             break
     med = float(np.median(times))
     return {"value": 1.0 / med, "unit": "cycles/s", "cores": 1, "kind": "port",
@@ -272,7 +273,8 @@ def cpu_baseline_stream_reference(map_size, box, frames, ctrl, budget_s=12.0, dt
         rf.search()
         rf.commit()
         times.append(time.perf_counter() - t0)
-        if len(times) >= 4 and time.perf_counter() - t_all > budget_s:
+        # one pass over the distinct frames at most: a frame seen again changes nothing and costs far less
+        if k >= len(frames) or (len(times) >= 4 and time.perf_counter() - t_all > budget_s):
             break
     med = float(np.median(times))
     return {"value": 1.0 / med, "unit": "cycles/s", "cores": 1, "kind": "reference",
@@ -435,7 +437,8 @@ def main():
     if streaming:
         map_size, n_obs, _ = WORKLOADS[args.workload]
         box = exploration_box(map_size)
-        frames = streaming_frames(map_size, n_obs, 24, seed=42 + rank)
+        # distinct frames for every step of the run (warm-up, the two short profiling passes, timed region)
+        frames = streaming_frames(map_size, n_obs, args.warmup + args.steps + 12, seed=42 + rank)
         rng = np.random.default_rng(1000 + 42 + rank)
         ctrl = make_trajectories(rng, args.candidates, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
         occ, n_known = None, 0
