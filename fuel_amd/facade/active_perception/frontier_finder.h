@@ -28,6 +28,7 @@ using std::vector;
 
 namespace fast_planner {
 class EDTEnvironment;
+class PerceptionUtils;  // active_perception/perception_utils.h (the package's own class, not replaced)
 
 // one sampled viewpoint of a frontier cluster: where to hover, where to look, how many of the cluster's
 // down-sampled cells it sees
@@ -80,6 +81,10 @@ public:
                          Eigen::MatrixXd& mat);
   void getPathForTour(const Vector3d& pos, const vector<int>& frontier_ids, vector<Vector3d>& path);
   void setNextFrontier(const int& id);
+
+  // camera model for the callers (field-of-view drawing); the device samples viewpoints with its own copy
+  // of the same perception_utils/* parameters
+  shared_ptr<PerceptionUtils> percep_utils_;
 
   // additions: clusters found by the last searchFrontiers() and the list positions it removed
   const list<Frontier>& newFrontiers() const { return tmp_frontiers_; }

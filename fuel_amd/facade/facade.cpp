@@ -11,6 +11,7 @@
 #include "plan_env/edt_environment.h"
 #include "active_perception/frontier_finder.h"
 #include "active_perception/graph_node.h"
+#include "active_perception/perception_utils.h"
 #include "bspline_opt/bspline_optimizer.h"
 
 namespace fast_planner {
@@ -227,6 +228,7 @@ double EDTEnvironment::evaluateCoarseEDT(Eigen::Vector3d& pos, double) { return 
 // ------------------------------------------------------------------------------------------------
 FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeHandle& nh) : dev_(nullptr), edt_env_(edt) {
   nh.param("frontier/cluster_min", cluster_min_, -1);
+  percep_utils_.reset(new PerceptionUtils(nh));  // for the callers (:44); the device has its own copy of the parameters
   resolution_ = edt_env_->sdf_map_->getResolution();
   double cluster_size_xy = -1.0;
   int down_sample = -1;

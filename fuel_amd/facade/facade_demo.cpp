@@ -14,6 +14,7 @@
 #include <active_perception/frontier_finder.h>
 #include <bspline_opt/bspline_optimizer.h>
 #include <active_perception/graph_node.h>
+#include <active_perception/perception_utils.h>
 
 namespace fast_planner {
 // ViewNode belongs to the part of active_perception the facade does not replace (graph_node.cpp: A*
@@ -24,6 +25,7 @@ double ViewNode::computeCost(const Eigen::Vector3d& p1, const Eigen::Vector3d& p
   path = {p1, p2};
   return (p2 - p1).norm() + 0.1 * std::fabs(y2 - y1);
 }
+PerceptionUtils::PerceptionUtils(ros::NodeHandle&) {}  // (the package's perception_utils.cpp in a FUEL workspace)
 double ViewNode::searchPath(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2, std::vector<Eigen::Vector3d>& path) {
   path = {p1, p2};
   return (p2 - p1).norm();
