@@ -421,3 +421,21 @@ def test_reference_cost_matrix_bookkeeping_equals_pairwise_costs():
     for a, b in zip(tour[:-1], tour[1:]):
         wpath += [tops[a][:3], tops[b][:3]]
     assert np.array_equal(path, np.array(wpath))
+
+
+def test_reference_map_ros_compiles_against_the_facade_header():
+    """The header-level contract of the drop-in: MapROS is a friend of SDFMap and reads / writes
+    md_ and mp_ fields by name (map_ros.cpp:142-170, 250-330).  The reference's own map_ros.cpp, unmodified, must
+    compile against fuel_amd/facade/plan_env/sdf_map.h (syntax check; ROS / OpenCV / PCL / Eigen are the same
+    header stand-ins the reference build uses)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = "/root/reference/fuel_planner/plan_env/src/map_ros.cpp"
+    if not os.path.exists(src):
+        pytest.skip("reference checkout not present")
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-w",
+           "-I", os.path.join(root, "fuel_amd", "facade"), "-I", os.path.join(root, "include"),
+           "-I", os.path.join(root, "oracle", "ref_build", "shim_ros"), "-I", os.path.join(root, "compat"),
+           "-I", "/root/reference/fuel_planner/plan_env/include", src]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
