@@ -14,6 +14,9 @@ struct Time {
   double toSec() const { return t; }
 };
 inline Duration operator-(const Time& a, const Time& b) { return Duration{a.t - b.t}; }
+inline bool operator>(const Time& a, const Time& b) { return a.t > b.t; }
+inline bool operator<(const Time& a, const Time& b) { return a.t < b.t; }
+inline bool ok() { return true; }
 struct TimerEvent { Time current_real, last_real; };
 struct Timer {};
 struct Publisher { template <typename M> void publish(const M&) const {} };

@@ -16,6 +16,10 @@
 
 #include <ros/ros.h>
 
+// struct ViewConstraint comes from the visibility module, as in the reference header (:5); in this
+// repository's own build the stand-in under facade/standin/ supplies it
+#include <active_perception/traj_visibility.h>
+
 #include "fuelmi.h"
 
 using std::shared_ptr;
@@ -24,12 +28,6 @@ using std::vector;
 
 namespace fast_planner {
 class EDTEnvironment;
-
-// view constraint handed over by the visibility module (active_perception/traj_visibility.h:18-24)
-struct ViewConstraint {
-  Eigen::Vector3d pt_, pc_, dir_, pcons_;
-  int idx_;
-};
 
 class BsplineOptimizer {
 public:
