@@ -130,6 +130,8 @@ SYMBOLS = {
     "fuelmi_map_set_updated_box": (C.c_int, [_P, _dp, _dp]),
     "fuelmi_map_upload_occupancy": (C.c_int, [_P, _dp]),
     "fuelmi_map_sync_host": (C.c_int, [_P, _ip, _ip, _dp, C.c_void_p, _dp]),
+    "fuelmi_map_register_mirrors": (C.c_int, [_P, _dp, C.c_void_p, _dp]),
+    "fuelmi_map_unregister_mirrors": (C.c_int, [_P]),
     "fuelmi_map_dist_grad": (C.c_int, [_P, _dp, C.c_int, _dp, _dp]),
     "fuelmi_map_coarse_dist": (C.c_int, [_P, _dp, C.c_int, _dp]),
     "fuelmi_map_query_state": (C.c_int, [_P, _ip, C.c_int, _ip, _ip]),

@@ -238,7 +238,8 @@ static int view_stage(fuelmi_frontier* f, size_t bytes, unsigned char** p) {
 
 extern "C" int fuelmi_frontier_set_viewpoint_cfg(fuelmi_frontier* f, const fuelmi_viewpoint_cfg* c) {
   ARGCHK(f && c);
-  ARGCHK(c->candidate_rnum > 0 && c->candidate_dphi > 0.0 && c->candidate_rmax >= c->candidate_rmin);
+  // rmax == rmin would make the reference's radius loop (:664-665, `rc += dr` with dr = 0) spin forever
+  ARGCHK(c->candidate_rnum > 0 && c->candidate_dphi > 0.0 && c->candidate_rmax > c->candidate_rmin);
   f->vcfg = *c;
   f->have_vcfg = true;
   return FUELMI_OK;

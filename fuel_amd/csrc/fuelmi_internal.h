@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,15 @@ struct fuelmi_map {
   double upd_min[3], upd_max[3];
   bool reset_updated_box = true;
 
+  // host-staged queries and mirror syncs of THIS map share its staging buffers: one lock per map (different
+  // maps -- a fleet in one process -- never wait for each other)
+  std::mutex qmu;
+  // host mirrors registered for zero-copy refreshes (fuelmi_map_register_mirrors): host pointer, its device
+  // alias, byte size; [0] occupancy f64, [1] inflate i8, [2] distance f64
+  struct Mirror {
+    void* host = nullptr;
+    void* dev = nullptr;
+  } mirror[3];
   // staging
   void* d_stage = nullptr;
   size_t d_stage_bytes = 0;

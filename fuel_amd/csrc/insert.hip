@@ -427,6 +427,14 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   long a_lo = (long)lo3[0] * g.nyz + (long)lo3[1] * g.nz + lo3[2];
   long a_hi = (long)hi3[0] * g.nyz + (long)hi3[1] * g.nz + hi3[2];
   int w_lo = (int)(a_lo >> 6), w_hi = (int)(a_hi >> 6);
+  // A camera outside the map (possible through inputPointCloud, which has no isInMap(camera) test): ray cells
+  // whose y / z index leaves the map still pass the reference's linear-address test (setCacheOccupancy,
+  // :243-257) and mark voxels of neighbouring rows -- anywhere in the grid.  They are applied in this frame
+  // like the reference applies them: sweep every word (words without marks cost one 16-byte read).
+  bool cam_in = true;
+  for (int k = 0; k < 3; ++k)
+    if (cam[k] < g.minb[k] + 1e-4 || cam[k] > g.maxb[k] - 1e-4) cam_in = false;
+  if (!cam_in) w_lo = 0, w_hi = g.W - 1;
   k_insert_update<<<(w_hi - w_lo + 256) / 256, 256, 0, m->stream>>>(
       g, m->hit_bits.p, m->miss_bits.p, m->occ, m->occ_bits.p, m->unk_bits.p, w_lo, w_hi, I.prob_hit_log,
       I.prob_miss_log, I.clamp_min_log, I.clamp_max_log, I.min_occupancy_log);

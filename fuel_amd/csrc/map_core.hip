@@ -32,7 +32,6 @@ extern "C" int fuelmi_device_count(void) {
   return n;
 }
 
-static std::mutex g_query_mutex;  // serialises host-staged queries (staging buffers are shared)
 
 // ---------------------------------------------------------------------------------------------
 // profiling scopes
@@ -229,6 +228,27 @@ __global__ void k_expand_dist(const float* __restrict__ dist, long a0, long n, d
   for (; i < n; i += (long)gridDim.x * blockDim.x) out[i] = dist_to_f64(dist[a0 + i], res);
 }
 
+// Mirror refresh of an index box (z fastest: a wave writes whole z-row pieces).  DIRECT: the outputs are the
+// caller's full-size host buffers mapped into the device address space (posted PCIe writes of exactly the box
+// bytes); otherwise compact [x][y][z] staging arrays.
+template <bool DIRECT>
+__global__ void __launch_bounds__(256)
+k_sync_box(Geo g, Box3 b, const double* __restrict__ occ, const u64* __restrict__ infl, const float* __restrict__ dist,
+           double* __restrict__ o_occ, char* __restrict__ o_infl, double* __restrict__ o_dist) {
+  const int zlen = b.hi[2] - b.lo[2] + 1, ylen = b.hi[1] - b.lo[1] + 1, xlen = b.hi[0] - b.lo[0] + 1;
+  const long total = (long)xlen * ylen * zlen;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long line = i / zlen;
+    const int zi = (int)(i - line * zlen);
+    const int xi = (int)(line / ylen), yi = (int)(line - (long)xi * ylen);
+    const long a = (long)(b.lo[0] + xi) * g.nyz + (long)(b.lo[1] + yi) * g.nz + b.lo[2] + zi;
+    const long o = DIRECT ? a : i;
+    if (o_occ) o_occ[o] = occ[a];
+    if (o_infl) o_infl[o] = (char)((infl[a >> 6] >> (a & 63)) & 1ull);
+    if (o_dist) o_dist[o] = dist_to_f64(dist[a], g.res);
+  }
+}
+
 __global__ void k_dist_grad(Geo g, const float* __restrict__ dist, const double* __restrict__ pos, int n,
                             double* __restrict__ out_d, double* __restrict__ out_g) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,6 +366,11 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
   I.clamp_max_log = logit(c->p_max);
   I.min_occupancy_log = logit(c->p_occ);
   I.inflate_step = (int)std::ceil(c->obstacles_inflation / c->resolution);
+  if (I.inflate_step < 0 || I.inflate_step > 31) {  // the z dilation shifts a 64-bit window by up to `step` bits
+    fuelmi_set_error("obstacles_inflation / resolution = %d voxels: the inflation stamp is limited to 31", I.inflate_step);
+    delete m;
+    return FUELMI_ELIMIT;
+  }
   pos_to_index(m, c->box_min, I.box_min);
   pos_to_index(m, c->box_max, I.box_max);
   for (int i = 0; i < 3; ++i) m->local_bound.lo[i] = m->local_bound.hi[i] = 0;
@@ -398,6 +423,8 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  for (auto& r : m->mirror)
+    if (r.host) (void)hipHostUnregister(r.host);
   Plane* planes[] = {&m->occ_bits, &m->unk_bits,  &m->infl_bits, &m->tmp_bits,
                      &m->tmp2_bits, &m->hit_bits, &m->miss_bits};
   for (Plane* p : planes)
@@ -518,7 +545,7 @@ extern "C" int fuelmi_map_set_occupied(fuelmi_map* m, const double* pos, int n, 
   }
   if (n == 0) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lk(g_query_mutex);
+  std::lock_guard<std::mutex> lk(m->qmu);
   size_t bytes = (size_t)n * 3 * sizeof(double);
   int rc = map_ensure_stage(m, bytes, 0);
   if (rc) return rc;
@@ -555,37 +582,114 @@ extern "C" int fuelmi_map_set_updated_box(fuelmi_map* m, const double bmin[3], c
   return FUELMI_OK;
 }
 
+extern "C" int fuelmi_map_register_mirrors(fuelmi_map* m, double* occupancy, char* inflate, double* distance) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(m->qmu);
+  HIPCHK(hipStreamSynchronize(m->stream));
+  void* host[3] = {occupancy, inflate, distance};
+  const size_t bytes[3] = {(size_t)m->g.N * sizeof(double), (size_t)m->g.N, (size_t)m->g.N * sizeof(double)};
+  for (int k = 0; k < 3; ++k) {
+    fuelmi_map::Mirror& r = m->mirror[k];
+    if (r.host && r.host != host[k]) {
+      (void)hipHostUnregister(r.host);
+      r.host = r.dev = nullptr;
+    }
+    if (!host[k] || r.host == host[k]) continue;
+    // pin the caller's buffer where it lies and map it: the refresh kernel then stores straight into it
+    HIPCHK(hipHostRegister(host[k], bytes[k], hipHostRegisterMapped));
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host[k], 0) != hipSuccess) {
+      (void)hipHostUnregister(host[k]);
+      fuelmi_set_error("hipHostGetDevicePointer failed for a mirror buffer");
+      return FUELMI_EHIP;
+    }
+    r.host = host[k];
+    r.dev = d;
+  }
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_map_unregister_mirrors(fuelmi_map* m) {
+  ARGCHK(m);
+  HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(m->qmu);
+  HIPCHK(hipStreamSynchronize(m->stream));
+  for (auto& r : m->mirror) {
+    if (r.host) (void)hipHostUnregister(r.host);
+    r.host = r.dev = nullptr;
+  }
+  return FUELMI_OK;
+}
+
 extern "C" int fuelmi_map_sync_host(fuelmi_map* m, const int bmin[3], const int bmax[3], double* occupancy,
                                     char* inflate, double* distance) {
   ARGCHK(m);
+  if (!occupancy && !inflate && !distance) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
   const Geo& g = m->g;
-  int x0 = 0, x1 = g.nx - 1;
-  if (bmin && bmax) {
-    ARGCHK(bmin[0] >= 0 && bmax[0] < g.nx && bmin[0] <= bmax[0]);
-    x0 = bmin[0], x1 = bmax[0];
+  Box3 b;
+  const int nv[3] = {g.nx, g.ny, g.nz};
+  for (int k = 0; k < 3; ++k) b.lo[k] = 0, b.hi[k] = nv[k] - 1;
+  if (bmin && bmax)
+    for (int k = 0; k < 3; ++k) {
+      ARGCHK(bmin[k] >= 0 && bmax[k] < nv[k] && bmin[k] <= bmax[k]);
+      b.lo[k] = bmin[k], b.hi[k] = bmax[k];
+    }
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
+  const long total = (long)xlen * ylen * zlen;
+  std::lock_guard<std::mutex> lk(m->qmu);
+  // (1) registered mirrors: one kernel stores the box voxels straight into the caller's pinned buffers
+  void* want[3] = {occupancy, inflate, distance};
+  void* dir[3] = {nullptr, nullptr, nullptr};
+  bool any_direct = false, any_staged = false;
+  for (int k = 0; k < 3; ++k) {
+    if (!want[k]) continue;
+    if (m->mirror[k].host == want[k])
+      dir[k] = m->mirror[k].dev, any_direct = true;
+    else
+      any_staged = true;
   }
-  long a0 = (long)x0 * g.nyz, n = (long)(x1 - x0 + 1) * g.nyz;
-  std::lock_guard<std::mutex> lk(g_query_mutex);
-  if (occupancy)
-    HIPCHK(hipMemcpyAsync(occupancy + a0, m->occ + a0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
-                          m->stream));
-  if (inflate || distance) {
-    int rc = map_ensure_stage(m, (size_t)n * sizeof(double), 0);
+  if (any_direct)
+    k_sync_box<true><<<blocks_for(total, 256, 8192), 256, 0, m->stream>>>(
+        g, b, m->occ, m->infl_bits.p, m->dist, (double*)dir[0], (char*)dir[1], (double*)dir[2]);
+  // (2) other buffers (pageable memory): compact box arrays -> pinned staging in ONE copy -> rows scattered
+  // by the host; the PCIe traffic is the box, not the x-slabs around it
+  unsigned char* h = nullptr;
+  size_t off[3] = {0, 0, 0};
+  if (any_staged) {
+    const size_t esz[3] = {sizeof(double), 1, sizeof(double)};
+    size_t bytes = 0;
+    for (int k = 0; k < 3; ++k)
+      if (want[k] && !dir[k]) off[k] = bytes, bytes += (((size_t)total * esz[k]) + 255) & ~(size_t)255;
+    int rc = map_ensure_stage(m, bytes, bytes);
     if (rc) return rc;
-  }
-  if (inflate) {
-    k_expand_bits<<<blocks_for(n, 256, 65536), 256, 0, m->stream>>>(m->infl_bits.p, a0, n, (char*)m->d_stage);
-    HIPCHK(hipMemcpyAsync(inflate + a0, m->d_stage, (size_t)n, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
-  }
-  if (distance) {
-    k_expand_dist<<<blocks_for(n, 256, 65536), 256, 0, m->stream>>>(m->dist, a0, n, g.res, (double*)m->d_stage);
-    HIPCHK(hipMemcpyAsync(distance + a0, m->d_stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
-                          m->stream));
+    unsigned char* d = reinterpret_cast<unsigned char*>(m->d_stage);
+    k_sync_box<false><<<blocks_for(total, 256, 8192), 256, 0, m->stream>>>(
+        g, b, m->occ, m->infl_bits.p, m->dist, (want[0] && !dir[0]) ? (double*)(d + off[0]) : nullptr,
+        (want[1] && !dir[1]) ? (char*)(d + off[1]) : nullptr, (want[2] && !dir[2]) ? (double*)(d + off[2]) : nullptr);
+    HIPCHK(hipMemcpyAsync(m->h_stage, m->d_stage, bytes, hipMemcpyDeviceToHost, m->stream));
+    h = reinterpret_cast<unsigned char*>(m->h_stage);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));  // the only wait
+  if (any_staged) {
+    const bool whole_rows = zlen == g.nz;  // rows of a full-height box are contiguous per x (or altogether)
+    for (int k = 0; k < 3; ++k) {
+      if (!want[k] || dir[k]) continue;
+      const size_t e = k == 1 ? 1 : sizeof(double);
+      unsigned char* dst = reinterpret_cast<unsigned char*>(want[k]);
+      const unsigned char* src = h + off[k];
+      if (whole_rows && ylen == g.ny) {
+        memcpy(dst + (size_t)b.lo[0] * g.nyz * e, src, (size_t)total * e);
+        continue;
+      }
+      for (int xi = 0; xi < xlen; ++xi)
+        for (int yi = 0; yi < ylen; ++yi) {
+          const size_t a = (size_t)(b.lo[0] + xi) * g.nyz + (size_t)(b.lo[1] + yi) * g.nz + b.lo[2];
+          memcpy(dst + a * e, src + ((size_t)xi * ylen + yi) * zlen * e, (size_t)zlen * e);
+        }
+    }
+  }
   return FUELMI_OK;
 }
 
@@ -593,7 +697,7 @@ extern "C" int fuelmi_map_dist_grad(fuelmi_map* m, const double* pos, int n, dou
   ARGCHK(m && n >= 0 && (n == 0 || (pos && dist && grad)));
   if (n == 0) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lk(g_query_mutex);
+  std::lock_guard<std::mutex> lk(m->qmu);
   size_t in_b = (size_t)n * 3 * sizeof(double), out_b = (size_t)n * 4 * sizeof(double);
   int rc = map_ensure_stage(m, in_b + out_b, 0);
   if (rc) return rc;
@@ -613,7 +717,7 @@ extern "C" int fuelmi_map_coarse_dist(fuelmi_map* m, const double* pos, int n, d
   ARGCHK(m && n >= 0 && (n == 0 || (pos && dist)));
   if (n == 0) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lk(g_query_mutex);
+  std::lock_guard<std::mutex> lk(m->qmu);
   size_t in_b = (size_t)n * 3 * sizeof(double);
   int rc = map_ensure_stage(m, in_b + (size_t)n * sizeof(double), 0);
   if (rc) return rc;
@@ -631,7 +735,7 @@ extern "C" int fuelmi_map_query_state(fuelmi_map* m, const int* idx, int n, int*
   ARGCHK(m && n >= 0 && (n == 0 || (idx && occupancy && inflate)));
   if (n == 0) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lk(g_query_mutex);
+  std::lock_guard<std::mutex> lk(m->qmu);
   size_t in_b = (size_t)n * 3 * sizeof(int);
   int rc = map_ensure_stage(m, in_b + (size_t)n * 2 * sizeof(int), 0);
   if (rc) return rc;

@@ -106,6 +106,11 @@ void SDFMap::initMap(ros::NodeHandle& nh) {
     md_->update_min_(i) = md_->update_max_(i) = 0.0;
     md_->local_bound_min_(i) = md_->local_bound_max_(i) = 0;
   }
+  // the mirrors never move again: pin and map them once, every refresh is then one kernel storing the box
+  // voxels straight into them (no staging copy, one synchronisation)
+  warn("fuelmi_map_register_mirrors",
+       fuelmi_map_register_mirrors(dev_, md_->occupancy_buffer_.data(), md_->occupancy_buffer_inflate_.data(),
+                                   md_->distance_buffer_.data()));
 }
 
 void SDFMap::setHostMirror(bool occupancy, bool inflate, bool distance) {
@@ -153,6 +158,16 @@ void SDFMap::clearAndInflateLocalMap() {
   boundIndex(lo);
   boundIndex(hi);
   syncMirrors(lo, hi, false, mirror_infl_, false);
+  // the virtual ceiling (sdf_map.cpp:464-471) rewrites occupancy_buffer_ in one z row over the x,y extent of
+  // the local bound: the callers' inline getOccupancy() must see it right away, as in the reference
+  if (mirror_occ_ && mp_->virtual_ceil_height_ > -0.5) {
+    const int ceil_id = (int)floor((mp_->virtual_ceil_height_ - mp_->map_origin_(2)) * mp_->resolution_inv_);
+    if (ceil_id >= 0 && ceil_id < mp_->map_voxel_num_(2)) {
+      Eigen::Vector3i clo = md_->local_bound_min_, chi = md_->local_bound_max_;
+      clo(2) = chi(2) = ceil_id;
+      syncMirrors(clo, chi, true, false, false);
+    }
+  }
 }
 
 void SDFMap::updateESDF3d() {
@@ -180,13 +195,53 @@ void SDFMap::resetBuffer(const Eigen::Vector3d& min_pos, const Eigen::Vector3d& 
 void SDFMap::setOccupied(const Eigen::Vector3d& pos, const int& occ) {
   if (!isInMap(pos)) return;
   const double p[3] = {pos(0), pos(1), pos(2)};
-  warn("fuelmi_map_set_occupied", fuelmi_map_set_occupied(dev_, p, 1, occ));
+  const int rc = fuelmi_map_set_occupied(dev_, p, 1, occ);
+  warn("fuelmi_map_set_occupied", rc);
+  if (rc != FUELMI_OK) return;  // the device refused the value (only 0 / 1 exist there): the mirror must not diverge
   Eigen::Vector3i id;
   posToIndex(pos, id);
   md_->occupancy_buffer_inflate_[toAddress(id)] = (char)occ;
 }
 
+// Trilinear distance + gradient (sdf_map.cpp:497-536).  The reference's callers ask point by point inside host
+// loops (traj_visibility.cpp:85,114,146, topo_prm.cpp:490): with the distance mirror on, the answer comes from
+// the host copy -- eight loads like the reference, the device's own arithmetic on the same f64 values, hence
+// the same doubles -- instead of a GPU round trip per point.  Batches go to the device (getDistWithGradBatch).
 double SDFMap::getDistWithGrad(const Eigen::Vector3d& pos, Eigen::Vector3d& grad) {
+  if (mirror_dist_) {
+    if (!isInMap(pos)) {
+      grad = Eigen::Vector3d(0, 0, 0);
+      return 0;
+    }
+    Eigen::Vector3i idx;
+    double diff[3];
+    for (int k = 0; k < 3; ++k) {
+      const double pm = pos(k) - 0.5 * mp_->resolution_ * 1.0;
+      idx(k) = (int)floor((pm - mp_->map_origin_(k)) * mp_->resolution_inv_);
+      const double centre = (idx(k) + 0.5) * mp_->resolution_ + mp_->map_origin_(k);
+      diff[k] = (pos(k) - centre) * mp_->resolution_inv_;
+    }
+    double v[2][2][2];
+    for (int x = 0; x < 2; ++x)
+      for (int y = 0; y < 2; ++y)
+        for (int z = 0; z < 2; ++z) v[x][y][z] = getDistance(Eigen::Vector3i(idx(0) + x, idx(1) + y, idx(2) + z));
+    const double ri = mp_->resolution_inv_;
+    const double v00 = (1 - diff[0]) * v[0][0][0] + diff[0] * v[1][0][0];
+    const double v01 = (1 - diff[0]) * v[0][0][1] + diff[0] * v[1][0][1];
+    const double v10 = (1 - diff[0]) * v[0][1][0] + diff[0] * v[1][1][0];
+    const double v11 = (1 - diff[0]) * v[0][1][1] + diff[0] * v[1][1][1];
+    const double v0 = (1 - diff[1]) * v00 + diff[1] * v10;
+    const double v1 = (1 - diff[1]) * v01 + diff[1] * v11;
+    const double dist = (1 - diff[2]) * v0 + diff[2] * v1;
+    grad(2) = (v1 - v0) * ri;
+    grad(1) = ((1 - diff[2]) * (v10 - v00) + diff[2] * (v11 - v01)) * ri;
+    double g0 = (1 - diff[2]) * (1 - diff[1]) * (v[1][0][0] - v[0][0][0]);
+    g0 += (1 - diff[2]) * diff[1] * (v[1][1][0] - v[0][1][0]);
+    g0 += diff[2] * (1 - diff[1]) * (v[1][0][1] - v[0][0][1]);
+    g0 += diff[2] * diff[1] * (v[1][1][1] - v[0][1][1]);
+    grad(0) = g0 * ri;
+    return dist;
+  }
   const double p[3] = {pos(0), pos(1), pos(2)};
   double d = 0.0, g[3] = {0, 0, 0};
   warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(dev_, p, 1, &d, g));
@@ -545,6 +600,14 @@ void BsplineOptimizer::setParam(ros::NodeHandle& nh) {
   nh.param("manager/bspline_degree", bspline_degree_, 3);
   cfg_.bspline_degree = bspline_degree_;
   time_lb_ = -1;
+  static bool told = false;
+  if (!told && (algorithm1_ >= 0 || algorithm2_ >= 0)) {
+    told = true;
+    std::fprintf(stderr,
+                 "[fuelmi] BsplineOptimizer: optimization/algorithm1,2 (NLopt ids %d, %d) and max_iteration_time* are "
+                 "not used -- every solve is one device launch of a box-projected L-BFGS under max_iteration_num*\n",
+                 algorithm1_, algorithm2_);
+  }
 }
 
 void BsplineOptimizer::setEnvironment(const shared_ptr<EDTEnvironment>& env) {

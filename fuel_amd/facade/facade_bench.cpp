@@ -1,0 +1,163 @@
+// facade_bench.cpp -- what a FUEL maintainer gets: the streaming plan cycle timed THROUGH the C++ facade
+// (the reference's class interfaces: MapROS::depthPoseCallback -> inputPointCloud -> clearAndInflateLocalMap,
+// updateESDFCallback -> updateESDF3d, planExploreMotion -> searchFrontiers + computeFrontiersToVisit), with
+// the host mirrors the callers' inline getters read switched on and off, beside the same sequence issued
+// straight at the C-ABI.  Scenario file as facade_demo's: header + point-cloud frames.
+//   facade_bench <scenario.bin> [repeat]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include <plan_env/sdf_map.h>
+#include <plan_env/edt_environment.h>
+#include <active_perception/frontier_finder.h>
+#include <active_perception/graph_node.h>
+#include <active_perception/perception_utils.h>
+
+namespace fast_planner {
+double ViewNode::computeCost(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2, const double& y1, const double& y2,
+                             const Eigen::Vector3d&, const double&, std::vector<Eigen::Vector3d>& path) {
+  path = {p1, p2};
+  return (p2 - p1).norm() + 0.1 * std::fabs(y2 - y1);
+}
+double ViewNode::searchPath(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2, std::vector<Eigen::Vector3d>& path) {
+  path = {p1, p2};
+  return (p2 - p1).norm();
+}
+PerceptionUtils::PerceptionUtils(ros::NodeHandle&) {}
+class MapROS {
+public:
+  static void inflate(SDFMap& m) { m.clearAndInflateLocalMap(); }
+};
+}  // namespace fast_planner
+using namespace fast_planner;
+
+struct Frame {
+  pcl::PointCloud<pcl::PointXYZ> cloud;
+  std::vector<float> xyz;
+  double cam[3];
+};
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+template <typename T>
+static void rd(FILE* f, T* p, size_t n) {
+  if (fread(p, sizeof(T), n, f) != n) {
+    std::fprintf(stderr, "short read\n");
+    std::exit(2);
+  }
+}
+
+static void params(ros::NodeHandle& nh, const double* hdr) {
+  auto& P = nh.num;
+  P["sdf_map/resolution"] = 0.1;
+  P["sdf_map/map_size_x"] = hdr[0], P["sdf_map/map_size_y"] = hdr[1], P["sdf_map/map_size_z"] = hdr[2];
+  P["sdf_map/obstacles_inflation"] = 0.199, P["sdf_map/local_bound_inflate"] = 0.5, P["sdf_map/ground_height"] = -1.0;
+  P["sdf_map/default_dist"] = 0.0, P["sdf_map/optimistic"] = 0, P["sdf_map/signed_dist"] = 0;
+  P["sdf_map/p_hit"] = 0.65, P["sdf_map/p_miss"] = 0.35, P["sdf_map/p_min"] = 0.12, P["sdf_map/p_max"] = 0.90;
+  P["sdf_map/p_occ"] = 0.80, P["sdf_map/max_ray_length"] = 4.5, P["sdf_map/virtual_ceil_height"] = -10;
+  const char* ax[3] = {"x", "y", "z"};
+  for (int i = 0; i < 3; ++i) {
+    P[std::string("sdf_map/box_min_") + ax[i]] = hdr[3 + i];
+    P[std::string("sdf_map/box_max_") + ax[i]] = hdr[6 + i];
+  }
+  P["frontier/cluster_min"] = hdr[9];
+}
+
+// one pass over the frames through the facade; returns seconds per cycle
+static double run_facade(const double* hdr, const std::vector<Frame>& frames, bool mirrors, int* n_clusters) {
+  ros::NodeHandle nh;
+  params(nh, hdr);
+  SDFMap::Ptr map(new SDFMap);
+  map->initMap(nh);
+  map->setHostMirror(mirrors, mirrors, mirrors);
+  EDTEnvironment::Ptr edt(new EDTEnvironment);
+  edt->setMap(map);
+  FrontierFinder ff(edt, nh);
+  fuelmi_map_synchronize(map->device());
+  const double t0 = now_s();
+  for (const Frame& f : frames) {
+    map->inputPointCloud(f.cloud, (int)f.cloud.points.size(), Eigen::Vector3d(f.cam[0], f.cam[1], f.cam[2]));
+    MapROS::inflate(*map);
+    map->updateESDF3d();
+    ff.searchFrontiers();
+    ff.computeFrontiersToVisit();
+  }
+  fuelmi_map_synchronize(map->device());
+  const double dt = now_s() - t0;
+  std::vector<std::vector<Eigen::Vector3d>> cl;
+  ff.getFrontiers(cl);
+  *n_clusters = (int)cl.size();
+  return dt / (double)frames.size();
+}
+
+// the same sequence at the C-ABI (no host lists, no mirrors)
+static double run_cabi(const double* hdr, const std::vector<Frame>& frames, int* n_clusters) {
+  fuelmi_map_cfg c;
+  c.resolution = 0.1;
+  for (int i = 0; i < 3; ++i) c.map_size[i] = hdr[i], c.box_min[i] = hdr[3 + i], c.box_max[i] = hdr[6 + i];
+  c.obstacles_inflation = 0.199, c.local_bound_inflate = 0.5, c.ground_height = -1.0, c.default_dist = 0.0;
+  c.optimistic = 0, c.signed_dist = 0;
+  c.p_hit = 0.65, c.p_miss = 0.35, c.p_min = 0.12, c.p_max = 0.90, c.p_occ = 0.80;
+  c.max_ray_length = 4.5, c.virtual_ceil_height = -10, c.device = 0;
+  fuelmi_map* m = nullptr;
+  if (fuelmi_map_create(&c, &m) != FUELMI_OK) return -1.0;
+  fuelmi_frontier_cfg fc;
+  fc.cluster_min = (int)hdr[9], fc.min_z = 0.4, fc.cluster_size_xy = -1.0, fc.down_sample = -1, fc.split = 0;
+  fuelmi_frontier* f = nullptr;
+  if (fuelmi_frontier_create(m, &fc, &f) != FUELMI_OK) return -1.0;
+  fuelmi_map_synchronize(m);
+  const double t0 = now_s();
+  for (const Frame& fr : frames) {
+    fuelmi_map_input_points(m, fr.xyz.data(), 12, (int)(fr.xyz.size() / 3), fr.cam);
+    fuelmi_frontier_search_begin(f);
+    fuelmi_map_inflate_local(m);
+    fuelmi_map_update_esdf(m);
+    int n_new = 0;
+    fuelmi_frontier_search_end(f, &n_new);
+    fuelmi_frontier_commit(f, 0);
+  }
+  fuelmi_map_synchronize(m);
+  const double dt = now_s() - t0;
+  *n_clusters = fuelmi_frontier_count(f, 1);
+  fuelmi_frontier_destroy(f);
+  fuelmi_map_destroy(m);
+  return dt / (double)frames.size();
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 1;
+  FILE* in = fopen(argv[1], "rb");
+  if (!in) return 1;
+  const int repeat = argc > 2 ? std::atoi(argv[2]) : 3;
+  double hdr[10];
+  rd(in, hdr, 10);
+  int n_frames;
+  rd(in, &n_frames, 1);
+  std::vector<Frame> frames(n_frames);
+  for (Frame& f : frames) {
+    int n;
+    rd(in, &n, 1);
+    rd(in, f.cam, 3);
+    f.xyz.resize((size_t)n * 3);
+    rd(in, f.xyz.data(), f.xyz.size());
+    f.cloud.points.resize(n);
+    for (int i = 0; i < n; ++i) f.cloud.points[i] = pcl::PointXYZ(f.xyz[3 * i], f.xyz[3 * i + 1], f.xyz[3 * i + 2]);
+  }
+  fclose(in);
+  double best[3] = {1e30, 1e30, 1e30};
+  int ncl[3] = {0, 0, 0};
+  for (int r = 0; r < repeat; ++r) {  // fresh map every pass: the same frames, the same work
+    best[0] = std::min(best[0], run_facade(hdr, frames, true, &ncl[0]));
+    best[1] = std::min(best[1], run_facade(hdr, frames, false, &ncl[1]));
+    best[2] = std::min(best[2], run_cabi(hdr, frames, &ncl[2]));
+  }
+  std::printf("{\"workload\": \"streaming cycle: %d point-cloud frames on a %.0fx%.0fx%.0f m map (fusion, local inflation, "
+              "local ESDF, incremental frontier search, commit)\", \"facade_mirrors_on_ms\": %.4f, "
+              "\"facade_mirrors_off_ms\": %.4f, \"c_abi_ms\": %.4f, \"mirrors_on_over_off\": %.3f, "
+              "\"clusters\": [%d, %d, %d]}\n",
+              n_frames, hdr[0], hdr[1], hdr[2], 1e3 * best[0], 1e3 * best[1], 1e3 * best[2], best[0] / best[1], ncl[0],
+              ncl[1], ncl[2]);
+  return 0;
+}

@@ -126,10 +126,17 @@ int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ);
 /* Host mirrors for the reference's inline getters (sdf_map.h:196-237 read host vectors
  * directly).  Each non-NULL pointer is a full-size host buffer laid out like the reference's
  * (occupancy_buffer_ double[N], occupancy_buffer_inflate_ char[N], distance_buffer_ double[N]);
- * the voxels inside [bmin,bmax] (inclusive indices; NULL = whole map) are refreshed from the
- * device.  Bytes outside the box may also be refreshed (contiguous slab copies). */
+ * exactly the voxels inside [bmin,bmax] (inclusive indices; NULL = whole map) are refreshed from
+ * the device, with one stream synchronisation per call. */
 int fuelmi_map_sync_host(fuelmi_map* m, const int bmin[3], const int bmax[3], double* occupancy,
                          char* inflate, double* distance);
+/* Optional, once per mirror buffer: pins the caller's full-size buffers where they lie (any may be NULL)
+ * and maps them into the device address space.  fuelmi_map_sync_host calls naming a registered buffer
+ * then store the box voxels straight into it -- one kernel, box-limited PCIe traffic, one
+ * synchronisation -- instead of staging them.  The buffers must outlive the registration
+ * (fuelmi_map_unregister_mirrors / fuelmi_map_destroy end it). */
+int fuelmi_map_register_mirrors(fuelmi_map* m, double* occupancy, char* inflate, double* distance);
+int fuelmi_map_unregister_mirrors(fuelmi_map* m);
 
 /* SDFMap::getDistWithGrad (sdf_map.cpp:497-536) == EDTEnvironment::evaluateEDTWithGrad
  * (plan_env/src/edt_environment.cpp:78-87) for n host positions; re-entrant w.r.t. queries */

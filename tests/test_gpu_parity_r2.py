@@ -1,0 +1,232 @@
+"""Round-2 parity cases through the C-ABI against the oracle: the virtual ceiling of clearAndInflateLocalMap,
+fusion from a camera outside the map (wrapped miss addresses), the optimistic ESDF at BASELINE's full
+400x400x100 size and on a sparse map (long outward scans)."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import fuel_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+ESDF_TOL = 1e-4
+BIG = 1e6
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import fuel_amd
+    assert fuel_amd.lib().fuelmi_device_count() > 0, "no GPU visible: the HIP path cannot run"
+    return fuel_amd
+
+
+def assert_map_equal(om, gm, box_idx=None, esdf=True):
+    h = gm.syncHost(occupancy=True, inflate=True, distance=esdf)
+    assert np.array_equal(h["occupancy"], om.occ), "occupancy log-odds not bit-exact"
+    assert np.array_equal(h["inflate"], om.infl), "inflated occupancy not bit-exact"
+    if esdf:
+        d_o = np.clip(om.dist, -BIG, BIG).reshape(om.nvox)
+        d_g = np.clip(h["distance"], -BIG, BIG).reshape(om.nvox)
+        if box_idx is not None:
+            sl = tuple(slice(box_idx[0][i], box_idx[1][i] + 1) for i in range(3))
+            d_o, d_g = d_o[sl], d_g[sl]
+        assert np.abs(d_o - d_g).max() <= ESDF_TOL
+    return h
+
+
+@pytest.mark.parametrize("ceil_h", [1.5, 1.55, 2.95])
+def test_virtual_ceiling(fa, ceil_h):
+    """sdf_map.cpp:464-471 (3.2 m in kino_algorithm.xml:75 / topo_algorithm.xml:70): the ceiling row is written
+    over the x,y extent of the local bound after the stamps; the next call inflates it; fusion keeps touching it;
+    the frontier scan sees it as occupied.  Pinned against the real sdf_map.cpp on the CPU
+    (test_oracle_vs_reference_cpu.py::test_virtual_ceiling_matches_reference)."""
+    map_size = (10.0, 8.0, 4.0)
+    box = ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    om = fo.OracleMap(map_size, *box, virtual_ceil_height=ceil_h)
+    gm = fa.SDFMap(map_size, *box, virtual_ceil_height=ceil_h)
+    truth = om.fixture_world(3, 14)
+    of = fo.OracleFrontier(om, 10)
+    gf = fa.FrontierFinder(gm, cluster_min=10)
+    for k in range(12):
+        pose = om.fixture_camera(truth, 5, k, 12, 0.9)
+        pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+        om.input_points(pts, pose[:3])
+        gm.inputPointCloud(pts, pose[:3])
+        om.inflate_local()
+        gm.clearAndInflateLocalMap()
+        if k % 3 == 2:
+            om.update_esdf()
+            gm.updateESDF3d()
+            assert_map_equal(om, gm, om.get_local_bound())
+            assert of.search() == gf.searchFrontiers()
+            for a, b in zip(of.clusters(0), gf.clusters(0)):
+                assert np.array_equal(np.sort(a), b)
+            assert np.array_equal(of.flags, gf.flags())
+            of.commit()
+            gf.commit()
+    ceil_id = int(np.floor((ceil_h - om.origin[2]) * (1.0 / om.res)))
+    assert (om.occ.reshape(om.nvox)[:, :, ceil_id] == om.l_max).sum() > 500
+    # local bounds whose z range ends at the ceiling row, below it, above it: the row is written all the same
+    occ = om.occ.copy()
+    for zhi in (ceil_id, ceil_id - 3, om.nvox[2] - 1):
+        occ.reshape(om.nvox)[20:40, 10:30, ceil_id] = om.l_min
+        om.occ[:] = occ
+        gm.uploadOccupancy(occ)
+        lo, hi = (15, 5, 2), (45, 35, zhi)
+        om.set_local_bound(lo, hi)
+        gm.setLocalBound(lo, hi)
+        om.inflate_local()
+        gm.clearAndInflateLocalMap()
+        om.update_esdf()
+        gm.updateESDF3d()
+        assert_map_equal(om, gm, (lo, hi))
+        occ = om.occ.copy()
+        # the occupancy STATE planes follow the ceiling too (the frontier scan and the queries read them)
+        idx = np.stack(np.meshgrid(np.arange(18, 42), np.arange(8, 32), [ceil_id - 1, ceil_id, ceil_id + 1],
+                                   indexing="ij"), -1).reshape(-1, 3)
+        st_o = np.array([om.L.fo_map_get_occupancy_idx(om.h, (fo.C.c_int * 3)(*map(int, i))) for i in idx])
+        assert np.array_equal(st_o, gm.getOccupancy(idx)[0])
+    gm.close()
+
+
+def test_ceiling_above_or_below_the_map_is_ignored(fa):
+    """a ceiling row outside [0, nz) would index another z-line in the reference (undefined behaviour when it
+    leaves the array); the device leaves the map untouched"""
+    for h in (7.0, -0.4):
+        gm = fa.SDFMap((4.0, 3.0, 2.0), virtual_ceil_height=h)
+        before = gm.syncHost(occupancy=True)["occupancy"].copy()
+        gm.setLocalBound((0, 0, 0), (39, 29, 19))
+        gm.clearAndInflateLocalMap()
+        assert np.array_equal(gm.syncHost(occupancy=True)["occupancy"], before)
+        gm.close()
+
+
+def test_fusion_with_the_camera_outside_the_map(fa):
+    """inputPointCloud has no isInMap(camera) test (sdf_map.cpp:259-345; cloudPoseCallback feeds it directly): rays
+    start at in-map end points and walk towards a camera above / beside the map; RayCaster cells whose y or z
+    index leaves the map still address voxels of neighbouring rows (setCacheOccupancy tests only the linear
+    address), so misses land at WRAPPED addresses.  They must be applied in the same frame as the reference
+    applies them (they used to fall outside the update window)."""
+    map_size = (6.0, 5.0, 3.0)
+    om = fo.OracleMap(map_size)
+    gm = fa.SDFMap(map_size)
+    rng = np.random.default_rng(4)
+    cams = [(0.3, 0.2, 3.5), (0.0, 3.4, 0.5), (-3.8, 0.1, 0.7), (1.0, -1.0, -1.6), (0.5, 0.5, 1.0), (2.0, 4.0, 3.0)]
+    for k, cam in enumerate(cams * 3):
+        cam = np.array(cam) + rng.normal(scale=0.05, size=3)
+        pts = (rng.random((600, 3)) * (np.array(map_size) - 0.4) + om.origin + 0.2).astype(np.float32)
+        far = (cam + rng.normal(scale=3.0, size=(60, 3))).astype(np.float32)  # some end points outside too
+        pts = np.vstack([pts, far])
+        om.input_points(pts, cam)
+        gm.inputPointCloud(pts, cam)
+        assert om.get_local_bound() == gm.getLocalBound(), k
+        h = gm.syncHost(occupancy=True)
+        assert np.array_equal(h["occupancy"], om.occ), "frame %d (camera %s)" % (k, cam)
+    gm.close()
+
+
+@pytest.mark.parametrize("signed", [0, 1])
+def test_full_size_g400_optimistic_esdf(fa, signed):
+    """updateESDF3d with optimistic = true (topo_algorithm.xml:71-72: only inflated voxels are sources) on the
+    400x400x100 grid, full box: distances are 10-100x those of the headline configuration, the outward scans
+    run long.  Against the oracle (<= 1e-4 m) plus exact-integer squared distances and zero on sources."""
+    from fuel_amd import synth
+    map_size = (40.0, 40.0, 10.0)
+    w = synth.World.for_map_size(map_size)
+    truth = w.world(42, 400)
+    occ, _ = w.known_state(truth, 42, 120)
+    org = (-20.0, -20.0, -1.0)
+    box = ((org[0] + 1, org[1] + 1, 0.0), (19.0, 19.0, 7.0))
+    om = fo.OracleMap(map_size, *box, optimistic=1, signed_dist=signed)
+    om.occ[:] = occ
+    gm = fa.SDFMap(map_size, *box, optimistic=1, signed_dist=signed)
+    gm.uploadOccupancy(occ)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    h = gm.syncHost(inflate=True, distance=True)
+    assert np.array_equal(h["inflate"], om.infl)
+    d_o = np.clip(om.dist, -BIG, BIG)
+    d_g = np.clip(h["distance"], -BIG, BIG)
+    assert np.abs(d_o - d_g).max() <= ESDF_TOL
+    if not signed:
+        assert np.all(d_g[om.infl == 1] == 0.0)
+        sq = (d_g / om.res) ** 2
+        assert np.abs(sq - np.rint(sq)).max() < 2e-2  # squared voxel distances are integers (f32 store)
+    gm.close()
+
+
+def test_sparse_map_long_scans(fa):
+    """optimistic ESDF on a mostly free map with a handful of obstacle voxels and NO floor: z-lines and whole
+    x-slabs without a source (INF through the passes), distances of hundreds of voxels; plus the all-free box
+    (no source at all: the reference's res*sqrt(DBL_MAX) everywhere)."""
+    map_size = (30.0, 26.0, 6.0)
+    om = fo.OracleMap(map_size, optimistic=1)
+    gm = fa.SDFMap(map_size, optimistic=1)
+    nv = om.nvox
+    rng = np.random.default_rng(12)
+    occ = np.full(om.N, om.l_min)  # known free
+    for _ in range(40):
+        i = rng.integers([3, 3, 3], np.array(nv) - 3)
+        occ.reshape(nv)[i[0], i[1], i[2]] = om.l_max
+    occ.reshape(nv)[200:203, 50:180, 30:34] = om.l_max  # one wall
+    om.occ[:] = occ
+    gm.uploadOccupancy(occ)
+    for lo, hi in [helpers.full_box(nv), ((10, 10, 5), (150, 120, 50)), ((220, 0, 0), (299, 259, 59))]:
+        om.set_local_bound(lo, hi)
+        gm.setLocalBound(lo, hi)
+        om.inflate_local()
+        om.update_esdf()
+        gm.clearAndInflateLocalMap()
+        gm.updateESDF3d()
+        assert_map_equal(om, gm, (lo, hi))
+    gm.close()
+
+
+def test_sync_host_is_box_limited_and_registered_mirrors_match(fa):
+    """fuelmi_map_sync_host refreshes exactly the box (bytes outside keep what the caller had), through the
+    staged path (pageable buffers) and through registered mirrors (the kernel stores straight into the caller's
+    pinned buffers); both give the same bytes."""
+    import ctypes as C
+    from fuel_amd._lib import check
+    om, _, _, box = helpers.explored_oracle_map((8.0, 6.0, 4.0), 12, 20)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    full = gm.syncHost(occupancy=True, inflate=True, distance=True)
+    N = om.N
+    dp = C.POINTER(C.c_double)
+    for blo, bhi in [((10, 5, 3), (60, 40, 30)), ((0, 0, 0), (79, 0, 39)), ((33, 17, 9), (33, 17, 9)),
+                     ((5, 0, 0), (20, 59, 39))]:
+        sl = tuple(slice(blo[i], bhi[i] + 1) for i in range(3))
+        results = []
+        for registered in (False, True):
+            o = np.full(N, -7.0)
+            i8 = np.full(N, 9, dtype=np.int8)
+            d = np.full(N, -5.0)
+            if registered:
+                check(gm.L.fuelmi_map_register_mirrors(gm.h, o.ctypes.data_as(dp), i8.ctypes.data, d.ctypes.data_as(dp)))
+            check(gm.L.fuelmi_map_sync_host(gm.h, (C.c_int * 3)(*blo), (C.c_int * 3)(*bhi), o.ctypes.data_as(dp),
+                                            i8.ctypes.data, d.ctypes.data_as(dp)))
+            if registered:
+                check(gm.L.fuelmi_map_unregister_mirrors(gm.h))
+            for got, ref_, fill in ((o, full["occupancy"], -7.0), (i8, full["inflate"], 9), (d, full["distance"], -5.0)):
+                g3, r3 = got.reshape(om.nvox), ref_.reshape(om.nvox)
+                assert np.array_equal(g3[sl], r3[sl])
+                outside = np.ones(om.nvox, dtype=bool)
+                outside[sl] = False
+                assert np.all(g3[outside] == fill), "bytes outside the box were touched"
+            results.append((o, i8, d))
+        for a, b in zip(*results):
+            assert np.array_equal(a, b)
+    gm.close()

@@ -82,6 +82,40 @@ def test_full_box_and_map_face_wrap():
     assert np.array_equal(om.infl, rm.infl) and np.array_equal(om.dist, rm.dist)
 
 
+@pytest.mark.parametrize("ceil_h", [1.5, 1.55, 2.95])
+def test_virtual_ceiling_matches_reference(ceil_h):
+    """clearAndInflateLocalMap's virtual ceiling (sdf_map.cpp:464-471; enabled at 3.2 m by kino_algorithm.xml:75 /
+    topo_algorithm.xml:70): occupancy_buffer_[x, y, ceil_id] = clamp_max_log over the x,y extent of the local
+    bound -- whatever the bound's z range -- AFTER the stamps, so the ceiling row is inflated only by the NEXT
+    call.  Fusion keeps updating the ceiling voxels in between (misses pull them down again)."""
+    box = ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2))
+    om, rm = twin((10.0, 8.0, 4.0), box, virtual_ceil_height=ceil_h)
+    truth = om.fixture_world(3, 14)
+    for k in range(12):
+        pose = om.fixture_camera(truth, 5, k, 12, 0.9)
+        pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+        for m in (om, rm):
+            m.input_points(pts, pose[:3])
+            m.inflate_local()
+            if k % 3 == 2:
+                m.update_esdf()
+        assert np.array_equal(om.occ, rm.occ), k
+        assert np.array_equal(om.infl, rm.infl), k
+        assert np.array_equal(om.dist, rm.dist), k
+    ceil_id = int(np.floor((ceil_h - om.origin[2]) * (1.0 / om.res)))
+    row = om.occ.reshape(om.nvox)[:, :, ceil_id]
+    assert (row == om.l_max).sum() > 500  # the ceiling is really there
+    # bounds whose z range ends AT the ceiling row, below it and above it: the row is written all the same
+    for zhi in (ceil_id, ceil_id - 3, om.nvox[2] - 1):
+        for m in (om, rm):
+            m.occ.reshape(m.nvox)[20:40, 10:30, ceil_id] = om.l_min  # knock a hole, let the next call close it
+            m.set_local_bound((15, 5, 2), (45, 35, zhi))
+            m.inflate_local()
+            m.update_esdf()
+        assert np.array_equal(om.occ, rm.occ) and np.array_equal(om.infl, rm.infl) and np.array_equal(om.dist, rm.dist)
+        assert np.all(om.occ.reshape(om.nvox)[20:40, 10:30, ceil_id] == om.l_max)
+
+
 def test_raycaster_cells_identical():
     om, rm = twin((8.0, 6.0, 4.0), ((-3, -2, 0), (3, 2, 2)))
     rng = np.random.default_rng(3)
