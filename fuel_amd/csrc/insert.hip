@@ -265,7 +265,8 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     if (!first) {  // the first reported cell (the end voxel itself) is discarded (:314)
       long av = (long)ix * g.nyz + (long)iy * g.nz + iz;
       bool send = av >= 0 && av < g.N && ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz;
-      const bool raw = av >= 0 && av < g.N;  // what the reference's bounds test lets through (wrapped rows included)
+      const bool raw = av >= 0 && av < g.N;  // a cell outside the index box still addresses a voxel (aliased rows);
+                                              // outside [0, N) the reference is undefined behaviour: dropped
       const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
       if (send && (ux | uy) < (u32)CUBE_XY && uz < 32u) {
         atomicOr(&s_seen[ux * CUBE_XY + uy], 1u << uz);  // flushed as whole words when the block is done
@@ -428,9 +429,10 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   long a_hi = (long)hi3[0] * g.nyz + (long)hi3[1] * g.nz + hi3[2];
   int w_lo = (int)(a_lo >> 6), w_hi = (int)(a_hi >> 6);
   // A camera outside the map (possible through inputPointCloud, which has no isInMap(camera) test): ray cells
-  // whose y / z index leaves the map still pass the reference's linear-address test (setCacheOccupancy,
-  // :243-257) and mark voxels of neighbouring rows -- anywhere in the grid.  They are applied in this frame
-  // like the reference applies them: sweep every word (words without marks cost one 16-byte read).
+  // whose y / z index leaves the map alias voxels of neighbouring rows (setCacheOccupancy, :243-257, indexes
+  // with the linear address and has no bounds test; addresses outside [0, N) are undefined behaviour there and
+  // dropped here) -- anywhere in the grid.  They are applied in this frame like the reference applies them:
+  // sweep every word (words without marks cost one 16-byte read).
   bool cam_in = true;
   for (int k = 0; k < 3; ++k)
     if (cam[k] < g.minb[k] + 1e-4 || cam[k] > g.maxb[k] - 1e-4) cam_in = false;

@@ -151,10 +151,17 @@ void SDFMap::inputPointCloud(const pcl::PointCloud<pcl::PointXYZ>& points, const
 
 void SDFMap::clearAndInflateLocalMap() {
   warn("fuelmi_map_inflate_local", fuelmi_map_inflate_local(dev_));
-  // stamps spill up to inflate_step voxels outside the box
+  // stamps spill up to inflate_step voxels outside the box; a stamp that leaves the map in z lands in the
+  // neighbouring y row at the other end of z, one that leaves it in y in the neighbouring x slab (the
+  // reference only tests the linear address, sdf_map.cpp:453-458): widen the refreshed box accordingly
   Eigen::Vector3i lo = md_->local_bound_min_, hi = md_->local_bound_max_;
   const int s = (int)std::ceil(mp_->obstacles_inflation_ / mp_->resolution_);
   for (int k = 0; k < 3; ++k) lo(k) -= s, hi(k) += s;
+  for (int k = 2; k >= 1; --k)
+    if (lo(k) < 0 || hi(k) > mp_->map_voxel_num_(k) - 1) {
+      lo(k) = 0, hi(k) = mp_->map_voxel_num_(k) - 1;
+      lo(k - 1) -= 1, hi(k - 1) += 1;
+    }
   boundIndex(lo);
   boundIndex(hi);
   syncMirrors(lo, hi, false, mirror_infl_, false);

@@ -92,8 +92,8 @@ def test_virtual_ceiling(fa, ceil_h):
 def test_ceiling_above_or_below_the_map_is_ignored(fa):
     """a ceiling row outside [0, nz) would index another z-line in the reference (undefined behaviour when it
     leaves the array); the device leaves the map untouched"""
-    for h in (7.0, -0.4):
-        gm = fa.SDFMap((4.0, 3.0, 2.0), virtual_ceil_height=h)
+    for h, ground in ((7.0, -1.0), (-0.3, 0.0)):  # ceil_id = 80 >= nz, ceil_id = -3
+        gm = fa.SDFMap((4.0, 3.0, 2.0), virtual_ceil_height=h, ground_height=ground)
         before = gm.syncHost(occupancy=True)["occupancy"].copy()
         gm.setLocalBound((0, 0, 0), (39, 29, 19))
         gm.clearAndInflateLocalMap()
@@ -101,22 +101,35 @@ def test_ceiling_above_or_below_the_map_is_ignored(fa):
         gm.close()
 
 
+def outside_camera_frames(origin, map_size, n_rounds=3, seed=4):
+    """camera beyond the +z / +y faces of the map, end points inside it and within max_ray_length: every ray
+    cell has a linear address in [0, N) (cells past a +y / +z face alias voxels of the next row / slab), which is
+    the part of this situation the reference defines -- setCacheOccupancy (sdf_map.cpp:243-257) has NO bounds
+    test, a cell past a -x/+x face or behind the last row is undefined behaviour there."""
+    rng = np.random.default_rng(seed)
+    cams = [(0.3, 0.2, 2.3), (0.0, 2.8, 0.5), (0.5, 0.5, 1.0), (-1.2, 2.7, 2.2)]
+    lo = origin + 0.15
+    hi = origin + np.array(map_size) - 0.15
+    lo[0] += 1.0
+    hi[0] -= 1.0
+    for cam in cams * n_rounds:
+        cam = np.array(cam) + rng.normal(scale=0.03, size=3)
+        d = rng.normal(size=(900, 3))
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        pts = cam + d * rng.uniform(0.5, 4.3, size=(900, 1))
+        yield pts[np.all((pts > lo) & (pts < hi), axis=1)].astype(np.float32), cam
+
+
 def test_fusion_with_the_camera_outside_the_map(fa):
-    """inputPointCloud has no isInMap(camera) test (sdf_map.cpp:259-345; cloudPoseCallback feeds it directly): rays
-    start at in-map end points and walk towards a camera above / beside the map; RayCaster cells whose y or z
-    index leaves the map still address voxels of neighbouring rows (setCacheOccupancy tests only the linear
-    address), so misses land at WRAPPED addresses.  They must be applied in the same frame as the reference
-    applies them (they used to fall outside the update window)."""
+    """inputPointCloud has no isInMap(camera) test (cloudPoseCallback feeds it directly): rays start at in-map end
+    points and walk towards a camera above / beside the map, marking misses at ALIASED addresses outside the
+    index box of camera and end points.  They must be applied in the same frame (they used to fall
+    outside the update window and surface frames later).  Pinned against the real sdf_map.cpp on the CPU
+    (test_oracle_vs_reference_cpu.py::test_fusion_from_outside_the_map_matches_reference)."""
     map_size = (6.0, 5.0, 3.0)
     om = fo.OracleMap(map_size)
     gm = fa.SDFMap(map_size)
-    rng = np.random.default_rng(4)
-    cams = [(0.3, 0.2, 3.5), (0.0, 3.4, 0.5), (-3.8, 0.1, 0.7), (1.0, -1.0, -1.6), (0.5, 0.5, 1.0), (2.0, 4.0, 3.0)]
-    for k, cam in enumerate(cams * 3):
-        cam = np.array(cam) + rng.normal(scale=0.05, size=3)
-        pts = (rng.random((600, 3)) * (np.array(map_size) - 0.4) + om.origin + 0.2).astype(np.float32)
-        far = (cam + rng.normal(scale=3.0, size=(60, 3))).astype(np.float32)  # some end points outside too
-        pts = np.vstack([pts, far])
+    for k, (pts, cam) in enumerate(outside_camera_frames(om.origin, map_size)):
         om.input_points(pts, cam)
         gm.inputPointCloud(pts, cam)
         assert om.get_local_bound() == gm.getLocalBound(), k

@@ -116,6 +116,21 @@ def test_virtual_ceiling_matches_reference(ceil_h):
         assert np.all(om.occ.reshape(om.nvox)[20:40, 10:30, ceil_id] == om.l_max)
 
 
+def test_fusion_from_outside_the_map_matches_reference():
+    """camera beyond the +z / +y faces, end points inside the map: ray cells past a face alias voxels of the next
+    row / slab (setCacheOccupancy has no bounds test at all, sdf_map.cpp:243-257); oracle == reference on the
+    part of that situation where every address stays in [0, N) (anything else is undefined behaviour there)."""
+    from test_gpu_parity_r2 import outside_camera_frames
+    map_size = (6.0, 5.0, 3.0)
+    om, rm = twin(map_size, (None, None))
+    for k, (pts, cam) in enumerate(outside_camera_frames(om.origin, map_size)):
+        om.input_points(pts, cam)
+        rm.input_points(pts, cam)
+        assert om.get_local_bound() == rm.get_local_bound()
+        assert np.array_equal(om.occ, rm.occ), k
+    assert (om.occ != om.occ.min()).sum() > 10000
+
+
 def test_raycaster_cells_identical():
     om, rm = twin((8.0, 6.0, 4.0), ((-3, -2, 0), (3, 2, 2)))
     rng = np.random.default_rng(3)
