@@ -71,7 +71,7 @@ class MapInfo(C.Structure):
 
 class FrontierCfg(C.Structure):
     _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double), ("cluster_size_xy", C.c_double),
-                ("down_sample", C.c_int), ("split", C.c_int)]
+                ("down_sample", C.c_int), ("split", C.c_int), ("reference_order", C.c_int)]
 
 
 class ViewpointCfg(C.Structure):

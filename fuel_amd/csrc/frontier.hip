@@ -224,19 +224,6 @@ __global__ void __launch_bounds__(256) k_pred(Geo g, FArgs F) {
 }
 __global__ void __launch_bounds__(1024) k_scan_sums(FArgs F) { scan_sums_tail(F); }
 
-__device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
-  int w = (int)(a >> 6);
-  int rel = w - F.var->w0;
-  u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
-  return (u32)pk + (u32)__popcll(F.qb[w] & ((1ull << (a & 63)) - 1ull));
-}
-__device__ __forceinline__ u32 rank_s(const FArgs& F, long a) {
-  int w = (int)(a >> 6);
-  int rel = w - F.var->w0;
-  u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
-  return (u32)(pk >> 32) + (u32)__popcll(F.sb[w] & ((1ull << (a & 63)) - 1ull));
-}
-
 // ordered compaction of Q0 cells and NQ seeds
 __global__ void __launch_bounds__(256) k_compact(Geo g, FArgs F) {
   if ((int)blockIdx.x >= F.var->nblocks) return;
@@ -1122,6 +1109,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->pool) (void)hipFree(f->pool);
   if (f->h_changed) (void)hipHostFree(f->h_changed);
   frontier_split_free(f);
+  frontier_order_free(f);
   for (hipGraphExec_t e : f->graph_exec)
     if (e) (void)hipGraphExecDestroy(e);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
@@ -1639,12 +1627,27 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   u32 ncl = nkept, ncells = n_out;
   std::vector<std::vector<float>> filtered;
   const bool split_mode = f->cfg.split != 0;
-  if (split_mode) {  // splitLargeFrontiers (:120) on the device; the pinned buffers then hold the pieces
-    int rc = frontier_split_run(f, nq, nkept, n_out, nkept <= 256 ? 1 : 0, &ncl, &ncells, &filtered);
+  const bool ref_order = f->cfg.reference_order != 0;
+  int fin = nkept <= 256 ? 1 : 0;  // buffer pair holding the grouped cells of the search
+  std::vector<u32> off2;
+  u32 n_in = n_out;
+  if (ref_order) {  // cells of every cluster in expandFrontier's order (an NQ seed first), into the other pair
+    int rc = frontier_reference_order(f, nq, nkept, n_out, fin, &n_in, &off2);
     if (rc) return rc;
+    fin = 1 - fin;
+    ncells = n_in;
   }
-  f->last_fin = ncl <= 256 ? 1 : 0;  // buffer holding the grouped cells the lazy clusters point into
-  const u32 nchunk = (ncells + SZ_CH - 1) / SZ_CH;
+  if (split_mode) {  // splitLargeFrontiers (:120) on the device; the pinned buffers then hold the pieces
+    int rc = frontier_split_run(f, nq, nkept, n_in, fin, &ncl, &ncells, &filtered);
+    if (rc) return rc;
+    fin = ncl <= 256 ? 1 : 0;  // where the regrouping of the pieces ended
+  } else if (ref_order) {
+    HIPCHK(hipMemcpyAsync(F.h_cells, F.ms_val[fin], (size_t)n_in * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+  }
+  f->last_fin = fin;  // buffer holding the grouped cells the lazy clusters point into
+  const u32 nchunk = (ref_order && !split_mode) ? 0u : (ncells + SZ_CH - 1) / SZ_CH;  // (records of the grouped
+                                                                                       // array, not of the ordered one)
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
     const u32 r = rec[0];
@@ -1666,12 +1669,16 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     const u32 cnt = kr.size - (seed ? 1u : 0u);
     c.lazy = reinterpret_cast<const int*>(h_cells) + kr.off;
     c.lazy_n = cnt;
+    if (ref_order && !split_mode) {  // ordered list: the seed (if any) is already its first cell
+      c.lazy = reinterpret_cast<const int*>(h_cells) + off2[r];
+      c.lazy_n = kr.size;
+    }
     unsigned long long sum[3] = {kr.sum[0], kr.sum[1], kr.sum[2]};
     u32 lo[3] = {kr.box[0], kr.box[1], kr.box[2]};
     u32 hi[3] = {kr.box[3], kr.box[4], kr.box[5]};
     if (split_mode) {
       // an NQ seed travels as the LAST cell of its piece (already in the sums): restore address order
-      if (cnt > 1 && c.lazy[cnt - 1] < c.lazy[cnt - 2]) {
+      if (!ref_order && cnt > 1 && c.lazy[cnt - 1] < c.lazy[cnt - 2]) {
         c.lazy_seed = c.lazy[cnt - 1];
         c.lazy_n = cnt - 1;
       }
@@ -1679,7 +1686,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     }
     if (seed) {
       const int a = (int)kr.addr;
-      c.lazy_seed = a;
+      if (!ref_order) c.lazy_seed = a;
       const u32 x = (u32)a / (u32)g.nyz, rr = (u32)a - x * (u32)g.nyz, y = rr / (u32)g.nz, z = rr - y * (u32)g.nz;
       const u32 id[3] = {x, y, z};
       for (int q = 0; q < 3; ++q) {
@@ -1694,6 +1701,29 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       c.avg[q] = ((double)sum[q] / nn + 0.5) * g.res + g.org[q];
       c.bmin[q] = ((int)lo[q] + 0.5) * g.res + g.org[q];
       c.bmax[q] = ((int)hi[q] + 0.5) * g.res + g.org[q];
+    }
+    if (ref_order) {
+      // the reference's own evaluation: cell centres added one by one in list order, then divided; the box
+      // from the same centres (identical to the index form above)
+      double sm[3] = {0.0, 0.0, 0.0};
+      u32 blo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bhi[3] = {0u, 0u, 0u};
+      const int* cl = c.lazy;
+      const u32 ncell = c.lazy_n;
+      for (u32 i = 0; i < ncell; ++i) {
+        const u32 a = (u32)cl[i];
+        const u32 x = a / (u32)g.nyz, rr = a - x * (u32)g.nyz, y = rr / (u32)g.nz, z = rr - y * (u32)g.nz;
+        const u32 id[3] = {x, y, z};
+        for (int q = 0; q < 3; ++q) {
+          sm[q] += ((double)id[q] + 0.5) * g.res + g.org[q];
+          blo[q] = std::min(blo[q], id[q]);
+          bhi[q] = std::max(bhi[q], id[q]);
+        }
+      }
+      for (int q = 0; q < 3; ++q) {
+        c.avg[q] = sm[q] / (double)ncell;
+        c.bmin[q] = ((int)blo[q] + 0.5) * g.res + g.org[q];
+        c.bmax[q] = ((int)bhi[q] + 0.5) * g.res + g.org[q];
+      }
     }
   }
   *n_new = (int)f->tmp.size();

@@ -74,6 +74,22 @@ struct FArgs {
   int keys_from_slots;    // multisplit pass 0 derives (key, value) from cell_slot / slot2rank / cell_adr
 };
 
+#ifdef __HIPCC__
+// compact index of the Q0 cell / NQ seed at voxel address a (valid after k_pred + k_scan_sums of this search)
+__device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
+  int w = (int)(a >> 6);
+  int rel = w - F.var->w0;
+  u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
+  return (u32)pk + (u32)__popcll(F.qb[w] & ((1ull << (a & 63)) - 1ull));
+}
+__device__ __forceinline__ u32 rank_s(const FArgs& F, long a) {
+  int w = (int)(a >> 6);
+  int rel = w - F.var->w0;
+  u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
+  return (u32)(pk >> 32) + (u32)__popcll(F.sb[w] & ((1ull << (a & 63)) - 1ull));
+}
+#endif
+
 #define MS_CH 2048  // cells per multisplit block (256 threads x 8)
 #define NOKEY 0xFFFFFFFFu
 
@@ -166,8 +182,16 @@ struct fuelmi_frontier {
   size_t pool_cap = 0, pool_used = 0;
   int last_fin = 1;     // which multisplit buffer holds the grouped cells of the last search
   struct SplitScratch* split = nullptr;  // device buffers of the split stage (frontier_split.hip)
+  struct OrderScratch* order = nullptr;  // device buffers of the reference-order stage (frontier_order.hip)
 };
 void frontier_split_free(fuelmi_frontier* f);
+void frontier_order_free(fuelmi_frontier* f);
+// cfg.reference_order: the cells of every kept cluster of this search in the order FrontierFinder::expandFrontier
+// discovers them (frontier_finder.cpp:123-164), an NQ seed first.  in: the grouped result of the search
+// (F.ms_val[fin] / F.ms_key[fin], records F.h_rec).  out: F.ms_val[1 - fin] / F.ms_key[1 - fin] hold *n_total =
+// n_out + (clusters started by an NQ seed) cells, cluster r at h_off2[r] .. h_off2[r + 1] (host vector).
+int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin, u32* n_total,
+                             std::vector<u32>* h_off2);
 // tmp cluster -> committed: materialises the host list and copies the cells into the device pool
 struct PoolPut {  // one cluster's copy into the cell pool
   u64 dst;

@@ -83,6 +83,11 @@ struct SArgs {
   u32 cap_filt;
   double size_xy;
   float inv_leaf;
+  // cfg.reference_order: cells arrive in the reference's BFS order; node means are the reference's sequential
+  // f64 sums (computed by the host between levels, nmean[2 * node + {0, 1}]); leaf members are kept by their
+  // position in `cells` so that the float centroid accumulates in that order
+  int ref;
+  const double* nmean;
 };
 
 __device__ __forceinline__ void decode(const Geo& g, u32 a, u32& x, u32& y, u32& z) {
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(256) k_sp_leaf(Geo g, SArgs S, u32 level) {
     }
     const u32 arr = atomicAdd(&S.hvals[h].cnt, 1u);
     if (arr < S.memb_cap)
-      S.hmemb[(size_t)h * S.memb_cap + arr] = S.cells[i];
+      S.hmemb[(size_t)h * S.memb_cap + arr] = S.ref ? i : S.cells[i];
     else
       S.ctr[3] = 1u;
   }
@@ -245,7 +250,7 @@ __global__ void __launch_bounds__(256) k_sp_centroid(Geo g, SArgs S) {
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (u32 i = 0; i < n; ++i) {
       u32 x, y, z;
-      decode(g, mb[i], x, y, z);
+      decode(g, S.ref ? S.cells[mb[i]] : mb[i], x, y, z);
       sx += (float)(((double)x + 0.5) * g.res + g.org[0]);
       sy += (float)(((double)y + 0.5) * g.res + g.org[1]);
       sz += (float)(((double)z + 0.5) * g.res + g.org[2]);
@@ -260,7 +265,12 @@ __global__ void __launch_bounds__(256) k_sp_centroid(Geo g, SArgs S) {
 __device__ __forceinline__ void centroid_of(const Geo&, const LeafAcc& a, float c[3]) {
   c[0] = a.c[0], c[1] = a.c[1], c[2] = a.c[2];
 }
-__device__ __forceinline__ void node_mean_xy(const Geo& g, const SNode& N, double m[2]) {
+__device__ __forceinline__ void node_mean_xy(const Geo& g, const SArgs& S, u32 nd, const SNode& N, double m[2]) {
+  if (S.ref) {
+    m[0] = S.nmean[2 * (size_t)nd];
+    m[1] = S.nmean[2 * (size_t)nd + 1];
+    return;
+  }
   const double n = (double)N.n;
   m[0] = ((double)N.sx / n + 0.5) * g.res + g.org[0];
   m[1] = ((double)N.sy / n + 0.5) * g.res + g.org[1];
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(256) k_sp_stats(Geo g, SArgs S) {
         float c[3];
         centroid_of(g, S.hvals[h], c);
         double m[2];
-        node_mean_xy(g, S.nodes[nd], m);
+        node_mean_xy(g, S, nd, S.nodes[nd], m);
         dx = (double)c[0] - m[0];
         dy = (double)c[1] - m[1];
         far = sqrt(dx * dx + dy * dy) > S.size_xy ? 1u : 0u;
@@ -448,7 +458,7 @@ __global__ void __launch_bounds__(256) k_sp_part(Geo g, SArgs S, u32 level) {
     u32 x, y, z;
     decode(g, S.cells[i], x, y, z);
     double m[2];
-    node_mean_xy(g, N, m);
+    node_mean_xy(g, S, nd, N, m);
     const double px = ((double)x + 0.5) * g.res + g.org[0], py = ((double)y + 0.5) * g.res + g.org[1];
     const double dot = (px - m[0]) * N.pc[0] + (py - m[1]) * N.pc[1];
     S.node[i] = N.child0 + (dot >= 0 ? 0u : 1u);
@@ -529,12 +539,13 @@ struct SplitScratch {
   u64* f_leaf = nullptr;
   float* f_xyz = nullptr;
   u32* h_ctr = nullptr;  // pinned [16]
+  double* nmean = nullptr;  // [cap_nodes][2] (reference order)
 };
 
 void frontier_split_free(fuelmi_frontier* f) {
   SplitScratch* s = f->split;
   if (!s) return;
-  void* dev[] = {s->cells, s->node,  s->ctr,    s->seeds,  s->counts, s->nodes,
+  void* dev[] = {s->cells, s->node,  s->ctr,    s->seeds,  s->counts, s->nodes,  s->nmean,
                  s->hkeys, s->hvals, s->hmemb, s->used,   s->f_node, s->f_leaf, s->f_xyz};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -556,6 +567,7 @@ static int split_ensure(fuelmi_frontier* f, u32 n) {
   if (!s->ctr) {
     s->cap_nodes = 2u * f->F.cap_kept;
     if ((rc = sp_alloc(&s->ctr, 16)) || (rc = sp_alloc(&s->counts, 16)) || (rc = sp_alloc(&s->nodes, s->cap_nodes)) ||
+        (rc = sp_alloc(&s->nmean, 2 * (size_t)s->cap_nodes)) ||
         (rc = sp_alloc(&s->seeds, 2 * (size_t)f->F.cap_kept)))
       return rc;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), 64, hipHostMallocDefault));
@@ -605,9 +617,11 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
     fuelmi_set_error("frontier split: too many clusters (%u)", nkept);
     return FUELMI_ELIMIT;
   }
-  // NQ seeds that started a kept cluster are not in the grouped Q0 array: append them
+  // NQ seeds that started a kept cluster are not in the grouped Q0 array: append them (in reference order
+  // they already lead their cluster in the input)
+  const bool ref = f->cfg.reference_order != 0;
   std::vector<u32> seeds;
-  for (u32 r = 0; r < nkept; ++r)
+  for (u32 r = 0; r < nkept && !ref; ++r)
     if (F.h_rec[r].slot >= nq) {
       seeds.push_back(F.h_rec[r].addr);
       seeds.push_back(r);
@@ -634,6 +648,49 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   S.size_xy = f->cfg.cluster_size_xy;
   const float leaf = (float)(g.res * (double)f->cfg.down_sample);  // setLeafSize(float...)
   S.inv_leaf = 1.0f / leaf;
+  S.ref = ref ? 1 : 0;
+  S.nmean = s->nmean;
+  // reference order: host copies of the cells (once) and of their node labels (every level) for the
+  // sequential means; the nodes evaluated at one level are a contiguous id range (children are allocated in
+  // pairs from one counter)
+  std::vector<u32> h_cells_ord, h_node;
+  std::vector<double> h_mean;
+  u32 lvl_lo = 0u, lvl_hi = nkept;
+  if (ref) {
+    h_cells_ord.resize(n);
+    h_node.resize(n);
+    HIPCHK(hipMemcpyAsync(h_cells_ord.data(), F.ms_val[fin], (size_t)n * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_node.data(), F.ms_key[fin], (size_t)n * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  // average_ of every node in [lo, hi) as computeFrontierInfo sums it (:374-390): cell centres added one by one
+  // in list order, then divided by the count
+  auto seq_means = [&](u32 lo, u32 hi) -> int {
+    const u32 cnt = hi - lo;
+    if (cnt == 0u) return FUELMI_OK;
+    std::vector<double> sum(3 * (size_t)cnt, 0.0);
+    std::vector<u32> num(cnt, 0u);
+    for (u32 i = 0; i < n; ++i) {
+      const u32 nd = h_node[i];
+      if (nd < lo || nd >= hi) continue;
+      const u32 a = h_cells_ord[i];
+      const u32 x = a / (u32)g.nyz, rr = a - x * (u32)g.nyz, y = rr / (u32)g.nz, z = rr - y * (u32)g.nz;
+      double* sm = &sum[3 * (size_t)(nd - lo)];
+      sm[0] += ((double)x + 0.5) * g.res + g.org[0];
+      sm[1] += ((double)y + 0.5) * g.res + g.org[1];
+      sm[2] += ((double)z + 0.5) * g.res + g.org[2];
+      ++num[nd - lo];
+    }
+    h_mean.resize(2 * (size_t)cnt);
+    for (u32 k = 0; k < cnt; ++k) {
+      const double dn = (double)num[k];
+      h_mean[2 * (size_t)k] = num[k] ? sum[3 * (size_t)k] / dn : 0.0;
+      h_mean[2 * (size_t)k + 1] = num[k] ? sum[3 * (size_t)k + 1] / dn : 0.0;
+    }
+    HIPCHK(hipMemcpyAsync(s->nmean + 2 * (size_t)lo, h_mean.data(), 2 * (size_t)cnt * sizeof(double),
+                          hipMemcpyHostToDevice, st));
+    return FUELMI_OK;
+  };
 
   const int gb = (int)std::min<u32>(2048u, (n + 255u) / 256u);
   const int gb4 = (int)std::min<u32>(2048u, (n + 1023u) / 1024u);
@@ -643,6 +700,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   u32 n_nodes = nkept;
   k_sp_clear<<<gt, 256, 0, st>>>(S.hkeys, S.hvals, t);
   for (u32 level = 0; level < 40u; ++level) {
+    if (ref && (rc = seq_means(lvl_lo, lvl_hi))) return rc;
     k_sp_sums<<<gb4, 256, 0, st>>>(g, S, level);
     k_sp_leaf<<<gb, 256, 0, st>>>(g, S, level);
     k_sp_centroid<<<256, 256, 0, st>>>(g, S);
@@ -651,15 +709,18 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
     k_sp_emit<<<256, 256, 0, st>>>(g, S, level);
     k_sp_part<<<gb, 256, 0, st>>>(g, S, level);
     HIPCHK(hipMemcpyAsync(s->h_ctr, s->ctr, 16 * sizeof(u32), hipMemcpyDeviceToHost, st));
+    if (ref) HIPCHK(hipMemcpyAsync(h_node.data(), S.node, (size_t)n * sizeof(u32), hipMemcpyDeviceToHost, st));
     k_sp_clear_used<<<256, 256, 0, st>>>(S);
     k_sp_next_level<<<1, 64, 0, st>>>(S);
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st));  // (h_mean's upload has completed as well: the vector is reused)
     if (s->h_ctr[3]) {
       fuelmi_set_error("frontier split capacity exceeded (nodes %u/%u, filtered %u/%u)", s->h_ctr[0], s->cap_nodes,
                        s->h_ctr[2], s->cap_filt);
       return FUELMI_ELIMIT;
     }
+    lvl_lo = n_nodes;  // the children created at this level are evaluated at the next
     n_nodes = s->h_ctr[0];
+    lvl_hi = n_nodes;
     if (s->h_ctr[1] == 0u) break;
   }
   const u32 nfinal = s->h_ctr[4], nfilt = s->h_ctr[2];

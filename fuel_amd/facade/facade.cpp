@@ -304,6 +304,11 @@ FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeH
   // searchFrontiers ends with splitLargeFrontiers (:120); without its two parameters the search stops
   // at the region-grown clusters
   c.split = (cluster_size_xy > 0.0 && down_sample > 0) ? 1 : 0;
+  // addition: frontier/reference_order = 1 lists cells_ in the reference's BFS order and sums average_ /
+  // the VoxelGrid centroids in that order (bit-identical means, filtered_cells_ and viewpoints; slower)
+  int ref_order = 0;
+  nh.param("frontier/reference_order", ref_order, 0);
+  c.reference_order = ref_order;
   warn("fuelmi_frontier_create", fuelmi_frontier_create(edt_env_->sdf_map_->device(), &c, &dev_));
   // viewpoint sampling parameters (frontier_finder.cpp:32-43, perception_utils.cpp:7-11)
   fuelmi_viewpoint_cfg v;

@@ -104,7 +104,7 @@ static double run_cabi(const double* hdr, const std::vector<Frame>& frames, int*
   fuelmi_map* m = nullptr;
   if (fuelmi_map_create(&c, &m) != FUELMI_OK) return -1.0;
   fuelmi_frontier_cfg fc;
-  fc.cluster_min = (int)hdr[9], fc.min_z = 0.4, fc.cluster_size_xy = -1.0, fc.down_sample = -1, fc.split = 0;
+  fc.cluster_min = (int)hdr[9], fc.min_z = 0.4, fc.cluster_size_xy = -1.0, fc.down_sample = -1, fc.split = 0, fc.reference_order = 0;
   fuelmi_frontier* f = nullptr;
   if (fuelmi_frontier_create(m, &fc, &f) != FUELMI_OK) return -1.0;
   fuelmi_map_synchronize(m);

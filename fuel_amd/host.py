@@ -249,12 +249,15 @@ class EDTEnvironment:
 class FrontierFinder:
     """Grid part of fast_planner::FrontierFinder (searchFrontiers / expandFrontier)."""
 
-    def __init__(self, edt_or_map, cluster_min=100, min_z=0.4, cluster_size_xy=2.0, down_sample=3, split=False):
+    def __init__(self, edt_or_map, cluster_min=100, min_z=0.4, cluster_size_xy=2.0, down_sample=3, split=False,
+                 reference_order=False):
         """split=True: searchFrontiers ends with splitLargeFrontiers (frontier_finder.cpp:120,166-242) and
-        every new cluster carries its down-sampled filtered_cells_."""
+        every new cluster carries its down-sampled filtered_cells_.  reference_order=True: cells in the
+        reference's BFS order, means / VoxelGrid centroids summed in that order (bit-exact against the reference;
+        default: ascending voxel address, order-free means)."""
         self.L = lib()
         self.map = edt_or_map.sdf_map_ if isinstance(edt_or_map, EDTEnvironment) else edt_or_map
-        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split))
+        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split), int(reference_order))
         h = C.c_void_p()
         check(self.L.fuelmi_frontier_create(self.map.h, C.byref(cfg), C.byref(h)))
         self.h = h

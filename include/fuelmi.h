@@ -161,6 +161,13 @@ typedef struct {
   int down_sample;        /* frontier/down_sample (3): VoxelGrid leaf = down_sample * resolution */
   int split;              /* 0: search stops before splitLargeFrontiers; 1: it runs, and every new cluster
                              carries its filtered_cells_ */
+  int reference_order;    /* 0 (default): a cluster lists its cells in ascending voxel address and its mean is
+                             evaluated order-free (exact integer sums) -- the fast path.  1: the reference's own
+                             order -- cells in the BFS order of expandFrontier (frontier_finder.cpp:123-164,
+                             neighbour order :848-860), average_ as its sequential f64 sum (:374-390), VoxelGrid
+                             centroids accumulated in that order (:757-774) -- so that means, filtered_cells_,
+                             split pieces and viewpoints reproduce the reference bit for bit; costs one BFS
+                             level sweep per cluster on the device and host-side means */
 } fuelmi_frontier_cfg;
 
 typedef struct fuelmi_frontier fuelmi_frontier;

@@ -682,6 +682,7 @@ struct fo_frontier {
   int down_sample = 3;
   int split = 0;
   int canonical_order = 0;
+  int flip_pc = 0;
   fo_viewpoint_cfg vp{};
   // PerceptionUtils state (perception_utils.cpp:6-19 constructor, :49-69 setPose)
   V3d pu_pos;
@@ -898,6 +899,7 @@ struct fo_frontier {
     c00 /= nf, c01 /= nf, c10 /= nf, c11 /= nf;
     double pc[2];
     principal_dir(c00, c01, c10, c11, pc);
+    if (flip_pc) pc[0] = -pc[0], pc[1] = -pc[1];
     Cluster f1, f2;
     for (auto& cell : ftr.cells) {
       if ((cell[0] - mean[0]) * pc[0] + (cell[1] - mean[1]) * pc[1] >= 0)
@@ -1062,6 +1064,7 @@ fo_frontier* fo_frontier_create(fo_map* m, const fo_frontier_cfg* cfg) {
   f->down_sample = cfg->down_sample;  // <= 0: filtered_cells_ not computed (F1-F4 contract only)
   f->split = cfg->split;
   f->canonical_order = cfg->canonical_order;
+  f->flip_pc = cfg->flip_principal_dir;
   f->flag.assign((size_t)m->total(), 0);
   return f;
 }

@@ -110,6 +110,9 @@ typedef struct {
                               address (the order libfuelmi lists cells in), and cluster means are
                               evaluated order-free from exact integer index sums -- changes only the float
                               summation order inside a leaf and the last bits (~1e-13) of the means */
+  int flip_principal_dir;  /* test knob: negate splitHorizontally's first principal direction (the SIGN Eigen's
+                              EigenSolver would return is not reproduced by the stand-in; flipping it must only
+                              permute the pieces) */
 } fo_frontier_cfg;
 typedef struct fo_frontier fo_frontier;
 

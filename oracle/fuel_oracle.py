@@ -38,7 +38,8 @@ class MapCfg(C.Structure):
 
 class FrontierCfg(C.Structure):
     _fields_ = [("cluster_min", C.c_int), ("min_z", C.c_double), ("cluster_size_xy", C.c_double),
-                ("down_sample", C.c_int), ("split", C.c_int), ("canonical_order", C.c_int)]
+                ("down_sample", C.c_int), ("split", C.c_int), ("canonical_order", C.c_int),
+                ("flip_principal_dir", C.c_int)]
 
 
 class BsplineCfg(C.Structure):
@@ -332,7 +333,7 @@ class OracleMap:
 
 class OracleFrontier:
     def __init__(self, omap, cluster_min=100, min_z=0.4, cluster_size_xy=2.0, down_sample=0, split=False,
-                 canonical_order=False):
+                 canonical_order=False, flip_principal_dir=False):
         """down_sample=3 fills filtered_cells_; split=True runs splitLargeFrontiers (needs down_sample);
         canonical_order=True feeds the VoxelGrid the cells in ascending voxel address instead of BFS order
         (libfuelmi's cell order: only the float summation order inside a leaf changes)."""
@@ -340,7 +341,8 @@ class OracleFrontier:
         self.map = omap
         if split and down_sample <= 0:
             down_sample = 3
-        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split), int(canonical_order))
+        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split), int(canonical_order),
+                          int(flip_principal_dir))
         self.h = self.L.fo_frontier_create(omap.h, C.byref(cfg))
         self.flags = np.ctypeslib.as_array(
             C.cast(self.L.fo_frontier_flags(self.h), C.POINTER(C.c_int8)), shape=(omap.N,))

@@ -33,6 +33,39 @@ cpu_ms = (time.perf_counter() - t0) * 1e3
 out["frontier_search_with_split"] = {"gpu_ms": gpu_ms, "cpu_oracle_ms": cpu_ms, "pieces_gpu": n, "pieces_cpu": n_o,
                                      "cells": int(sum(len(c) for c in gf.clusters(0)))}
 
+# the same search in reference_order (cells in expandFrontier's BFS order, sequential means, in-order VoxelGrid
+# sums: bit-exact against the reference) -- what the mode costs; checked against the literal oracle
+gfr = fuel_amd.FrontierFinder(gm, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True, reference_order=True)
+tr = []
+for it in range(6):
+    gfr.reset()
+    gm.setUpdatedBox(box[0], box[1])
+    t0 = time.perf_counter()
+    nr = gfr.searchFrontiers()
+    tr.append(time.perf_counter() - t0)
+ofl = fo.OracleFrontier(om, cluster_min=100, cluster_size_xy=2.0, down_sample=3, split=True)
+om.set_updated_box(box[0], box[1])
+t0 = time.perf_counter()
+n_l = ofl.search()
+cpu_l_ms = (time.perf_counter() - t0) * 1e3
+same = n_l == nr and all(np.array_equal(a, b) for a, b in zip(ofl.clusters(0), gfr.clusters(0))) and \
+    all(np.array_equal(ofl.cluster_info(0, k)[0], gfr.clusterInfo(0, k)[0]) for k in range(nr))
+gfu = fuel_amd.FrontierFinder(gm, cluster_min=100, reference_order=True)  # without splitting
+tu = []
+for it in range(6):
+    gfu.reset()
+    gm.setUpdatedBox(box[0], box[1])
+    t0 = time.perf_counter()
+    nu = gfu.searchFrontiers()
+    tu.append(time.perf_counter() - t0)
+out["frontier_search_reference_order"] = {"gpu_ms_with_split": float(np.median(tr[1:]) * 1e3),
+                                          "gpu_ms_without_split": float(np.median(tu[1:]) * 1e3),
+                                          "gpu_ms_default_order_with_split": gpu_ms, "cpu_oracle_literal_ms": cpu_l_ms,
+                                          "pieces": int(nr), "clusters_unsplit": int(nu),
+                                          "bit_exact_vs_literal_oracle": bool(same)}
+gfr.close()
+gfu.close()
+
 # ---- rank 1: viewpoint sampling for every piece (computeFrontiersToVisit) -----------------------------
 gm.setLocalBound((0, 0, 0), tuple(v - 1 for v in gm.nvox))
 gm.clearAndInflateLocalMap()

@@ -121,6 +121,19 @@ def run(backend, frames, ctrl):
     out["viewpoint_counts"] = np.array([len(ff.viewpoints(1, k)[1]) for k in range(len(ff.clusters(1)))], np.int32)
     out["best_visib"] = np.array([ff.viewpoints(1, k)[1][0] for k in range(len(ff.clusters(1)))], np.int32)
     out["best_viewpoint"] = np.array([ff.viewpoints(1, k)[0][0] for k in range(len(ff.clusters(1)))])
+    # the complete answer of the reference for the active clusters, in ITS order: cells (BFS order), average_,
+    # filtered_cells_, every viewpoint (position, yaw, visib_num_) -- what fuelmi_frontier_cfg.reference_order
+    # reproduces bit for bit
+    act = ff.clusters(1)
+    out["active_offsets"] = np.cumsum([0] + [len(c) for c in act]).astype(np.int32)
+    out["active_cells_bfs"] = np.concatenate(act).astype(np.int32)
+    out["active_average"] = np.array([ff.cluster_info(1, k)[0] for k in range(len(act))])
+    filt = [ff.filtered(1, k).astype(np.float32) for k in range(len(act))]
+    out["filtered_offsets"] = np.cumsum([0] + [len(c) for c in filt]).astype(np.int32)
+    out["filtered_cells"] = np.concatenate(filt)
+    vps = [ff.viewpoints(1, k) for k in range(len(act))]
+    out["viewpoint_pos_yaw"] = np.concatenate([v[0] for v in vps])
+    out["viewpoint_visib"] = np.concatenate([v[1] for v in vps]).astype(np.int32)
     dt = 0.25
     st = np.zeros((3, 3))
     en = np.zeros((3, 3))

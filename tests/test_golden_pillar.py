@@ -60,21 +60,38 @@ def test_device_reproduces_the_reference_fixture():
     assert sha(h["occupancy"]) == str(z["occupancy_sha256"])  # f64 log-odds, bit for bit
     assert sha(h["inflate"]) == str(z["inflate_sha256"])
     assert np.abs(np.minimum(h["distance"].reshape(-1)[::97], 1e6) - z["distance_sample"]).max() <= 1e-4
-    ff = fa.FrontierFinder(gm, cluster_min=mk.CLUSTER_MIN, cluster_size_xy=mk.CLUSTER_XY, down_sample=3, split=True)
+    # default mode (cells in ascending address): the reference's pieces in its order, as cell sets
+    ff0 = fa.FrontierFinder(gm, cluster_min=mk.CLUSTER_MIN, cluster_size_xy=mk.CLUSTER_XY, down_sample=3, split=True)
+    assert ff0.searchFrontiers() == int(z["n_clusters"])
+    off = z["cluster_offsets"]
+    for k, c in enumerate(ff0.clusters(0)):
+        assert np.array_equal(c, z["cluster_cells"][off[k]:off[k + 1]])
+    ff0.close()
+    gm.setUpdatedBox(z["updated_box"][:3], z["updated_box"][3:])
+    # reference_order: everything the real frontier_finder.cpp produced, bit for bit -- cells in BFS order,
+    # average_, filtered_cells_, every viewpoint's position and visib_num_ (integers that rank the viewpoints
+    # and pick the tour target); yaws to 1e-9 rad (device libm vs glibc)
+    ff = fa.FrontierFinder(gm, cluster_min=mk.CLUSTER_MIN, cluster_size_xy=mk.CLUSTER_XY, down_sample=3, split=True,
+                           reference_order=True)
     ff.setViewpointConfig(ff.viewpointConfig())
     assert ff.searchFrontiers() == int(z["n_clusters"])
-    off = z["cluster_offsets"]
-    for k, c in enumerate(ff.clusters(0)):  # the reference's pieces, in its order (cells as sorted addresses)
-        assert np.array_equal(c, z["cluster_cells"][off[k]:off[k + 1]])
+    for k, c in enumerate(ff.clusters(0)):
+        assert np.array_equal(np.sort(c), z["cluster_cells"][off[k]:off[k + 1]])
     na, nd = ff.computeFrontiersToVisit()
     assert (na, nd) == (int(z["n_active"]), int(z["n_dormant"]))
-    # viewpoints: the reference feeds PCL its cells in BFS order, the device in address order -- the last
-    # float bit of a leaf centroid can move a ray's start voxel, so coverage counts may differ
-    # by a cell or two; the best viewpoint of every cluster is the same sample position
-    cnt = np.array([len(ff.viewpoints(1, k)[1]) for k in range(na)])
-    assert np.abs(cnt - z["viewpoint_counts"]).max() <= 2
-    best = np.array([ff.viewpoints(1, k)[1][0] for k in range(na)])
-    assert np.abs(best - z["best_visib"]).max() <= 3
+    ao, fo_, vo = z["active_offsets"], z["filtered_offsets"], np.cumsum(np.r_[0, z["viewpoint_counts"]])
+    act = ff.clusters(1)
+    for k in range(na):
+        assert np.array_equal(act[k], z["active_cells_bfs"][ao[k]:ao[k + 1]]), "cells_ order of cluster %d" % k
+        assert np.array_equal(ff.clusterInfo(1, k)[0], z["active_average"][k]), "average_ of cluster %d" % k
+        assert np.array_equal(ff.filtered(1, k), z["filtered_cells"][fo_[k]:fo_[k + 1]]), "filtered_cells_ %d" % k
+        py, vis = ff.viewpoints(1, k)
+        want = z["viewpoint_pos_yaw"][vo[k]:vo[k + 1]]
+        assert len(vis) == int(z["viewpoint_counts"][k])
+        assert np.array_equal(vis, z["viewpoint_visib"][vo[k]:vo[k + 1]]), "visib_num_ of cluster %d" % k
+        assert np.array_equal(py[:, :3], want[:, :3]), "viewpoint positions of cluster %d" % k
+        dyaw = np.abs(py[:, 3] - want[:, 3])
+        assert np.minimum(dyaw, 2 * np.pi - dyaw).max() <= 1e-9
     dt = 0.25
     st = np.zeros((1, 3, 3))
     en = np.zeros((1, 3, 3))

@@ -243,3 +243,148 @@ def test_sync_host_is_box_limited_and_registered_mirrors_match(fa):
         for a, b in zip(*results):
             assert np.array_equal(a, b)
     gm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# reference_order: the reference's own cell order (BFS), sequential means, in-order VoxelGrid sums --
+# against the LITERAL oracle (canonical_order = False), which is the mode pinned to the real reference
+# ------------------------------------------------------------------------------------------------
+def _assert_exact_clusters(of, gf, which=0, filtered=False):
+    ca, cb = of.clusters(which), gf.clusters(which)
+    assert len(ca) == len(cb)
+    for k in range(len(ca)):
+        assert np.array_equal(ca[k], cb[k]), "cluster %d: cells differ or are in a different order" % k
+        for x, y in zip(of.cluster_info(which, k), gf.clusterInfo(which, k)):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), "cluster %d: average_/box not bit-equal" % k
+        if filtered:
+            fa_, fb_ = of.filtered(which, k), gf.filtered(which, k)
+            assert fa_.shape == fb_.shape and len(fa_) > 0
+            assert np.array_equal(fa_.astype(np.float32), fb_), "cluster %d: filtered_cells_ differ" % k
+    return len(ca)
+
+
+def test_reference_order_cells_and_means_incremental(fa):
+    """searchFrontiers over incremental rounds with reference_order: every cluster lists its cells exactly in
+    expandFrontier's order (frontier_finder.cpp:123-164) and average_ is the sequential f64 sum (:374-390)."""
+    map_size = (20.0, 20.0, 5.0)
+    org = (-10.0, -10.0, -1.0)
+    box = ((org[0] + 1, org[1] + 1, 0.0), (9.0, 9.0, 3.0))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    truth = om.fixture_world(42, 60)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100, reference_order=True)
+    k = 0
+    total = 0
+    for r in range(4):
+        for _ in range(12):
+            pose = om.fixture_camera(truth, 7, k, 60, 0.7)
+            k += 1
+            pts = om.fixture_render(truth, pose, 160, 120, 2, 2)
+            om.input_points(pts, pose[:3])
+            gm.inputPointCloud(pts, pose[:3])
+        assert of.search() == gf.searchFrontiers()
+        total += _assert_exact_clusters(of, gf)
+        assert np.array_equal(of.flags, gf.flags())
+        of.commit(r == 2)
+        gf.commit(r == 2)
+        for which in (1, 2):
+            _assert_exact_clusters(of, gf, which)
+    assert total > 5
+    gm.close()
+
+
+def test_reference_order_with_low_z_seeds(fa):
+    """clusters started by a seed below min_z / on the box face: the seed is cells_[0], its member neighbours
+    follow in allNeighbors order (:848-860), several components may hang off one seed"""
+    map_size = (8.0, 6.0, 4.0)
+    box = ((-2.0, -1.5, -0.5), (1.0, 2.0, 1.0))
+    om = fo.OracleMap(map_size, *box)
+    truth = om.fixture_world(5, 6)
+    om.fixture_known_state(truth, 5, 6, 1.0, 2.2)
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(om.occ)
+    n = 0
+    for cmin in (0, 5, 60):
+        of = fo.OracleFrontier(om, cmin)
+        gf = fa.FrontierFinder(gm, cluster_min=cmin, reference_order=True)
+        om.set_updated_box((-1.0, -1.0, 0.2), (0.5, 1.0, 0.8))
+        gm.setUpdatedBox((-1.0, -1.0, 0.2), (0.5, 1.0, 0.8))
+        assert of.search() == gf.searchFrontiers()
+        n += _assert_exact_clusters(of, gf)
+        gf.close()
+    assert n > 3
+    gm.close()
+
+
+@pytest.mark.parametrize("seed,size_xy", [(42, 2.0), (7, 1.2), (11, 3.0)])
+def test_reference_order_split_pieces_exact(fa, seed, size_xy):
+    """splitLargeFrontiers with reference_order against the literal oracle: same pieces, cells in the same order,
+    bit-equal average_ / boxes / filtered_cells_ (VoxelGrid float sums in BFS order)"""
+    om, truth, frames, box = helpers.explored_oracle_map((16.0, 14.0, 4.0), 30, 28, seed=seed)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    ub = om.get_updated_box(reset=False)
+    gm.setUpdatedBox(*ub)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    gf = fa.FrontierFinder(gm, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True,
+                           reference_order=True)
+    n1, n2 = of.search(), gf.searchFrontiers()
+    assert n1 == n2 > 0
+    assert _assert_exact_clusters(of, gf, filtered=True) == n1
+    gf.commit()
+    of.commit()
+    _assert_exact_clusters(of, gf, 1, filtered=True)
+    gf.close()
+    gm.close()
+
+
+def test_reference_order_split_with_seed_clusters(fa):
+    om, truth, frames, box = helpers.explored_oracle_map((12.0, 12.0, 4.0), 16, 22, seed=5, extent=0.8)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    ub = om.get_updated_box(reset=False)
+    gm.setUpdatedBox(*ub)
+    of = fo.OracleFrontier(om, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True)
+    gf = fa.FrontierFinder(gm, cluster_min=20, cluster_size_xy=1.0, down_sample=3, split=True, reference_order=True)
+    n1, n2 = of.search(), gf.searchFrontiers()
+    assert n1 == n2 > 0
+    _assert_exact_clusters(of, gf, filtered=True)
+    gf.close()
+    gm.close()
+
+
+@pytest.mark.parametrize("seed,size_xy", [(42, 2.0), (7, 1.2)])
+def test_reference_order_viewpoints_exact(fa, seed, size_xy):
+    """computeFrontiersToVisit with reference_order against the literal oracle: same partition, per cluster the
+    same viewpoints in the same order, identical coverage counts and bit-equal positions (the sample centre is
+    average_); yaws to 1e-9 rad (device libm)"""
+    om, truth, frames, box = helpers.explored_oracle_map((16.0, 14.0, 4.0), 30, 28, seed=seed)
+    om.inflate_local()
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    gm.setLocalBound(*om.get_local_bound())
+    gm.clearAndInflateLocalMap()
+    ub = om.get_updated_box(reset=False)
+    gm.setUpdatedBox(*ub)
+    of = fo.OracleFrontier(om, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True)
+    of.set_viewpoint_cfg(fo.viewpoint_cfg(min_visib_num=5))
+    gf = fa.FrontierFinder(gm, cluster_min=60, cluster_size_xy=size_xy, down_sample=3, split=True, reference_order=True)
+    gf.setViewpointConfig(gf.viewpointConfig(min_visib_num=5))
+    assert of.search() == gf.searchFrontiers() > 0
+    of.compute_to_visit()
+    na, nd = gf.computeFrontiersToVisit()
+    assert na == len(of.clusters(1)) > 0 and nd == len(of.clusters(2))
+    total = 0
+    for k in range(na):
+        (pa, va), (pb, vb) = of.viewpoints(1, k), gf.viewpoints(1, k)
+        assert np.array_equal(va, vb), "coverage counts of cluster %d differ" % k
+        assert np.array_equal(pa[:, :3], pb[:, :3])
+        dyaw = np.abs(pa[:, 3] - pb[:, 3])
+        assert np.minimum(dyaw, 2 * np.pi - dyaw).max() <= 1e-9
+        total += len(va)
+    assert total > 20
+    for which in (1, 2):
+        _assert_exact_clusters(of, gf, which, filtered=True)
+    gf.close()
+    gm.close()
