@@ -146,6 +146,9 @@ SYMBOLS = {
     "fuelmi_frontier_create": (C.c_int, [_P, C.POINTER(FrontierCfg), _PP]),
     "fuelmi_frontier_destroy": (None, [_P]),
     "fuelmi_frontier_reset": (C.c_int, [_P]),
+    "fuelmi_frontier_stats": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "fuelmi_frontier_synchronize": (C.c_int, [_P]),
+    "fuelmi_bench_cycles": (C.c_int, [_P, _P, _P, _dp, _dp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
     "fuelmi_frontier_search": (C.c_int, [_P, _ip]),
     "fuelmi_frontier_search_begin": (C.c_int, [_P]),
     "fuelmi_frontier_search_end": (C.c_int, [_P, _ip]),

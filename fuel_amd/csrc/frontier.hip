@@ -19,6 +19,8 @@
 // prefix sums) -> ordered compaction -> lock-free union-find over the compact cells (neighbour
 // lookup = bit test + popcount rank) -> atomicMin claims -> sizes -> flags.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -295,6 +297,33 @@ __device__ __forceinline__ void uf_union(u32* parent, u32 a, u32 b) {
 // local component leaves the kernel flat.  (2) k_union: only neighbour relations that cross a tile
 // face go through the global lock-free union-find.  (3) k_flatten.
 #define LNONE 0xFFFFFFFFu
+// find with path halving for the long-lived structures of the fast chain (a few thousand tile roots hanging off
+// one giant component): the shortcut is an atomicMin, so a concurrent link is never overwritten by a larger value
+__device__ __forceinline__ u32 lds_find_h(u32* lab, u32 i) {
+  u32 p = reinterpret_cast<volatile u32*>(lab)[i];
+  while (p != i) {
+    const u32 gp = reinterpret_cast<volatile u32*>(lab)[p];
+    if (gp != p) atomicMin(&lab[i], gp);
+    i = p;
+    p = gp;
+  }
+  return i;
+}
+__device__ __forceinline__ void lds_union_h(u32* lab, u32 a, u32 b) {
+  while (true) {
+    a = lds_find_h(lab, a);
+    b = lds_find_h(lab, b);
+    if (a == b) return;
+    if (a < b) {
+      u32 t = a;
+      a = b;
+      b = t;
+    }
+    u32 old = atomicMin(&lab[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
 __device__ __forceinline__ u32 lds_find(volatile u32* lab, u32 i) {
   u32 p = lab[i];
   while (p != i) {
@@ -1053,6 +1082,894 @@ __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* _
   for (; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (char)((bits[i >> 6] >> (i & 63)) & 1ull);
 }
 
+// =================================================================================================
+// FAST PATH of the clustering chain ("tile-root resolve")
+//
+// The legacy chain above runs the cross-tile merge, the claims, the cluster sizes, the kept list and
+// its ranking on the ~10^5 CELLS through device-scope atomics: five dependent kernels (k_union ..
+// k_rank_kept, ~60 us) whose time is atomic latency.  Here a tile describes each of its local
+// components by ONE record (k_ccl_tile: size, lowest claimer inside the scan box, index sums, index box)
+// and lists the component pairs that touch across tile faces; one workgroup then does all of the above
+// on those few thousand records in its LDS (k_resolve).  The cells are visited twice more, in address
+// order: flags + per-block histogram (k_flags_hist), stable scatter into the grouped result (k_scatter2).
+//   k_pred2 -> k_scan_sums -> k_compact2 -> k_ccl_tile -> k_seed_claim -> k_resolve -> k_flags_hist
+//   -> k_scatter2
+// Capacity limits (FR_* in frontier_internal.h) are those of pathological inputs (noise-like occupancy);
+// when one is hit, or cluster_min < 1 (every NQ seed is then a cluster of its own), the search runs the
+// legacy chain instead.  Results are identical (tests run both).
+// =================================================================================================
+
+// predicate planes + in-block packed prefix (k_pred) with the per-search arguments read straight from the
+// pinned host copy (no k_load_var launch) and fuelmi_frontier_reset folded in (V.fresh)
+__global__ void __launch_bounds__(256) k_pred2(Geo g, FArgs F, const FVar* __restrict__ hvar) {
+  __shared__ FVar s_var;
+  __shared__ u64 wsum[4];
+  const int nvw = (int)(sizeof(FVar) / 4);
+  if ((int)threadIdx.x < nvw) reinterpret_cast<u32*>(&s_var)[threadIdx.x] = reinterpret_cast<const u32*>(hvar)[threadIdx.x];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < nvw) reinterpret_cast<u32*>(F.var_w)[threadIdx.x] = reinterpret_cast<const u32*>(&s_var)[threadIdx.x];
+    if (threadIdx.x < 32) F.fctr[threadIdx.x] = 0u;
+  }
+  const FVar& V = s_var;
+  if ((int)blockIdx.x >= V.nblocks) return;
+  const int rel = blockIdx.x * 256 + threadIdx.x;
+  const int w = V.w0 + rel;
+  u64 q = 0ull, s = 0ull;
+  if (w < g.W) {
+    u64 z0, zl, y0, yl, mq, ms;
+    word_masks(g, w, V.qreg, V.sbox, z0, zl, y0, yl, mq, ms);
+    const u64 fl = V.fresh ? 0ull : F.flag[w];
+    if (V.fresh) F.flag[w] = 0ull;
+    if ((mq | ms) != 0ull) {
+      u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~fl;
+      q = f1 & mq;
+      s = f1 & ms & ~mq;
+    }
+    F.qb[w] = q;
+    F.sb[w] = s;
+  }
+  u64 packed = (u64)__popcll(q) | ((u64)__popcll(s) << 32);
+  u64 v = packed;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    u64 t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  u64 woff = 0;
+  for (int k = 0; k < wave; ++k) woff += wsum[k];
+  u64 excl = v - packed + woff;
+  F.pref[rel] = excl;
+  if (threadIdx.x == 255) F.blocksum[blockIdx.x] = excl + packed;
+}
+
+// ordered compaction (k_compact without the per-cell union-find / claim state of the legacy chain).  The scan
+// of the block sums is folded in: every block adds up the sums of the blocks in front of it (a few KB from L2),
+// the last one publishes the totals -- no single-block scan kernel between the predicate and the compaction.
+__global__ void __launch_bounds__(256) k_compact2(Geo g, FArgs F) {
+  __shared__ u64 s_part[4];
+  const int nblocks = F.var->nblocks;
+  if ((int)blockIdx.x >= nblocks) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 acc = 0ull;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) acc += F.blocksum[b];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  const u64 bpre = s_part[0] + s_part[1] + s_part[2] + s_part[3];  // packed (q, s) cells in front of this block
+  if (threadIdx.x == 0) {
+    F.blockscan[blockIdx.x] = bpre;
+    if ((int)blockIdx.x == nblocks - 1) {
+      const u64 run = bpre + F.blocksum[blockIdx.x];
+      u32 nq = (u32)run, ns = (u32)(run >> 32), ovf = 0u;
+      if (nq > F.cap_q) nq = F.cap_q, ovf = 1u;
+      if (ns > F.cap_s) ns = F.cap_s, ovf = 1u;
+      F.counts[0] = nq, F.counts[1] = ns, F.counts[2] = ovf, F.counts[3] = 0u, F.counts[5] = 0u;
+    }
+  }
+  const int rel = blockIdx.x * 256 + threadIdx.x;
+  const int w = F.var->w0 + rel;
+  if (w >= g.W) return;
+  u64 q = F.qb[w], s = F.sb[w];
+  if ((q | s) == 0ull) return;
+  u64 pk = bpre + F.pref[rel];
+  u32 iq = (u32)pk, is = (u32)(pk >> 32);
+  while (q) {
+    int b = __builtin_ctzll(q);
+    q &= q - 1;
+    if (iq < F.cap_q) F.cell_adr[iq] = (u32)(64L * w + b);
+    ++iq;
+  }
+  while (s) {
+    int b = __builtin_ctzll(s);
+    s &= s - 1;
+    if (is < F.cap_s) F.seed_adr[is] = (u32)(64L * w + b);
+    ++is;
+  }
+}
+
+// one wave-level reduction step of the per-component accumulators (sum / min / max over the lanes that share
+// the leading key)
+struct CAcc {
+  u32 n, sx, sy, sz, cl, lx, ly, lz, hx, hy, hz;
+};
+__device__ __forceinline__ void cacc_reduce(CAcc& a) {
+  for (int off = 32; off > 0; off >>= 1) {
+    a.n += (u32)__shfl_xor((int)a.n, off, 64);
+    a.sx += (u32)__shfl_xor((int)a.sx, off, 64);
+    a.sy += (u32)__shfl_xor((int)a.sy, off, 64);
+    a.sz += (u32)__shfl_xor((int)a.sz, off, 64);
+    a.cl = min(a.cl, (u32)__shfl_xor((int)a.cl, off, 64));
+    a.lx = min(a.lx, (u32)__shfl_xor((int)a.lx, off, 64));
+    a.ly = min(a.ly, (u32)__shfl_xor((int)a.ly, off, 64));
+    a.lz = min(a.lz, (u32)__shfl_xor((int)a.lz, off, 64));
+    a.hx = max(a.hx, (u32)__shfl_xor((int)a.hx, off, 64));
+    a.hy = max(a.hy, (u32)__shfl_xor((int)a.hy, off, 64));
+    a.hz = max(a.hz, (u32)__shfl_xor((int)a.hz, off, 64));
+  }
+}
+__device__ __forceinline__ void cacc_atomic(u32* acc /* [11] in LDS */, const CAcc& a) {
+  atomicAdd(&acc[0], a.n);
+  atomicAdd(&acc[1], a.sx);
+  atomicAdd(&acc[2], a.sy);
+  atomicAdd(&acc[3], a.sz);
+  atomicMin(&acc[4], a.cl);
+  atomicMin(&acc[5], a.lx);
+  atomicMin(&acc[6], a.ly);
+  atomicMin(&acc[7], a.lz);
+  atomicMax(&acc[8], a.hx);
+  atomicMax(&acc[9], a.hy);
+  atomicMax(&acc[10], a.hz);
+}
+
+// Tile CCL.  Labels are SPARSE (one per Q0 cell of the tile, addressed through a tile-local prefix of the
+// per-segment popcounts), so a tile costs ~35 KiB of LDS whatever nz is.
+template <int NT>
+__global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY) {
+  if ((int)blockIdx.x >= F.var->ntiles) return;
+  const Box3 QR = F.var->qreg;
+  const Box3 sbox = F.var->sbox;
+  const int nty = F.var->nty;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nz = g.nz, nseg = (nz + 31) >> 5;
+  const int items = TX * TY * nseg;
+  u32* lab = reinterpret_cast<u32*>(smem_raw);       // [FR_TCELL] union-find over the tile-local cell indices
+  u32* segb = lab + FR_TCELL;                         // [items] Q0 bits of each 32-voxel segment
+  u32* segpre = segb + items;                         // [items + 1] tile-local index of the first cell at/after it
+  u32* rowr = segpre + items + 1;                     // [2 * TX] compact index range of each x-row
+  u32* acc = rowr + 2 * TX;                           // [FR_TROOT][11]
+  unsigned short* rootno = reinterpret_cast<unsigned short*>(acc + FR_TROOT * 11);  // [FR_TCELL]
+  __shared__ u32 s_wsum[NT / 64];
+  __shared__ u32 s_nroots, s_base, s_flag;
+  const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
+  const int x0 = QR.lo[0] + tx * TX, y0 = QR.lo[1] + ty * TY;
+  const int nxl = min(TX, QR.hi[0] - x0 + 1), nyl = min(TY, QR.hi[1] - y0 + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_nroots = 0u, s_flag = 0u;
+  FR_DBG_MARK(F, blockIdx.x, 0);
+  // ---- Q0 bits of the tile and their tile-local prefix ----
+  u32 run = 0u;
+  for (int it0 = 0; it0 < items; it0 += NT) {
+    const int it = it0 + threadIdx.x;
+    u32 bits = 0u;
+    if (it < items) {
+      const int line = it / nseg, c = it - line * nseg, lx = line / TY, ly = line - lx * TY;
+      const int zn = min(32, nz - 32 * c);
+      if (lx < nxl && ly < nyl) {
+        bits = (u32)plane_window(F.qb, (long)(x0 + lx) * g.nyz + (long)(y0 + ly) * nz + 32 * c);
+        if (zn < 32) bits &= (1u << zn) - 1u;
+      }
+      segb[it] = bits;
+    }
+    const u32 cnt = (u32)__popc(bits);
+    u32 v = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 t = (u32)__shfl_up((int)v, off, 64);
+      if (lane >= off) v += t;
+    }
+    if (lane == 63) s_wsum[wave] = v;
+    __syncthreads();
+    u32 woff = 0u, tot = 0u;
+    for (int k = 0; k < NT / 64; ++k) {
+      if (k < wave) woff += s_wsum[k];
+      tot += s_wsum[k];
+    }
+    if (it < items) segpre[it] = run + woff + v - cnt;
+    run += tot;
+    __syncthreads();
+  }
+  const u32 total = run;  // uniform
+  FR_DBG_MARK(F, blockIdx.x, 1);
+  if (total == 0u) return;
+  if (total > FR_TCELL) {
+    if (threadIdx.x == 0) F.fctr[9] = 1u;
+    return;
+  }
+  if (threadIdx.x == 0) segpre[items] = total;
+  if ((int)threadIdx.x < 2 * TX) {
+    const int lx = threadIdx.x >> 1, hi = threadIdx.x & 1;
+    u32 rk = 0u;
+    if (lx < nxl) rk = min(rank_q(F, (long)(x0 + lx) * g.nyz + (long)(y0 + (hi ? nyl : 0)) * nz), F.cap_q);
+    rowr[threadIdx.x] = rk;
+  }
+  for (int t = threadIdx.x; t < FR_TROOT * 11; t += NT) {
+    const int k = t % 11;
+    acc[t] = (k >= 4 && k <= 7) ? 0xFFFFFFFFu : 0u;  // claim / box minima start at +inf
+  }
+  __syncthreads();
+  // ---- labels: start of the cell's z-run inside its segment (runs are pre-joined) ----
+  for (int it = threadIdx.x; it < items; it += NT) {
+    u32 bits = segb[it];
+    const u32 all = bits, base = segpre[it];
+    while (bits) {
+      const int z = __builtin_ctz(bits);
+      bits &= bits - 1;
+      const u32 below = all & ((1u << z) - 1u);
+      const u32 holes = ~all & ((1u << z) - 1u);
+      const int start = holes ? 32 - __builtin_clz(holes) : 0;
+      lab[base + (u32)__popc(below)] = base + (u32)__popc(all & ((1u << start) - 1u));
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 2);
+  // the t-th cell of the tile: compact index, address, line, z, tile-local index (x-rows of the tile are
+  // contiguous in the compact order)
+  auto locate = [&](u32 t, u32& ci, long& a, int& lx, int& ly, int& z, u32& l) {
+    lx = 0;
+    u32 tt = t;
+    for (; lx < nxl - 1; ++lx) {
+      const u32 n = rowr[2 * lx + 1] - rowr[2 * lx];
+      if (tt < n) break;
+      tt -= n;
+    }
+    ci = rowr[2 * lx] + tt;
+    a = (long)F.cell_adr[ci];
+    const int rem = (int)(a - ((long)(x0 + lx) * g.nyz + (long)y0 * nz));
+    ly = rem / nz;
+    z = rem - ly * nz;
+    const int it = (lx * TY + ly) * nseg + (z >> 5);
+    l = segpre[it] + (u32)__popc(segb[it] & ((1u << (z & 31)) - 1u));
+  };
+  auto local_of = [&](int line, int z) -> u32 {  // tile-local index of the (set) cell (line, z)
+    const int it = line * nseg + (z >> 5);
+    return segpre[it] + (u32)__popc(segb[it] & ((1u << (z & 31)) - 1u));
+  };
+  // ---- unions: segment seam + the four lower z-lines inside the tile ----
+  for (u32 t = threadIdx.x; t < total; t += NT) {
+    u32 ci, l;
+    long a;
+    int lx, ly, z;
+    locate(t, ci, a, lx, ly, z, l);
+    const int line = lx * TY + ly, c = z >> 5, zz = z & 31;
+    if (zz == 0 && c > 0 && (segb[line * nseg + c - 1] >> 31)) lds_union_h(lab, l, l - 1);
+    for (int k = 0; k < 4; ++k) {
+      const int nlx = lx + (k < 3 ? -1 : 0), nly = ly + (k < 3 ? k - 1 : -1);
+      if (nlx < 0 || nly < 0 || nly >= TY) continue;
+      const int nline = nlx * TY + nly;
+      const int zlo = z - 1;
+      const int s0 = max(zlo, 0) >> 5;
+      const unsigned long long w = (unsigned long long)segb[nline * nseg + s0] |
+          ((s0 + 1 < nseg) ? ((unsigned long long)segb[nline * nseg + s0 + 1] << 32) : 0ull);
+      u32 pat = (zlo >= 0) ? (u32)((w >> (zlo - 32 * s0)) & 7ull) : (u32)((w << 1) & 6ull);
+      if (z + 1 >= nz) pat &= 3u;
+      if (!pat) continue;
+      const u32 ln = local_of(nline, zlo + __builtin_ctz(pat));
+      lds_union_h(lab, l, ln);
+      if (pat == 5u) lds_union_h(lab, l, ln + 1u);  // the next cell of that line sits at zlo + 2
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 3);
+  // ---- roots: dense numbers, then flat labels ----
+  for (u32 l = threadIdx.x; l < total; l += NT)
+    if (lab[l] == l) {
+      const u32 la = atomicAdd(&s_nroots, 1u);
+      rootno[l] = (unsigned short)min(la, 0xFFFFu);
+    }
+  __syncthreads();
+  const u32 nroots = s_nroots;
+  if (nroots > FR_TROOT) {
+    if (threadIdx.x == 0) F.fctr[9] = 1u;
+    return;
+  }
+  // ---- ids of the components: one contiguous range per tile inside the XCD's part of the id space (the
+  // returning atomic is issued here so that its latency hides behind the record loop) ----
+  if (threadIdx.x == 0) {
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 b = atomicAdd(&F.fctr[xcd], nroots);
+    if (b + nroots > FR_RC8) {
+      F.fctr[9] = 1u;
+      s_flag = 1u;
+    }
+    s_base = xcd * FR_RC8 + b;
+  }
+  FR_DBG_MARK(F, blockIdx.x, 4);
+  // ---- per-component records (one wave-level reduction per distinct component of every 64 cells) ----
+  const u32 total_r = (total + 63u) & ~63u;
+  for (u32 t = threadIdx.x; t < total_r; t += NT) {
+    const bool live = t < total;
+    u32 key = 0u;
+    CAcc A;
+    A.n = 0u, A.sx = A.sy = A.sz = 0u, A.cl = A.lx = A.ly = A.lz = 0xFFFFFFFFu, A.hx = A.hy = A.hz = 0u;
+    if (live) {
+      u32 ci, l;
+      long a;
+      int lx, ly, z;
+      locate(t, ci, a, lx, ly, z, l);
+      key = (u32)rootno[lds_find_h(lab, l)];
+      const u32 x = (u32)(x0 + lx), y = (u32)(y0 + ly);
+      A.n = 1u, A.sx = x, A.sy = y, A.sz = (u32)z, A.lx = A.hx = x, A.ly = A.hy = y, A.lz = A.hz = (u32)z;
+      const bool inb = (int)x >= sbox.lo[0] && (int)x <= sbox.hi[0] && (int)y >= sbox.lo[1] && (int)y <= sbox.hi[1] &&
+                       z >= sbox.lo[2] && z <= sbox.hi[2];
+      A.cl = inb ? (u32)a : 0xFFFFFFFFu;
+      F.cell_rank[ci] = key;  // (scratch until k_flags_hist: the tile-local component number)
+    }
+    u64 todo = __ballot(live);
+    while (todo) {  // usually one or two components per 64 consecutive cells
+      const int leader = __builtin_ctzll(todo);
+      const u32 first = (u32)__shfl((int)key, leader, 64);
+      const bool mine = live && key == first;
+      CAcc B = A;
+      if (!mine) B.n = 0u, B.sx = B.sy = B.sz = 0u, B.cl = B.lx = B.ly = B.lz = 0xFFFFFFFFu, B.hx = B.hy = B.hz = 0u;
+      cacc_reduce(B);
+      if (lane == leader) cacc_atomic(acc + first * 11, B);
+      todo &= ~__ballot(mine);
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 5);
+  if (s_flag) return;
+  FR_DBG_MARK(F, blockIdx.x, 6);
+  const u32 gbase = s_base;
+  if (threadIdx.x < nroots) {
+    const u32* r = acc + threadIdx.x * 11;
+    TRec T;
+    T.size = r[0], T.sx = r[1], T.sy = r[2], T.sz = r[3];
+    T.lo[0] = r[5], T.lo[1] = r[6], T.lo[2] = r[7], T.hi[0] = r[8], T.hi[1] = r[9], T.hi[2] = r[10];
+    T.pad[0] = T.pad[1] = 0u;
+    F.trec[gbase + threadIdx.x] = T;
+    F.tclaim[gbase + threadIdx.x] = r[4];
+  }
+  // ---- tile-root id of every cell (k_cross joins the tiles through them) ----
+  for (u32 t = threadIdx.x; t < total; t += NT) {
+    u32 ci, l;
+    long a;
+    int lx, ly, z;
+    locate(t, ci, a, lx, ly, z, l);
+    F.tgid[ci] = (unsigned short)(gbase + F.cell_rank[ci]);
+  }
+  FR_DBG_MARK(F, blockIdx.x, 7);
+  if (F.dbg && threadIdx.x == 0) F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 8] = total;
+}
+
+// Joins across tile faces + seed claims, one launch after k_ccl_tile (every cell knows its tile root by now).
+// Blocks [0, ntiles): the cells of the tile that sit on a lower face look across it; the relation is recorded as
+// a pair of TILE ROOTS, and a tile keeps one record per distinct pair (LDS set: a surface crossing a face gives
+// the same pair from all of its cells) -- a few thousand records per search instead of one per adjacent cell
+// pair.  Blocks beyond: NQ seeds claim the tile roots touching their 26-neighbourhood (the seed half of k_claim).
+#define XC_SET 256
+__global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F, int TX, int TY) {
+  if (F.fctr[9]) return;
+  const int ntiles = F.var->ntiles;
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x >= ntiles) {
+    // ---- seeds: one lane per (seed, neighbour z-line) -- nine independent short chains per seed instead of one
+    // long one.  A tile root is only ever claimed by the seeds next to ITS tile (a few hundred at most), so plain
+    // atomics do here what needed wave-level aggregation on whole components.
+    const u32 ns = F.counts[1];
+    const u32 items = ns * 9u;
+    const u32 nsb = gridDim.x - (u32)ntiles;
+    for (u32 it = (blockIdx.x - (u32)ntiles) * blockDim.x + threadIdx.x; it < items; it += nsb * blockDim.x) {
+      const u32 i = it / 9u;
+      const int l = (int)(it - i * 9u);
+      const long a = F.seed_adr[i];
+      const int x = (int)(a / g.nyz);
+      const int rr = (int)(a - (long)x * g.nyz);
+      const int y = rr / g.nz, z = rr - y * g.nz;
+      const int dx = l / 3 - 1, dy = l % 3 - 1;
+      const int xx = x + dx, yy = y + dy;
+      if (xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny) continue;
+      const long nb0 = a + (long)dx * g.nyz + (long)dy * g.nz - 1;
+      u32 p = (u32)(plane_window(F.qb, nb0) & 7ull);
+      if (z == 0) p &= ~1u;
+      if (z == g.nz - 1) p &= ~4u;
+      if (!p) continue;
+      const u32 j = rank_q(F, nb0 + __builtin_ctz(p));
+      if (j >= F.cap_q) continue;
+      const u32 r = F.tgid[j];
+      if (F.tclaim[r] > (u32)a) atomicMin(&F.tclaim[r], (u32)a);
+      if (p == 5u && j + 1 < F.cap_q) {
+        const u32 r2 = F.tgid[j + 1];
+        if (r2 != r && F.tclaim[r2] > (u32)a) atomicMin(&F.tclaim[r2], (u32)a);
+      }
+    }
+    return;
+  }
+  // ---- tile faces ----
+  // Only cells on a lower face look out of the tile: the whole x-row 0 and, in the other x-rows, the lines
+  // ly = 0 and ly = TY - 1.  Each of these is a contiguous range of the compact order.
+  __shared__ u32 s_rlo[40], s_rn[40];  // face ranges: first compact index, cells
+  __shared__ u32 s_set[XC_SET];        // distinct (root, root) pairs of this tile: open addressing
+  __shared__ u32 s_list[XC_SET];       // ... in insertion order
+  __shared__ u32 s_n, s_base;
+  const Box3 QR = F.var->qreg;
+  const int nty = F.var->nty;
+  const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
+  const int x0 = QR.lo[0] + tx * TX, y0 = QR.lo[1] + ty * TY;
+  const int nxl = min(TX, QR.hi[0] - x0 + 1), nyl = min(TY, QR.hi[1] - y0 + 1);
+  const int nz = g.nz;
+  const int nrange = 1 + 2 * (nxl - 1);
+  if ((int)threadIdx.x < 2 * nrange) {
+    // range r = 0: x-row 0, lines 0 .. nyl; r = 2 lx - 1: (lx, line 0); r = 2 lx: (lx, line TY - 1)
+    const int r = threadIdx.x >> 1, hi = threadIdx.x & 1;
+    int lx = 0, l0 = 0, l1 = nyl;
+    if (r > 0) {
+      lx = (r + 1) >> 1;
+      l0 = (r & 1) ? 0 : TY - 1;
+      l1 = l0 + 1;
+      if (l0 >= nyl) l1 = l0 = 0;  // a clipped tile has no line TY - 1 (its y-neighbour lies outside the region)
+    }
+    const u32 rk = min(rank_q(F, (long)(x0 + lx) * g.nyz + (long)(y0 + (hi ? l1 : l0)) * nz), F.cap_q);
+    if (hi)
+      s_rn[r] = rk;
+    else
+      s_rlo[r] = rk;
+  }
+  s_set[threadIdx.x] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) s_n = 0u;
+  FR_DBG_MARK(F, blockIdx.x, 9);
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 10);
+  u32 total = 0u;
+  for (int r = 0; r < nrange; ++r) total += s_rn[r] - s_rlo[r];  // (s_rn holds the END of the range)
+  if (total == 0u) return;
+  // one lane per (face cell, lower z-line): the four look-ups of a cell run side by side
+  const u32 items = total * 4u;
+  const u32 items_r = (items + 63u) & ~63u;
+  for (u32 it = threadIdx.x; it < items_r; it += blockDim.x) {
+    u32 pk[2] = {0u, 0u};
+    bool pon[2] = {false, false};
+    if (it < items) {
+      const u32 t = it >> 2;
+      const int k = (int)(it & 3u);
+      const int kdx = k < 3 ? -1 : 0, kdy = k < 3 ? k - 1 : -1;
+      int r = 0;
+      u32 tt = t;
+      for (; r < nrange - 1; ++r) {
+        const u32 n = s_rn[r] - s_rlo[r];
+        if (tt < n) break;
+        tt -= n;
+      }
+      const u32 ci = s_rlo[r] + tt;
+      const int lx = r == 0 ? 0 : (r + 1) >> 1;
+      const long a = (long)F.cell_adr[ci];
+      const int rem = (int)(a - ((long)(x0 + lx) * g.nyz + (long)y0 * nz));
+      const int ly = rem / nz, z = rem - ly * nz;
+      const int xx = x0 + lx + kdx, yy = y0 + ly + kdy;
+      const bool cross = (kdx < 0 && lx == 0) || (kdy < 0 && ly == 0) || (kdy > 0 && ly == TY - 1);
+      if (cross && xx >= 0 && yy >= 0 && yy < g.ny) {
+        const long nb0 = a + (long)kdx * g.nyz + (long)kdy * nz - 1;
+        u32 p = (u32)(plane_window(F.qb, nb0) & 7ull);
+        if (z == 0) p &= ~1u;
+        if (z == nz - 1) p &= ~4u;
+        if (p) {
+          const u32 cj = rank_q(F, nb0 + __builtin_ctz(p));
+          if (cj < F.cap_q) {
+            const u32 ga = F.tgid[ci], gb = F.tgid[cj];
+            if (gb != ga) pk[0] = (min(ga, gb) << 16) | max(ga, gb), pon[0] = true;
+            if (p == 5u && cj + 1 < F.cap_q) {  // a second run starts at z + 1: the next cell of that line
+              const u32 gc = F.tgid[cj + 1];
+              if (gc != ga) pk[1] = (min(ga, gc) << 16) | max(ga, gc), pon[1] = true;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      u64 todo = __ballot(pon[k]);
+      while (todo) {  // one insertion per distinct pair of the wave
+        const int leader = __builtin_ctzll(todo);
+        const u32 key = (u32)__shfl((int)pk[k], leader, 64);
+        todo &= ~__ballot(pon[k] && pk[k] == key);
+        if (lane == leader) {
+          u32 h = (key * 2654435761u) >> 24;
+          bool done = false;
+          for (int probe = 0; probe < XC_SET && !done; ++probe) {
+            const u32 old = atomicCAS(&s_set[h], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu) {
+              s_list[atomicAdd(&s_n, 1u)] = key;
+              done = true;
+            } else if (old == key)
+              done = true;
+            h = (h + 1u) & (XC_SET - 1u);
+          }
+          if (!done) F.fctr[9] = 1u;  // more than XC_SET distinct root pairs around one tile
+        }
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 11);
+  const u32 n = s_n;
+  if (n == 0u) return;
+  const u32 xcd = blockIdx.x & 7u;
+  if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[16 + xcd], n);
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 12);
+  const u32 base = s_base;
+  if (base + n > FR_PCAP / 8u) {
+    if (threadIdx.x == 0) F.fctr[9] = 1u;
+    return;
+  }
+  if (threadIdx.x < n) F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x] = s_list[threadIdx.x];
+}
+
+// Everything between "tile-local components" and "kept clusters in creation order", on the tile-root records,
+// inside one workgroup: cross-tile union-find, sizes and claims per final component, clusters (a component
+// claimed by one of its own cells is a cluster; components claimed by the same NQ seed form one with it), the
+// kept list, its ranking by claimer address (= the reference's creation order), offsets of the grouped cell
+// array, per-cluster index sums / boxes -- and the result records, written straight to pinned host memory.
+#define RS_T 1024
+#define RS_SH 512  // seed-claimed clusters (hash slots)
+__global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32* par = reinterpret_cast<u32*>(smem_raw);  // [FR_RCAP] union-find over the DENSE numbers of the tile roots
+  u32* siz = par + FR_RCAP;                     // [FR_RCAP] cells of the final component (at its root)
+  u32* clm = siz + FR_RCAP;                     // [FR_RCAP] lowest claimer address (at its root)
+  u32* rko = clm + FR_RCAP;                     // [FR_RCAP] at a root: index into the kept list | FR_NOTKEPT | FR_UNCLAIMED
+  u32* k_adr = rko + FR_RCAP;                   // [FR_KCAP] kept list: claimer address
+  u32* k_slot = k_adr + FR_KCAP;                //   slot (compact index of the claimer | nq + seed index)
+  u32* k_size = k_slot + FR_KCAP;               //   cluster size (the seed counts)
+  u32* k_nq = k_size + FR_KCAP;                 //   its Q0 cells
+  u32* k_rank = k_nq + FR_KCAP;                 //   rank by claimer address
+  u32* k_off = k_rank + FR_KCAP;                //   first position in the grouped cell array
+  u32* kbox = k_off + FR_KCAP;                  // [FR_KCAP][6] index box per kept cluster (by kept index)
+  u32* h_adr = kbox + FR_KCAP * 6;              // [RS_SH] seed hash: claimer address
+  u32* h_sum = h_adr + RS_SH;                   //   cells of the components it claims
+  u32* h_kept = h_sum + RS_SH;                  //   index into the kept list | FR_NOTKEPT
+  unsigned long long* ksum = reinterpret_cast<unsigned long long*>(h_kept + RS_SH);  // [FR_KCAP][3] index sums
+  __shared__ u32 s_nk, s_ovf, s_nout;
+  __shared__ u32 s_pre[9];  // dense number of the first tile root of every XCD range
+  const int lane = threadIdx.x & 63;
+  const u32 nq = F.counts[0];
+  if (threadIdx.x == 0) {
+    s_nk = 0u, s_ovf = F.fctr[9] | F.counts[2], s_nout = 0u;
+    u32 run = 0u;
+    for (int k = 0; k < 8; ++k) {
+      s_pre[k] = run;
+      run += min(F.fctr[k], (u32)FR_RC8);
+    }
+    s_pre[8] = run;
+  }
+  const int dblk = F.var->ntiles;  // time stamps of this kernel go behind those of the tiles
+  FR_DBG_MARK(F, dblk, 0);
+  __syncthreads();
+  const bool dead = s_ovf != 0u;  // an earlier kernel hit a capacity limit: report, leave everything untouched
+  const u32 R = s_pre[8];         // tile roots of this search
+  // tile-root id (XCD range | index) <-> dense number
+  auto dense_of = [&](u32 gidx) { return s_pre[gidx / FR_RC8] + (gidx & (FR_RC8 - 1u)); };
+  auto gid_of = [&](u32 d) {
+    u32 xc = 0u;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) xc += d >= s_pre[k] ? 1u : 0u;
+    return xc * FR_RC8 + (d - s_pre[xc]);
+  };
+  const u32 Rr = (R + RS_T - 1u) / RS_T * RS_T;
+  if (!dead) {
+    for (u32 d = threadIdx.x; d < R; d += RS_T) {
+      const u32 gi = gid_of(d);
+      par[d] = d;
+      siz[d] = F.trec[gi].size;
+      clm[d] = F.tclaim[gi];
+      rko[d] = FR_UNCLAIMED;
+    }
+    for (u32 i = threadIdx.x; i < RS_SH; i += RS_T) h_adr[i] = NOCLAIM, h_sum[i] = 0u, h_kept[i] = FR_NOTKEPT;
+    for (u32 i = threadIdx.x; i < FR_KCAP * 6; i += RS_T) kbox[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u;
+    for (u32 i = threadIdx.x; i < FR_KCAP * 3; i += RS_T) ksum[i] = 0ull;
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 1);
+  if (!dead) {
+    // ---- cross-tile unions (one list of distinct root pairs per XCD) ----
+    for (u32 xc = 0; xc < 8u; ++xc) {
+      const u32 np = min(F.fctr[16 + xc], FR_PCAP / 8u);
+      const u32* lst = F.pairs + (size_t)xc * (FR_PCAP / 8u);
+      for (u32 p = threadIdx.x; p < np; p += RS_T) {
+        const u32 key = lst[p];
+        lds_union_h(par, dense_of(key >> 16), dense_of(key & 0xFFFFu));
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 2);
+  // ---- flatten; cells and lowest claimer of every final component (wave-reduced per distinct root) ----
+  if (!dead) {
+    for (u32 d0 = 0; d0 < Rr; d0 += RS_T) {
+      const u32 d = d0 + threadIdx.x;
+      const u32 rt = d < R ? lds_find_h(par, d) : 0u;
+      const bool mov = d < R && rt != d;
+      const u32 sz = mov ? siz[d] : 0u, cl = mov ? clm[d] : NOCLAIM;
+      u64 todo = __ballot(mov);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const u32 first = (u32)__shfl((int)rt, leader, 64);
+        const bool mine = mov && rt == first;
+        u32 s2 = mine ? sz : 0u, c2 = mine ? cl : NOCLAIM;
+        for (int off = 32; off > 0; off >>= 1) {
+          s2 += (u32)__shfl_xor((int)s2, off, 64);
+          c2 = min(c2, (u32)__shfl_xor((int)c2, off, 64));
+        }
+        if (lane == leader) {
+          atomicAdd(&siz[first], s2);
+          atomicMin(&clm[first], c2);
+        }
+        todo &= ~__ballot(mine);
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 3);
+  if (!dead) {
+    // (every find above ran before any sibling was re-parented by another thread's halving in a way that
+    // matters: halving only ever installs ancestors; par[] is flat enough for the single look-ups below)
+    // ---- clusters: own-claimed components straight to the kept list, seed-claimed ones through the hash ----
+    for (u32 d = threadIdx.x; d < R; d += RS_T) {
+      if (lds_find_h(par, d) != d || clm[d] == NOCLAIM) continue;
+      const u32 cl = clm[d];
+      const bool own = (F.qb[cl >> 6] >> (cl & 63)) & 1ull;
+      if (own) {
+        if ((int)siz[d] > F.cluster_min) {
+          const u32 e = atomicAdd(&s_nk, 1u);
+          if (e < FR_KCAP) {
+            k_adr[e] = cl, k_slot[e] = rank_q(F, (long)cl), k_size[e] = siz[d], k_nq[e] = siz[d];
+            rko[d] = e;
+          } else
+            s_ovf = 1u;
+        } else
+          rko[d] = FR_NOTKEPT;
+      } else {
+        u32 h = (cl * 2654435761u) >> 23;  // 9 bits
+        bool done = false;
+        for (int probe = 0; probe < RS_SH && !done; ++probe) {
+          const u32 old = atomicCAS(&h_adr[h], NOCLAIM, cl);
+          if (old == NOCLAIM || old == cl) {
+            atomicAdd(&h_sum[h], siz[d]);
+            rko[d] = 0x80000000u | h;  // resolved below
+            done = true;
+          }
+          h = (h + 1u) & (RS_SH - 1u);
+        }
+        if (!done) s_ovf = 1u;
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 4);
+  if (!dead && threadIdx.x < RS_SH && h_adr[threadIdx.x] != NOCLAIM) {
+    const u32 cl = h_adr[threadIdx.x], sum = h_sum[threadIdx.x];
+    if ((int)(sum + 1u) > F.cluster_min) {
+      const u32 e = atomicAdd(&s_nk, 1u);
+      if (e < FR_KCAP) {
+        k_adr[e] = cl, k_slot[e] = nq + rank_s(F, (long)cl), k_size[e] = sum + 1u, k_nq[e] = sum;
+        h_kept[threadIdx.x] = e;
+      } else
+        s_ovf = 1u;
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 5);
+  const u32 nk = min(s_nk, (u32)FR_KCAP);
+  const bool bad = dead || s_ovf != 0u;
+  if (!bad) {
+    // ---- creation order = ascending claimer address; offsets of the grouped cell array ----
+    if (threadIdx.x < nk) {
+      const u32 ai = k_adr[threadIdx.x];
+      u32 rank = 0u, off = 0u;
+      for (u32 j = 0; j < nk; ++j)
+        if (k_adr[j] < ai) {
+          ++rank;
+          off += k_nq[j];
+        }
+      k_rank[threadIdx.x] = rank;
+      k_off[threadIdx.x] = off;
+      atomicAdd(&s_nout, k_nq[threadIdx.x]);
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 6);
+  if (!bad) {
+    // ---- code of every tile root; index sums / boxes of the kept clusters ----
+    for (u32 d0 = 0; d0 < Rr; d0 += RS_T) {
+      const u32 d = d0 + threadIdx.x;
+      u32 e = FR_UNCLAIMED, gi = 0u;
+      if (d < R) {
+        gi = gid_of(d);
+        e = rko[lds_find_h(par, d)];
+        if (e != FR_UNCLAIMED && e != FR_NOTKEPT && (e & 0x80000000u)) e = h_kept[e & 0x7FFFFFFFu];
+      }
+      const bool kept = e < FR_KCAP;
+      if (d < R) F.rcode[gi] = kept ? k_rank[e] : e;
+      CAcc A;
+      A.n = 0u, A.sx = A.sy = A.sz = 0u, A.cl = A.lx = A.ly = A.lz = 0xFFFFFFFFu, A.hx = A.hy = A.hz = 0u;
+      if (kept) {
+        const TRec T = F.trec[gi];
+        A.sx = T.sx, A.sy = T.sy, A.sz = T.sz, A.lx = T.lo[0], A.ly = T.lo[1], A.lz = T.lo[2];
+        A.hx = T.hi[0], A.hy = T.hi[1], A.hz = T.hi[2];
+      }
+      u64 todo = __ballot(kept);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const u32 first = (u32)__shfl((int)e, leader, 64);
+        const bool mine = kept && e == first;
+        CAcc B = A;
+        if (!mine) B.sx = B.sy = B.sz = 0u, B.lx = B.ly = B.lz = 0xFFFFFFFFu, B.hx = B.hy = B.hz = 0u;
+        cacc_reduce(B);
+        if (lane == leader) {
+          unsigned long long* qs = ksum + first * 3u;
+          u32* q = kbox + first * 6u;
+          atomicAdd(&qs[0], (unsigned long long)B.sx), atomicAdd(&qs[1], (unsigned long long)B.sy);
+          atomicAdd(&qs[2], (unsigned long long)B.sz);
+          atomicMin(&q[0], B.lx), atomicMin(&q[1], B.ly), atomicMin(&q[2], B.lz);
+          atomicMax(&q[3], B.hx), atomicMax(&q[4], B.hy), atomicMax(&q[5], B.hz);
+        }
+        todo &= ~__ballot(mine);
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 7);
+  if (F.dbg && threadIdx.x == 0) {
+    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 9] = F.fctr[16] + F.fctr[17] + F.fctr[18] + F.fctr[19] + F.fctr[20] + F.fctr[21] + F.fctr[22] + F.fctr[23];
+    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 10] = R;
+    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 11] = F.counts[1];
+  }
+  // ---- records: device copy for the kernels that follow, pinned host copy for _search_end ----
+  if (!bad && threadIdx.x < nk) {
+    const u32 e = threadIdx.x;
+    KeptRec r;
+    r.addr = k_adr[e], r.slot = k_slot[e], r.size = k_size[e], r.off = k_off[e];
+    r.sum[0] = ksum[e * 3u], r.sum[1] = ksum[e * 3u + 1u], r.sum[2] = ksum[e * 3u + 2u];
+    for (int k = 0; k < 6; ++k) r.box[k] = kbox[e * 6u + (u32)k];
+    r.pad[0] = r.pad[1] = 0u;
+    F.krec[k_rank[e]] = r;
+    F.h_rec[k_rank[e]] = r;
+  }
+  if (threadIdx.x == 0) {
+    F.counts[2] = bad ? 2u : 0u;  // 2: capacity of the fast path exceeded -> the host runs the legacy chain
+    F.counts[3] = bad ? 0u : nk;
+    F.counts[5] = bad ? 0u : s_nout;
+    F.fctr[9] = bad ? 1u : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
+  // the barrier orders every thread's record stores before thread 0's system-scope release (cumulative): one
+  // write-back instead of one per wave
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 8);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&F.h_counts[15], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // "records are in"
+  }
+}
+
+// flags (every claimed cell, every NQ seed), cluster rank of every cell, cells per (cluster, 256-word block).
+// One lane per CELL of the block's compact range (a lane per word left the lanes of a wall word with 30
+// dependent look-ups each).
+__global__ void __launch_bounds__(256) k_flags_hist(Geo g, FArgs F) {
+  __shared__ u32 h[FR_KCAP];
+  if ((int)blockIdx.x >= F.var->nblocks) return;
+  if (F.fctr[9]) return;
+  const u32 nkept = F.counts[3];
+  h[threadIdx.x] = 0u;
+  const int rel = blockIdx.x * 256 + threadIdx.x;
+  const int w = F.var->w0 + rel;
+  const int lane = threadIdx.x & 63;
+  if (w < g.W) {
+    const u64 sd = F.sb[w];
+    if (sd) atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[w]), sd);  // every NQ seed is flagged
+  }
+  __syncthreads();
+  const u32 i0 = (u32)F.blockscan[blockIdx.x];
+  const u32 i1 = (int)blockIdx.x + 1 < F.var->nblocks ? (u32)F.blockscan[blockIdx.x + 1] : F.counts[0];
+  for (u32 ib = i0; ib < i1; ib += 256u) {
+    const u32 i = ib + threadIdx.x;
+    const bool live = i < i1 && i < F.cap_q;
+    u32 code = FR_UNCLAIMED;
+    if (live) {
+      code = F.rcode[F.tgid[i]];
+      F.cell_rank[i] = code < FR_KCAP ? code : NOKEY;
+      if (code != FR_UNCLAIMED) {
+        const u32 a = F.cell_adr[i];
+        atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[a >> 6]), 1ull << (a & 63));
+      }
+    }
+    const bool kept = code < FR_KCAP;
+    u64 todo = __ballot(kept);
+    while (todo) {  // one LDS atomic per cluster per wave
+      const int leader = __builtin_ctzll(todo);
+      const u32 first = (u32)__shfl((int)code, leader, 64);
+      const u64 same = __ballot(kept && code == first);
+      if (lane == leader) atomicAdd(&h[first], (u32)__popcll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nkept) F.whist[(size_t)threadIdx.x * F.whist_nb + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter of the kept cells into the grouped result (cluster by cluster in creation order, ascending
+// address inside): position = offset of the cluster + its cells in earlier blocks + its earlier cells of this
+// block.
+__global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) {
+  __shared__ u32 running[FR_KCAP];
+  __shared__ u32 wcnt[4][FR_KCAP];
+  if ((int)blockIdx.x >= F.var->nblocks) return;
+  if (F.fctr[9]) return;
+  const u32 nkept = F.counts[3];
+  const int nb = F.whist_nb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // cells of this block: compact range [i0, i1)
+  const u32 i0 = (u32)F.blockscan[blockIdx.x];
+  const u32 i1 = (int)blockIdx.x + 1 < F.var->nblocks ? (u32)F.blockscan[blockIdx.x + 1] : F.counts[0];
+  if (i1 <= i0) return;
+  // first position of every cluster present in this block
+  const u32 mine = threadIdx.x < nkept ? F.whist[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
+  running[threadIdx.x] = 0u;
+  const u64 present = __ballot(mine != 0u);
+  __shared__ u64 s_present[4];
+  if (lane == 0) s_present[wave] = present;
+  __syncthreads();
+  if (!(s_present[0] | s_present[1] | s_present[2] | s_present[3])) return;
+  for (int wv = 0; wv < 4; ++wv) {
+    u64 m = s_present[wv];
+    while (m) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1;
+      const u32 d = (u32)(wv * 64 + b);
+      // every wave takes the clusters d with d % 4 == its number (usually one or two clusters in all)
+      if ((int)(d & 3u) != wave) continue;
+      u32 sum = 0u;
+      for (int bb = lane; bb < (int)blockIdx.x; bb += 64) sum += F.whist[(size_t)d * nb + bb];
+      for (int off = 32; off > 0; off >>= 1) sum += (u32)__shfl_xor((int)sum, off, 64);
+      if (lane == 0) running[d] = F.krec[d].off + sum;
+    }
+  }
+  __syncthreads();
+  u32* key_out = F.ms_key[1];
+  u32* val_out = F.ms_val[1];
+  for (u32 base = i0; base < i1; base += 256u) {
+    for (int wv = 0; wv < 4; ++wv) wcnt[wv][threadIdx.x] = 0u;
+    __syncthreads();
+    const u32 i = base + threadIdx.x;
+    const u32 kk = i < i1 ? F.cell_rank[i] : NOKEY;
+    const bool active = kk != NOKEY;
+    u32 lane_rank = 0u;
+    u64 todo = __ballot(active);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const u32 dl = (u32)__shfl((int)kk, leader, 64);
+      const u64 same = __ballot(active && kk == dl) & todo;
+      if (active && kk == dl) lane_rank = (u32)__popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wcnt[wave][dl] = (u32)__popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (active) {
+      u32 pos = running[kk] + lane_rank;
+      for (int wv = 0; wv < wave; ++wv) pos += wcnt[wv][kk];
+      const u32 a = F.cell_adr[i];
+      key_out[pos] = kk;
+      val_out[pos] = a;
+      F.h_cells[pos] = a;  // posted write over PCIe, coalesced per wave
+    }
+    __syncthreads();
+    running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1102,6 +2019,12 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
     (void)hipStreamDestroy(f->stream);
   }
   if (f->ev_dep) (void)hipEventDestroy(f->ev_dep);
+  if (f->copy_stream) {
+    (void)hipStreamSynchronize(f->copy_stream);
+    (void)hipStreamDestroy(f->copy_stream);
+  }
+  if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
+  if (f->ev_copy) (void)hipEventDestroy(f->ev_copy);
   if (f->d_stage) (void)hipFree(f->d_stage);
   for (void* p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
@@ -1112,6 +2035,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   frontier_order_free(f);
   for (hipGraphExec_t e : f->graph_exec)
     if (e) (void)hipGraphExecDestroy(e);
+  if (f->fast_exec) (void)hipGraphExecDestroy(f->fast_exec);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
@@ -1163,6 +2087,24 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   }
   F.kept = F.counts + 16;
   F.keys_from_slots = 1;
+  F.whist_nb = (int)(nwords / 256 + 1);
+  if ((rc = dmalloc(f, &F.tgid, F.cap_q)) || (rc = dmalloc(f, &F.trec, FR_RCAP)) || (rc = dmalloc(f, &F.tclaim, FR_RCAP)) ||
+      (rc = dmalloc(f, &F.rcode, FR_RCAP)) || (rc = dmalloc(f, &F.pairs, (size_t)FR_PCAP)) ||
+      (rc = dmalloc(f, &F.fctr, 32)) || (rc = dmalloc(f, &F.cell_rank, F.cap_q)) ||
+      (rc = dmalloc(f, &F.whist, (size_t)FR_KCAP * F.whist_nb))) {
+    fuelmi_frontier_destroy(f);
+    return rc;
+  }
+  HIPCHK(hipMemsetAsync(F.fctr, 0, 32 * sizeof(u32), m->stream));
+  F.dbg = nullptr;
+  if (getenv("FUELMI_FR_TIMING")) {  // dev aid: phase time stamps of the fast chain (one row per tile + one for k_resolve)
+    const size_t nrow = (size_t)((g.nx + 0) * (g.ny + 0) / 16 + 64);
+    if ((rc = dmalloc(f, &F.dbg, nrow * FR_DBG_SLOTS))) {
+      fuelmi_frontier_destroy(f);
+      return rc;
+    }
+    HIPCHK(hipMemsetAsync(F.dbg, 0, nrow * FR_DBG_SLOTS * sizeof(unsigned long long), m->stream));
+  }
   F.occ = m->occ_bits.p;
   F.unk = m->unk_bits.p;
   F.flag = f->flag.p;
@@ -1177,6 +2119,9 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi_p));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
+  HIPCHK(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&f->ev_copy, hipEventDisableTiming));
 
   // ---- everything below is constant for the life of the object (the kernel chain is replayed
   // as a graph with these arguments baked in) ----
@@ -1200,6 +2145,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     return rc;
   }
   F.var = f->d_var;
+  F.var_w = f->d_var;
   // results land in one pinned host buffer [counts | cluster records | chunk records | cells]
   f->pin_bytes = 64 + (size_t)F.cap_kept * sizeof(KeptRec) + ((size_t)F.cap_q / SZ_CH + 2) * 40 + (size_t)F.cap_q * 4;
   HIPCHK(hipHostMalloc(&f->h_pin, f->pin_bytes, hipHostMallocDefault));
@@ -1233,7 +2179,21 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local<512>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->ccl_lds));
     }
+    // fast path: sparse labels, the same tile grid
+    const size_t items = (size_t)TX * TY * ((g.nz + 31) / 32);
+    f->tile_lds = (FR_TCELL + 2 * items + 1 + 2 * (size_t)TX + (size_t)FR_TROOT * 11) * sizeof(u32) + FR_TCELL * sizeof(unsigned short);
+    f->tile_lds = (f->tile_lds + 15) & ~(size_t)15;
+    if (f->tile_lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_tile<512>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->tile_lds));
   }
+  f->resolve_lds = (4 * (size_t)FR_RCAP + 6 * (size_t)FR_KCAP + 6 * (size_t)FR_KCAP + 3 * (size_t)RS_SH) * sizeof(u32) +
+                   3 * (size_t)FR_KCAP * sizeof(unsigned long long);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)f->resolve_lds));
+  // the fast path needs tiles, a cluster threshold that rules out one-seed clusters, and tile-local indices
+  // that fit the 16-bit root numbers
+  f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && f->tile_lds <= 150 * 1024 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
   *out = f;
   return FUELMI_OK;
 }
@@ -1275,6 +2235,10 @@ static int pool_reserve(fuelmi_frontier* f, size_t need) {
 // commit this search's clusters to the pool: the ones whose cells still sit grouped on the device are
 // copied there by ONE launch (a table of {destination, source, count, seed} per cluster)
 int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
+  {
+    int rct = frontier_tail_sync(f);  // the host lists are materialised from the pinned cell buffer
+    if (rct) return rct;
+  }
   size_t need = 0, nlazy = 0;
   for (HCluster& c : clusters) need += c.size(), nlazy += c.lazy ? 1 : 0;
   int rc = pool_reserve(f, need);
@@ -1444,6 +2408,29 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   return FUELMI_OK;
 }
 
+// the fast chain (capturable); falls back to the legacy one through counts[2] == 2
+static int frontier_enqueue_fast(fuelmi_frontier* f) {
+  const Geo& g = f->map->g;
+  FArgs& F = f->F;
+  const int nb_max = (g.W + 255) / 256 + 1;
+  k_pred2<<<nb_max, 256, 0, f->stream>>>(g, F, f->h_var);
+  FDBG("k_pred2");
+  k_compact2<<<nb_max, 256, 0, f->stream>>>(g, F);
+  FDBG("k_compact2");
+  k_ccl_tile<512><<<f->ccl_tiles, 512, f->tile_lds, f->stream>>>(g, F, f->TX, f->TY);
+  FDBG("k_ccl_tile");
+  k_cross<<<f->ccl_tiles + 192, 256, 0, f->stream>>>(g, F, f->TX, f->TY);
+  FDBG("k_cross");
+  k_resolve<<<1, RS_T, f->resolve_lds, f->stream>>>(g, F);
+  FDBG("k_resolve");
+  k_flags_hist<<<nb_max, 256, 0, f->stream>>>(g, F);
+  FDBG("k_flags_hist");
+  k_scatter2<<<nb_max, 256, 0, f->stream>>>(g, F);
+  FDBG("k_scatter2");
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
 // searchFrontiers, first half: drops changed clusters and enqueues the whole device pipeline on the
 // frontier's own stream (asynchronous).  The caller may queue other work of the cycle (inflation,
 // ESDF, B-spline evaluation on the map's stream) before collecting the result with _search_end.
@@ -1487,7 +2474,14 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   }
   f->pending = true;
   f->search_empty = empty;
-  if (empty) return FUELMI_OK;
+  f->fast_launched = false;
+  if (empty) {
+    if (f->fresh_pending) {  // a reset nobody has executed yet
+      k_zero_words<<<fblocks(g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, g.W);
+      f->fresh_pending = false;
+    }
+    return FUELMI_OK;
+  }
 
   // Region that can hold Q0 cells: the scan box, the boxes of the clusters just dropped (their flags were
   // cleared), or the whole exploration box when flags / occupancy changed behind the updated-box
@@ -1529,7 +2523,23 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   const int w_hi = (int)(a_hi >> 6);
   hv.nblocks = (w_hi - hv.w0) / 256 + 1;
   hv.nwords = hv.nblocks * 256;
-  *f->h_var = hv;  // pinned; the previous search has been collected (_search_end synchronises)
+  const bool fast = f->fast_ok;
+  hv.fresh = 0;
+  if (f->fresh_pending) {
+    // fuelmi_frontier_reset: every flag an earlier search could have set lies in the words this search
+    // processes (dirty_all widened the region to the whole exploration box), so the fast chain's first kernel
+    // clears them on the way; the legacy chain gets the clearing kernel in front
+    if (fast)
+      hv.fresh = 1;
+    else
+      k_zero_words<<<fblocks(g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, g.W);
+    f->fresh_pending = false;
+  }
+  hv.epoch = ++f->epoch;
+  if (hv.epoch == 0u) hv.epoch = f->epoch = 1u;
+  // pinned; read by the first kernel of the chain.  (The previous search's first kernel ran long ago -- its
+  // result was collected -- and the tail that may still be running reads the device copy.)
+  *f->h_var = hv;
 
   // the second radix pass is needed only beyond 256 kept clusters: guess from the previous search
   f->npass = f->last_nkept > 192 ? 2 : 1;
@@ -1539,6 +2549,22 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   // behind F.var): replay it as a hipGraph -- the host-side launch cost of the individual kernels
   // (~6 us each) was longer than the kernels themselves.
   static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || getenv("FUELMI_DEBUG_SYNC") != nullptr;
+  if (fast) {
+    f->fast_launched = true;
+    if (no_graph) return frontier_enqueue_fast(f);
+    if (!f->fast_exec) {
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
+      const int rc2 = frontier_enqueue_fast(f);
+      const hipError_t ec = hipStreamEndCapture(f->stream, &graph);
+      if (rc2) return rc2;
+      HIPCHK(ec);
+      HIPCHK(hipGraphInstantiate(&f->fast_exec, graph, nullptr, nullptr, 0));
+      HIPCHK(hipGraphDestroy(graph));
+    }
+    HIPCHK(hipGraphLaunch(f->fast_exec, f->stream));
+    return FUELMI_OK;
+  }
   if (no_graph) return frontier_enqueue_chain(f, f->npass);
   hipGraphExec_t& exec = f->graph_exec[f->npass - 1];
   if (!exec) {
@@ -1585,8 +2611,91 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   const u32* h_part = F.h_part;
   const u32* h_cells = F.h_cells;
   // poll instead of a blocking wait: the caller is about to consume the result and the chain is
-  // ~200 us long, an interrupt-driven wake-up costs a noticeable fraction of that
-  {
+  // ~100 us long, an interrupt-driven wake-up costs a noticeable fraction of that
+  F.fast = 0;
+  if (f->fast_launched) {
+    // the fast chain publishes counts + cluster records from k_resolve and stamps them with the search's epoch;
+    // the two kernels behind it (flags, regrouping + copy-out of the cells) keep running -- whoever touches the
+    // cell lists waits for them (frontier_tail_sync)
+    volatile u32* stamp = counts + 15;
+    const u32 want = f->h_var->epoch;
+    unsigned spins = 0;
+    while (*stamp != want) {
+      if ((++spins & 0x3FFFu) == 0u) {  // every ~16k polls: has the stream died under us?
+        const hipError_t q = hipStreamQuery(f->stream);
+        if (q != hipErrorNotReady && q != hipSuccess) HIPCHK(q);
+        if (q == hipSuccess && *stamp != want) {
+          fuelmi_set_error("frontier search: the chain finished without publishing its result");
+          return FUELMI_EHIP;
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    f->tail_pending = true;
+    F.fast = 1;
+    if (F.dbg) {  // FUELMI_FR_TIMING: where the tile kernel and the resolve kernel spend their time (100 MHz ticks)
+      (void)hipStreamSynchronize(f->stream);
+      const int nt = f->h_var->ntiles;
+      std::vector<unsigned long long> d((size_t)(nt + 1) * FR_DBG_SLOTS);
+      (void)hipMemcpy(d.data(), F.dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull, t1 = 0;
+      double phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int busiest = 0, nonempty = 0;
+      for (int b = 0; b < nt; ++b) {
+        const unsigned long long* r = &d[(size_t)b * FR_DBG_SLOTS];
+        if (!r[0]) continue;
+        t0 = std::min(t0, r[0]);
+        for (int k = 1; k < 8; ++k)
+          if (r[k]) t1 = std::max(t1, r[k]);
+        if (r[8] > d[(size_t)busiest * FR_DBG_SLOTS + 8]) busiest = b;
+        if (r[8]) ++nonempty;
+      }
+      const unsigned long long* rb = &d[(size_t)busiest * FR_DBG_SLOTS];
+      for (int k = 1; k < 8; ++k) phase[k] = rb[k] && rb[k - 1] ? (double)(rb[k] - rb[k - 1]) / 100.0 : 0.0;
+      std::fprintf(stderr, "[fr-timing] tiles %d (non-empty %d) span %.1f us; busiest tile %d (%llu cells, start +%.1f us): "
+                   "bits %.1f labels %.1f unions %.1f roots %.1f records %.1f ids %.1f pairs %.1f us\n", nt, nonempty,
+                   (double)(t1 - t0) / 100.0, busiest, rb[8], (double)(rb[0] - t0) / 100.0, phase[1], phase[2], phase[3],
+                   phase[4], phase[5], phase[6], phase[7]);
+      {
+        unsigned long long c0 = ~0ull, c1 = 0;
+        double mx[3] = {0, 0, 0}, av[3] = {0, 0, 0};
+        int cnt = 0;
+        for (int b = 0; b < nt; ++b) {
+          const unsigned long long* r = &d[(size_t)b * FR_DBG_SLOTS];
+          if (!r[9]) continue;
+          c0 = std::min(c0, r[9]);
+          for (int k = 10; k <= 12; ++k)
+            if (r[k]) c1 = std::max(c1, r[k]);
+          if (r[10] && r[11] && r[12]) {
+            const double ph[3] = {(double)(r[10] - r[9]) / 100.0, (double)(r[11] - r[10]) / 100.0, (double)(r[12] - r[11]) / 100.0};
+            for (int k = 0; k < 3; ++k) mx[k] = std::max(mx[k], ph[k]), av[k] += ph[k];
+            ++cnt;
+          }
+        }
+        std::fprintf(stderr, "[fr-timing] cross: span %.1f us over %d tiles with pairs; rowr avg %.1f max %.1f, look-ups avg %.1f max %.1f, "
+                     "slot atomic avg %.1f max %.1f us\n", (double)(c1 - c0) / 100.0, cnt, av[0] / std::max(cnt, 1), mx[0],
+                     av[1] / std::max(cnt, 1), mx[1], av[2] / std::max(cnt, 1), mx[2]);
+      }
+      const unsigned long long* rr = &d[(size_t)nt * FR_DBG_SLOTS];
+      std::fprintf(stderr, "[fr-timing] resolve: init %.1f unions %.1f find %.1f reduce %.1f clusters %.1f seeds %.1f rank %.1f "
+                   "codes %.1f publish %.1f us; pairs %llu roots %llu seeds %llu\n", (rr[1] - rr[0]) / 100.0,
+                   (rr[2] - rr[1]) / 100.0, (rr[3] - rr[2]) / 100.0, (rr[4] - rr[3]) / 100.0, (rr[5] - rr[4]) / 100.0, 0.0,
+                   (rr[6] - rr[5]) / 100.0, (rr[7] - rr[6]) / 100.0, (rr[8] - rr[7]) / 100.0, rr[9], rr[10], rr[11]);
+    }
+    ++f->n_fast;
+    if (counts[2] == 2u) {
+      // a capacity of the fast path was exceeded (noise-like input): nothing was modified; run the legacy chain
+      --f->n_fast;
+      ++f->n_fallback;
+      HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
+      F.fast = 0;
+      f->npass = 1;
+      int rcl = frontier_enqueue_chain(f, f->npass);
+      if (rcl) return rcl;
+      HIPCHK(hipStreamSynchronize(f->stream));
+    }
+  } else {
+    ++f->n_legacy;
     hipError_t q;
     while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {
     }
@@ -1631,6 +2740,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   int fin = nkept <= 256 ? 1 : 0;  // buffer pair holding the grouped cells of the search
   std::vector<u32> off2;
   u32 n_in = n_out;
+  if (ref_order || split_mode) HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
   if (ref_order) {  // cells of every cluster in expandFrontier's order (an NQ seed first), into the other pair
     int rc = frontier_reference_order(f, nq, nkept, n_out, fin, &n_in, &off2);
     if (rc) return rc;
@@ -1646,7 +2756,9 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     HIPCHK(hipStreamSynchronize(f->stream));
   }
   f->last_fin = fin;  // buffer holding the grouped cells the lazy clusters point into
-  const u32 nchunk = (ref_order && !split_mode) ? 0u : (ncells + SZ_CH - 1) / SZ_CH;  // (records of the grouped
+  // (the fast chain's records are complete; the legacy chain and the regrouping of the split pieces leave
+  // per-chunk partial records to fold)
+  const u32 nchunk = ((ref_order || F.fast) && !split_mode) ? 0u : (ncells + SZ_CH - 1) / SZ_CH;  // (records of the grouped
                                                                                        // array, not of the ordered one)
   for (u32 c = 0; c < nchunk; ++c) {  // fold the per-chunk records into the per-cluster totals
     const u32* rec = h_part + (size_t)c * 10;
@@ -1740,6 +2852,20 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
   return fuelmi_frontier_search_end(f, n_new);
 }
 
+extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
+  ARGCHK(f);
+  HIPCHK(hipSetDevice(f->map->device));
+  f->tail_pending = false;
+  HIPCHK(hipStreamSynchronize(f->stream));
+  if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
+  ARGCHK(f && out3);
+  out3[0] = f->n_fast, out3[1] = f->n_legacy, out3[2] = f->n_fallback;
+  return FUELMI_OK;
+}
+
 extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   ARGCHK(f);
   FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_reset");
@@ -1751,8 +2877,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   f->removed_ids.clear();
   f->dirty_all = true;
   f->pool_used = 0;
-  k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
-  FDBG("k_zero_words");
+  f->fresh_pending = true;  // executed by the next search (folded into its first kernel) or by whoever reads the flags
   return FUELMI_OK;
 }
 
@@ -1791,6 +2916,10 @@ extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which
   ARGCHK(f && adr);
   const HCluster* c = nth(f, which, k);
   ARGCHK(c);
+  if (c->lazy) {
+    int rc = frontier_tail_sync(f);
+    if (rc) return rc;
+  }
   c->copy_to(adr);
   return FUELMI_OK;
 }
@@ -1830,10 +2959,47 @@ extern "C" int fuelmi_frontier_get_flags(fuelmi_frontier* f, char* flags) {
   long n = m->g.N;
   int rc = frontier_ensure_stage(f, (size_t)n);
   if (rc) return rc;
+  if (f->fresh_pending) {
+    k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
+    f->fresh_pending = false;
+  }
   k_expand_flag_bits<<<fblocks(n, 256), 256, 0, f->stream>>>(f->flag.p, n, (char*)f->d_stage);
   FDBG("k_expand_flag_bits");
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(flags, f->d_stage, (size_t)n, hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
+  return FUELMI_OK;
+}
+
+
+// ---- measurement driver (bench.py): the plan cycle issued from C++ ---------------------------------------
+extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, const double ub_min[3],
+                                   const double ub_max[3], int n, int serial, int* n_clusters, double* seconds) {
+  ARGCHK(m && f && ub_min && ub_max && n >= 0 && n_clusters && seconds && f->map == m);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  int rc = FUELMI_OK, ncl = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
+    if ((rc = fuelmi_frontier_reset(f))) break;
+    if ((rc = fuelmi_map_set_updated_box(m, ub_min, ub_max))) break;
+    if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
+    if ((rc = fuelmi_map_inflate_local(m))) break;
+    if ((rc = fuelmi_map_update_esdf(m))) break;
+    if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
+    if (serial) {
+      HIPCHK(hipStreamSynchronize(m->stream));
+      if ((rc = fuelmi_frontier_search_begin(f))) break;
+    }
+    if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
+  }
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));
+  f->tail_pending = false;
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *n_clusters = ncl;
   return FUELMI_OK;
 }

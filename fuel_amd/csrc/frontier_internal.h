@@ -28,12 +28,34 @@ struct FVar {
   int w0;      // first word processed (multiple of 256)
   int nwords;  // words processed (multiple of 256)
   int nblocks; // nwords / 256
-  int pad;
+  int fresh;   // 1: frontier_flag_ counts as all-zero and is rewritten by this search (fuelmi_frontier_reset
+               // folded into the first kernel; the processed words then cover every flag that can be set)
   // Q0 cells can only exist inside the region touched since the last search (scan box, boxes of the
   // clusters just dropped; the whole exploration box after untracked changes): the CCL tiles cover
   // this part of F.qbox only
   Box3 qreg;
   int nty, ntiles;
+  u32 epoch;  // search counter, echoed next to the result the host polls for
+  int pad2;
+};
+
+// ---- fast path of the clustering chain (frontier.hip, "tile-root resolve") ---------------------------------
+// A workgroup labels one spatial tile in LDS (k_ccl_tile) and describes every tile-local component by ONE record;
+// the cross-tile merge, the claims, the cluster sizes, the kept list and its ranking then run on those few
+// thousand records inside a single workgroup's LDS (k_resolve) instead of on the cells through global atomics.
+#define FR_RCAP 8192            // tile-local components per search (8 per-XCD ranges of FR_RC8)
+#define FR_RC8 (FR_RCAP / 8)
+#define FR_TCELL 2048           // Q0 cells per tile
+#define FR_TROOT 128            // components per tile
+#define FR_KCAP 256             // kept clusters (one 8-bit multisplit digit)
+#define FR_PCAP (1u << 18)      // cross-tile adjacency records
+#define FR_UNCLAIMED 0xFFFFFFFFu  // rcode: component claimed by nobody (no flag, no cluster)
+#define FR_NOTKEPT 0xFFFFFFFEu    // rcode: claimed (flag set) but its cluster is too small
+struct TRec {  // one tile-local component
+  u32 size;            // cells
+  u32 sx, sy, sz;      // voxel-index sums
+  u32 lo[3], hi[3];    // index box
+  u32 pad[2];
 };
 
 struct FArgs {
@@ -72,7 +94,25 @@ struct FArgs {
   u32* h_part;            // like info_part
   u32* h_cells;           // [cap_q] grouped cell addresses
   int keys_from_slots;    // multisplit pass 0 derives (key, value) from cell_slot / slot2rank / cell_adr
+  // fast path
+  FVar* var_w;            // == var (the first kernel refreshes it from the pinned host copy)
+  unsigned short* tgid;   // [cap_q] tile-root id of every Q0 cell
+  struct TRec* trec;      // [FR_RCAP]
+  u32* tclaim;            // [FR_RCAP] lowest claimer address of every tile root (own in-box cells, NQ seeds)
+  u32* rcode;             // [FR_RCAP] cluster rank | FR_NOTKEPT | FR_UNCLAIMED per tile root
+  u32* pairs;             // [8][FR_PCAP / 8] distinct pairs of tile roots that touch across a tile face (lo << 16 | hi)
+  u32* fctr;              // [32] [0..7] roots per XCD range, [9] overflow -> legacy chain, [16..23] pairs per XCD
+  u32* cell_rank;         // [cap_q] cluster rank of the kept cells, NOKEY otherwise
+  u32* whist;             // [FR_KCAP][nb] cells per (cluster, 256-word block)
+  int whist_nb;           // row length of whist
+  int fast;               // the result of the last search came from the fast path
+  unsigned long long* dbg;  // FUELMI_FR_TIMING: per-block phase time stamps of the fast chain's kernels (else null)
 };
+#define FR_DBG_SLOTS 16
+#define FR_DBG_MARK(F, blk, k)                                                                   \
+  do {                                                                                           \
+    if ((F).dbg && threadIdx.x == 0) (F).dbg[(size_t)(blk) * FR_DBG_SLOTS + (k)] = wall_clock64(); \
+  } while (0)
 
 #ifdef __HIPCC__
 // compact index of the Q0 cell / NQ seed at voxel address a (valid after k_pred + k_scan_sums of this search)
@@ -162,6 +202,19 @@ struct fuelmi_frontier {
   size_t ccl_lds = 0;
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
   bool pending = false, search_empty = false;
+  // fast path: _search_end returns as soon as the cluster records have arrived; the kernels that regroup the
+  // cells and ship them to the host are still running then.  Everything that reads the cell lists waits here.
+  mutable bool tail_pending = false;
+  bool fast_launched = false;  // the chain of the running search is the fast one
+  u32 epoch = 0;
+  hipGraphExec_t fast_exec = nullptr;
+  hipStream_t copy_stream = nullptr;  // ships the grouped cells of the fast chain to the host
+  hipEvent_t ev_tail = nullptr, ev_copy = nullptr;
+  bool copy_pending = false;
+  bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
+  bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
+  int n_fast = 0, n_legacy = 0, n_fallback = 0;
+  size_t tile_lds = 0, resolve_lds = 0;
   std::unique_ptr<StageScope> scope;
   bool dirty_all = true;    // flags / occupancy changed outside the updated-box bookkeeping
   unsigned seen_epoch = 0;  // map->occ_epoch at the last completed search
@@ -199,6 +252,14 @@ struct PoolPut {  // one cluster's copy into the cell pool
   int seed, pad;
 };
 int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters);
+// wait for the tail of the last search (cell regrouping + copy-out); cheap when nothing is pending
+static inline int frontier_tail_sync(const fuelmi_frontier* f) {
+  if (!f->tail_pending) return FUELMI_OK;
+  f->tail_pending = false;
+  HIPCHK(hipStreamSynchronize(f->stream));
+  if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));  // (the event stays armed for the next search)
+  return FUELMI_OK;
+}
 // between _search_begin and _search_end the cluster lists belong to the running search (its verdicts on
 // changed clusters are applied in _search_end): calls that would modify them are refused
 #define FRONTIER_NOT_SEARCHING(f, what)                                                        \

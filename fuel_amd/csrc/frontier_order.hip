@@ -55,7 +55,7 @@ __device__ __forceinline__ void st_agent(u32* p, u32 v) {
 
 // member neighbours of the cell at address a, in allNeighbors order: calls fn(idx27, compact index)
 template <typename Fn>
-__device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs& F, long a, int slot, Fn fn) {
+__device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs& F, long a, int slot, u32 rank, Fn fn) {
   const int x = (int)(a / g.nyz);
   const int r = (int)(a - (long)x * g.nyz);
   const int y = r / g.nz, z = r - y * g.nz;
@@ -74,7 +74,9 @@ __device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs&
         const int b = __builtin_ctz(bits);
         bits &= bits - 1u;
         const u32 cj = rank_q(F, nb0 + b);
-        if (cj < F.cap_q && F.cell_slot[cj] == slot) fn((dx + 1) * 9 + (dy + 1) * 3 + b, cj);
+        // member of this cluster?  (fast chain: per-cell cluster rank; legacy chain: per-cell claimer slot)
+        if (cj < F.cap_q && (F.fast ? F.cell_rank[cj] == rank : F.cell_slot[cj] == slot))
+          fn((dx + 1) * 9 + (dy + 1) * 3 + b, cj);
       }
     }
   }
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
       const u32 ci = ld_agent(&B.ord_ci[base0 + lev_lo + j]);
       const long a = ci == NOIDX ? (long)kr.addr : (long)F.cell_adr[ci];
       const u32 kbase = (lev_lo + j) * 27u + 1u;
-      for_member_neighbours(g, F, a, slot, [&](int idx27, u32 cj) {
+      for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 cj) {
         (void)__hip_atomic_fetch_min(&B.key[cj], kbase + (u32)idx27, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       });
     }
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
         const u32 ci = ld_agent(&B.ord_ci[base0 + lev_lo + j]);
         a = ci == NOIDX ? (long)kr.addr : (long)F.cell_adr[ci];
         const u32 kbase = (lev_lo + j) * 27u + 1u;
-        for_member_neighbours(g, F, a, slot, [&](int idx27, u32 cj) {
+        for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 cj) {
           if (ld_agent(&B.key[cj]) == kbase + (u32)idx27) wmask |= 1u << idx27;
         });
       }

@@ -292,6 +292,17 @@ class FrontierFinder:
     def reset(self):
         check(self.L.fuelmi_frontier_reset(self.h))
 
+    def sync(self):
+        """wait for everything the finder has queued (incl. the regrouping tail of the last search)"""
+        from ._lib import check as _c
+        _c(self.L.fuelmi_frontier_synchronize(self.h))
+
+    def stats(self):
+        """(searches on the fast chain, on the legacy chain, fast-chain searches that fell back)"""
+        o = (C.c_int * 3)()
+        check(self.L.fuelmi_frontier_stats(self.h, o))
+        return tuple(o)
+
     def clusters(self, which=0):
         out = []
         cnt = self.L.fuelmi_frontier_count(self.h, which)

@@ -177,6 +177,13 @@ void fuelmi_frontier_destroy(fuelmi_frontier* f);
 /* forget all clusters and clear frontier_flag_ (== constructing a fresh FrontierFinder,
  * frontier_finder.cpp:23-27) */
 int fuelmi_frontier_reset(fuelmi_frontier* f);
+/* diagnostics: searches answered by the fast clustering chain [0], by the legacy chain [1], and searches that
+ * started on the fast chain and fell back because an input exceeded one of its capacities [2] */
+int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]);
+/* waits for everything queued on the finder's stream.  fuelmi_frontier_search_end returns as soon as the cluster
+ * records have arrived; the regrouping of the cells and their copy to the host finish behind it (calls that read
+ * cell lists wait by themselves) */
+int fuelmi_frontier_synchronize(fuelmi_frontier* f);
 /* Viewpoint sampling and coverage (frontier_finder.cpp:392-423,662-755,697-719; camera frustum
  * perception_utils.cpp:6-19,49-69,84-93).  Fields are the ROS parameters of the same names. */
 typedef struct {
@@ -327,6 +334,14 @@ int fuelmi_bspline_boundary_states(fuelmi_map* m, int n_traj, int n_ctrl, int de
  * control points, knot span ts, pt_dist_, start state (pos, vel, acc) and end position; asynchronous on
  * the map's stream, the next _dev_eval / _dev_optimize uses them.  Rows 1..2 of end_state keep what
  * the batch was created with (the planners pass end_n = 1). */
+/* Measurement driver: n full-box plan cycles issued back to back from C++ (no interpreter between the calls) --
+ * per cycle fuelmi_frontier_reset, fuelmi_map_set_updated_box(ub_min, ub_max), fuelmi_frontier_search_begin,
+ * fuelmi_map_inflate_local, fuelmi_map_update_esdf, fuelmi_bspline_dev_eval(batch) (batch may be NULL),
+ * fuelmi_frontier_search_end; with `serial` != 0 the search runs after the map chain instead of beside it.
+ * Both streams are drained before the clock starts and before it stops.  *n_clusters: clusters of the last
+ * search; *seconds: elapsed wall time. */
+int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, const double ub_min[3],
+                        const double ub_max[3], int n, int serial, int* n_clusters, double* seconds);
 int fuelmi_bspline_dev_load_samples(fuelmi_bspline_dev* b, int n_points, const double* ts, const double* points,
                                     const double* derivs);
 
