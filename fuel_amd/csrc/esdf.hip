@@ -435,6 +435,130 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   }
 }
 
+// Persistent, software-pipelined x pass: a workgroup walks over column tiles; while it scans tile k out of the
+// LDS, the global loads of tile k + 1 are already in flight into registers (P = ceil(xlen / rows) uint4 per lane),
+// so the HBM fetch runs BESIDE the scan instead of in front of it (k_esdf_x4 does load -> barrier -> scan per
+// tile, and with one or two resident workgroups per CU nothing overlaps the fetch).
+template <int OUT, int P>
+__global__ void __launch_bounds__(1024)
+k_esdf_x4p(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, int ntiles) {
+  constexpr int SEGS = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int ncol = ylen * zlen_a;
+  const int seg = threadIdx.x & (SEGS - 1);
+  const int row0 = threadIdx.x / SEGS;  // 0..127
+  constexpr int rows = 1024 / SEGS;
+  const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
+  const float resf = (float)g.res;
+  uint4 nxt[P];
+  // (a macro, not a lambda: capturing the array by reference sent it to scratch memory)
+#define X4P_FETCH(T)                                                                                             \
+  {                                                                                                              \
+    const int t_ = (T);                                                                                          \
+    const int col_ = t_ * (4 * SEGS) + seg * 4;                                                                  \
+    const bool valid_ = t_ < ntiles && col_ < ncol;                                                              \
+    const int yy_ = valid_ ? col_ / zlen_a : 0;                                                                  \
+    const int z_ = z0a + (valid_ ? col_ - yy_ * zlen_a : 0);                                                     \
+    const u32* src_ = tmp + (long)b.lo[0] * g.nyz + (long)(b.lo[1] + yy_) * g.nz + z_;                          \
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {                                                              \
+      const int xi_ = row0 + p * rows;                                                                           \
+      nxt[p] = inf4;                                                                                             \
+      if (valid_ && xi_ < xlen) nxt[p] = *reinterpret_cast<const uint4*>(src_ + (long)xi_ * g.nyz);             \
+    }                                                                                                            \
+  }
+  X4P_FETCH(blockIdx.x)
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int xi = row0 + p * rows;
+      if (xi < xlen) tile[xi * SEGS + seg] = nxt[p];
+    }
+    __syncthreads();
+    X4P_FETCH(t + (int)gridDim.x)  // in flight during the scan below
+    const int col = t * (4 * SEGS) + seg * 4;
+    const bool valid = col < ncol;
+    const int yy = valid ? col / zlen_a : 0;
+    const int z = z0a + (valid ? col - yy * zlen_a : 0);
+    const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
+    const bool full = z >= b.lo[2] && z + 3 <= b.hi[2];
+    if (valid)
+      for (int xi = row0; xi < xlen; xi += rows) {
+        uint4 bb = tile[xi * SEGS + seg];
+        u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
+        const int rmax = max(xi, xlen - 1 - xi);
+        for (int r = 1; r <= rmax && (u32)(r * r) < mx; r += 2) {
+          const u32 rr = (u32)(r * r), rr2 = (u32)((r + 1) * (r + 1));
+          const uint4 va = tile[max(xi - r, 0) * SEGS + seg];
+          const uint4 vb = tile[min(xi + r, xlen - 1) * SEGS + seg];
+          const uint4 vc = tile[max(xi - r - 1, 0) * SEGS + seg];
+          const uint4 vd = tile[min(xi + r + 1, xlen - 1) * SEGS + seg];
+          bb.x = min(bb.x, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
+          bb.y = min(bb.y, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
+          bb.z = min(bb.z, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
+          bb.w = min(bb.w, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
+          mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
+        }
+        float* dst = dist + (long)(b.lo[0] + xi) * g.nyz + coloff;
+        if (OUT == 0) {
+          if (full) {
+            *reinterpret_cast<float4*>(dst) =
+                make_float4(esdf_out(bb.x, resf), esdf_out(bb.y, resf), esdf_out(bb.z, resf), esdf_out(bb.w, resf));
+          } else {
+            if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_out(bb.x, resf);
+            if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_out(bb.y, resf);
+            if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_out(bb.z, resf);
+            if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_out(bb.w, resf);
+          }
+        } else {
+          if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_merge_neg(dst[0], bb.x, resf);
+          if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_merge_neg(dst[1], bb.y, resf);
+          if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_merge_neg(dst[2], bb.z, resf);
+          if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_merge_neg(dst[3], bb.w, resf);
+        }
+      }
+    __syncthreads();  // the tile is rewritten at the top of the next trip
+  }
+#undef X4P_FETCH
+}
+
+template <int OUT, int P>
+static int launch_x4p_n(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
+  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
+  const int zlen_a = z1a - z0a + 1;
+  const size_t lds = (size_t)xlen * 8 * 4 * sizeof(u32);
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4p<OUT, P>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int ncol = ylen * zlen_a;
+  const int ntiles = (ncol + 31) / 32;
+  static const char* xg = getenv("FUELMI_X_GRID");  // tuning hook: workgroups per CU
+  const int per_cu = xg ? atoi(xg) : std::max(1, std::min(2, (int)((150 * 1024) / std::max<size_t>(lds, 1))));
+  const int grid = std::min(ntiles, 256 * per_cu);
+  STAGE_LAUNCH(m, (k_esdf_x4p<OUT, P>), grid, 1024, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a, ntiles);
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+template <int OUT>
+static int launch_x4p(fuelmi_map* m, const Box3& b) {
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  switch ((xlen + 127) / 128) {
+    case 1: return launch_x4p_n<OUT, 1>(m, b);
+    case 2: return launch_x4p_n<OUT, 2>(m, b);
+    case 3: return launch_x4p_n<OUT, 3>(m, b);
+    case 4: return launch_x4p_n<OUT, 4>(m, b);
+    case 5: return launch_x4p_n<OUT, 5>(m, b);
+    case 6: return launch_x4p_n<OUT, 6>(m, b);
+    case 7: return launch_x4p_n<OUT, 7>(m, b);
+    case 8: return launch_x4p_n<OUT, 8>(m, b);
+    default: return -1;
+  }
+}
+
 static inline bool use_vec4(const Geo& g, int xlen) { return (g.nz % 4) == 0 && (size_t)xlen * 64 <= 150 * 1024; }
 
 template <int MODE>
@@ -488,6 +612,15 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
 template <int OUT>
 static int launch_x4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
+  static const bool piped = getenv("FUELMI_X_NOPIPE") == nullptr;
+  if (piped && (size_t)xlen * 128 <= 150 * 1024) {
+    // big enough to keep every CU busy for several tiles? small boxes keep the one-tile-per-workgroup kernel
+    const int ylen = b.hi[1] - b.lo[1] + 1, zlen_a = (b.hi[2] | 3) - (b.lo[2] & ~3) + 1;
+    if ((long)ylen * zlen_a / 32 >= 512) {
+      const int rc = launch_x4p<OUT>(m, b);
+      if (rc >= 0) return rc;
+    }
+  }
   static const char* force = getenv("FUELMI_X_SEGS");  // tuning hook: "4" or "8"
   // the 32-column tile is faster whenever it fits (measured on 800-voxel lines: 0.32 vs 0.37 ms), the
   // 16-column one extends the vector path to x lines of up to 2400 voxels

@@ -1228,10 +1228,10 @@ __device__ __forceinline__ void cacc_atomic(u32* acc /* [11] in LDS */, const CA
 // per-segment popcounts), so a tile costs ~35 KiB of LDS whatever nz is.
 template <int NT>
 __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY) {
-  if ((int)blockIdx.x >= F.var->ntiles) return;
+  if ((int)blockIdx.x >= F.var->ntiles_f) return;
   const Box3 QR = F.var->qreg;
   const Box3 sbox = F.var->sbox;
-  const int nty = F.var->nty;
+  const int nty = F.var->nty_f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nz = g.nz, nseg = (nz + 31) >> 5;
   const int items = TX * TY * nseg;
@@ -1284,7 +1284,7 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
   FR_DBG_MARK(F, blockIdx.x, 1);
   if (total == 0u) return;
   if (total > FR_TCELL) {
-    if (threadIdx.x == 0) F.fctr[9] = 1u;
+    if (threadIdx.x == 0) F.fctr[9] = 11u;  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
     return;
   }
   if (threadIdx.x == 0) segpre[items] = total;
@@ -1371,7 +1371,7 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
   __syncthreads();
   const u32 nroots = s_nroots;
   if (nroots > FR_TROOT) {
-    if (threadIdx.x == 0) F.fctr[9] = 1u;
+    if (threadIdx.x == 0) F.fctr[9] = 12u;
     return;
   }
   // ---- ids of the components: one contiguous range per tile inside the XCD's part of the id space (the
@@ -1380,7 +1380,7 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
     const u32 xcd = blockIdx.x & 7u;
     const u32 b = atomicAdd(&F.fctr[xcd], nroots);
     if (b + nroots > FR_RC8) {
-      F.fctr[9] = 1u;
+      F.fctr[9] = 13u;
       s_flag = 1u;
     }
     s_base = xcd * FR_RC8 + b;
@@ -1452,7 +1452,7 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
 #define XC_SET 256
 __global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F, int TX, int TY) {
   if (F.fctr[9]) return;
-  const int ntiles = F.var->ntiles;
+  const int ntiles = F.var->ntiles_f;
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x >= ntiles) {
     // ---- seeds: one lane per (seed, neighbour z-line) -- nine independent short chains per seed instead of one
@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F, int TX, int TY) {
   __shared__ u32 s_list[XC_SET];       // ... in insertion order
   __shared__ u32 s_n, s_base;
   const Box3 QR = F.var->qreg;
-  const int nty = F.var->nty;
+  const int nty = F.var->nty_f;
   const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
   const int x0 = QR.lo[0] + tx * TX, y0 = QR.lo[1] + ty * TY;
   const int nxl = min(TX, QR.hi[0] - x0 + 1), nyl = min(TY, QR.hi[1] - y0 + 1);
@@ -1586,7 +1586,7 @@ __global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F, int TX, int TY) {
               done = true;
             h = (h + 1u) & (XC_SET - 1u);
           }
-          if (!done) F.fctr[9] = 1u;  // more than XC_SET distinct root pairs around one tile
+          if (!done) F.fctr[9] = 15u;  // more than XC_SET distinct root pairs around one tile
         }
       }
     }
@@ -1601,7 +1601,7 @@ __global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F, int TX, int TY) {
   FR_DBG_MARK(F, blockIdx.x, 12);
   const u32 base = s_base;
   if (base + n > FR_PCAP / 8u) {
-    if (threadIdx.x == 0) F.fctr[9] = 1u;
+    if (threadIdx.x == 0) F.fctr[9] = 14u;
     return;
   }
   if (threadIdx.x < n) F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x] = s_list[threadIdx.x];
@@ -1644,7 +1644,7 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
     }
     s_pre[8] = run;
   }
-  const int dblk = F.var->ntiles;  // time stamps of this kernel go behind those of the tiles
+  const int dblk = F.var->ntiles_f;  // time stamps of this kernel go behind those of the tiles
   FR_DBG_MARK(F, dblk, 0);
   __syncthreads();
   const bool dead = s_ovf != 0u;  // an earlier kernel hit a capacity limit: report, leave everything untouched
@@ -1673,14 +1673,18 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   __syncthreads();
   FR_DBG_MARK(F, dblk, 1);
   if (!dead) {
-    // ---- cross-tile unions (one list of distinct root pairs per XCD) ----
-    for (u32 xc = 0; xc < 8u; ++xc) {
-      const u32 np = min(F.fctr[16 + xc], FR_PCAP / 8u);
-      const u32* lst = F.pairs + (size_t)xc * (FR_PCAP / 8u);
-      for (u32 p = threadIdx.x; p < np; p += RS_T) {
-        const u32 key = lst[p];
-        lds_union_h(par, dense_of(key >> 16), dense_of(key & 0xFFFFu));
-      }
+    // ---- cross-tile unions (one list of distinct root pairs per XCD, walked as one sequence so that all
+    // lanes are busy at once) ----
+    u32 pp[9];
+    pp[0] = 0u;
+#pragma unroll
+    for (int xc = 0; xc < 8; ++xc) pp[xc + 1] = pp[xc] + min(F.fctr[16 + xc], FR_PCAP / 8u);
+    for (u32 p = threadIdx.x; p < pp[8]; p += RS_T) {
+      u32 xc = 0u;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) xc += p >= pp[k] ? 1u : 0u;
+      const u32 key = F.pairs[(size_t)xc * (FR_PCAP / 8u) + (p - pp[xc])];
+      lds_union_h(par, dense_of(key >> 16), dense_of(key & 0xFFFFu));
     }
   }
   __syncthreads();
@@ -1799,23 +1803,33 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
         A.sx = T.sx, A.sy = T.sy, A.sz = T.sz, A.lx = T.lo[0], A.ly = T.lo[1], A.lz = T.lo[2];
         A.hx = T.hi[0], A.hy = T.hi[1], A.hz = T.hi[2];
       }
-      u64 todo = __ballot(kept);
-      while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const u32 first = (u32)__shfl((int)e, leader, 64);
+      // the cluster most of the wave's roots belong to (the giant surface) is reduced across the lanes; the few
+      // roots of other clusters add themselves (distinct LDS words, no contention to speak of)
+      const u64 km = __ballot(kept);
+      if (km) {
+        u32 first = (u32)__shfl((int)e, __builtin_ctzll(km), 64);
+        {  // majority vote between the first two distinct clusters of the wave
+          const u64 same = __ballot(kept && e == first);
+          const u64 rest = km & ~same;
+          if (rest) {
+            const u32 second = (u32)__shfl((int)e, __builtin_ctzll(rest), 64);
+            if (__popcll(__ballot(kept && e == second)) > __popcll(same)) first = second;
+          }
+        }
         const bool mine = kept && e == first;
-        CAcc B = A;
-        if (!mine) B.sx = B.sy = B.sz = 0u, B.lx = B.ly = B.lz = 0xFFFFFFFFu, B.hx = B.hy = B.hz = 0u;
-        cacc_reduce(B);
-        if (lane == leader) {
-          unsigned long long* qs = ksum + first * 3u;
-          u32* q = kbox + first * 6u;
+        auto add = [&](u32 ke, const CAcc& B) {
+          unsigned long long* qs = ksum + ke * 3u;
+          u32* q = kbox + ke * 6u;
           atomicAdd(&qs[0], (unsigned long long)B.sx), atomicAdd(&qs[1], (unsigned long long)B.sy);
           atomicAdd(&qs[2], (unsigned long long)B.sz);
           atomicMin(&q[0], B.lx), atomicMin(&q[1], B.ly), atomicMin(&q[2], B.lz);
           atomicMax(&q[3], B.hx), atomicMax(&q[4], B.hy), atomicMax(&q[5], B.hz);
-        }
-        todo &= ~__ballot(mine);
+        };
+        if (kept && !mine) add(e, A);
+        CAcc B = A;
+        if (!mine) B.sx = B.sy = B.sz = 0u, B.lx = B.ly = B.lz = 0xFFFFFFFFu, B.hx = B.hy = B.hz = 0u;
+        cacc_reduce(B);
+        if (lane == __builtin_ctzll(__ballot(mine))) add(first, B);
       }
     }
   }
@@ -1839,6 +1853,7 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   }
   if (threadIdx.x == 0) {
     F.counts[2] = bad ? 2u : 0u;  // 2: capacity of the fast path exceeded -> the host runs the legacy chain
+    F.counts[6] = dead ? F.fctr[9] : (s_ovf ? 16u : 0u);  // which one
     F.counts[3] = bad ? 0u : nk;
     F.counts[5] = bad ? 0u : s_nout;
     F.fctr[9] = bad ? 1u : 0u;
@@ -2179,9 +2194,18 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local<512>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->ccl_lds));
     }
-    // fast path: sparse labels, the same tile grid
-    const size_t items = (size_t)TX * TY * ((g.nz + 31) / 32);
-    f->tile_lds = (FR_TCELL + 2 * items + 1 + 2 * (size_t)TX + (size_t)FR_TROOT * 11) * sizeof(u32) + FR_TCELL * sizeof(unsigned short);
+    // fast path: sparse labels -- the tile is not bound by nz.  32 z-lines deep, 8 wide, 16 wide once that
+    // still leaves >= 512 tiles (measured on 400^2 x 100 and 800^2 x 200 maps: fewer tile roots and face pairs
+    // for k_cross / k_resolve outweigh the longer tiles); FUELMI_FTILE = "TXxTY" overrides
+    f->FTY = 32;
+    f->FTX = ((qx + 15) / 16) * ((qy + 31) / 32) >= 512 ? 16 : 8;
+    if (const char* e = getenv("FUELMI_FTILE")) {
+      int a = 0, b = 0;
+      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && a <= 20 && b > 0 && b <= 64) f->FTX = a, f->FTY = b;
+    }
+    f->fast_tiles = ((qx + f->FTX - 1) / f->FTX) * ((qy + f->FTY - 1) / f->FTY);
+    const size_t items = (size_t)f->FTX * f->FTY * ((g.nz + 31) / 32);
+    f->tile_lds = (FR_TCELL + 2 * items + 1 + 2 * (size_t)f->FTX + (size_t)FR_TROOT * 11) * sizeof(u32) + FR_TCELL * sizeof(unsigned short);
     f->tile_lds = (f->tile_lds + 15) & ~(size_t)15;
     if (f->tile_lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_tile<512>),
@@ -2417,9 +2441,9 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
   FDBG("k_pred2");
   k_compact2<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_compact2");
-  k_ccl_tile<512><<<f->ccl_tiles, 512, f->tile_lds, f->stream>>>(g, F, f->TX, f->TY);
+  k_ccl_tile<512><<<f->fast_tiles, 512, f->tile_lds, f->stream>>>(g, F, f->FTX, f->FTY);
   FDBG("k_ccl_tile");
-  k_cross<<<f->ccl_tiles + 192, 256, 0, f->stream>>>(g, F, f->TX, f->TY);
+  k_cross<<<f->fast_tiles + 192, 256, 0, f->stream>>>(g, F, f->FTX, f->FTY);
   FDBG("k_cross");
   k_resolve<<<1, RS_T, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
@@ -2504,10 +2528,13 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   if (!have_q)
     for (int k = 0; k < 3; ++k) hv.qreg.lo[k] = 1, hv.qreg.hi[k] = 0;
   hv.nty = hv.ntiles = 0;
+  hv.nty_f = hv.ntiles_f = 0;
   if (have_q) {
     const int qx = hv.qreg.hi[0] - hv.qreg.lo[0] + 1, qy = hv.qreg.hi[1] - hv.qreg.lo[1] + 1;
     hv.nty = (qy + f->TY - 1) / f->TY;
     hv.ntiles = ((qx + f->TX - 1) / f->TX) * hv.nty;  // <= f->ccl_tiles (tiles of the whole Q box)
+    hv.nty_f = (qy + f->FTY - 1) / f->FTY;
+    hv.ntiles_f = ((qx + f->FTX - 1) / f->FTX) * hv.nty_f;
   }
   // words to process: the x-slabs of the region plus one slab either side (neighbour look-ups of the
   // claims / unions read the Q0 plane there: it must not hold bits of an earlier search)
@@ -2635,7 +2662,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     F.fast = 1;
     if (F.dbg) {  // FUELMI_FR_TIMING: where the tile kernel and the resolve kernel spend their time (100 MHz ticks)
       (void)hipStreamSynchronize(f->stream);
-      const int nt = f->h_var->ntiles;
+      const int nt = f->h_var->ntiles_f;
       std::vector<unsigned long long> d((size_t)(nt + 1) * FR_DBG_SLOTS);
       (void)hipMemcpy(d.data(), F.dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       unsigned long long t0 = ~0ull, t1 = 0;
@@ -2687,6 +2714,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       // a capacity of the fast path was exceeded (noise-like input): nothing was modified; run the legacy chain
       --f->n_fast;
       ++f->n_fallback;
+      if (getenv("FUELMI_FR_TIMING")) std::fprintf(stderr, "[fr-timing] fallback to the legacy chain: capacity code %u\n", counts[6]);
       HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
       F.fast = 0;
       f->npass = 1;

@@ -37,6 +37,7 @@ struct FVar {
   int nty, ntiles;
   u32 epoch;  // search counter, echoed next to the result the host polls for
   int pad2;
+  int nty_f, ntiles_f;  // tile grid of the fast chain (its tiles are sized independently of the legacy ones)
 };
 
 // ---- fast path of the clustering chain (frontier.hip, "tile-root resolve") ---------------------------------
@@ -45,7 +46,7 @@ struct FVar {
 // thousand records inside a single workgroup's LDS (k_resolve) instead of on the cells through global atomics.
 #define FR_RCAP 8192            // tile-local components per search (8 per-XCD ranges of FR_RC8)
 #define FR_RC8 (FR_RCAP / 8)
-#define FR_TCELL 2048           // Q0 cells per tile
+#define FR_TCELL 4096           // Q0 cells per tile
 #define FR_TROOT 128            // components per tile
 #define FR_KCAP 256             // kept clusters (one 8-bit multisplit digit)
 #define FR_PCAP (1u << 18)      // cross-tile adjacency records
@@ -199,6 +200,7 @@ struct fuelmi_frontier {
   FVar* h_var = nullptr;  // pinned per-search arguments
   FVar* d_var = nullptr;
   int TX = 1, TY = 16, ccl_tiles = 0;
+  int FTX = 8, FTY = 16, fast_tiles = 0;  // tiles of the fast chain (sparse labels: no LDS bound from nz)
   size_t ccl_lds = 0;
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
   bool pending = false, search_empty = false;
