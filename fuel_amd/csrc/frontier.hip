@@ -1343,7 +1343,12 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
     int lx, ly, z;
     locate(t, ci, a, lx, ly, z, l);
     const int line = lx * TY + ly, c = z >> 5, zz = z & 31;
-    if (zz == 0 && c > 0 && (segb[line * nseg + c - 1] >> 31)) lds_union_h(lab, l, l - 1);
+    const bool seam = zz == 0 && c > 0 && (segb[line * nseg + c - 1] >> 31);
+    if (seam) lds_union_h(lab, l, l - 1);
+    // a cell whose z-predecessor is a cell too (same z-run) shares that cell's windows except for the voxel
+    // z + 1 of each lower line -- and that one only matters when it starts a new run there (its line's voxel z is
+    // empty): walls (long z-runs) cost one look per cell and line instead of a union
+    const bool has_prev = seam || (zz > 0 && ((segb[line * nseg + c] >> (zz - 1)) & 1u));
     for (int k = 0; k < 4; ++k) {
       const int nlx = lx + (k < 3 ? -1 : 0), nly = ly + (k < 3 ? k - 1 : -1);
       if (nlx < 0 || nly < 0 || nly >= TY) continue;
@@ -1354,6 +1359,7 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
           ((s0 + 1 < nseg) ? ((unsigned long long)segb[nline * nseg + s0 + 1] << 32) : 0ull);
       u32 pat = (zlo >= 0) ? (u32)((w >> (zlo - 32 * s0)) & 7ull) : (u32)((w << 1) & 6ull);
       if (z + 1 >= nz) pat &= 3u;
+      if (has_prev) pat = (pat & 6u) == 4u ? 4u : 0u;
       if (!pat) continue;
       const u32 ln = local_of(nline, zlo + __builtin_ctz(pat));
       lds_union_h(lab, l, ln);
