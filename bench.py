@@ -31,6 +31,7 @@ WORKLOADS = {
     "G400": ((40.0, 40.0, 10.0), 400, 120),
     "G800": ((80.0, 80.0, 20.0), 3200, 960),
     "G100": ((10.0, 10.0, 5.0), 25, 8),  # smoke-sized
+    "G200": ((20.0, 20.0, 5.0), 100, 30),  # fleet test: four of these share one GPU
     # streaming variants (BASELINE config #4): the map starts unknown, one 640x480 depth frame per step
     # (sparser worlds than the full-box recipe, so that a frame sees several metres of free space)
     "G800S": ((80.0, 80.0, 20.0), 600, 0),
