@@ -1227,8 +1227,9 @@ __device__ __forceinline__ void cacc_atomic(u32* acc /* [11] in LDS */, const CA
 // Tile CCL.  Labels are SPARSE (one per Q0 cell of the tile, addressed through a tile-local prefix of the
 // per-segment popcounts), so a tile costs ~35 KiB of LDS whatever nz is.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY) {
+__global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F) {
   if ((int)blockIdx.x >= F.var->ntiles_f) return;
+  const int TX = F.var->ftx, TY = F.var->fty;
   const Box3 QR = F.var->qreg;
   const Box3 sbox = F.var->sbox;
   const int nty = F.var->nty_f;
@@ -1456,8 +1457,9 @@ __global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F, int TX, int TY)
 // the same pair from all of its cells) -- a few thousand records per search instead of one per adjacent cell
 // pair.  Blocks beyond: NQ seeds claim the tile roots touching their 26-neighbourhood (the seed half of k_claim).
 #define XC_SET 256
-__global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F, int TX, int TY) {
+__global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F) {
   if (F.fctr[9]) return;
+  const int TX = F.var->ftx, TY = F.var->fty;
   const int ntiles = F.var->ntiles_f;
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x >= ntiles) {
@@ -2056,7 +2058,8 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   frontier_order_free(f);
   for (hipGraphExec_t e : f->graph_exec)
     if (e) (void)hipGraphExecDestroy(e);
-  if (f->fast_exec) (void)hipGraphExecDestroy(f->fast_exec);
+  for (hipGraphExec_t e : f->fast_exec)
+    if (e) (void)hipGraphExecDestroy(e);
   Plane* pl[] = {&f->flag, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
@@ -2203,15 +2206,17 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     // fast path: sparse labels -- the tile is not bound by nz.  32 z-lines deep, 8 wide, 16 wide once that
     // still leaves >= 512 tiles (measured on 400^2 x 100 and 800^2 x 200 maps: fewer tile roots and face pairs
     // for k_cross / k_resolve outweigh the longer tiles); FUELMI_FTILE = "TXxTY" overrides
-    f->FTY = 32;
-    f->FTX = ((qx + 15) / 16) * ((qy + 31) / 32) >= 512 ? 16 : 8;
+    // The tile of a search is picked from a menu by the size of its region (frontier_pick_tile); the launch grid
+    // and the LDS budget are those of the extremes.
+    f->FTX = f->FTY = 0;
     if (const char* e = getenv("FUELMI_FTILE")) {
       int a = 0, b = 0;
-      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && a <= 20 && b > 0 && b <= 64) f->FTX = a, f->FTY = b;
+      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && a <= 16 && b > 0 && b <= 32) f->FTX = a, f->FTY = b;
     }
-    f->fast_tiles = ((qx + f->FTX - 1) / f->FTX) * ((qy + f->FTY - 1) / f->FTY);
-    const size_t items = (size_t)f->FTX * f->FTY * ((g.nz + 31) / 32);
-    f->tile_lds = (FR_TCELL + 2 * items + 1 + 2 * (size_t)f->FTX + (size_t)FR_TROOT * 11) * sizeof(u32) + FR_TCELL * sizeof(unsigned short);
+    f->fast_tiles = ((qx + 3) / 4) * ((qy + 7) / 8);  // smallest tile of the menu over the whole Q box
+    if (f->FTX) f->fast_tiles = ((qx + f->FTX - 1) / f->FTX) * ((qy + f->FTY - 1) / f->FTY);
+    const size_t items = (size_t)(f->FTX ? f->FTX * f->FTY : 16 * 32) * ((g.nz + 31) / 32);
+    f->tile_lds = (FR_TCELL + 2 * items + 1 + 2 * (size_t)16 + (size_t)FR_TROOT * 11) * sizeof(u32) + FR_TCELL * sizeof(unsigned short);
     f->tile_lds = (f->tile_lds + 15) & ~(size_t)15;
     if (f->tile_lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_tile<512>),
@@ -2439,17 +2444,22 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
 }
 
 // the fast chain (capturable); falls back to the legacy one through counts[2] == 2
+static const int kFastMenu[4][2] = {{16, 32}, {8, 32}, {8, 16}, {4, 8}};
 static int frontier_enqueue_fast(fuelmi_frontier* f) {
   const Geo& g = f->map->g;
   FArgs& F = f->F;
   const int nb_max = (g.W + 255) / 256 + 1;
+  // launch grid of the tile kernels: the chosen tile over the whole Q box (the search's region is a part of it)
+  const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 1, qy = F.qbox.hi[1] - F.qbox.lo[1] + 1;
+  const int ftx = f->FTX ? f->FTX : kFastMenu[f->fast_menu][0], fty = f->FTX ? f->FTY : kFastMenu[f->fast_menu][1];
+  const int tiles = ((qx + ftx - 1) / ftx) * ((qy + fty - 1) / fty);
   k_pred2<<<nb_max, 256, 0, f->stream>>>(g, F, f->h_var);
   FDBG("k_pred2");
   k_compact2<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_compact2");
-  k_ccl_tile<512><<<f->fast_tiles, 512, f->tile_lds, f->stream>>>(g, F, f->FTX, f->FTY);
+  k_ccl_tile<512><<<tiles, 512, f->tile_lds, f->stream>>>(g, F);
   FDBG("k_ccl_tile");
-  k_cross<<<f->fast_tiles + 192, 256, 0, f->stream>>>(g, F, f->FTX, f->FTY);
+  k_cross<<<tiles + 192, 256, 0, f->stream>>>(g, F);
   FDBG("k_cross");
   k_resolve<<<1, RS_T, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
@@ -2535,12 +2545,27 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     for (int k = 0; k < 3; ++k) hv.qreg.lo[k] = 1, hv.qreg.hi[k] = 0;
   hv.nty = hv.ntiles = 0;
   hv.nty_f = hv.ntiles_f = 0;
+  hv.ftx = 4, hv.fty = 8;
   if (have_q) {
     const int qx = hv.qreg.hi[0] - hv.qreg.lo[0] + 1, qy = hv.qreg.hi[1] - hv.qreg.lo[1] + 1;
     hv.nty = (qy + f->TY - 1) / f->TY;
     hv.ntiles = ((qx + f->TX - 1) / f->TX) * hv.nty;  // <= f->ccl_tiles (tiles of the whole Q box)
-    hv.nty_f = (qy + f->FTY - 1) / f->FTY;
-    hv.ntiles_f = ((qx + f->FTX - 1) / f->FTX) * hv.nty_f;
+    // tile of this search: 32 z-lines deep and 16 or 8 wide while that leaves >= 512 tiles (measured on full
+    // 400^2 x 100 / 800^2 x 200 boxes: fewer tile roots and face pairs outweigh the longer tiles); smaller
+    // tiles for small regions (a streaming search covers ~100 x 100 lines: a handful of big tiles would run
+    // one after the other on a handful of CUs)
+    int pick = 3;
+    for (int k = 0; k < 4; ++k)
+      if (((qx + kFastMenu[k][0] - 1) / kFastMenu[k][0]) * ((qy + kFastMenu[k][1] - 1) / kFastMenu[k][1]) >= 512) {
+        pick = k;
+        break;
+      }
+    f->fast_menu = pick;
+    int ftx = kFastMenu[pick][0], fty = kFastMenu[pick][1];
+    if (f->FTX) ftx = f->FTX, fty = f->FTY;
+    hv.ftx = ftx, hv.fty = fty;
+    hv.nty_f = (qy + fty - 1) / fty;
+    hv.ntiles_f = ((qx + ftx - 1) / ftx) * hv.nty_f;
   }
   // words to process: the x-slabs of the region plus one slab either side (neighbour look-ups of the
   // claims / unions read the Q0 plane there: it must not hold bits of an earlier search)
@@ -2585,17 +2610,18 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   if (fast) {
     f->fast_launched = true;
     if (no_graph) return frontier_enqueue_fast(f);
-    if (!f->fast_exec) {
+    hipGraphExec_t& fexec = f->fast_exec[f->FTX ? 0 : f->fast_menu];
+    if (!fexec) {
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
       const int rc2 = frontier_enqueue_fast(f);
       const hipError_t ec = hipStreamEndCapture(f->stream, &graph);
       if (rc2) return rc2;
       HIPCHK(ec);
-      HIPCHK(hipGraphInstantiate(&f->fast_exec, graph, nullptr, nullptr, 0));
+      HIPCHK(hipGraphInstantiate(&fexec, graph, nullptr, nullptr, 0));
       HIPCHK(hipGraphDestroy(graph));
     }
-    HIPCHK(hipGraphLaunch(f->fast_exec, f->stream));
+    HIPCHK(hipGraphLaunch(fexec, f->stream));
     return FUELMI_OK;
   }
   if (no_graph) return frontier_enqueue_chain(f, f->npass);

@@ -38,6 +38,7 @@ struct FVar {
   u32 epoch;  // search counter, echoed next to the result the host polls for
   int pad2;
   int nty_f, ntiles_f;  // tile grid of the fast chain (its tiles are sized independently of the legacy ones)
+  int ftx, fty;         // ... and its tile, chosen per search: few big tiles would serialise a small region
 };
 
 // ---- fast path of the clustering chain (frontier.hip, "tile-root resolve") ---------------------------------
@@ -209,7 +210,8 @@ struct fuelmi_frontier {
   mutable bool tail_pending = false;
   bool fast_launched = false;  // the chain of the running search is the fast one
   u32 epoch = 0;
-  hipGraphExec_t fast_exec = nullptr;
+  hipGraphExec_t fast_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // one per tile of the menu (launch grids differ)
+  int fast_menu = 0;  // menu entry of the running search
   hipStream_t copy_stream = nullptr;  // ships the grouped cells of the fast chain to the host
   hipEvent_t ev_tail = nullptr, ev_copy = nullptr;
   bool copy_pending = false;

@@ -26,7 +26,10 @@ struct InsertArgs {
   u64* miss;
   u32* owner;
   unsigned char* flag_rayend;
-  u64* bbox;     // [6] sortable-encoded min xyz, max xyz
+  u64* h_out;    // pinned host: [0..5] sortable-encoded min xyz, max xyz of camera + end points, [6] projected
+                 // points of the frame, [7] frame stamp (written last)
+  u64* head;     // device: [6] projected points (depth front end), re-zeroed here for the next frame
+  u64 epoch;
   u64* partial;  // [classify blocks][6] per-block boxes, folded by block 0 of k_insert_raycast
   int nblk;      // classify blocks
 };
@@ -41,12 +44,6 @@ static inline double dec_f64(u64 e) {
   memcpy(&d, &u, sizeof(d));
   return d;
 }
-static inline u64 enc_f64_host(double d) {
-  u64 u;
-  memcpy(&u, &d, sizeof(u));
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-
 __device__ __forceinline__ bool in_map_pos(const Geo& g, const double p[3]) {
   for (int i = 0; i < 3; ++i)
     if (p[i] < g.minb[i] + 1e-4) return false;
@@ -195,10 +192,18 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     __syncthreads();
     if (threadIdx.x < 6) {
       const int k = threadIdx.x;
-      u64 r = A.bbox[k];
+      u64 r = enc_f64(A.cam[k < 3 ? k : k - 3]);  // update_min = update_max = camera_pos (:265-266)
       for (int w = 0; w < 4; ++w) r = k < 3 ? min(r, s_red[w][k]) : max(r, s_red[w][k]);
-      A.bbox[k] = r;
+      A.h_out[k] = r;
     }
+    if (threadIdx.x == 6) {
+      A.h_out[6] = A.head[6];
+      A.head[6] = 0ull;
+    }
+    // the host is waiting for exactly these eight words (it sizes the next launches by the box): publish them
+    // now, the ray walks of this block follow
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&A.h_out[7], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // Only the first point of every end voxel casts a ray (~1 point in 4): compact the casters of the
   // block into LDS first, so that the walk runs with full waves and the other waves retire at once
@@ -354,12 +359,6 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   const fuelmi_map_info& I = m->info;
   const signed char num_before = m->raycast_num;
   m->raycast_num = (signed char)(m->raycast_num + 1);  // char wrap like the reference
-  u64 h_bbox[8];
-  for (int k = 0; k < 3; ++k) {
-    h_bbox[k] = enc_f64_host(cam[k]);  // update_min = update_max = camera_pos (:265-266)
-    h_bbox[3 + k] = h_bbox[k];
-  }
-  HIPCHK(hipMemcpyAsync(d_bbox, h_bbox, 6 * sizeof(u64), hipMemcpyHostToDevice, m->stream));
   {
     const size_t need = (size_t)((n + 255) / 256) * 6;
     if (need > m->ins_partial_cap) {
@@ -381,15 +380,34 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   A.miss = m->miss_bits.p;
   A.owner = m->ray_owner;
   A.flag_rayend = m->flag_rayend;
-  A.bbox = d_bbox;
+  A.h_out = m->h_ins;
+  A.head = m->ins_head;
+  A.epoch = ++m->ins_epoch;
   int nb = (n + 255) / 256;
   A.nblk = nb;
   A.partial = m->ins_partial;
   k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
   k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  // the end-point box sizes the next launches: poll the stamp the fusion's second kernel writes into pinned memory
+  // (a blocking stream synchronisation costs ~40 us of wake-up latency per frame)
+  u64 h_bbox[8];
+  {
+    volatile u64* hv = m->h_ins;
+    unsigned spins = 0;
+    while (hv[7] != A.epoch) {
+      if ((++spins & 0x3FFFu) == 0u) {
+        const hipError_t q = hipStreamQuery(m->stream);
+        if (q != hipErrorNotReady && q != hipSuccess) HIPCHK(q);
+        if (q == hipSuccess && hv[7] != A.epoch) {
+          fuelmi_set_error("fusion: the kernels finished without publishing the end-point box");
+          return FUELMI_EHIP;
+        }
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int k = 0; k < 8; ++k) h_bbox[k] = hv[k];
+  }
   if (counted) {
     if (n_valid) *n_valid = (int)h_bbox[6];
     if (h_bbox[6] == 0) {  // nothing projected: the reference returns before touching any state
@@ -497,7 +515,7 @@ __global__ void __launch_bounds__(256) k_project_depth(DepthArgs D) {
     reinterpret_cast<float4*>(D.out)[s] = o;
   }
   const u64 m = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.count, (u64)__popcll(m));
+  if (D.count && (threadIdx.x & 63) == 0 && m) atomicAdd(D.count, (u64)__popcll(m));
 }
 
 static void quat_to_rot(const double q[4], double R[9]) {  // Eigen's toRotationMatrix(), q = (w,x,y,z)
@@ -514,7 +532,7 @@ static void quat_to_rot(const double q[4], double R[9]) {  // Eigen's toRotation
 // uploads the image, projects it; *d_pts_out / *d_head_out point into the map's device staging area
 static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
                              const fuelmi_depth_cfg* c, const double pos[3], const double q[4], float** d_pts_out,
-                             u64** d_head_out, int* nslots_out) {
+                             u64** d_head_out, int* nslots_out, bool count = true) {
   const int margin = c->depth_filter_margin, skip = c->skip_pixel;
   const int nu = cols - 2 * margin > 0 ? (cols - 2 * margin + skip - 1) / skip : 0;
   const int nvv = rows - 2 * margin > 0 ? (rows - 2 * margin + skip - 1) / skip : 0;
@@ -530,7 +548,6 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   float* d_pts = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(m->d_stage) + 256 + img_bytes);
   *d_pts_out = d_pts;
   *d_head_out = d_head;
-  HIPCHK(hipMemsetAsync(d_head, 0, 64, m->stream));
   if (nslots == 0) return FUELMI_OK;
   // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
   memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
@@ -544,7 +561,7 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   quat_to_rot(q, D.R);
   for (int k = 0; k < 3; ++k) D.t[k] = pos[k];
   D.out = d_pts;
-  D.count = d_head + 6;
+  D.count = count ? m->ins_head + 6 : nullptr;  // (read and re-zeroed by the fusion; stays device-side)
   k_project_depth<<<(nslots + 255) / 256, 256, 0, m->stream>>>(D);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
@@ -563,7 +580,7 @@ extern "C" int fuelmi_map_project_depth(fuelmi_map* m, const unsigned short* dep
   float* d_pts;
   u64* d_head;
   int nslots;
-  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &d_head, &nslots);
+  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &d_head, &nslots, false);
   if (rc) return rc;
   std::vector<float> h((size_t)nslots * 4);
   if (nslots) HIPCHK(hipMemcpyAsync(h.data(), d_pts, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
