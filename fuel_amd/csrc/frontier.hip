@@ -108,39 +108,72 @@ __device__ __forceinline__ bool f1_cell(const Geo& g, const u64* __restrict__ oc
 }
 
 // committed clusters' cells live in one device pool; candidate k of a changed-cluster test owns the
-// global indices [cand_start[k], cand_start[k+1])
-__device__ __forceinline__ int pool_cluster_of(const u32* __restrict__ cand_start, int ncand, u32 i) {
+// global indices [start[k], start[k+1]).  The (pool offset, start) table is read straight from the pinned host
+// copy and staged in LDS (no H2D copy node in front of the search), verdicts go straight back to pinned memory.
+struct RmCand {
+  u64 off;    // pool offset of the cluster's cells
+  u32 start;  // first flat index
+  u32 pad;
+};
+#define RM_LDS 1024  // candidates staged per block
+__device__ __forceinline__ int rm_cluster_of(const u32* s_start, int ncand, u32 i) {
   int lo = 0, hi = ncand - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (cand_start[mid] <= i)
+    if (s_start[mid] <= i)
       lo = mid;
     else
       hi = mid - 1;
   }
   return lo;
 }
-__global__ void k_check_pool(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk,
-                             const u32* __restrict__ pool, const u64* __restrict__ cand_off,
-                             const u32* __restrict__ cand_start, int ncand, u32 total, int* __restrict__ changed) {
+// MODE 0: "did a cell stop being a frontier cell?" -> d_mark[k] = mark, h_changed[k] = 1
+// MODE 1: clear the flags of the clusters marked by MODE 0
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_rm_pool(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u64* flag, const u32* __restrict__ pool,
+          const RmCand* __restrict__ cand, int ncand, u32 total, int* d_mark, int mark, int* h_changed) {
+  __shared__ u32 s_start[RM_LDS];
+  __shared__ u64 s_off[RM_LDS];
+  const bool staged = ncand <= RM_LDS;  // else `cand` is a device copy and the look-ups go to memory
+  if (staged) {
+    for (int k = threadIdx.x; k < ncand; k += 256) {
+      const RmCand c = cand[k];
+      s_start[k] = c.start;
+      s_off[k] = c.off;
+    }
+    __syncthreads();
+  }
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int k = pool_cluster_of(cand_start, ncand, i);
-  const u32 a = pool[cand_off[k] + (i - cand_start[k])];
-  if (!f1_cell(g, occ, unk, a)) changed[k] = 1;
-}
-__global__ void k_clear_pool(u64* flag, const u32* __restrict__ pool, const u64* __restrict__ cand_off,
-                             const u32* __restrict__ cand_start, int ncand, u32 total,
-                             const int* __restrict__ changed) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int k = pool_cluster_of(cand_start, ncand, i);
-  if (!changed[k]) return;
-  const long a = pool[cand_off[k] + (i - cand_start[k])];
-  atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
+  int k;
+  u32 a;
+  if (staged) {
+    k = rm_cluster_of(s_start, ncand, i);
+    a = pool[s_off[k] + (i - s_start[k])];
+  } else {
+    int lo = 0, hi = ncand - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (cand[mid].start <= i)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    k = lo;
+    a = pool[cand[k].off + (i - cand[k].start)];
+  }
+  if (MODE == 0) {
+    if (!f1_cell(g, occ, unk, a) && d_mark[k] != mark) {
+      d_mark[k] = mark;
+      h_changed[k] = 1;
+    }
+  } else {
+    if (d_mark[k] == mark) atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
+  }
 }
 __global__ void k_pool_put(u32* __restrict__ pool, const u32* __restrict__ cells, const PoolPut* __restrict__ table) {
-  const PoolPut e = table[blockIdx.x];  // one workgroup per cluster
+  const PoolPut e = table[blockIdx.x];  // one workgroup per cluster (the table sits in pinned host memory)
   u32* dst = pool + e.dst;
   const u32* src = cells + e.src;
   for (u32 i = threadIdx.x; i < e.n; i += blockDim.x) dst[i] = src[i];
@@ -2054,6 +2087,9 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->h_var) (void)hipHostFree(f->h_var);
   if (f->pool) (void)hipFree(f->pool);
   if (f->h_changed) (void)hipHostFree(f->h_changed);
+  if (f->h_cand) (void)hipHostFree(f->h_cand);
+  if (f->h_put) (void)hipHostFree(f->h_put);
+  if (f->d_mark) (void)hipFree(f->d_mark);
   frontier_split_free(f);
   frontier_order_free(f);
   for (hipGraphExec_t e : f->graph_exec)
@@ -2296,10 +2332,18 @@ int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
     c.materialize();
   }
   if (table.empty()) return FUELMI_OK;
-  if ((rc = frontier_ensure_stage(f, table.size() * sizeof(PoolPut)))) return rc;
-  HIPCHK(hipMemcpyAsync(f->d_stage, table.data(), table.size() * sizeof(PoolPut), hipMemcpyHostToDevice, f->stream));
+  if (table.size() > f->h_put_cap) {
+    if (f->h_put) HIPCHK(hipHostFree(f->h_put));
+    f->h_put = nullptr;
+    f->h_put_cap = 0;
+    const size_t cap = table.size() + table.size() / 2 + 64;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_put), cap * sizeof(PoolPut), hipHostMallocDefault));
+    f->h_put_cap = cap;
+  }
+  // (the table of the previous commit was consumed before the search in between was collected)
+  memcpy(f->h_put, table.data(), table.size() * sizeof(PoolPut));
   k_pool_put<<<(unsigned)table.size(), 256, 0, f->stream>>>(f->pool, f->F.ms_val[f->last_fin],
-                                                             reinterpret_cast<const PoolPut*>(f->d_stage));
+                                                             reinterpret_cast<const PoolPut*>(f->h_put));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -2338,29 +2382,38 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
   }
   if (nc > f->h_changed_cap) {
     if (f->h_changed) HIPCHK(hipHostFree(f->h_changed));
+    if (f->h_cand) HIPCHK(hipHostFree(f->h_cand));
+    if (f->d_mark) HIPCHK(hipFree(f->d_mark));
     f->h_changed = nullptr;
+    f->h_cand = nullptr;
+    f->d_mark = nullptr;
     f->h_changed_cap = 0;
     const size_t cap = nc + nc / 2 + 64;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_changed), cap * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_cand), cap * sizeof(RmCand), hipHostMallocDefault));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&f->d_mark), cap * sizeof(int)));
+    HIPCHK(hipMemsetAsync(f->d_mark, 0, cap * sizeof(int), f->stream));
+    f->rm_mark = 0;
     f->h_changed_cap = cap;
   }
-  const size_t b_off = nc * sizeof(u64), b_start = ((nc * sizeof(u32) + 7) / 8) * 8;
-  int rc = frontier_ensure_stage(f, b_off + b_start + nc * sizeof(int) + 64);
-  if (rc) return rc;
-  u64* d_off = reinterpret_cast<u64*>(f->d_stage);
-  u32* d_start = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(f->d_stage) + b_off);
-  int* d_changed = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(f->d_stage) + b_off + b_start);
-  HIPCHK(hipMemcpyAsync(d_off, off.data(), b_off, hipMemcpyHostToDevice, f->stream));
-  HIPCHK(hipMemcpyAsync(d_start, start.data(), nc * sizeof(u32), hipMemcpyHostToDevice, f->stream));
-  HIPCHK(hipMemsetAsync(d_changed, 0, nc * sizeof(int), f->stream));
-  k_check_pool<<<fblocks((long)total, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->pool, d_off,
-                                                                d_start, (int)nc, total, d_changed);
-  FDBG("k_check_pool");
-  k_clear_pool<<<fblocks((long)total, 256), 256, 0, f->stream>>>(f->flag.p, f->pool, d_off, d_start, (int)nc, total,
-                                                                d_changed);
-  FDBG("k_clear_pool");
-  HIPCHK(hipMemcpyAsync(f->h_changed, d_changed, nc * sizeof(int), hipMemcpyDeviceToHost, f->stream));
-  // (off / start are pageable: their uploads were staged by the runtime before hipMemcpyAsync returned)
+  RmCand* hc = reinterpret_cast<RmCand*>(f->h_cand);
+  for (size_t k = 0; k < nc; ++k) {
+    hc[k].off = off[k], hc[k].start = start[k], hc[k].pad = 0u;
+    f->h_changed[k] = 0;
+  }
+  if (nc > RM_LDS) {  // too many candidates for the LDS table: the kernels search a device copy
+    int rcs = frontier_ensure_stage(f, nc * sizeof(RmCand));
+    if (rcs) return rcs;
+    HIPCHK(hipMemcpyAsync(f->d_stage, hc, nc * sizeof(RmCand), hipMemcpyHostToDevice, f->stream));
+    hc = reinterpret_cast<RmCand*>(f->d_stage);
+  }
+  const int mark = ++f->rm_mark;  // (marks of earlier searches never match: no clearing pass)
+  k_rm_pool<0><<<fblocks((long)total, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc,
+                                                               (int)nc, total, f->d_mark, mark, f->h_changed);
+  FDBG("k_rm_pool<0>");
+  k_rm_pool<1><<<fblocks((long)total, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc,
+                                                               (int)nc, total, f->d_mark, mark, f->h_changed);
+  FDBG("k_rm_pool<1>");
   return FUELMI_OK;
 }
 // after the stream has drained: apply the verdicts.  removed_ids_ semantics (:74-85): index in

@@ -235,6 +235,11 @@ struct fuelmi_frontier {
   std::vector<PendingRm> pend_rm;
   int* h_changed = nullptr;  // pinned verdicts
   size_t h_changed_cap = 0;
+  void* h_cand = nullptr;    // pinned (pool offset, first index) table of the candidates, read by the kernels
+  int* d_mark = nullptr;     // device: search number in which candidate k was last found changed
+  int rm_mark = 0;
+  void* h_put = nullptr;     // pinned table of k_pool_put
+  size_t h_put_cap = 0;
   u32* pool = nullptr;  // device copies of the cells of frontiers_ / dormant_frontiers_
   size_t pool_cap = 0, pool_used = 0;
   int last_fin = 1;     // which multisplit buffer holds the grouped cells of the last search

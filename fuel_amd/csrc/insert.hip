@@ -16,9 +16,41 @@
 
 #include "fuelmi_internal.h"
 
+struct DepthArgs {
+  const unsigned short* img;
+  int rows, cols, margin, skip, nu, nslots;
+  double fx, fy, cx, cy, maxdist, mindist, inv_factor;
+  double R[9], t[3];
+  float* out;  // [nslots][4]
+  u64* count;  // valid points
+};
+// one sampled pixel -> world point (MapROS::proessDepthImage, plan_env/src/map_ros.cpp:176-215): slot s = iv*nu + iu
+// keeps the reference's point order; false = dropped by the min-distance filter.  f64 in the reference's order,
+// result rounded to float like pcl::PointXYZ.  Quirk kept: the depth comes from pixel u, the zero test reads the
+// pixel `skip` further (:190-198); past the end of the image it counts as 0.
+__device__ __forceinline__ bool project_pixel(const DepthArgs& D, int s, float o[3]) {
+  const int iv = s / D.nu, iu = s - iv * D.nu;
+  const int v = D.margin + iv * D.skip, u = D.margin + iu * D.skip;
+  const long at = (long)v * D.cols + u;
+  double depth = (double)D.img[at] * D.inv_factor;
+  const long nxt = at + D.skip;
+  const unsigned short ztest = nxt < (long)D.rows * D.cols ? D.img[nxt] : (unsigned short)0;
+  if (ztest == 0 || depth > D.maxdist)
+    depth = D.maxdist;
+  else if (depth < D.mindist)
+    return false;
+  const double c0 = (u - D.cx) * depth / D.fx, c1 = (v - D.cy) * depth / D.fy, c2 = depth;
+  o[0] = (float)(D.R[0] * c0 + D.R[1] * c1 + D.R[2] * c2 + D.t[0]);
+  o[1] = (float)(D.R[3] * c0 + D.R[4] * c1 + D.R[5] * c2 + D.t[1]);
+  o[2] = (float)(D.R[6] * c0 + D.R[7] * c1 + D.R[8] * c2 + D.t[2]);
+  return true;
+}
+
 struct InsertArgs {
-  const unsigned char* pts;  // device copy of the records
+  const unsigned char* pts;  // device copy of the records (from_depth == 0)
   int stride, n;
+  int from_depth;            // 1: point i is pixel slot i of D, projected on the fly (no point buffer in between)
+  DepthArgs D;
   double cam[3];
   double max_ray;
   signed char num;  // raycast_num_ after increment
@@ -54,11 +86,15 @@ __device__ __forceinline__ bool in_map_pos(const Geo& g, const double p[3]) {
 
 // classify one point exactly like sdf_map.cpp:276-303; returns false if the point is dropped
 __device__ __forceinline__ bool classify(const Geo& g, const InsertArgs& A, int i, double pt[3], int& flag) {
-  const float* p = reinterpret_cast<const float*>(A.pts + (size_t)i * A.stride);
-  if (isnan(p[0])) return false;  // empty slot of a device-projected depth frame (see k_project_depth)
-  pt[0] = p[0];
-  pt[1] = p[1];
-  pt[2] = p[2];
+  if (A.from_depth) {
+    float q[3];
+    if (!project_pixel(A.D, i, q)) return false;  // dropped by the min-distance filter: no point in this slot
+    pt[0] = q[0], pt[1] = q[1], pt[2] = q[2];
+  } else {
+    const float* p = reinterpret_cast<const float*>(A.pts + (size_t)i * A.stride);
+    if (isnan(p[0])) return false;
+    pt[0] = p[0], pt[1] = p[1], pt[2] = p[2];
+  }
   double length;
   if (!in_map_pos(g, pt)) {
     // closetPointInMap (:347-362)
@@ -108,6 +144,11 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
   double pt[3];
   int flag = 0;
   bool ok = (i < A.n) && classify(g, A, i, pt, flag);
+  if (A.from_depth) {  // proj_points_cnt: pixels that survive the projection (whatever the fusion does with them)
+    float q[3];
+    const u64 pm = __ballot(i < A.n && project_pixel(A.D, i, q));
+    if ((threadIdx.x & 63) == 0 && pm) atomicAdd(A.head + 6, (u64)__popcll(pm));
+  }
   long a = -1;
   if (ok) {
     a = pos_adr(g, pt);
@@ -354,7 +395,7 @@ k_insert_update(Geo g, u64* __restrict__ hit, u64* __restrict__ miss, double* __
 // ([0..5] sortable-encoded bbox, [6] number of valid points when `counted`).  Frames whose slots are
 // all empty leave the map untouched, like `if (point_num == 0) return;` (:260).
 static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stride, int n, const double cam[3],
-                             u64* d_bbox, bool counted, int* n_valid) {
+                             const DepthArgs* depth, bool counted, int* n_valid) {
   const Geo& g = m->g;
   const fuelmi_map_info& I = m->info;
   const signed char num_before = m->raycast_num;
@@ -373,6 +414,11 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   A.pts = d_pts;
   A.stride = stride;
   A.n = n;
+  A.from_depth = depth ? 1 : 0;
+  if (depth)
+    A.D = *depth;
+  else
+    memset(&A.D, 0, sizeof(A.D));
   for (int k = 0; k < 3; ++k) A.cam[k] = cam[k];
   A.max_ray = m->cfg.max_ray_length;
   A.num = m->raycast_num;
@@ -467,11 +513,10 @@ int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const doub
   size_t pbytes = (size_t)n * stride;
   int rc = map_ensure_stage(m, pbytes + 64, 0);
   if (rc) return rc;
-  u64* d_bbox = reinterpret_cast<u64*>(m->d_stage);
   unsigned char* d_pts = reinterpret_cast<unsigned char*>(m->d_stage) + 64;
   StageScope sc(m, FUELMI_K_INSERT);
   HIPCHK(hipMemcpyAsync(d_pts, xyz, pbytes, hipMemcpyHostToDevice, m->stream));
-  return insert_points_dev(m, d_pts, stride, n, cam, d_bbox, false, nullptr);
+  return insert_points_dev(m, d_pts, stride, n, cam, nullptr, false, nullptr);
 }
 
 // ---- depth image -> world points on the device (MapROS::proessDepthImage, plan_env/src/map_ros.cpp:176-215)
@@ -481,38 +526,13 @@ int insert_points(fuelmi_map* m, const float* xyz, int stride, int n, const doub
 // advanced in between, :190-198); past the end of the image (reference: out-of-bounds read) it
 // counts as 0.  Output slot s = iv*nu + iu keeps the reference's point order; a pixel dropped by the
 // min-distance filter leaves x = NaN in its slot, which the fusion kernels skip.
-struct DepthArgs {
-  const unsigned short* img;
-  int rows, cols, margin, skip, nu, nslots;
-  double fx, fy, cx, cy, maxdist, mindist, inv_factor;
-  double R[9], t[3];
-  float* out;  // [nslots][4]
-  u64* count;  // valid points
-};
 __global__ void __launch_bounds__(256) k_project_depth(DepthArgs D) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = false;
   if (s < D.nslots) {
-    const int iv = s / D.nu, iu = s - iv * D.nu;
-    const int v = D.margin + iv * D.skip, u = D.margin + iu * D.skip;
-    const long at = (long)v * D.cols + u;
-    double depth = (double)D.img[at] * D.inv_factor;
-    const long nxt = at + D.skip;
-    const unsigned short ztest = nxt < (long)D.rows * D.cols ? D.img[nxt] : (unsigned short)0;
-    valid = true;
-    if (ztest == 0 || depth > D.maxdist)
-      depth = D.maxdist;
-    else if (depth < D.mindist)
-      valid = false;
-    float4 o = make_float4(NAN, 0.f, 0.f, 1.f);
-    if (valid) {
-      const double c0 = (u - D.cx) * depth / D.fx, c1 = (v - D.cy) * depth / D.fy, c2 = depth;
-      const double w0 = D.R[0] * c0 + D.R[1] * c1 + D.R[2] * c2 + D.t[0];
-      const double w1 = D.R[3] * c0 + D.R[4] * c1 + D.R[5] * c2 + D.t[1];
-      const double w2 = D.R[6] * c0 + D.R[7] * c1 + D.R[8] * c2 + D.t[2];
-      o = make_float4((float)w0, (float)w1, (float)w2, 1.f);
-    }
-    reinterpret_cast<float4*>(D.out)[s] = o;
+    float q[3];
+    valid = project_pixel(D, s, q);
+    reinterpret_cast<float4*>(D.out)[s] = valid ? make_float4(q[0], q[1], q[2], 1.f) : make_float4(NAN, 0.f, 0.f, 1.f);
   }
   const u64 m = __ballot(valid);
   if (D.count && (threadIdx.x & 63) == 0 && m) atomicAdd(D.count, (u64)__popcll(m));
@@ -530,9 +550,11 @@ static void quat_to_rot(const double q[4], double R[9]) {  // Eigen's toRotation
 }
 
 // uploads the image, projects it; *d_pts_out / *d_head_out point into the map's device staging area
+// uploads the image and fills the projection arguments; launch: also write the projected points to the staging
+// area (fuelmi_map_project_depth) -- the fusion projects on the fly instead
 static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
                              const fuelmi_depth_cfg* c, const double pos[3], const double q[4], float** d_pts_out,
-                             u64** d_head_out, int* nslots_out, bool count = true) {
+                             DepthArgs* D_out, int* nslots_out, bool launch) {
   const int margin = c->depth_filter_margin, skip = c->skip_pixel;
   const int nu = cols - 2 * margin > 0 ? (cols - 2 * margin + skip - 1) / skip : 0;
   const int nvv = rows - 2 * margin > 0 ? (rows - 2 * margin + skip - 1) / skip : 0;
@@ -547,7 +569,7 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   unsigned short* d_img = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(m->d_stage) + 256);
   float* d_pts = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(m->d_stage) + 256 + img_bytes);
   *d_pts_out = d_pts;
-  *d_head_out = d_head;
+  (void)d_head;
   if (nslots == 0) return FUELMI_OK;
   // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
   memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
@@ -561,8 +583,9 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   quat_to_rot(q, D.R);
   for (int k = 0; k < 3; ++k) D.t[k] = pos[k];
   D.out = d_pts;
-  D.count = count ? m->ins_head + 6 : nullptr;  // (read and re-zeroed by the fusion; stays device-side)
-  k_project_depth<<<(nslots + 255) / 256, 256, 0, m->stream>>>(D);
+  D.count = nullptr;
+  *D_out = D;
+  if (launch) k_project_depth<<<(nslots + 255) / 256, 256, 0, m->stream>>>(D);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -578,9 +601,9 @@ extern "C" int fuelmi_map_project_depth(fuelmi_map* m, const unsigned short* dep
   ARGCHK(m && depth && cam_pos && cam_q_wxyz && n_points && depth_args_ok(cfg, rows, cols) && (cap == 0 || xyz));
   HIPCHK(hipSetDevice(m->device));
   float* d_pts;
-  u64* d_head;
+  DepthArgs D;
   int nslots;
-  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &d_head, &nslots, false);
+  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &D, &nslots, true);
   if (rc) return rc;
   std::vector<float> h((size_t)nslots * 4);
   if (nslots) HIPCHK(hipMemcpyAsync(h.data(), d_pts, h.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
@@ -609,12 +632,11 @@ extern "C" int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth
   HIPCHK(hipSetDevice(m->device));
   StageScope sc(m, FUELMI_K_INSERT);
   float* d_pts;
-  u64* d_head;
+  DepthArgs D;
   int nslots;
-  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &d_head, &nslots);
+  int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &D, &nslots, false);
   if (rc || nslots == 0) return rc;
-  return insert_points_dev(m, reinterpret_cast<const unsigned char*>(d_pts), 16, nslots, cam_pos, d_head, true,
-                           n_points);
+  return insert_points_dev(m, nullptr, 16, nslots, cam_pos, &D, true, n_points);
 }
 
 extern "C" int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,
