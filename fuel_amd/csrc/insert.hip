@@ -360,35 +360,39 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   }
 }
 
-// log-odds update of every touched voxel (:332-344) + refresh of the state planes
+// log-odds update of every touched voxel (:332-344) + refresh of the state planes.  One WAVE per 64-voxel word,
+// one lane per voxel: the f64 read-modify-write of a word's voxels is one coalesced 512-byte access instead of a
+// serial loop over its set bits, and the new state bits of the word are two ballots.
 __global__ void __launch_bounds__(256)
 k_insert_update(Geo g, u64* __restrict__ hit, u64* __restrict__ miss, double* __restrict__ occ,
                 u64* __restrict__ occ_bits, u64* __restrict__ unk_bits, int w_lo, int w_hi, double l_hit,
                 double l_miss, double l_min, double l_max, double l_occ) {
-  int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = w_lo + (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (w > w_hi) return;
-  u64 h = hit[w], ms = miss[w];
-  u64 t = h | ms;
-  if (t == 0ull) return;
-  hit[w] = 0ull;
-  miss[w] = 0ull;
-  u64 ob = occ_bits[w], ub = unk_bits[w];
+  const u64 h = hit[w], ms = miss[w];
+  const u64 t = h | ms;
+  if (t == 0ull) return;  // (wave-uniform)
   const double thr_unk = l_min - 1e-3;
-  while (t) {
-    int b = __builtin_ctzll(t);
-    t &= t - 1;
-    long a = 64L * w + b;
-    double upd = ((h >> b) & 1ull) ? l_hit : l_miss;
+  const bool touched = (t >> lane) & 1ull;
+  bool is_occ = (occ_bits[w] >> lane) & 1ull, is_unk = (unk_bits[w] >> lane) & 1ull;
+  if (touched) {
+    const long a = 64L * w + lane;
+    const double upd = ((h >> lane) & 1ull) ? l_hit : l_miss;
     double o = occ[a];
     if (o < thr_unk) o = l_occ;
     o = fmin(fmax(o + upd, l_min), l_max);
     occ[a] = o;
-    u64 bit = 1ull << b;
-    ob = (o > l_occ) ? (ob | bit) : (ob & ~bit);
-    ub = (o < thr_unk) ? (ub | bit) : (ub & ~bit);
+    is_occ = o > l_occ;
+    is_unk = o < thr_unk;
   }
-  occ_bits[w] = ob;
-  unk_bits[w] = ub;
+  const u64 ob = __ballot(is_occ), ub = __ballot(is_unk);
+  if (lane == 0) {
+    hit[w] = 0ull;
+    miss[w] = 0ull;
+    occ_bits[w] = ob;
+    unk_bits[w] = ub;
+  }
 }
 
 // fusion of n point records already resident on the device.  d_head: 64-byte device scratch
@@ -501,7 +505,7 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   for (int k = 0; k < 3; ++k)
     if (cam[k] < g.minb[k] + 1e-4 || cam[k] > g.maxb[k] - 1e-4) cam_in = false;
   if (!cam_in) w_lo = 0, w_hi = g.W - 1;
-  k_insert_update<<<(w_hi - w_lo + 256) / 256, 256, 0, m->stream>>>(
+  k_insert_update<<<(w_hi - w_lo + 4) / 4, 256, 0, m->stream>>>(
       g, m->hit_bits.p, m->miss_bits.p, m->occ, m->occ_bits.p, m->unk_bits.p, w_lo, w_hi, I.prob_hit_log,
       I.prob_miss_log, I.clamp_min_log, I.clamp_max_log, I.min_occupancy_log);
   HIPCHK(hipGetLastError());
@@ -573,9 +577,13 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   if (nslots == 0) return FUELMI_OK;
   // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
   memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
-  HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
+  static const bool zero_copy = getenv("FUELMI_DEPTH_H2D") == nullptr;
+  // the fusion kernels read the (pinned) staged image over PCIe themselves -- ~0.6 MB per 640 x 480 frame, read by
+  // two kernels -- instead of waiting for a DMA copy in front of them; the stand-alone projection keeps the copy
+  if (!zero_copy || launch)
+    HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
   DepthArgs D;
-  D.img = d_img;
+  D.img = (zero_copy && !launch) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img;
   D.rows = rows, D.cols = cols, D.margin = margin, D.skip = skip, D.nu = nu, D.nslots = nslots;
   D.fx = c->fx, D.fy = c->fy, D.cx = c->cx, D.cy = c->cy;
   D.maxdist = c->depth_filter_maxdist, D.mindist = c->depth_filter_mindist;
