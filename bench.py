@@ -32,6 +32,10 @@ WORKLOADS = {
     "G800": ((80.0, 80.0, 20.0), 3200, 960),
     "G100": ((10.0, 10.0, 5.0), 25, 8),  # smoke-sized
     "G200": ((20.0, 20.0, 5.0), 100, 30),  # fleet test: four of these share one GPU
+    # ESDF worst-case regimes: the whole map explored, optimistic = true (only inflated
+    # obstacle voxels are sources, topo_algorithm.xml:71-72): distances of 10-100 voxels instead of ~1.4
+    "G400K": ((40.0, 40.0, 10.0), 400, -1),   # the headline world, fully known
+    "G400E": ((40.0, 40.0, 10.0), 12, -1),    # a nearly empty hall: floor + a dozen obstacles
     # streaming variants (BASELINE config #4): the map starts unknown, one 640x480 depth frame per step
     # (sparser worlds than the full-box recipe, so that a frame sees several metres of free space)
     "G800S": ((80.0, 80.0, 20.0), 600, 0),
@@ -81,7 +85,12 @@ def build_inputs(workload, seed, n_traj=64):
     map_size, n_obs, n_sph = WORKLOADS[workload]
     w = synth.World.for_map_size(map_size)
     truth = w.world(seed, n_obs)
-    occ, n_known = w.known_state(truth, seed, n_sph)
+    if n_sph < 0:  # everything explored: free -> clamp_min_log, solid -> clamp_max_log
+        lo5 = synth.logodds()
+        occ = np.where(truth.astype(bool), lo5[3], lo5[2]).astype(np.float64)
+        n_known = occ.size
+    else:
+        occ, n_known = w.known_state(truth, seed, n_sph)
     lo, hi = exploration_box(map_size)
     rng = np.random.default_rng(1000 + seed)
     ctrl = make_trajectories(rng, n_traj, 32, np.array(lo) + 0.5, np.array(hi) - 0.5)
@@ -91,10 +100,10 @@ def build_inputs(workload, seed, n_traj=64):
 class GpuCycle:
     """The hot path on one GPU through the C-ABI (fuel_amd.host mirrors the reference classes)."""
 
-    def __init__(self, map_size, box, occ, ctrl, device, dt=0.175):
+    def __init__(self, map_size, box, occ, ctrl, device, dt=0.175, **map_kw):
         import fuel_amd
         self.fa = fuel_amd
-        self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device)
+        self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device, **map_kw)
         self.map.uploadOccupancy(occ)
         nv = self.map.nvox
         self.map.setLocalBound((0, 0, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1))
@@ -460,7 +469,8 @@ def main():
         cyc = GpuStreamCycle(map_size, box, frames, ctrl, device=local_rank)
     else:
         map_size, box, occ, ctrl, n_known = build_inputs(args.workload, seed=42 + rank, n_traj=args.candidates)
-        cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank)
+        map_kw = {"optimistic": 1} if args.workload in ("G400K", "G400E") else {}
+        cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank, **map_kw)
     if args.serial_stages:
         cyc.step = cyc.step_serial
 
@@ -529,7 +539,7 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/), else null
         traffic = None
         try:
-            pmc_file = {"G400": "r02_pmc_hbm_traffic_G400.json", "G800": "r02_pmc_hbm_traffic_G800.json"}[args.workload]
+            pmc_file = {"G400": "r02_pmc_hbm_traffic_G400.json", "G800": "r02_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
             key = {"esdf_zy": "k_esdf_zy4<0>", "esdf_x": "k_esdf_x4<0>", "inflate": "k_inflate_yz",
                    "bspline": "k_bspline_cost_grad"}[dominant]

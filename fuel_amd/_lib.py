@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfuelmi.so")
+LIB_PATH = os.environ.get("FUELMI_LIB_PATH") or os.path.join(_HERE, "libfuelmi.so")  # (override: A/B runs of two builds)
 _LIB = None
 
 K_INFLATE, K_ESDF_ZY, K_ESDF_X, K_FRONTIER, K_BSPLINE, K_INSERT, K_COUNT = range(7)

@@ -240,12 +240,180 @@ __device__ __forceinline__ int line_src_up(const u64* __restrict__ infl, const u
   }
 }
 
-template <int MODE>
+// ------------------------------------------------------------------------------------------------
+// Outward scan of one line for 4 z-adjacent outputs.
+// The plain scan looks at rows i +- r while r^2 < best: O(distance) LDS reads per output -- ~2 in a half-explored
+// map (unknown voxels are sources), ~100 in an explored hall whose only source is the floor.  The FAR kernels
+// (picked by the host when most outputs of the previous update were far from sources, esdf_use_far) add two
+// exact lower bounds over the staged tile:
+//   cm[col]    = min f over the whole line: no candidate f(p) + r^2, r >= 1, beats best when cm + 1 >= best
+//                (flat fields -- most lines of an empty hall -- end here, with one LDS read);
+//   bm[k][col] = min f over rows 8k .. 8k+7: after `near` rows each side the scan walks BLOCKS outwards, and a
+//                block whose nearest row is d away is skipped when bm + d^2 >= best (all of its candidates are
+//                at least that).
+// Both bounds only remove candidates that cannot lower the minimum: D(q) = min_p f(p) + (q-p)^2 stays exact.
+// Building them costs a pass over the tile and a barrier (~5 us per kernel on the 400^2 x 100 map), which is why
+// the half-explored regime keeps the plain kernels.
+// ------------------------------------------------------------------------------------------------
+#define ESDF_FAR_D 8u  // statistic: an output counts as "far from sources" beyond this many voxels
+static int esdf_near() {  // rows the FAR kernels scan one by one before the block walk (even: two rows per trip)
+  static const char* e = getenv("FUELMI_ESDF_NEAR");
+  static const int v = e ? std::max(2, atoi(e) & ~1) : 2;
+  return v;
+}
+__device__ __forceinline__ uint4 lds4(const unsigned char* p, int off) { return *reinterpret_cast<const uint4*>(p + off); }
+__device__ __forceinline__ u32 max4(u32 a, u32 b, u32 c, u32 d) { return max(max(a, b), max(c, d)); }
+
+// block and line minima of a staged tile: rows of `stride` bytes, `vec_per_row` uint4 per row, n rows.  cm must
+// hold INF32 before the call (with a barrier in between); a barrier must follow before scan_far4.
+__device__ __forceinline__ void build_block_minima(const unsigned char* tile, unsigned char* bm, u32* cm, int stride,
+                                                   int vec_per_row, int n) {
+  const int nblk = (n + 7) >> 3;
+  for (int it = threadIdx.x; it < nblk * vec_per_row; it += blockDim.x) {
+    const int k = it / vec_per_row, v = it - k * vec_per_row;
+    const int last = (n - 1) * stride + 16 * v;
+    int o = __mul24(8 * k, stride) + 16 * v;
+    uint4 m = lds4(tile, o);
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+      o = min(o + stride, last);
+      const uint4 q = lds4(tile, o);
+      m.x = min(m.x, q.x), m.y = min(m.y, q.y), m.z = min(m.z, q.z), m.w = min(m.w, q.w);
+    }
+    *reinterpret_cast<uint4*>(bm + __mul24(k, stride) + 16 * v) = m;
+    atomicMin(cm + 4 * v, m.x);
+    atomicMin(cm + 4 * v + 1, m.y);
+    atomicMin(cm + 4 * v + 2, m.z);
+    atomicMin(cm + 4 * v + 3, m.w);
+  }
+}
+
+// near phase for the 4 columns at byte offset `col` of row i: min over |p - i| <= near (all p when near == 0).
+// open = true when rows further out can still lower one of the four minima.
+__device__ __forceinline__ uint4 scan_near4(const unsigned char* tile, int stride, int n, int i, int col, int near,
+                                            bool& open) {
+  const int base = __mul24(i, stride) + col;
+  const uint4 v0 = lds4(tile, base);
+  u32 b0 = v0.x, b1 = v0.y, b2 = v0.z, b3 = v0.w;
+  u32 mx = max4(b0, b1, b2, b3);
+  const u32 cap = near ? (u32)__mul24(near + 1, near + 1) : 0xffffffffu;
+  const int rmax = max(i, n - 1 - i);
+  const u32 lim = (u32)__mul24(rmax + 1, rmax + 1);
+  const int hi_off = __mul24(n - 1, stride) + col;
+  int oa = base, ob = base;
+  u32 rr = 1u, inc = 3u;
+  // two rows out per trip: four LDS reads in flight behind one wait and one exit test.  The second step may be
+  // one more than the exit test would have allowed -- every candidate f(i +- r) + r^2 is a true upper bound, so
+  // extra ones cannot change the minimum.  r^2 advances by additions (32-bit multiplies are quarter rate).
+  while (rr < min(min(mx, lim), cap)) {
+    const int oa1 = max(oa - stride, col), ob1 = min(ob + stride, hi_off);
+    oa = max(oa1 - stride, col);
+    ob = min(ob1 + stride, hi_off);
+    const uint4 va = lds4(tile, oa1), vb = lds4(tile, ob1), vc = lds4(tile, oa), vd = lds4(tile, ob);
+    const u32 rr2 = rr + inc;
+    // a clamped row repeats a candidate already seen with a smaller r: harmless; INF32 + r^2 stays above every
+    // finite value and below 2^31
+    b0 = min(b0, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
+    b1 = min(b1, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
+    b2 = min(b2, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
+    b3 = min(b3, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
+    mx = max4(b0, b1, b2, b3);
+    rr = rr2 + inc + 2u;
+    inc += 4u;
+  }
+  open = rr < min(mx, lim);
+  return make_uint4(b0, b1, b2, b3);
+}
+
+// the line minimum first: in a flat field nothing can beat the output's own f
+__device__ __forceinline__ bool line_can_improve(const unsigned char* tile, const unsigned char* cm, int stride, int i,
+                                                 int col, uint4& v0) {
+  v0 = lds4(tile, __mul24(i, stride) + col);
+  const uint4 c = lds4(cm, col);
+  return (c.x + 1u < v0.x) | (c.y + 1u < v0.y) | (c.z + 1u < v0.z) | (c.w + 1u < v0.w);
+}
+
+// far phase: bb = the running minima of an output the near phase left open (all rows within `near` seen); returns the exact minima
+__device__ __forceinline__ uint4 scan_far4(const unsigned char* tile, const unsigned char* bm, const unsigned char* cm,
+                                           int stride, int n, int i, int col, uint4 bb) {
+  (void)cm;
+  u32 b0 = bb.x, b1 = bb.y, b2 = bb.z, b3 = bb.w;
+  u32 mx = max4(b0, b1, b2, b3);
+  const int hi_off = __mul24(n - 1, stride) + col;
+  // block walk: blocks kb -+ j, nearest rows dl / du away (seeing the rows of the near phase again is harmless)
+  const int kb = i >> 3, off = i & 7, nblk = (n + 7) >> 3;
+  {  // the output's own block first (the near phase may have stopped short of its ends)
+    int o = __mul24(8 * kb, stride) + col;
+#pragma unroll 4
+    for (int t = 0; t < 8; ++t) {
+      const uint4 q = lds4(tile, min(o, hi_off));
+      const u32 r2 = (u32)__mul24(t - off, t - off);
+      b0 = min(b0, q.x + r2), b1 = min(b1, q.y + r2), b2 = min(b2, q.z + r2), b3 = min(b3, q.w + r2);
+      o += stride;
+    }
+    mx = max4(b0, b1, b2, b3);
+  }
+  for (int j = 1;; ++j) {
+    const int dl = off + 8 * j - 7, du = 8 * j - off;
+    const u32 dl2 = (u32)__mul24(dl, dl), du2 = (u32)__mul24(du, du);
+    const bool lo = kb - j >= 0 && dl2 < mx;
+    const bool up = kb + j < nblk && du2 < mx;
+    if (!(lo | up)) break;
+    if (lo) {
+      const uint4 m = lds4(bm, __mul24(kb - j, stride) + col);
+      if ((m.x + dl2 < b0) | (m.y + dl2 < b1) | (m.z + dl2 < b2) | (m.w + dl2 < b3)) {
+        int o = __mul24(8 * (kb - j) + 7, stride) + col;
+        u32 r2 = dl2, ic = 2u * (u32)dl + 1u;
+#pragma unroll 4
+        for (int t = 0; t < 8; ++t) {
+          const uint4 q = lds4(tile, o);
+          b0 = min(b0, q.x + r2), b1 = min(b1, q.y + r2), b2 = min(b2, q.z + r2), b3 = min(b3, q.w + r2);
+          o -= stride;
+          r2 += ic;
+          ic += 2u;
+        }
+      }
+    }
+    if (up) {
+      const uint4 m = lds4(bm, __mul24(kb + j, stride) + col);
+      if ((m.x + du2 < b0) | (m.y + du2 < b1) | (m.z + du2 < b2) | (m.w + du2 < b3)) {
+        int o = __mul24(8 * (kb + j), stride) + col;
+        u32 r2 = du2, ic = 2u * (u32)du + 1u;
+#pragma unroll 4
+        for (int t = 0; t < 8; ++t) {
+          const uint4 q = lds4(tile, min(o, hi_off));  // past the last row: that row again, with a larger r
+          b0 = min(b0, q.x + r2), b1 = min(b1, q.y + r2), b2 = min(b2, q.z + r2), b3 = min(b3, q.w + r2);
+          o += stride;
+          r2 += ic;
+          ic += 2u;
+        }
+      }
+    }
+    mx = max4(b0, b1, b2, b3);
+  }
+  return make_uint4(b0, b1, b2, b3);
+}
+
+// exact min_p f(p) + (i-p)^2 for the 4 columns at byte offset `col` of row i
+template <bool FAR>
+__device__ __forceinline__ uint4 scan_line4(const unsigned char* tile, const unsigned char* bm, const unsigned char* cm,
+                                            int stride, int n, int i, int col, int near) {
+  bool open = false;
+  uint4 bb;
+  if (!FAR) return scan_near4(tile, stride, n, i, col, 0, open);
+  if (line_can_improve(tile, cm, stride, i, col, bb)) bb = scan_near4(tile, stride, n, i, col, near, open);
+  if (open) bb = scan_far4(tile, bm, cm, stride, n, i, col, bb);
+  return bb;
+}
+
+template <int MODE, bool FAR>
 __global__ void __launch_bounds__(512)
 k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp,
-           int ZC, int nzc, int z0a) {
+           int ZC, int nzc, int z0a, int near, u32* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32* tile = reinterpret_cast<u32*>(smem_raw);  // [ylen][ZC] dz^2 or INF32 (u32: the scan loop adds without sentinel tests), ZC % 4 == 0, ZC <= 64
+  // [ylen][ZC] dz^2 or INF32 (u32: the scan loop adds without sentinel tests), ZC % 4 == 0, ZC <= 64; FAR: then
+  // the block minima [ceil(ylen/8)][ZC] and the line minima [ZC]
+  u32* tile = reinterpret_cast<u32*>(smem_raw);
   // XCD-aware order: workgroup i runs on XCD i % 8, and each XCD has its own L2.  The nzc chunk-blocks of
   // one x-slab read the same bit-plane lines and write interleaved pieces of the same tmp lines, so they
   // are given to the SAME XCD (slab x -> XCD x % 8) instead of being dealt round-robin over all eight.
@@ -258,6 +426,9 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   const int T = blockDim.x;
   // z pass: one lane per row of the chunk; chunk source bits live in one register
   const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);  // in-box part of the chunk
+  unsigned char* bm = smem_raw + (size_t)ylen * ZC * 4;
+  u32* cm = reinterpret_cast<u32*>(bm + (size_t)((ylen + 7) >> 3) * ZC * 4);
+  if (FAR && (int)threadIdx.x < ZC) cm[threadIdx.x] = INF32;
   for (int yi = threadIdx.x; yi < ylen; yi += T) {
     u32* row = tile + yi * ZC;
     const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
@@ -309,57 +480,32 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
     }
   }
   __syncthreads();
-  // y pass: one lane per 4 z-adjacent outputs.  The scan walks outwards one row per step with byte
-  // offsets and r^2 advanced by additions (32-bit multiplies are quarter rate) and a single exit test
-  // r^2 < min(mx, (rmax+1)^2).
+  if (FAR) {
+    build_block_minima(smem_raw, bm, cm, ZC * 4, ZC >> 2, ylen);
+    __syncthreads();
+  }
+  // y pass: one lane per 4 z-adjacent outputs
   const int G = ZC >> 2;
   const int total = ylen * G;
+  const int stride = ZC * 4;
   const int dyi = T / G, dgi = T - dyi * G;
-  const int stride = ZC * 4;                   // bytes per tile row
-  const int last_row = (ylen - 1) * stride;
+  // every 16th slab reports how many of its outputs are further than ESDF_FAR_D voxels from every source: the
+  // host picks the FAR or the plain kernels for the NEXT update from that (esdf_update)
+  const bool sampled = stat != nullptr && (xrel & 15) == 0;
+  int n_far = 0;
   int yi = threadIdx.x / G, gi = threadIdx.x - yi * G;
   for (int o = threadIdx.x; o < total; o += T) {
-    const int col = 16 * gi;
-    const int base = __mul24(yi, stride) + col;
-    const uint4 v0 = *reinterpret_cast<const uint4*>(smem_raw + base);
-    u32 b0 = v0.x, b1 = v0.y, b2 = v0.z, b3 = v0.w;
-    u32 mx = max(max(b0, b1), max(b2, b3));
-    const int rmax = max(yi, ylen - 1 - yi);
-    const u32 lim = (u32)__mul24(rmax + 1, rmax + 1);
-    const int hi_off = last_row + col;
-    int oa = base, ob = base;
-    u32 rr = 1u, inc = 3u;
-    // two rows out per trip: four LDS reads in flight behind one wait and one exit test.  The second
-    // step may be one more than the exit test would have allowed -- every candidate f(y +- r) + r^2 is a
-    // true upper bound, so extra ones cannot change the minimum.
-    while (rr < min(mx, lim)) {
-      const int oa1 = max(oa - stride, col), ob1 = min(ob + stride, hi_off);
-      oa = max(oa1 - stride, col);
-      ob = min(ob1 + stride, hi_off);
-      const uint4 va = *reinterpret_cast<const uint4*>(smem_raw + oa1);
-      const uint4 vb = *reinterpret_cast<const uint4*>(smem_raw + ob1);
-      const uint4 vc = *reinterpret_cast<const uint4*>(smem_raw + oa);
-      const uint4 vd = *reinterpret_cast<const uint4*>(smem_raw + ob);
-      const u32 rr2 = rr + inc;
-      // a clamped row repeats a candidate already seen with a smaller r: harmless; INF32 + r^2 stays
-      // above every finite value and below 2^31
-      b0 = min(b0, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
-      b1 = min(b1, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
-      b2 = min(b2, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
-      b3 = min(b3, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
-      mx = max(max(b0, b1), max(b2, b3));
-      rr = rr2 + inc + 2u;
-      inc += 4u;
-    }
+    const uint4 bb = scan_line4<FAR>(smem_raw, bm, reinterpret_cast<const unsigned char*>(cm), stride, ylen, yi, 16 * gi, near);
+    if (sampled) n_far += __popcll(__ballot(min(min(bb.x, bb.y), min(bb.z, bb.w)) > ESDF_FAR_D * ESDF_FAR_D));
     const int z = zc0 + 4 * gi;
     u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz + z;
     if (z >= b.lo[2] && z + 3 <= b.hi[2]) {
-      *reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
+      *reinterpret_cast<uint4*>(dst) = bb;
     } else {
-      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = b0;
-      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = b1;
-      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = b2;
-      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = b3;
+      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = bb.x;
+      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = bb.y;
+      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = bb.z;
+      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = bb.w;
     }
     yi += dyi;
     gi += dgi;
@@ -368,16 +514,57 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
       ++yi;
     }
   }
+  if (sampled && (threadIdx.x & 63) == 0) {
+    atomicAdd(stat, (u32)n_far);
+    if (threadIdx.x == 0) atomicAdd(stat + 1, (u32)total);
+  }
+}
+
+// The y pass of this update has counted its far outputs in stat[0..1] (device); the first workgroup of the x pass
+// hands the pair to the host (pinned, no synchronisation: esdf_update reads whatever has landed) and clears it.
+__device__ __forceinline__ void forward_stat(u32* stat, volatile u32* h_stat) {
+  if (stat != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const u32 nf = stat[0], nt = stat[1];
+    stat[0] = 0u;
+    stat[1] = 0u;
+    if (nt) {
+      h_stat[0] = nf;
+      h_stat[1] = nt;
+    }
+  }
+}
+
+// the 4 outputs of one lane: distance_buffer_ values (OUT 0) or the negative pass merged in place (OUT 1)
+template <int OUT>
+__device__ __forceinline__ void x_store4(float* dst, int z, int zlo, int zhi, uint4 bb, float resf) {
+  if (OUT == 0) {
+    if (z >= zlo && z + 3 <= zhi) {
+      *reinterpret_cast<float4*>(dst) =
+          make_float4(esdf_out(bb.x, resf), esdf_out(bb.y, resf), esdf_out(bb.z, resf), esdf_out(bb.w, resf));
+    } else {
+      if (z >= zlo && z <= zhi) dst[0] = esdf_out(bb.x, resf);
+      if (z + 1 >= zlo && z + 1 <= zhi) dst[1] = esdf_out(bb.y, resf);
+      if (z + 2 >= zlo && z + 2 <= zhi) dst[2] = esdf_out(bb.z, resf);
+      if (z + 3 >= zlo && z + 3 <= zhi) dst[3] = esdf_out(bb.w, resf);
+    }
+  } else {
+    if (z >= zlo && z <= zhi) dst[0] = esdf_merge_neg(dst[0], bb.x, resf);
+    if (z + 1 >= zlo && z + 1 <= zhi) dst[1] = esdf_merge_neg(dst[1], bb.y, resf);
+    if (z + 2 >= zlo && z + 2 <= zhi) dst[2] = esdf_merge_neg(dst[2], bb.z, resf);
+    if (z + 3 >= zlo && z + 3 <= zhi) dst[3] = esdf_merge_neg(dst[3], bb.w, resf);
+  }
 }
 
 // x pass, 4*SEGS columns (SEGS lanes x 4) per tile row; SEGS = 8: a wave covers 8 x-rows x 32 columns
 // (128 B per row); SEGS = 4 halves the LDS tile for long x lines so that several workgroups still
 // share a CU
-template <int OUT, int SEGS>
+template <int OUT, int SEGS, bool FAR>
 __global__ void __launch_bounds__(1024)
-k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a) {
+k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, int near,
+          u32* stat, volatile u32* h_stat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4
+  forward_stat(stat, h_stat);
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4 (FAR: + block / line minima)
   const int xlen = b.hi[0] - b.lo[0] + 1;
   const int ylen = b.hi[1] - b.lo[1] + 1;
   const int ncol = ylen * zlen_a;
@@ -391,47 +578,21 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
   const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
   const float resf = (float)g.res;
+  unsigned char* bm = smem_raw + (size_t)xlen * SEGS * 16;
+  u32* cm = reinterpret_cast<u32*>(bm + (size_t)((xlen + 7) >> 3) * SEGS * 16);
 #pragma unroll 4
   for (int xi = row0; xi < xlen; xi += rows)
     tile[xi * SEGS + seg] = valid ? *reinterpret_cast<const uint4*>(tmp + (long)(b.lo[0] + xi) * g.nyz + coloff) : inf4;
+  if (FAR && (int)threadIdx.x < 4 * SEGS) cm[threadIdx.x] = INF32;
   __syncthreads();
+  if (FAR) {
+    build_block_minima(smem_raw, bm, cm, SEGS * 16, SEGS, xlen);
+    __syncthreads();
+  }
   if (!valid) return;
-  const bool full = z >= b.lo[2] && z + 3 <= b.hi[2];
   for (int xi = row0; xi < xlen; xi += rows) {
-    uint4 bb = tile[xi * SEGS + seg];
-    u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
-    const int rmax = max(xi, xlen - 1 - xi);
-    // two rows out per trip (four LDS reads behind one wait, one exit test); extra candidates are true
-    // upper bounds, clamped rows repeat earlier ones: neither can change the minimum
-    for (int r = 1; r <= rmax && (u32)(r * r) < mx; r += 2) {
-      const u32 rr = (u32)(r * r), rr2 = (u32)((r + 1) * (r + 1));
-      const uint4 va = tile[max(xi - r, 0) * SEGS + seg];
-      const uint4 vb = tile[min(xi + r, xlen - 1) * SEGS + seg];
-      const uint4 vc = tile[max(xi - r - 1, 0) * SEGS + seg];
-      const uint4 vd = tile[min(xi + r + 1, xlen - 1) * SEGS + seg];
-      bb.x = min(bb.x, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
-      bb.y = min(bb.y, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
-      bb.z = min(bb.z, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
-      bb.w = min(bb.w, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
-      mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
-    }
-    float* dst = dist + (long)(b.lo[0] + xi) * g.nyz + coloff;
-    if (OUT == 0) {
-      if (full) {
-        *reinterpret_cast<float4*>(dst) =
-            make_float4(esdf_out(bb.x, resf), esdf_out(bb.y, resf), esdf_out(bb.z, resf), esdf_out(bb.w, resf));
-      } else {
-        if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_out(bb.x, resf);
-        if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_out(bb.y, resf);
-        if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_out(bb.z, resf);
-        if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_out(bb.w, resf);
-      }
-    } else {
-      if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_merge_neg(dst[0], bb.x, resf);
-      if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_merge_neg(dst[1], bb.y, resf);
-      if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_merge_neg(dst[2], bb.z, resf);
-      if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_merge_neg(dst[3], bb.w, resf);
-    }
+    const uint4 bb = scan_line4<FAR>(smem_raw, bm, reinterpret_cast<const unsigned char*>(cm), SEGS * 16, xlen, xi, 16 * seg, near);
+    x_store4<OUT>(dist + (long)(b.lo[0] + xi) * g.nyz + coloff, z, b.lo[2], b.hi[2], bb, resf);
   }
 }
 
@@ -439,13 +600,19 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
 // LDS, the global loads of tile k + 1 are already in flight into registers (P = ceil(xlen / rows) uint4 per lane),
 // so the HBM fetch runs BESIDE the scan instead of in front of it (k_esdf_x4 does load -> barrier -> scan per
 // tile, and with one or two resident workgroups per CU nothing overlaps the fetch).
-template <int OUT, int P>
-__global__ void __launch_bounds__(1024)
-k_esdf_x4p(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, int ntiles) {
+// (P <= 4: x lines of up to 512 voxels, two workgroups share a CU's LDS -- hold the kernel to 64 VGPRs so that
+// they also share its register file)
+template <int OUT, int P, bool FAR>
+__global__ void __launch_bounds__(1024, (P <= 4 ? 8 : 4))
+k_esdf_x4p(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, int ntiles, int near,
+           u32* stat, volatile u32* h_stat) {
   constexpr int SEGS = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4
+  forward_stat(stat, h_stat);
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4 (FAR: + block / line minima)
   const int xlen = b.hi[0] - b.lo[0] + 1;
+  unsigned char* bm = smem_raw + (size_t)xlen * SEGS * 16;
+  u32* cm = reinterpret_cast<u32*>(bm + (size_t)((xlen + 7) >> 3) * SEGS * 16);
   const int ylen = b.hi[1] - b.lo[1] + 1;
   const int ncol = ylen * zlen_a;
   const int seg = threadIdx.x & (SEGS - 1);
@@ -476,92 +643,76 @@ k_esdf_x4p(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist,
       const int xi = row0 + p * rows;
       if (xi < xlen) tile[xi * SEGS + seg] = nxt[p];
     }
+    if (FAR && threadIdx.x < 4 * SEGS) cm[threadIdx.x] = INF32;
     __syncthreads();
     X4P_FETCH(t + (int)gridDim.x)  // in flight during the scan below
+    if (FAR) {
+      build_block_minima(smem_raw, bm, cm, SEGS * 16, SEGS, xlen);
+      __syncthreads();
+    }
     const int col = t * (4 * SEGS) + seg * 4;
     const bool valid = col < ncol;
     const int yy = valid ? col / zlen_a : 0;
     const int z = z0a + (valid ? col - yy * zlen_a : 0);
     const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
-    const bool full = z >= b.lo[2] && z + 3 <= b.hi[2];
     if (valid)
       for (int xi = row0; xi < xlen; xi += rows) {
-        uint4 bb = tile[xi * SEGS + seg];
-        u32 mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
-        const int rmax = max(xi, xlen - 1 - xi);
-        for (int r = 1; r <= rmax && (u32)(r * r) < mx; r += 2) {
-          const u32 rr = (u32)(r * r), rr2 = (u32)((r + 1) * (r + 1));
-          const uint4 va = tile[max(xi - r, 0) * SEGS + seg];
-          const uint4 vb = tile[min(xi + r, xlen - 1) * SEGS + seg];
-          const uint4 vc = tile[max(xi - r - 1, 0) * SEGS + seg];
-          const uint4 vd = tile[min(xi + r + 1, xlen - 1) * SEGS + seg];
-          bb.x = min(bb.x, min(min(va.x, vb.x) + rr, min(vc.x, vd.x) + rr2));
-          bb.y = min(bb.y, min(min(va.y, vb.y) + rr, min(vc.y, vd.y) + rr2));
-          bb.z = min(bb.z, min(min(va.z, vb.z) + rr, min(vc.z, vd.z) + rr2));
-          bb.w = min(bb.w, min(min(va.w, vb.w) + rr, min(vc.w, vd.w) + rr2));
-          mx = max(max(bb.x, bb.y), max(bb.z, bb.w));
-        }
-        float* dst = dist + (long)(b.lo[0] + xi) * g.nyz + coloff;
-        if (OUT == 0) {
-          if (full) {
-            *reinterpret_cast<float4*>(dst) =
-                make_float4(esdf_out(bb.x, resf), esdf_out(bb.y, resf), esdf_out(bb.z, resf), esdf_out(bb.w, resf));
-          } else {
-            if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_out(bb.x, resf);
-            if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_out(bb.y, resf);
-            if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_out(bb.z, resf);
-            if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_out(bb.w, resf);
-          }
-        } else {
-          if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = esdf_merge_neg(dst[0], bb.x, resf);
-          if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = esdf_merge_neg(dst[1], bb.y, resf);
-          if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = esdf_merge_neg(dst[2], bb.z, resf);
-          if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = esdf_merge_neg(dst[3], bb.w, resf);
-        }
+        const uint4 bb = scan_line4<FAR>(smem_raw, bm, reinterpret_cast<const unsigned char*>(cm), SEGS * 16, xlen, xi, 16 * seg, near);
+        x_store4<OUT>(dist + (long)(b.lo[0] + xi) * g.nyz + coloff, z, b.lo[2], b.hi[2], bb, resf);
       }
     __syncthreads();  // the tile is rewritten at the top of the next trip
   }
 #undef X4P_FETCH
 }
 
-template <int OUT, int P>
+// the device and the pinned-host slots of the far-output statistic (the insert stage's little blocks have room)
+template <int OUT>
+static u32* esdf_stat_dev(fuelmi_map* m) {
+  static const bool off = getenv("FUELMI_ESDF_NOSTAT") != nullptr;
+  return OUT == 0 && !off ? reinterpret_cast<u32*>(m->ins_head + 8) : nullptr;
+}
+static volatile u32* esdf_stat_host(fuelmi_map* m) { return reinterpret_cast<volatile u32*>(m->h_ins + 8); }
+
+template <int OUT, int P, bool FAR>
 static int launch_x4p_n(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
-  const size_t lds = (size_t)xlen * 8 * 4 * sizeof(u32);
+  const size_t lds = (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * 8 * 4 * sizeof(u32);
+  if (lds > 160 * 1024) return -1;
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4p<OUT, P>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4p<OUT, P, FAR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int ncol = ylen * zlen_a;
   const int ntiles = (ncol + 31) / 32;
   static const char* xg = getenv("FUELMI_X_GRID");  // tuning hook: workgroups per CU
   const int per_cu = xg ? atoi(xg) : std::max(1, std::min(2, (int)((150 * 1024) / std::max<size_t>(lds, 1))));
   const int grid = std::min(ntiles, 256 * per_cu);
-  STAGE_LAUNCH(m, (k_esdf_x4p<OUT, P>), grid, 1024, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a, ntiles);
+  STAGE_LAUNCH(m, (k_esdf_x4p<OUT, P, FAR>), grid, 1024, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a, ntiles,
+               esdf_near(), esdf_stat_dev<OUT>(m), esdf_stat_host(m));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
-template <int OUT>
+template <int OUT, bool FAR>
 static int launch_x4p(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
   switch ((xlen + 127) / 128) {
-    case 1: return launch_x4p_n<OUT, 1>(m, b);
-    case 2: return launch_x4p_n<OUT, 2>(m, b);
-    case 3: return launch_x4p_n<OUT, 3>(m, b);
-    case 4: return launch_x4p_n<OUT, 4>(m, b);
-    case 5: return launch_x4p_n<OUT, 5>(m, b);
-    case 6: return launch_x4p_n<OUT, 6>(m, b);
-    case 7: return launch_x4p_n<OUT, 7>(m, b);
-    case 8: return launch_x4p_n<OUT, 8>(m, b);
+    case 1: return launch_x4p_n<OUT, 1, FAR>(m, b);
+    case 2: return launch_x4p_n<OUT, 2, FAR>(m, b);
+    case 3: return launch_x4p_n<OUT, 3, FAR>(m, b);
+    case 4: return launch_x4p_n<OUT, 4, FAR>(m, b);
+    case 5: return launch_x4p_n<OUT, 5, FAR>(m, b);
+    case 6: return launch_x4p_n<OUT, 6, FAR>(m, b);
+    case 7: return launch_x4p_n<OUT, 7, FAR>(m, b);
+    case 8: return launch_x4p_n<OUT, 8, FAR>(m, b);
     default: return -1;
   }
 }
 
 static inline bool use_vec4(const Geo& g, int xlen) { return (g.nz % 4) == 0 && (size_t)xlen * 64 <= 150 * 1024; }
 
-template <int MODE>
+template <int MODE, bool FAR>
 static int launch_zy4(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
@@ -577,47 +728,50 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   int nzc = (zlen_a + zc_max - 1) / zc_max;
   int ZC = (((zlen_a + nzc - 1) / nzc) + 3) & ~3;
   nzc = (zlen_a + ZC - 1) / ZC;
-  size_t lds = (size_t)ylen * ZC * sizeof(u32);
+  size_t lds = (size_t)(FAR ? ylen + ((ylen + 7) >> 3) + 1 : ylen) * ZC * sizeof(u32);  // tile (+ block and line minima)
   if (lds > 160 * 1024) {
     fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
     return FUELMI_ELIMIT;
   }
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE, FAR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  STAGE_LAUNCH(m, (k_esdf_zy4<MODE>), ((xlen + 7) / 8) * 8 * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
-               m->esdf_tmp, ZC, nzc, z0a);
+  STAGE_LAUNCH(m, (k_esdf_zy4<MODE, FAR>), ((xlen + 7) / 8) * 8 * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
+               m->esdf_tmp, ZC, nzc, z0a, esdf_near(), MODE == 2 ? nullptr : reinterpret_cast<u32*>(m->ins_head + 8));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
 
-template <int OUT, int SEGS>
+template <int OUT, int SEGS, bool FAR>
 static int launch_x4s(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
-  size_t lds = (size_t)xlen * SEGS * 4 * sizeof(u32);
+  const size_t lds = (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * SEGS * 4 * sizeof(u32);
+  if (lds > 160 * 1024) return -1;  // (FAR only: the longest lines, > 2270 voxels, scan without the far phase)
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS, FAR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int ncol = ylen * zlen_a;
   static const char* xt = getenv("FUELMI_X_THREADS");  // tuning hook
   const int threads = xt ? atoi(xt) : 1024;
-  STAGE_LAUNCH(m, (k_esdf_x4<OUT, SEGS>), (ncol + 4 * SEGS - 1) / (4 * SEGS), threads, lds, g, b, (const u32*)m->esdf_tmp,
-               m->dist, z0a, zlen_a);
+  STAGE_LAUNCH(m, (k_esdf_x4<OUT, SEGS, FAR>), (ncol + 4 * SEGS - 1) / (4 * SEGS), threads, lds, g, b, (const u32*)m->esdf_tmp,
+               m->dist, z0a, zlen_a, esdf_near(), esdf_stat_dev<OUT>(m), esdf_stat_host(m));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
-template <int OUT>
+template <int OUT, bool FAR>
 static int launch_x4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
   static const bool piped = getenv("FUELMI_X_NOPIPE") == nullptr;
-  if (piped && (size_t)xlen * 128 <= 150 * 1024) {
+  // the persistent kernel pays when two of its workgroups share a CU (x lines of up to ~560 voxels; measured on
+  // 800-voxel lines, one workgroup per CU: 0.275 ms against 0.250 ms for the one-tile-per-workgroup kernel)
+  if (piped && (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * 128 * 2 <= 160 * 1024) {
     // big enough to keep every CU busy for several tiles? small boxes keep the one-tile-per-workgroup kernel
     const int ylen = b.hi[1] - b.lo[1] + 1, zlen_a = (b.hi[2] | 3) - (b.lo[2] & ~3) + 1;
     if ((long)ylen * zlen_a / 32 >= 512) {
-      const int rc = launch_x4p<OUT>(m, b);
+      const int rc = launch_x4p<OUT, FAR>(m, b);
       if (rc >= 0) return rc;
     }
   }
@@ -625,12 +779,14 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
   // the 32-column tile is faster whenever it fits (measured on 800-voxel lines: 0.32 vs 0.37 ms), the
   // 16-column one extends the vector path to x lines of up to 2400 voxels
   const bool narrow = force ? atoi(force) == 4 : (size_t)xlen * 128 > 150 * 1024;
-  return narrow ? launch_x4s<OUT, 4>(m, b) : launch_x4s<OUT, 8>(m, b);
+  const int rc = narrow ? launch_x4s<OUT, 4, FAR>(m, b) : launch_x4s<OUT, 8, FAR>(m, b);
+  if (rc >= 0 || !FAR) return rc;
+  return narrow ? launch_x4s<OUT, 4, false>(m, b) : launch_x4s<OUT, 8, false>(m, b);
 }
 
-template <int MODE>
+template <int MODE, bool FAR>
 static int launch_zy(fuelmi_map* m, const Box3& b) {
-  if (use_vec4(m->g, b.hi[0] - b.lo[0] + 1)) return launch_zy4<MODE>(m, b);
+  if (use_vec4(m->g, b.hi[0] - b.lo[0] + 1)) return launch_zy4<MODE, FAR>(m, b);
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
   // z-chunk: LDS tile <= 16 KiB so several WGs share a CU, chunks balanced over the z extent
@@ -667,10 +823,10 @@ static int launch_x_s(fuelmi_map* m, const Box3& b) {
   return FUELMI_OK;
 }
 
-template <int OUT>
+template <int OUT, bool FAR>
 static int launch_x(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
-  if (use_vec4(m->g, xlen)) return launch_x4<OUT>(m, b);
+  if (use_vec4(m->g, xlen)) return launch_x4<OUT, FAR>(m, b);
   const size_t budget = 64 * 1024;
   if ((size_t)xlen * 32 * 4 <= budget) return launch_x_s<32, OUT>(m, b);
   if ((size_t)xlen * 16 * 4 <= 128 * 1024) return launch_x_s<16, OUT>(m, b);
@@ -679,27 +835,44 @@ static int launch_x(fuelmi_map* m, const Box3& b) {
   return FUELMI_ELIMIT;
 }
 
+// Which kernels: the y pass of every update counts (on every 16th slab) the outputs further than ESDF_FAR_D voxels
+// from all sources, the x pass hands the count to the host.  When most outputs were far LAST time -- an explored
+// hall, optimistic_ maps -- this update runs the FAR kernels (block / line minima bound the scan), otherwise the
+// plain ones, which cost nothing extra in the half-explored maps exploration spends its time in.  Both are exact;
+// FUELMI_ESDF_FAR=0/1 pins the choice.
+static bool esdf_use_far(fuelmi_map* m) {
+  const char* e = getenv("FUELMI_ESDF_FAR");  // (read per update: the parity tests flip it between calls)
+  if (e && *e) return atoi(e) != 0;
+  const volatile u32* h = esdf_stat_host(m);
+  const u32 nf = h[0], nt = h[1];
+  return nt != 0u && 2ull * nf > nt;
+}
+
 int esdf_update(fuelmi_map* m) {
   const Box3& b = m->local_bound;
+  const bool far = esdf_use_far(m);
   int rc;
   {
     StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
-    rc = m->cfg.optimistic ? launch_zy<1>(m, b) : launch_zy<0>(m, b);
+    if (far)
+      rc = m->cfg.optimistic ? launch_zy<1, true>(m, b) : launch_zy<0, true>(m, b);
+    else
+      rc = m->cfg.optimistic ? launch_zy<1, false>(m, b) : launch_zy<0, false>(m, b);
   }
   if (rc) return rc;
   {
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
-    rc = launch_x<0>(m, b);
+    rc = far ? launch_x<0, true>(m, b) : launch_x<0, false>(m, b);
   }
   if (rc) return rc;
-  if (m->cfg.signed_dist) {
+  if (m->cfg.signed_dist) {  // inside obstacles the nearest free voxel is never far: plain kernels
     {
       StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
-      rc = launch_zy<2>(m, b);
+      rc = launch_zy<2, false>(m, b);
     }
     if (rc) return rc;
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
-    rc = launch_x<1>(m, b);
+    rc = launch_x<1, false>(m, b);
   }
   return rc;
 }

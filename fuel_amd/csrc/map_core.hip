@@ -409,13 +409,13 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
   (void)hipMemsetAsync(m->ray_owner, 0xFF, Npad * sizeof(u32), m->stream);
   k_state_planes<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(
       g, m->occ, m->occ_bits.p, m->unk_bits.p, I.min_occupancy_log, I.clamp_min_log - 1e-3, 0, g.W - 1);
-  if (hipMalloc(reinterpret_cast<void**>(&m->ins_head), 8 * sizeof(u64)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&m->h_ins), 8 * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void**>(&m->ins_head), 16 * sizeof(u64)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&m->h_ins), 16 * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
     fuelmi_set_error("allocation of the fusion's result words failed");
     return fail(FUELMI_ENOMEM);
   }
-  (void)hipMemsetAsync(m->ins_head, 0, 8 * sizeof(u64), m->stream);
-  memset(m->h_ins, 0, 8 * sizeof(u64));
+  (void)hipMemsetAsync(m->ins_head, 0, 16 * sizeof(u64), m->stream);
+  memset(m->h_ins, 0, 16 * sizeof(u64));
   if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_planes, hipEventDisableTiming) != hipSuccess ||
       hipStreamSynchronize(m->stream) != hipSuccess || hipGetLastError() != hipSuccess) {

@@ -138,8 +138,16 @@ def test_fusion_with_the_camera_outside_the_map(fa):
     gm.close()
 
 
+@pytest.fixture(params=["plain", "far"])
+def esdf_kernels(request, monkeypatch):
+    """both ESDF kernel families (esdf.hip: esdf_use_far picks one per update from the previous update's statistic;
+    FUELMI_ESDF_FAR pins it): they must give the same bits"""
+    monkeypatch.setenv("FUELMI_ESDF_FAR", "1" if request.param == "far" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("signed", [0, 1])
-def test_full_size_g400_optimistic_esdf(fa, signed):
+def test_full_size_g400_optimistic_esdf(fa, signed, esdf_kernels):
     """updateESDF3d with optimistic = true (topo_algorithm.xml:71-72: only inflated voxels are sources) on the
     400x400x100 grid, full box: distances are 10-100x those of the headline configuration, the outward scans
     run long.  Against the oracle (<= 1e-4 m) plus exact-integer squared distances and zero on sources."""
@@ -173,7 +181,7 @@ def test_full_size_g400_optimistic_esdf(fa, signed):
     gm.close()
 
 
-def test_sparse_map_long_scans(fa):
+def test_sparse_map_long_scans(fa, esdf_kernels):
     """optimistic ESDF on a mostly free map with a handful of obstacle voxels and NO floor: z-lines and whole
     x-slabs without a source (INF through the passes), distances of hundreds of voxels; plus the all-free box
     (no source at all: the reference's res*sqrt(DBL_MAX) everywhere)."""
@@ -197,6 +205,57 @@ def test_sparse_map_long_scans(fa):
         gm.clearAndInflateLocalMap()
         gm.updateESDF3d()
         assert_map_equal(om, gm, (lo, hi))
+    gm.close()
+
+
+@pytest.mark.parametrize("optimistic", [0, 1])
+def test_esdf_kernel_families_agree_on_ragged_boxes(fa, optimistic, esdf_kernels):
+    """half-explored world (short scans) and boxes that are not 4-aligned in z, not 8-aligned in x / y: the block
+    minima of the FAR kernels have partial last blocks and garbage columns outside the box"""
+    om, _, _, box = helpers.explored_oracle_map((9.0, 7.0, 4.0), 14, 25, optimistic=optimistic)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1], optimistic=optimistic)
+    gm.uploadOccupancy(om.occ)
+    nv = om.nvox
+    for lo, hi in [helpers.full_box(nv), ((3, 5, 1), (nv[0] - 6, nv[1] - 2, nv[2] - 3)), ((17, 9, 2), (58, 43, 30)),
+                   ((0, 0, 5), (9, 8, 6))]:
+        om.set_local_bound(lo, hi)
+        gm.setLocalBound(lo, hi)
+        om.inflate_local()
+        om.update_esdf()
+        gm.clearAndInflateLocalMap()
+        gm.updateESDF3d()
+        assert_map_equal(om, gm, (lo, hi))
+    gm.close()
+
+
+def test_esdf_switches_kernels_from_the_previous_update(fa, monkeypatch):
+    """the adaptive path: an explored hall (optimistic, floor + one pillar) makes the first update report mostly
+    far outputs, the second one then runs the FAR kernels; a half-explored map keeps the plain ones.  Either way
+    the distances equal the oracle's, and the stage timings show the hall getting cheaper on the second update."""
+    monkeypatch.delenv("FUELMI_ESDF_FAR", raising=False)
+    map_size = (20.0, 20.0, 6.0)
+    om = fo.OracleMap(map_size, optimistic=1)
+    gm = fa.SDFMap(map_size, optimistic=1)
+    nv = om.nvox
+    occ = np.full(om.N, om.l_min).reshape(nv)
+    occ[:, :, 0] = om.l_max
+    occ[90:96, 100:104, 1:40] = om.l_max
+    om.occ[:] = occ.reshape(-1)
+    gm.uploadOccupancy(om.occ)
+    lo, hi = helpers.full_box(nv)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    from fuel_amd._lib import K_ESDF_ZY, K_ESDF_X
+    gm.profileEnable((1 << K_ESDF_ZY) | (1 << K_ESDF_X))
+    for _ in range(3):
+        gm.updateESDF3d()
+        assert_map_equal(om, gm, (lo, hi))
+    esdf_ms = gm.profileSamples(K_ESDF_ZY)[:3] + gm.profileSamples(K_ESDF_X)[:3]
+    print("explored hall, ESDF ms per update:", ["%.3f" % v for v in esdf_ms])
+    assert esdf_ms[2] < 0.8 * esdf_ms[0], esdf_ms
     gm.close()
 
 
