@@ -541,9 +541,9 @@ def main():
         try:
             pmc_file = {"G400": "r02_pmc_hbm_traffic_G400.json", "G800": "r02_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-            key = {"esdf_zy": "k_esdf_zy4<0>", "esdf_x": "k_esdf_x4<0>", "inflate": "k_inflate_yz",
+            key = {"esdf_zy": "k_esdf_zy4<", "esdf_x": "k_esdf_x4", "inflate": "k_inflate_yz",
                    "bspline": "k_bspline_cost_grad"}[dominant]
-            hit = [v for k, v in pmc.items() if k.endswith(key)]
+            hit = [v for k, v in pmc.items() if key in k]
             traffic = hit[0]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None

@@ -261,6 +261,13 @@ static int esdf_near() {  // rows the FAR kernels scan one by one before the blo
   static const int v = e ? std::max(2, atoi(e) & ~1) : 2;
   return v;
 }
+// one 16-byte global store that stays one instruction (a plain uint4 assignment next to the per-component edge
+// path came out as a 12-byte plus a 4-byte store)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(void* p, uint4 v) {
+  u32x4_t w = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<u32x4_t*>(p) = w;
+}
 __device__ __forceinline__ uint4 lds4(const unsigned char* p, int off) { return *reinterpret_cast<const uint4*>(p + off); }
 __device__ __forceinline__ u32 max4(u32 a, u32 b, u32 c, u32 d) { return max(max(a, b), max(c, d)); }
 
@@ -406,6 +413,53 @@ __device__ __forceinline__ uint4 scan_line4(const unsigned char* tile, const uns
   return bb;
 }
 
+// dz^2 of one tile row from the chunk's source bits and the nearest sources below / above the chunk
+__device__ __forceinline__ void zy_fill_row(u32* row, int ZC, u64 bits, int below, int above, int zs, int ze) {
+  // two sweeps over the chunk (distance to the nearest source below / above), 4 voxels per LDS
+  // access.  Columns outside the box get garbage that the y pass never stores nor mixes in (a
+  // column only reads itself in other rows).
+  const u32 BIGD = 1u << 20;  // "no source yet": stays >= BIGD after any number of +1 steps
+  u32 d = below >= 0 ? (u32)(zs - 1 - below) : BIGD;
+  for (int zi = 0; zi < ZC; zi += 4) {
+    const u32 nib = (u32)(bits >> zi);
+    uint4 o;
+    d = (nib & 1u) ? 0u : d + 1u;
+    o.x = d;
+    d = (nib & 2u) ? 0u : d + 1u;
+    o.y = d;
+    d = (nib & 4u) ? 0u : d + 1u;
+    o.z = d;
+    d = (nib & 8u) ? 0u : d + 1u;
+    o.w = d;
+    *reinterpret_cast<uint4*>(row + zi) = o;
+  }
+  d = above >= 0 ? (u32)(above - (ze + 1)) : BIGD;
+  for (int zi = ZC - 4; zi >= 0; zi -= 4) {
+    const u32 nib = (u32)(bits >> zi);
+    uint4 o = *reinterpret_cast<const uint4*>(row + zi);
+    d = (nib & 8u) ? 0u : d + 1u;
+    o.w = min(o.w, d);
+    d = (nib & 4u) ? 0u : d + 1u;
+    o.z = min(o.z, d);
+    d = (nib & 2u) ? 0u : d + 1u;
+    o.y = min(o.y, d);
+    d = (nib & 1u) ? 0u : d + 1u;
+    o.x = min(o.x, d);
+    o.x = o.x >= BIGD ? INF32 : o.x * o.x;
+    o.y = o.y >= BIGD ? INF32 : o.y * o.y;
+    o.z = o.z >= BIGD ? INF32 : o.z * o.z;
+    o.w = o.w >= BIGD ? INF32 : o.w * o.w;
+    *reinterpret_cast<uint4*>(row + zi) = o;
+  }
+}
+
+#define ZY_ROUNDS 2  // rows per lane whose plane words are fetched up front (y lines of up to 1024 voxels)
+// bits of word k of a multi-word line that lie in positions [A, B]
+__device__ __forceinline__ u64 range_mask(int k, int A, int B) {
+  const int lo = max(A - 64 * k, 0), hi = min(B - 64 * k, 63);
+  return lo <= hi ? bit_range(lo, hi - lo + 1) : 0ull;
+}
+
 template <int MODE, bool FAR>
 __global__ void __launch_bounds__(512)
 k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp,
@@ -429,54 +483,67 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   unsigned char* bm = smem_raw + (size_t)ylen * ZC * 4;
   u32* cm = reinterpret_cast<u32*>(bm + (size_t)((ylen + 7) >> 3) * ZC * 4);
   if (FAR && (int)threadIdx.x < ZC) cm[threadIdx.x] = INF32;
-  for (int yi = threadIdx.x; yi < ylen; yi += T) {
-    u32* row = tile + yi * ZC;
-    const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
-    u64 bits = 0ull;
-    int below = -1, above = -1;
-    if (zs <= ze) {
-      u64 lo = src_word<MODE>(infl, unk, (linebit + zc0) >> 6), hi = src_word<MODE>(infl, unk, ((linebit + zc0) >> 6) + 1);
-      int sh = (int)((linebit + zc0) & 63);
-      bits = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-      bits &= bit_range(zs - zc0, ze - zs + 1);
-      below = line_src_down<MODE>(infl, unk, linebit, b.lo[2], zs - 1);
-      above = line_src_up<MODE>(infl, unk, linebit, ze + 1, b.hi[2]);
+  // Source bits of the rows.  When the box's part of a z-line fits three plane words (z extents up to 129
+  // voxels) every row takes ONE round of independent loads -- issued for all of the lane's rows before the first
+  // is used -- instead of a chain of dependent ones (word pair of the chunk, then the searches below and above it):
+  // the kernel is latency-bound and that chain was half of a workgroup's life.
+  if (b.hi[2] - z0a + 1 <= 129 && ylen <= ZY_ROUNDS * T) {
+    u64 L[ZY_ROUNDS][3];
+#pragma unroll
+    for (int r = 0; r < ZY_ROUNDS; ++r) {
+      const int yi = threadIdx.x + r * T;
+      L[r][0] = L[r][1] = L[r][2] = 0ull;
+      if (yi < ylen && zs <= ze) {
+        const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
+        const long w0 = (linebit + z0a) >> 6, w1 = (linebit + b.hi[2]) >> 6;
+        L[r][0] = src_word<MODE>(infl, unk, w0);
+        if (w0 + 1 <= w1) L[r][1] = src_word<MODE>(infl, unk, w0 + 1);
+        if (w0 + 2 <= w1) L[r][2] = src_word<MODE>(infl, unk, w0 + 2);
+      }
     }
-    // two sweeps over the chunk (distance to the nearest source below / above), 4 voxels per LDS
-    // access.  Columns outside the box get garbage that the y pass never stores nor mixes in (a
-    // column only reads itself in other rows).
-    const u32 BIGD = 1u << 20;  // "no source yet": stays >= BIGD after any number of +1 steps
-    u32 d = below >= 0 ? (u32)(zs - 1 - below) : BIGD;
-    for (int zi = 0; zi < ZC; zi += 4) {
-      const u32 nib = (u32)(bits >> zi);
-      uint4 o;
-      d = (nib & 1u) ? 0u : d + 1u;
-      o.x = d;
-      d = (nib & 2u) ? 0u : d + 1u;
-      o.y = d;
-      d = (nib & 4u) ? 0u : d + 1u;
-      o.z = d;
-      d = (nib & 8u) ? 0u : d + 1u;
-      o.w = d;
-      *reinterpret_cast<uint4*>(row + zi) = o;
+#pragma unroll
+    for (int r = 0; r < ZY_ROUNDS; ++r) {
+      const int yi = threadIdx.x + r * T;
+      if (yi >= ylen) break;
+      const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
+      u64 bits = 0ull;
+      int below = -1, above = -1;
+      if (zs <= ze) {
+        const u64 L0 = L[r][0], L1 = L[r][1], L2 = L[r][2];
+        const int p0 = (int)((linebit + z0a) & 63) - z0a;  // position of voxel z in the 192-bit line = p0 + z
+        const int pc = p0 + zc0, q = pc >> 6, sh = pc & 63;
+        const u64 a = q == 0 ? L0 : (q == 1 ? L1 : L2), c = q == 0 ? L1 : (q == 1 ? L2 : 0ull);
+        bits = sh ? ((a >> sh) | (c << (64 - sh))) : a;
+        bits &= bit_range(zs - zc0, ze - zs + 1);
+        if (zs - 1 >= b.lo[2]) {  // highest source below the chunk
+          const int A = p0 + b.lo[2], B = p0 + zs - 1;
+          const u64 m2 = L2 & range_mask(2, A, B), m1 = L1 & range_mask(1, A, B), m0 = L0 & range_mask(0, A, B);
+          const int hp = m2 ? 191 - __builtin_clzll(m2) : (m1 ? 127 - __builtin_clzll(m1) : (m0 ? 63 - __builtin_clzll(m0) : -1));
+          if (hp >= 0) below = hp - p0;
+        }
+        if (ze + 1 <= b.hi[2]) {  // lowest source above it
+          const int A = p0 + ze + 1, B = p0 + b.hi[2];
+          const u64 m0 = L0 & range_mask(0, A, B), m1 = L1 & range_mask(1, A, B), m2 = L2 & range_mask(2, A, B);
+          const int lp = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 + __builtin_ctzll(m2) : -1));
+          if (lp >= 0) above = lp - p0;
+        }
+      }
+      zy_fill_row(tile + yi * ZC, ZC, bits, below, above, zs, ze);
     }
-    d = above >= 0 ? (u32)(above - (ze + 1)) : BIGD;
-    for (int zi = ZC - 4; zi >= 0; zi -= 4) {
-      const u32 nib = (u32)(bits >> zi);
-      uint4 o = *reinterpret_cast<const uint4*>(row + zi);
-      d = (nib & 8u) ? 0u : d + 1u;
-      o.w = min(o.w, d);
-      d = (nib & 4u) ? 0u : d + 1u;
-      o.z = min(o.z, d);
-      d = (nib & 2u) ? 0u : d + 1u;
-      o.y = min(o.y, d);
-      d = (nib & 1u) ? 0u : d + 1u;
-      o.x = min(o.x, d);
-      o.x = o.x >= BIGD ? INF32 : o.x * o.x;
-      o.y = o.y >= BIGD ? INF32 : o.y * o.y;
-      o.z = o.z >= BIGD ? INF32 : o.z * o.z;
-      o.w = o.w >= BIGD ? INF32 : o.w * o.w;
-      *reinterpret_cast<uint4*>(row + zi) = o;
+  } else {
+    for (int yi = threadIdx.x; yi < ylen; yi += T) {
+      const long linebit = (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz;
+      u64 bits = 0ull;
+      int below = -1, above = -1;
+      if (zs <= ze) {
+        u64 lo = src_word<MODE>(infl, unk, (linebit + zc0) >> 6), hi = src_word<MODE>(infl, unk, ((linebit + zc0) >> 6) + 1);
+        int sh = (int)((linebit + zc0) & 63);
+        bits = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+        bits &= bit_range(zs - zc0, ze - zs + 1);
+        below = line_src_down<MODE>(infl, unk, linebit, b.lo[2], zs - 1);
+        above = line_src_up<MODE>(infl, unk, linebit, ze + 1, b.hi[2]);
+      }
+      zy_fill_row(tile + yi * ZC, ZC, bits, below, above, zs, ze);
     }
   }
   __syncthreads();
@@ -493,13 +560,18 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   // host picks the FAR or the plain kernels for the NEXT update from that (esdf_update)
   const bool sampled = stat != nullptr && (xrel & 15) == 0;
   int n_far = 0;
+  const bool z_aligned = (b.lo[2] & 3) == 0 && (b.hi[2] & 3) == 3;
   int yi = threadIdx.x / G, gi = threadIdx.x - yi * G;
   for (int o = threadIdx.x; o < total; o += T) {
     const uint4 bb = scan_line4<FAR>(smem_raw, bm, reinterpret_cast<const unsigned char*>(cm), stride, ylen, yi, 16 * gi, near);
     if (sampled) n_far += __popcll(__ballot(min(min(bb.x, bb.y), min(bb.z, bb.w)) > ESDF_FAR_D * ESDF_FAR_D));
     const int z = zc0 + 4 * gi;
     u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + yi) * g.nz + z;
-    if (z >= b.lo[2] && z + 3 <= b.hi[2]) {
+    // (z_aligned is uniform: the common 4-aligned box keeps ONE 16-byte store; folded into the per-lane test the
+    // compiler merged the two paths into a 12-byte and a 4-byte store)
+    if (z_aligned) {
+      if (z >= b.lo[2] && z <= b.hi[2]) store16(dst, bb);  // (chunks may reach past the box)
+    } else if (z >= b.lo[2] && z + 3 <= b.hi[2]) {
       *reinterpret_cast<uint4*>(dst) = bb;
     } else {
       if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = bb.x;
@@ -538,7 +610,10 @@ __device__ __forceinline__ void forward_stat(u32* stat, volatile u32* h_stat) {
 template <int OUT>
 __device__ __forceinline__ void x_store4(float* dst, int z, int zlo, int zhi, uint4 bb, float resf) {
   if (OUT == 0) {
-    if (z >= zlo && z + 3 <= zhi) {
+    if ((zlo & 3) == 0 && (zhi & 3) == 3) {  // uniform: one 16-byte store (see k_esdf_zy4); z is inside the box
+      store16(dst, make_uint4(__float_as_uint(esdf_out(bb.x, resf)), __float_as_uint(esdf_out(bb.y, resf)),
+                              __float_as_uint(esdf_out(bb.z, resf)), __float_as_uint(esdf_out(bb.w, resf))));
+    } else if (z >= zlo && z + 3 <= zhi) {
       *reinterpret_cast<float4*>(dst) =
           make_float4(esdf_out(bb.x, resf), esdf_out(bb.y, resf), esdf_out(bb.z, resf), esdf_out(bb.w, resf));
     } else {
@@ -729,6 +804,8 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   int ZC = (((zlen_a + nzc - 1) / nzc) + 3) & ~3;
   nzc = (zlen_a + ZC - 1) / ZC;
   size_t lds = (size_t)(FAR ? ylen + ((ylen + 7) >> 3) + 1 : ylen) * ZC * sizeof(u32);  // tile (+ block and line minima)
+  static const char* pad = getenv("FUELMI_ZY_LDS_PAD_KB");  // tuning: fewer workgroups per CU
+  if (pad) lds += (size_t)atoi(pad) * 1024;
   if (lds > 160 * 1024) {
     fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
     return FUELMI_ELIMIT;
@@ -764,7 +841,11 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
 template <int OUT, bool FAR>
 static int launch_x4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
-  static const bool piped = getenv("FUELMI_X_NOPIPE") == nullptr;
+  // The persistent kernel is the faster x pass on its own (400^2 x 100: 26.5 us against 31) but not in a plan
+  // cycle: its two 1024-thread workgroups hold every wave slot of every CU for the whole pass, and the frontier
+  // finder's chain of short kernels (the cycle's critical path, on its own stream) waits behind them -- measured
+  // 7050 cycles/s with it, 7450 without.  FUELMI_X_PIPE=1 selects it (stand-alone ESDF updates).
+  static const bool piped = getenv("FUELMI_X_PIPE") != nullptr;
   // the persistent kernel pays when two of its workgroups share a CU (x lines of up to ~560 voxels; measured on
   // 800-voxel lines, one workgroup per CU: 0.275 ms against 0.250 ms for the one-tile-per-workgroup kernel)
   if (piped && (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * 128 * 2 <= 160 * 1024) {

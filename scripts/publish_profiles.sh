@@ -1,16 +1,20 @@
 #!/bin/bash
-# copy the summaries scripts/collect_profiles.sh left under gpurun_out/prof_r01 into profiles/ (tracked)
-O=gpurun_out/prof_r01; P=profiles; R=${1:-r01}
-tail -1 $O/bench.json > $P/${R}_bench_G400.json
-tail -1 $O/bench_C1.json > $P/${R}_bench_G400_C1.json
-tail -1 $O/bench_C256.json > $P/${R}_bench_G400_C256.json
-tail -1 $O/bench_under_rocprof.json > $P/${R}_bench_G400_under_rocprof.json
-tail -1 $O/bench_G800S.json > $P/${R}_bench_G800S_streaming.json
-cp $O/cycle/s_kernel_stats.csv $P/${R}_bench_G400_kernel_stats.csv
-cp $O/serial/s_kernel_stats.csv $P/${R}_bench_G400_serial_stages_kernel_stats.csv
+# copy the summaries scripts/collect_profiles.sh left under gpurun_out/prof_<round> into profiles/ (tracked)
+R=${1:-r02}; O=gpurun_out/prof_$R; P=profiles
+for f in bench_G400 bench_G800 bench_G400K bench_G400E bench_G400_C1 bench_G400_C256 bench_G400_under_rocprof bench_G800_under_rocprof; do
+  [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${R}_$f.json
+done
+[ -s $O/bench_G800S.json ] && tail -1 $O/bench_G800S.json > $P/${R}_bench_G800S_streaming.json
+for WL in G400 G800; do
+  cp $O/cycle_$WL/s_kernel_stats.csv $P/${R}_bench_${WL}_kernel_stats.csv
+  cp $O/serial_$WL/s_kernel_stats.csv $P/${R}_bench_${WL}_serial_stages_kernel_stats.csv
+  cp $O/pmc_hbm_traffic_$WL.json $P/${R}_pmc_hbm_traffic_$WL.json
+  [ -s $O/pmc_sq_$WL.json ] && cp $O/pmc_sq_$WL.json $P/${R}_pmc_sq_$WL.json
+done
+for WL in G400K G400E; do cp $O/serial_$WL/s_kernel_stats.csv $P/${R}_bench_${WL}_serial_stages_kernel_stats.csv; done
 cp $O/stream/s_kernel_stats.csv $P/${R}_bench_G800S_streaming_kernel_stats.csv
 cp $O/next/s_kernel_stats.csv $P/${R}_next_rows_kernel_stats.csv
 cp $O/next_rows.json $P/${R}_next_rows.json
-cp $O/pmc_fetch/s_counter_collection.csv $P/${R}_pmc_FETCH_SIZE_counter_collection.csv
-cp $O/pmc_write/s_counter_collection.csv $P/${R}_pmc_WRITE_SIZE_counter_collection.csv
-cp $O/pmc_hbm_traffic.json $P/${R}_pmc_hbm_traffic.json
+[ -s $O/facade_bench_G800S.json ] && tail -1 $O/facade_bench_G800S.json > $P/${R}_facade_bench_G800S.json
+cp $O/fleet_one_device.txt $P/${R}_fleet_one_device.txt
+ls $P | grep ${R}_ | wc -l
