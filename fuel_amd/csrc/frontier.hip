@@ -1958,7 +1958,7 @@ __global__ void __launch_bounds__(256) k_flags_hist(Geo g, FArgs F) {
 // stable scatter of the kept cells into the grouped result (cluster by cluster in creation order, ascending
 // address inside): position = offset of the cluster + its cells in earlier blocks + its earlier cells of this
 // block.
-__global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) {
+__device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
   __shared__ u32 running[FR_KCAP];
   __shared__ u32 wcnt[4][FR_KCAP];
   if ((int)blockIdx.x >= F.var->nblocks) return;
@@ -2023,6 +2023,23 @@ __global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) {
     __syncthreads();
     running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
     __syncthreads();
+  }
+}
+// the last kernel of the fast chain: regroups the cells, copies them out, and the workgroup that finishes last
+// stamps the pinned result block ("cells are in") -- frontier_tail_sync polls that word instead of paying a
+// blocking stream synchronisation
+__global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) {
+  const int nblocks = F.var->nblocks;  // the grid is sized for the largest box; the rest leaves at once
+  if ((int)blockIdx.x >= nblocks) return;
+  scatter2_body(g, F);
+  // (the barrier waits for this workgroup's h_cells stores to be acknowledged; fences here -- system scope per
+  // thread, or even device scope per workgroup -- wrote the L2 back thousands of times per search and stalled
+  // everything else on the device; the one release below publishes the lot)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 done = atomicAdd(&F.fctr[24], 1u);  // (zeroed with the other counters by k_pred2)
+    if ((int)done == nblocks - 1)
+      __hip_atomic_store(&F.h_counts[14], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -2269,6 +2286,17 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   return FUELMI_OK;
 }
 
+// copy the cell lists of kept-but-still-lazy clusters out of the pinned result buffer (see frontier_keep_clusters)
+int frontier_materialize_lists(fuelmi_frontier* f) {
+  if (!f->lazy_kept) return FUELMI_OK;
+  const int rc = frontier_tail_sync(f);
+  if (rc) return rc;
+  for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
+    for (HCluster& c : *L) c.materialize();
+  f->lazy_kept = false;
+  return FUELMI_OK;
+}
+
 // ---- device pool of committed clusters' cells ---------------------------------------------------
 static int pool_upload(fuelmi_frontier* f, HCluster& c) {  // from the host list (rebuilds)
   c.pool_off = f->pool_used;
@@ -2282,6 +2310,10 @@ static int pool_reserve(fuelmi_frontier* f, size_t need) {
   if (f->pool_used + need <= f->pool_cap) return FUELMI_OK;
   // compact (erased clusters leave holes) and grow: re-upload the live clusters from their host lists
   size_t live = need;
+  {
+    const int rcm = frontier_materialize_lists(f);
+    if (rcm) return rcm;
+  }
   for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
     for (HCluster& c : *L) live += c.cells.size();
   HIPCHK(hipStreamSynchronize(f->stream));
@@ -2306,10 +2338,10 @@ static int pool_reserve(fuelmi_frontier* f, size_t need) {
 // commit this search's clusters to the pool: the ones whose cells still sit grouped on the device are
 // copied there by ONE launch (a table of {destination, source, count, seed} per cluster)
 int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
-  {
-    int rct = frontier_tail_sync(f);  // the host lists are materialised from the pinned cell buffer
-    if (rct) return rct;
-  }
+  // The kept clusters stay "lazy" -- their cell lists still sit in the pinned result buffer, which the tail of
+  // the search may not even have filled yet: the pool copy below is ordered behind that tail on the stream, and
+  // the host lists are materialised by frontier_materialize_lists before the buffer is reused (next search) or
+  // when somebody asks for them.  Waiting for the tail here cost ~25 us per streaming cycle.
   size_t need = 0, nlazy = 0;
   for (HCluster& c : clusters) need += c.size(), nlazy += c.lazy ? 1 : 0;
   int rc = pool_reserve(f, need);
@@ -2329,7 +2361,7 @@ int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
     table.push_back(e);
     c.pool_off = f->pool_used;
     f->pool_used += c.size();
-    c.materialize();
+    f->lazy_kept = true;
   }
   if (table.empty()) return FUELMI_OK;
   if (table.size() > f->h_put_cap) {
@@ -2370,7 +2402,7 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
     const HCluster& c = *f->pend_rm[k].it;
     off[k] = c.pool_off;
     start[k] = total;
-    total += (u32)c.cells.size();
+    total += (u32)c.size();
     for (int q = 0; q < 3; ++q) {  // if dropped, its cells lose their flags and may be re-grown from the scan box
       const int lo = (int)std::floor((c.bmin[q] - m->g.org[q]) * m->g.res_inv);
       const int hi = (int)std::floor((c.bmax[q] - m->g.org[q]) * m->g.res_inv);
@@ -2535,6 +2567,10 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   const Geo& g = m->g;
   FArgs& F = f->F;
   f->tmp.clear();
+  {
+    const int rcm = frontier_materialize_lists(f);  // (the result buffer is about to be reused)
+    if (rcm) return rcm;
+  }
   double umin[3], umax[3];
   fuelmi_map_get_updated_box(m, umin, umax, 1);
 

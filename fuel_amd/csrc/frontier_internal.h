@@ -207,6 +207,7 @@ struct fuelmi_frontier {
   bool pending = false, search_empty = false;
   // fast path: _search_end returns as soon as the cluster records have arrived; the kernels that regroup the
   // cells and ship them to the host are still running then.  Everything that reads the cell lists waits here.
+  bool lazy_kept = false;  // committed clusters whose host cell lists still sit in the pinned result buffer
   mutable bool tail_pending = false;
   bool fast_launched = false;  // the chain of the running search is the fast one
   u32 epoch = 0;
@@ -261,10 +262,22 @@ struct PoolPut {  // one cluster's copy into the cell pool
   int seed, pad;
 };
 int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters);
+int frontier_materialize_lists(fuelmi_frontier* f);
 // wait for the tail of the last search (cell regrouping + copy-out); cheap when nothing is pending
 static inline int frontier_tail_sync(const fuelmi_frontier* f) {
   if (!f->tail_pending) return FUELMI_OK;
   f->tail_pending = false;
+  if (f->fast_launched && f->F.fast) {  // the fast chain's last kernel stamps the pinned block when the cells are in
+    volatile u32* stamp = f->F.h_counts + 14;
+    const u32 want = f->h_var->epoch;
+    for (unsigned spins = 0; *stamp != want;)
+      if ((++spins & 0x3FFFu) == 0u) {
+        const hipError_t q = hipStreamQuery(f->stream);
+        if (q == hipSuccess) break;  // (everything ran: the stamp is there or the legacy path took over)
+        if (q != hipErrorNotReady) HIPCHK(q);
+      }
+    if (*stamp == want) return FUELMI_OK;
+  }
   HIPCHK(hipStreamSynchronize(f->stream));
   if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));  // (the event stays armed for the next search)
   return FUELMI_OK;

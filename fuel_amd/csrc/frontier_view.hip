@@ -413,7 +413,7 @@ extern "C" int fuelmi_frontier_is_covered(fuelmi_frontier* f, int* covered) {
         if (std::max(c.bmin[i], umin[i]) > std::min(c.bmax[i], umax[i]) + 1e-3) ov = false;
       if (!ov) continue;
       cand.push_back(&c);
-      ncell += c.cells.size();
+      ncell += c.size();
     }
   if (cand.empty()) return FUELMI_OK;
   const size_t nc = cand.size();
@@ -423,7 +423,7 @@ extern "C" int fuelmi_frontier_is_covered(fuelmi_frontier* f, int* covered) {
   for (size_t k = 0; k < nc; ++k) {
     off[k] = cand[k]->pool_off;
     start[k] = total;
-    total += (u32)cand[k]->cells.size();
+    total += (u32)cand[k]->size();
   }
   (void)ncell;
   unsigned char* d;
@@ -447,7 +447,7 @@ extern "C" int fuelmi_frontier_is_covered(fuelmi_frontier* f, int* covered) {
   for (size_t k = 0; k < cand.size(); ++k) {
     // "++change_num >= change_thresh" inside the loop over changed cells: true iff at least one cell
     // changed and the count reaches int(min_view_finish_fraction * cells.size())
-    const int thresh = (int)(f->vcfg.min_view_finish_fraction * cand[k]->cells.size());
+    const int thresh = (int)(f->vcfg.min_view_finish_fraction * cand[k]->size());
     if (changed[k] >= 1u && (int)changed[k] >= thresh) {
       *covered = 1;
       break;

@@ -64,6 +64,7 @@ struct InsertArgs {
   u64 epoch;
   u64* partial;  // [classify blocks][6] per-block boxes, folded by block 0 of k_insert_raycast
   int nblk;      // classify blocks
+  int dbg;       // FUELMI_INS_DBG timing experiments (results wrong): 1 no global miss marks in the walk, 2 no walk
 };
 
 __device__ __forceinline__ u64 enc_f64(double d) {
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     }
   }
   __syncthreads();
-  if (threadIdx.x < s_cnt) {
+  if (threadIdx.x < s_cnt && !(A.dbg & 2)) {
   const double pt[3] = {s_pt[threadIdx.x][0], s_pt[threadIdx.x][1], s_pt[threadIdx.x][2]};
 
   // RayCaster::input(pt_w, camera_pos) (raycast.cpp:329-372)
@@ -315,8 +316,8 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
                                               // outside [0, N) the reference is undefined behaviour: dropped
       const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
       if (send && (ux | uy) < (u32)CUBE_XY && uz < 32u) {
-        atomicOr(&s_seen[ux * CUBE_XY + uy], 1u << uz);  // flushed as whole words when the block is done
-      } else if (raw) {
+        if (!(A.dbg & 4)) atomicOr(&s_seen[ux * CUBE_XY + uy], 1u << uz);  // flushed as whole words when the block is done
+      } else if (raw && !(A.dbg & 1)) {
         atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
       }
     }
@@ -436,6 +437,10 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   int nb = (n + 255) / 256;
   A.nblk = nb;
   A.partial = m->ins_partial;
+  {
+    static const char* e = getenv("FUELMI_INS_DBG");
+    A.dbg = e ? atoi(e) : 0;
+  }
   k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
   k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
   HIPCHK(hipGetLastError());
