@@ -183,10 +183,24 @@ class GpuStreamCycle:
 
     def __init__(self, map_size, box, frames, ctrl, device, dt=0.175):
         import fuel_amd
+        import torch
         self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device)
         self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100)
         self.frames = frames
         self.k = 0
+        # where the depth frames live when a step hands one over (frame_source):
+        #   "device"   -- resident in HBM before the timed region starts (what `value` is quoted on)
+        #   "pinned"   -- a registered host ring, read in place over PCIe by the fusion kernels
+        #   "pageable" -- an ordinary host array (a cv::Mat): staged through the map's pinned buffer
+        stack = np.ascontiguousarray(np.stack([f[0] for f in frames]).astype(np.uint16))
+        self.rows, self.cols = stack.shape[1], stack.shape[2]
+        self.dev_frames = torch.from_numpy(stack.view(np.int16)).to("cuda:%d" % device)
+        self.pinned = stack.copy()
+        fuel_amd._lib.check(self.map.L.fuelmi_host_register(self.pinned.ctypes.data, self.pinned.nbytes))
+        fb = self.rows * self.cols * 2
+        self.ptr = {"device": [self.dev_frames.data_ptr() + i * fb for i in range(len(frames))],
+                    "pinned": [self.pinned.ctypes.data + i * fb for i in range(len(frames))]}
+        self.frame_source = "device"
         self.opt = fuel_amd.BsplineOptimizer()
         self.opt.setEnvironment(self.map)
         x, ptd, st, en = bspline_problem(ctrl, dt)
@@ -196,11 +210,17 @@ class GpuStreamCycle:
         self.n_clusters = 0
         self.box_vox = []  # voxels of the local bound of every frame (the ESDF / inflation box)
 
+    def fuse(self, i):
+        img, pos, q = self.frames[i]
+        if self.frame_source == "pageable":
+            return self.map.inputDepthImage(img, pos, q)
+        return self.map.inputDepthImageAt(self.ptr[self.frame_source][i], self.rows, self.cols, pos, q)
+
     def step(self):
-        img, pos, q = self.frames[self.k % len(self.frames)]
+        i = self.k % len(self.frames)
         self.k += 1
         m = self.map
-        fused = m.inputDepthImage(img, pos, q) > 0  # MapROS::depthPoseCallback
+        fused = self.fuse(i) > 0                      # MapROS::depthPoseCallback
         # the scan only reads the occupancy planes the fusion just rewrote: queue it first (own stream), the
         # inflation -> ESDF -> B-spline chain beside it, collect the clusters last (same order as GpuCycle)
         self.ff.searchFrontiersBegin()                # consumes the accumulated updated box
@@ -215,10 +235,10 @@ class GpuStreamCycle:
 
     def step_serial(self):
         """Diagnostic order: the frontier search after the map chain instead of beside it."""
-        img, pos, q = self.frames[self.k % len(self.frames)]
+        i = self.k % len(self.frames)
         self.k += 1
         m = self.map
-        if m.inputDepthImage(img, pos, q) > 0:
+        if self.fuse(i) > 0:
             lo, hi = m.getLocalBound()
             self.box_vox.append(float(np.prod(np.array(hi) - np.array(lo) + 1)))
             m.clearAndInflateLocalMap()
@@ -462,7 +482,7 @@ def main():
         map_size, n_obs, _ = WORKLOADS[args.workload]
         box = exploration_box(map_size)
         # distinct frames for every step of the run (warm-up, the two short profiling passes, timed region)
-        frames = streaming_frames(map_size, n_obs, args.warmup + args.steps + 12, seed=42 + rank)
+        frames = streaming_frames(map_size, n_obs, args.warmup + 3 * args.steps + 12, seed=42 + rank)
         rng = np.random.default_rng(1000 + 42 + rank)
         ctrl = make_trajectories(rng, args.candidates, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
         occ, n_known = None, 0
@@ -515,6 +535,17 @@ def main():
         elapsed = timed_fleet_run(lambda: cyc.run_native(args.steps, args.serial_stages), cyc.finish, 1, dist,
                                   torch.cuda.synchronize)
     n_launch, dom_total_ms = cyc.map.profileGet(stages[dominant])
+    frame_source = None
+    if streaming:
+        # the same K frames handed over from host memory instead (the map keeps growing: slightly later frames of
+        # the same path), reported beside `value`
+        frame_source = {"device_resident_ms_per_frame": 1e3 * elapsed / args.steps}
+        cyc.map.profileEnable(0)
+        for src in ("pinned", "pageable"):
+            cyc.frame_source = src
+            t = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
+            frame_source[src + "_host_ms_per_frame"] = 1e3 * t / args.steps
+        cyc.frame_source = "device"
     if not streaming:
         cyc.map.profileEnable(0)
         t_py = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
@@ -601,6 +632,8 @@ def main():
         out["roofline"]["critical"] = crit
         if host_loop is not None:
             out["host_loop"] = host_loop
+        if frame_source is not None:
+            out["frame_source"] = frame_source
         out["frontier_path"] = dict(zip(("fast", "legacy", "fallback"), cyc.ff.stats()))
         out["cycle_hbm"] = {"algorithmic_bytes_per_cycle": cyc_bytes, "achieved": cyc_bytes * cps_per_gpu / 1e9,
                             "unit": "GB/s", "frac": cyc_bytes * cps_per_gpu / 1e9 / HBM_PEAK_GBS}

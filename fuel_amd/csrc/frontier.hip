@@ -2025,22 +2025,13 @@ __device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
     __syncthreads();
   }
 }
-// the last kernel of the fast chain: regroups the cells, copies them out, and the workgroup that finishes last
-// stamps the pinned result block ("cells are in") -- frontier_tail_sync polls that word instead of paying a
-// blocking stream synchronisation
-__global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) {
-  const int nblocks = F.var->nblocks;  // the grid is sized for the largest box; the rest leaves at once
-  if ((int)blockIdx.x >= nblocks) return;
-  scatter2_body(g, F);
-  // (the barrier waits for this workgroup's h_cells stores to be acknowledged; fences here -- system scope per
-  // thread, or even device scope per workgroup -- wrote the L2 back thousands of times per search and stalled
-  // everything else on the device; the one release below publishes the lot)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const u32 done = atomicAdd(&F.fctr[24], 1u);  // (zeroed with the other counters by k_pred2)
-    if ((int)done == nblocks - 1)
-      __hip_atomic_store(&F.h_counts[14], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+// the last kernels of the fast chain: regroup the cells and copy them out; then one thread stamps the pinned result
+// block ("cells are in") -- frontier_tail_sync polls that word instead of paying a blocking stream synchronisation.
+// (Counting finished workgroups inside k_scatter2 instead put ~1000 same-address atomics, 15 us, into the kernel;
+// fences there -- system scope per thread, or device scope per workgroup -- wrote the L2 back thousands of times.)
+__global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) { scatter2_body(g, F); }
+__global__ void k_tail_stamp(FArgs F) {
+  __hip_atomic_store(&F.h_counts[14], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2552,6 +2543,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
   FDBG("k_flags_hist");
   k_scatter2<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_scatter2");
+  k_tail_stamp<<<1, 1, 0, f->stream>>>(F);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }

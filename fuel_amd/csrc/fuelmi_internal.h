@@ -88,6 +88,8 @@ struct fuelmi_map {
   Plane hit_bits, miss_bits;    // per-frame touched voxels
   u64* ins_partial = nullptr;   // per-block end-point boxes of the fusion's classify kernel
   size_t ins_partial_cap = 0;
+  void* ins_rec = nullptr;      // per-slot records of the fusion's classify kernel (32 B each)
+  size_t ins_rec_cap = 0;
   u64* ins_head = nullptr;      // [16] device; [8] = the ESDF far-output statistic (two u32, esdf.hip); [0..7]: [6] = points projected by the depth front end of the current frame
   u64* h_ins = nullptr;         // [16] pinned; [8] = the ESDF statistic as the x pass handed it over; [0..7]: end-point box [0..5], projected points [6], frame stamp [7] -- written
                                 // by the fusion's second kernel, polled by the host (no blocking stream sync)

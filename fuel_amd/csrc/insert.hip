@@ -62,11 +62,15 @@ struct InsertArgs {
                  // points of the frame, [7] frame stamp (written last)
   u64* head;     // device: [6] projected points (depth front end), re-zeroed here for the next frame
   u64 epoch;
-  u64* partial;  // [classify blocks][6] per-block boxes, folded by block 0 of k_insert_raycast
+  u64* partial;  // [classify blocks][8] per-block boxes + projected-pixel counts, folded by block 0 of k_insert_raycast
+  struct InsRec* rec;  // [n] what k_insert_classify found for every slot (k_insert_raycast does not redo it)
   int nblk;      // classify blocks
-  int dbg;       // FUELMI_INS_DBG timing experiments (results wrong): 1 no global miss marks in the walk, 2 no walk
 };
 
+struct InsRec {
+  double pt[3];  // the (clamped) end point
+  long a;        // its voxel address, -1: the slot adds nothing
+};
 __device__ __forceinline__ u64 enc_f64(double d) {
   u64 u = (u64)__double_as_longlong(d);
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
@@ -145,15 +149,21 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
   double pt[3];
   int flag = 0;
   bool ok = (i < A.n) && classify(g, A, i, pt, flag);
-  if (A.from_depth) {  // proj_points_cnt: pixels that survive the projection (whatever the fusion does with them)
+  u32 n_proj = 0u;  // proj_points_cnt: pixels that survive the projection (whatever the fusion does with them)
+  if (A.from_depth) {
     float q[3];
-    const u64 pm = __ballot(i < A.n && project_pixel(A.D, i, q));
-    if ((threadIdx.x & 63) == 0 && pm) atomicAdd(A.head + 6, (u64)__popcll(pm));
+    n_proj = (u32)__popcll(__ballot(i < A.n && project_pixel(A.D, i, q)));
   }
   long a = -1;
   if (ok) {
     a = pos_adr(g, pt);
     if (!(a >= 0 && a < g.N)) ok = false;
+  }
+  if (i < A.n) {
+    InsRec r;
+    r.pt[0] = pt[0], r.pt[1] = pt[1], r.pt[2] = pt[2];
+    r.a = ok ? a : -1L;
+    A.rec[i] = r;
   }
   {
     // neighbouring pixels end in the same voxel more often than not: a lane whose predecessor holds the
@@ -174,6 +184,7 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
   // one record per block; the next kernel folds the records (per-wave atomics on six words were
   // ~1200 same-address operations per frame and made this the longest kernel of the fusion)
   __shared__ u64 s_lo[16][3], s_hi[16][3];
+  __shared__ u32 s_proj[16];
   u64 lo[3], hi[3];
   for (int k = 0; k < 3; ++k) {
     lo[k] = ok ? enc_f64(pt[k]) : ~0ull;
@@ -186,21 +197,32 @@ __global__ void __launch_bounds__(256) k_insert_classify(Geo g, InsertArgs A) {
     }
   }
   const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  if ((threadIdx.x & 63) == 0)
+  if ((threadIdx.x & 63) == 0) {
     for (int k = 0; k < 3; ++k) s_lo[wave][k] = lo[k], s_hi[wave][k] = hi[k];
+    s_proj[wave] = n_proj;
+  }
   __syncthreads();
   if (threadIdx.x < 3) {
     const int k = threadIdx.x;
     u64 l = ~0ull, h = 0ull;
     for (int w = 0; w < nwave; ++w) l = min(l, s_lo[w][k]), h = max(h, s_hi[w][k]);
-    A.partial[(size_t)blockIdx.x * 6 + k] = l;
-    A.partial[(size_t)blockIdx.x * 6 + 3 + k] = h;
+    A.partial[(size_t)blockIdx.x * 8 + k] = l;
+    A.partial[(size_t)blockIdx.x * 8 + 3 + k] = h;
+  }
+  if (threadIdx.x == 3) {  // (one same-address atomic per wave on a frame counter made this an 18 us kernel)
+    u64 c = 0ull;
+    for (int w = 0; w < nwave; ++w) c += s_proj[w];
+    A.partial[(size_t)blockIdx.x * 8 + 6] = c;
   }
 }
 
 // RayCaster helpers (raycast.cpp:6-23)
-__device__ __forceinline__ double rc_mod(double value, double modulus) {
-  return fmod(fmod(value, modulus) + modulus, modulus);
+// fmod(x, 1) == x - trunc(x) bit for bit (the difference is exactly representable; only the sign of a zero result
+// can differ, and the "+ modulus" that follows erases it) -- the library fmod is a long loop
+__device__ __forceinline__ double rc_fmod1(double x) { return x - trunc(x); }
+__device__ __forceinline__ double rc_mod(double value, double modulus) {  // only ever called with modulus 1
+  (void)modulus;
+  return rc_fmod1(rc_fmod1(value) + 1.0);
 }
 __device__ __forceinline__ double rc_intbound(double s, double ds) {
   if (ds < 0) {
@@ -211,6 +233,7 @@ __device__ __forceinline__ double rc_intbound(double s, double ds) {
   return (1 - s) / ds;
 }
 
+#define RC_SPLIT 4  // lanes per ray (k_insert_raycast)
 #ifndef CUBE_XY
 #define CUBE_XY 32  // lines per side of the near-camera cube (x 32 voxels in z); 64 measured slower (longer flush)
 #endif
@@ -219,11 +242,17 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
                           // loop over ~300 records by six threads cost 40 us of dependent loads)
     __shared__ u64 s_red[4][6];
     u64 v[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-    for (int b = threadIdx.x; b < A.nblk; b += 256)
+    u64 cnt = 0ull;
+    for (int b = threadIdx.x; b < A.nblk; b += 256) {
       for (int k = 0; k < 6; ++k) {
-        const u64 p = A.partial[(size_t)b * 6 + k];
+        const u64 p = A.partial[(size_t)b * 8 + k];
         v[k] = k < 3 ? min(v[k], p) : max(v[k], p);
       }
+      cnt += A.partial[(size_t)b * 8 + 6];
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __shared__ u64 s_cntw[4];
+    if ((threadIdx.x & 63) == 0) s_cntw[threadIdx.x >> 6] = cnt;
     for (int k = 0; k < 6; ++k)
       for (int off = 32; off > 0; off >>= 1) {
         const u64 t = __shfl_down(v[k], off, 64);
@@ -238,10 +267,7 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
       for (int w = 0; w < 4; ++w) r = k < 3 ? min(r, s_red[w][k]) : max(r, s_red[w][k]);
       A.h_out[k] = r;
     }
-    if (threadIdx.x == 6) {
-      A.h_out[6] = A.head[6];
-      A.head[6] = 0ull;
-    }
+    if (threadIdx.x == 6) A.h_out[6] = s_cntw[0] + s_cntw[1] + s_cntw[2] + s_cntw[3];
     // the host is waiting for exactly these eight words (it sizes the next launches by the box): publish them
     // now, the ray walks of this block follow
     __syncthreads();
@@ -264,13 +290,13 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   // one LDS word = the 32 z-neighbours cv[2] .. cv[2]+31 of the line (cv[0] + ux, cv[1] + uy)
   {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double p0[3];
-    int flag = 0;
-    bool cast = i < A.n && classify(g, A, i, p0, flag);
+    double p0[3] = {0.0, 0.0, 0.0};
+    const long a = i < A.n ? A.rec[i].a : -1L;
+    bool cast = a >= 0;
     if (cast) {
-      const long a = pos_adr(g, p0);
-      cast = a >= 0 && a < g.N && A.owner[a] == (u32)i;  // the first point of this end voxel
+      cast = A.owner[a] == (u32)i;  // the first point of this end voxel
       if (cast) {
+        p0[0] = A.rec[i].pt[0], p0[1] = A.rec[i].pt[1], p0[2] = A.rec[i].pt[2];
         A.owner[a] = 0xFFFFFFFFu;  // leave the owner table clean for the next frame
         cast = (signed char)A.flag_rayend[a] != A.num;
         if (cast) A.flag_rayend[a] = (unsigned char)A.num;
@@ -282,8 +308,16 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     }
   }
   __syncthreads();
-  if (threadIdx.x < s_cnt && !(A.dbg & 2)) {
-  const double pt[3] = {s_pt[threadIdx.x][0], s_pt[threadIdx.x][1], s_pt[threadIdx.x][2]};
+  // Every ray is walked by RC_SPLIT lanes, each doing the cells whose crossing parameter lies in its quarter
+  // [q, q+1) / RC_SPLIT of the ray.  A lane reaches its starting state without walking: the tMax of an axis after j
+  // steps is tMax + tDelta added j times whatever the other axes did, so it advances every axis on its own while
+  // tMax < q / RC_SPLIT (the same additions in the same order as the reference's walk: same bits), which is exactly
+  // the state the sequential walk is in when it has consumed every crossing below that parameter -- the walk
+  // takes crossings in increasing tMax order (ties z, y, x).  The sequential walk was the longest dependent chain
+  // of the fusion (~80 steps x ~350 ns on a lone wave).
+  for (u32 task = threadIdx.x; task < s_cnt * RC_SPLIT; task += 256) {
+  const u32 ray = task / RC_SPLIT, part = task % RC_SPLIT;
+  const double pt[3] = {s_pt[ray][0], s_pt[ray][1], s_pt[ray][2]};
 
   // RayCaster::input(pt_w, camera_pos) (raycast.cpp:329-372)
   double s[3], e[3];
@@ -304,43 +338,62 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   }
   const double off[3] = {0.5 - g.org[0] / g.res, 0.5 - g.org[1] / g.res, 0.5 - g.org[2] / g.res};
   int guard = abs(ec[0] - c[0]) + abs(ec[1] - c[1]) + abs(ec[2] - c[2]) + 4;
-  bool first = true;
-  while (true) {
-    // nextId (:374-407): report current cell, stop at the end cell, else step
-    int ix = (int)((double)c[0] + off[0]), iy = (int)((double)c[1] + off[1]), iz = (int)((double)c[2] + off[2]);
-    if (c[0] == ec[0] && c[1] == ec[1] && c[2] == ec[2]) break;
-    if (!first) {  // the first reported cell (the end voxel itself) is discarded (:314)
-      long av = (long)ix * g.nyz + (long)iy * g.nz + iz;
-      bool send = av >= 0 && av < g.N && ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz;
-      const bool raw = av >= 0 && av < g.N;  // a cell outside the index box still addresses a voxel (aliased rows);
-                                              // outside [0, N) the reference is undefined behaviour: dropped
-      const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
-      if (send && (ux | uy) < (u32)CUBE_XY && uz < 32u) {
-        if (!(A.dbg & 4)) atomicOr(&s_seen[ux * CUBE_XY + uy], 1u << uz);  // flushed as whole words when the block is done
-      } else if (raw && !(A.dbg & 1)) {
-        atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
-      }
+  // nextId (:374-407) reports the current cell ((tmp + offset_).cast<int>()), stops at the end cell, else steps
+  // along the axis with the smallest tMax (ties: z before y before x).  The first reported cell -- the end voxel
+  // itself -- is discarded (:314).  One wave walks alone on its SIMD, so the step is written branch-free: the
+  // nested ifs of the reference cost ~150 instructions per cell as divergent code, the selects below ~60.
+  // A ray whose first and last cell both index into the map stays inside it (every axis moves one way only):
+  // its cells need no bounds tests.
+  int c0 = c[0], c1 = c[1], c2 = c[2];
+  double t0 = tmax[0], t1 = tmax[1], t2 = tmax[2];
+  const double tau_lo = (double)part / RC_SPLIT;
+  const double tau_hi = part + 1 < RC_SPLIT ? (double)(part + 1) / RC_SPLIT : INFINITY;
+  if (part) {  // (an axis that does not move has tMax = inf: untouched)
+    while (t0 < tau_lo) t0 += tdel[0], c0 += st[0];
+    while (t1 < tau_lo) t1 += tdel[1], c1 += st[1];
+    while (t2 < tau_lo) t2 += tdel[2], c2 += st[2];
+  }
+  const int is0 = (int)((double)c0 + off[0]), is1 = (int)((double)c1 + off[1]), is2 = (int)((double)c2 + off[2]);
+  const int ie0 = (int)((double)ec[0] + off[0]), ie1 = (int)((double)ec[1] + off[1]), ie2 = (int)((double)ec[2] + off[2]);
+  const bool inside = min(is0, ie0) >= 0 && max(is0, ie0) < g.nx && min(is1, ie1) >= 0 && max(is1, ie1) < g.ny &&
+                      min(is2, ie2) >= 0 && max(is2, ie2) < g.nz;
+#define RC_STEP()                                                         \
+  {                                                                       \
+    const bool xy = t0 < t1, xz = t0 < t2, yz = t1 < t2;                  \
+    const bool sx = xy && xz, sy = !xy && yz, sz = !(sx || sy);           \
+    c0 += sx ? st[0] : 0, c1 += sy ? st[1] : 0, c2 += sz ? st[2] : 0;     \
+    t0 = sx ? t0 + tdel[0] : t0;                                          \
+    t1 = sy ? t1 + tdel[1] : t1;                                          \
+    t2 = sz ? t2 + tdel[2] : t2;                                          \
+  }
+  bool more = !(c0 == ec[0] && c1 == ec[1] && c2 == ec[2]) && fmin(fmin(t0, t1), t2) < tau_hi;
+  if (more && c0 == c[0] && c1 == c[1] && c2 == c[2]) {  // the ray's first cell (the end voxel itself) is reported
+                                                           // first and discarded; it falls to the lane that owns
+                                                           // the first crossing
+    RC_STEP()
+    more = --guard >= 0;
+  }
+  while (more) {
+    const int ix = (int)((double)c0 + off[0]), iy = (int)((double)c1 + off[1]), iz = (int)((double)c2 + off[2]);
+    if (((c0 ^ ec[0]) | (c1 ^ ec[1]) | (c2 ^ ec[2])) == 0) break;
+    if (!(t0 < tau_hi || t1 < tau_hi || t2 < tau_hi)) break;  // the next lane's cells start here
+    const long av = (long)ix * g.nyz + (long)iy * g.nz + iz;
+    bool send = true, raw = true;
+    if (!inside) {
+      send = av >= 0 && av < g.N && ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz;
+      raw = av >= 0 && av < g.N;  // a cell outside the index box still addresses a voxel (aliased rows); outside
+                                  // [0, N) the reference is undefined behaviour: dropped
     }
-    first = false;
-    if (tmax[0] < tmax[1]) {
-      if (tmax[0] < tmax[2]) {
-        c[0] += st[0];
-        tmax[0] += tdel[0];
-      } else {
-        c[2] += st[2];
-        tmax[2] += tdel[2];
-      }
-    } else {
-      if (tmax[1] < tmax[2]) {
-        c[1] += st[1];
-        tmax[1] += tdel[1];
-      } else {
-        c[2] += st[2];
-        tmax[2] += tdel[2];
-      }
+    const u32 ux = (u32)(ix - cv[0]), uy = (u32)(iy - cv[1]), uz = (u32)(iz - cv[2]);
+    if (send && (ux | uy) < (u32)CUBE_XY && uz < 32u) {
+      atomicOr(&s_seen[ux * CUBE_XY + uy], 1u << uz);  // flushed as whole words when the block is done
+    } else if (raw) {
+      atomicOr(&A.miss[av >> 6], 1ull << (av & 63));
     }
+    RC_STEP()
     if (--guard < 0) break;
   }
+#undef RC_STEP
   }  // walkers
   // flush the cube: every non-empty LDS word is 32 z-consecutive voxels of one line, i.e. one or two
   // words of the miss plane
@@ -406,7 +459,7 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   const signed char num_before = m->raycast_num;
   m->raycast_num = (signed char)(m->raycast_num + 1);  // char wrap like the reference
   {
-    const size_t need = (size_t)((n + 255) / 256) * 6;
+    const size_t need = (size_t)((n + 255) / 256) * 8;
     if (need > m->ins_partial_cap) {
       if (m->ins_partial) HIPCHK(hipFree(m->ins_partial));
       m->ins_partial = nullptr;
@@ -437,10 +490,14 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   int nb = (n + 255) / 256;
   A.nblk = nb;
   A.partial = m->ins_partial;
-  {
-    static const char* e = getenv("FUELMI_INS_DBG");
-    A.dbg = e ? atoi(e) : 0;
+  if ((size_t)n > m->ins_rec_cap) {
+    if (m->ins_rec) HIPCHK(hipFree(m->ins_rec));
+    m->ins_rec = nullptr;
+    m->ins_rec_cap = 0;
+    HIPCHK(hipMalloc(&m->ins_rec, ((size_t)n + 1024) * sizeof(InsRec)));
+    m->ins_rec_cap = (size_t)n + 1024;
   }
+  A.rec = reinterpret_cast<InsRec*>(m->ins_rec);
   k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
   k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
   HIPCHK(hipGetLastError());
@@ -580,15 +637,30 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   *d_pts_out = d_pts;
   (void)d_head;
   if (nslots == 0) return FUELMI_OK;
-  // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
-  memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
+  // An image the device can address -- device memory, or host memory that is pinned / registered (hipHostMalloc,
+  // hipHostRegister, fuelmi_host_register) -- is read where it lies: no staging copy, and for device memory no
+  // PCIe traffic inside the cycle either.  The caller keeps it unchanged until the next call on this map.
+  const unsigned short* direct = nullptr;
+  {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, depth) == hipSuccess &&
+        (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged) &&
+        at.devicePointer)
+      direct = reinterpret_cast<const unsigned short*>(at.devicePointer);
+    else
+      (void)hipGetLastError();  // ordinary pageable memory (a cv::Mat): not an error
+  }
   static const bool zero_copy = getenv("FUELMI_DEPTH_H2D") == nullptr;
-  // the fusion kernels read the (pinned) staged image over PCIe themselves -- ~0.6 MB per 640 x 480 frame, read by
-  // two kernels -- instead of waiting for a DMA copy in front of them; the stand-alone projection keeps the copy
-  if (!zero_copy || launch)
-    HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
+  if (!direct) {
+    // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
+    memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
+    // the fusion kernels read the (pinned) staged image over PCIe themselves -- ~0.6 MB per 640 x 480 frame, read
+    // by two kernels -- instead of waiting for a DMA copy in front of them; the stand-alone projection keeps the copy
+    if (!zero_copy || launch)
+      HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
+  }
   DepthArgs D;
-  D.img = (zero_copy && !launch) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img;
+  D.img = direct ? direct : ((zero_copy && !launch) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img);
   D.rows = rows, D.cols = cols, D.margin = margin, D.skip = skip, D.nu = nu, D.nslots = nslots;
   D.fx = c->fx, D.fy = c->fy, D.cx = c->cx, D.cy = c->cy;
   D.maxdist = c->depth_filter_maxdist, D.mindist = c->depth_filter_mindist;
@@ -650,6 +722,19 @@ extern "C" int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth
   int rc = project_depth_dev(m, depth, rows, cols, cfg, cam_pos, cam_q_wxyz, &d_pts, &D, &nslots, false);
   if (rc || nslots == 0) return rc;
   return insert_points_dev(m, nullptr, 16, nslots, cam_pos, &D, true, n_points);
+}
+
+/* Pin a host buffer the caller will hand to fuelmi_map_input_depth again and again (a camera driver's frame ring):
+ * frames inside it are read by the kernels directly, without the staging copy. */
+extern "C" int fuelmi_host_register(void* ptr, size_t bytes) {
+  ARGCHK(ptr && bytes);
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_host_unregister(void* ptr) {
+  ARGCHK(ptr);
+  HIPCHK(hipHostUnregister(ptr));
+  return FUELMI_OK;
 }
 
 extern "C" int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,

@@ -436,7 +436,7 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
                      &m->tmp2_bits, &m->hit_bits, &m->miss_bits};
   for (Plane* p : planes)
     if (p->base) (void)hipFree(p->base);
-  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial, m->ins_head};
+  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial, m->ins_head, m->ins_rec};
   if (m->h_ins) (void)hipHostFree(m->h_ins);
   for (void* b : bufs)
     if (b) (void)hipFree(b);

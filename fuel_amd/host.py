@@ -110,6 +110,16 @@ class SDFMap:
                                             _d3(camera_pos), q, C.byref(n)))
         return n.value
 
+    def inputDepthImageAt(self, ptr, rows, cols, camera_pos, camera_q_wxyz, cfg=None):
+        """inputDepthImage for a frame addressed by a raw pointer: device memory (e.g. a torch CUDA tensor's
+        data_ptr()), pinned / registered host memory, or pageable host memory.  The first two are read in place."""
+        cfg = cfg or self.depthConfig()
+        n = C.c_int(0)
+        q = (C.c_double * 4)(*[float(v) for v in camera_q_wxyz])
+        check(self.L.fuelmi_map_input_depth(self.h, C.c_void_p(int(ptr)), int(rows), int(cols), C.byref(cfg),
+                                            _d3(camera_pos), q, C.byref(n)))
+        return n.value
+
     def projectDepthImage(self, depth, camera_pos, camera_q_wxyz, cfg=None):
         """MapROS::proessDepthImage only: the projected world points (float32 [n,3])."""
         img = np.ascontiguousarray(depth, dtype=np.uint16)

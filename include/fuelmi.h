@@ -20,6 +20,7 @@
 #ifndef FUELMI_H_
 #define FUELMI_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -91,10 +92,14 @@ typedef struct {
   double k_depth_scaling_factor; /* raw 16-bit depth units per metre (1000 for millimetres) */
   int skip_pixel;
 } fuelmi_depth_cfg;
-/* depth: rows x cols row-major 16UC1 image in host memory; cam_q_wxyz: camera orientation quaternion
- * (pose->orientation, w first).  Projects on the device and fuses the points without a host round
+/* depth: rows x cols row-major 16UC1 image; cam_q_wxyz: camera orientation quaternion (pose->orientation, w
+ * first).  The image may lie in pageable host memory (a cv::Mat: staged through a pinned buffer, free again on
+ * return), in pinned / registered host memory (fuelmi_host_register: read in place over PCIe) or in device memory
+ * (read in place); in the last two cases the caller leaves it unchanged until its next call on this map.  Projects on the device and fuses the points without a host round
  * trip; a frame taken from outside the map is ignored like the reference does.  *n_points (may be
  * NULL) receives proj_points_cnt.  Follow with fuelmi_map_inflate_local (local_updated_ branch). */
+int fuelmi_host_register(void* ptr, size_t bytes); /* hipHostRegister(mapped) of a frame ring; undo with _unregister */
+int fuelmi_host_unregister(void* ptr);
 int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
                            const fuelmi_depth_cfg* cfg, const double cam_pos[3], const double cam_q_wxyz[4],
                            int* n_points);
