@@ -1901,12 +1901,11 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   }
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
-  // the barrier orders every thread's record stores before thread 0's system-scope release (cumulative): one
-  // write-back instead of one per wave
+  // the barrier waits for every thread's record stores (see the note on stamps in frontier_internal.h)
   __syncthreads();
   FR_DBG_MARK(F, dblk, 8);
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&F.h_counts[15], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // "records are in"
+    __hip_atomic_store(&F.h_counts[15], F.var->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // "records are in"
   }
 }
 
@@ -2030,8 +2029,8 @@ __device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
 // (Counting finished workgroups inside k_scatter2 instead put ~1000 same-address atomics, 15 us, into the kernel;
 // fences there -- system scope per thread, or device scope per workgroup -- wrote the L2 back thousands of times.)
 __global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) { scatter2_body(g, F); }
-__global__ void k_tail_stamp(FArgs F) {
-  __hip_atomic_store(&F.h_counts[14], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ void k_tail_stamp(FArgs F) {  // (the kernel boundary behind k_scatter2 is the ordering here)
+  __hip_atomic_store(&F.h_counts[14], F.var->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------

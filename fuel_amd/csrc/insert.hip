@@ -75,6 +75,10 @@ __device__ __forceinline__ u64 enc_f64(double d) {
   u64 u = (u64)__double_as_longlong(d);
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
+__device__ __forceinline__ double dec_f64_dev(u64 e) {
+  const u64 u = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+  return __longlong_as_double((long long)u);
+}
 static inline double dec_f64(u64 e) {
   u64 u = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
   double d;
@@ -233,9 +237,14 @@ __device__ __forceinline__ double rc_intbound(double s, double ds) {
   return (1 - s) / ds;
 }
 
+#ifndef RC_SPLIT
 #define RC_SPLIT 4  // lanes per ray (k_insert_raycast)
+#endif
+#ifndef RC_SLOTS
+#define RC_SLOTS 64  // point slots per workgroup of k_insert_raycast (256 threads = 64 rays x RC_SPLIT lanes at most)
+#endif
 #ifndef CUBE_XY
-#define CUBE_XY 32  // lines per side of the near-camera cube (x 32 voxels in z); 64 measured slower (longer flush)
+#define CUBE_XY 64  // lines per side of the workgroup's LDS bitmap (x 32 voxels in z)
 #endif
 __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
   if (blockIdx.x == 0) {  // fold the per-block boxes of k_insert_classify (all 256 threads: a serial
@@ -271,27 +280,26 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     // the host is waiting for exactly these eight words (it sizes the next launches by the box): publish them
     // now, the ray walks of this block follow
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&A.h_out[7], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(&A.h_out[7], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // Only the first point of every end voxel casts a ray (~1 point in 4): compact the casters of the
   // block into LDS first, so that the walk runs with full waves and the other waves retire at once
   __shared__ double s_pt[256][3];
   __shared__ u32 s_cnt;
-  // The rays of a workgroup (neighbouring pixels) converge on the camera and revisit the same voxels
-  // there: the miss marks of the 32^3 voxels around the camera voxel are collected in an LDS bitmap (one
-  // word = 32 z-neighbours of a line) and flushed once per workgroup as whole words -- a few hundred
-  // atomics instead of one per ray step, and far fewer same-address operations on the memory side.
+  // The rays of a workgroup (neighbouring pixels) form a thin fan that converges on the camera and revisits the
+  // same voxels over and over: the miss marks inside a CUBE_XY x CUBE_XY x 32 voxel box laid over the fan (its
+  // end voxels and the camera voxel; when the fan is larger, the camera's end of it) are collected in an LDS
+  // bitmap (one word = 32 z-neighbours of a line) and flushed once per workgroup as whole words -- a few
+  // hundred atomics instead of one per ray step.  With the walk split over four lanes per ray the global
+  // atomics of the cells outside a small camera-centred cube had become the kernel's bottleneck.
   __shared__ u32 s_seen[CUBE_XY * CUBE_XY];
   for (int t = threadIdx.x; t < CUBE_XY * CUBE_XY; t += 256) s_seen[t] = 0u;
   if (threadIdx.x == 0) s_cnt = 0u;
   __syncthreads();
-  int cv[3];
-  for (int k = 0; k < 3; ++k) cv[k] = (int)floor((A.cam[k] - g.org[k]) * g.res_inv) - (k < 2 ? CUBE_XY / 2 : 16);
-  // one LDS word = the 32 z-neighbours cv[2] .. cv[2]+31 of the line (cv[0] + ux, cv[1] + uy)
   {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * RC_SLOTS + threadIdx.x;
     double p0[3] = {0.0, 0.0, 0.0};
-    const long a = i < A.n ? A.rec[i].a : -1L;
+    const long a = (threadIdx.x < RC_SLOTS && i < A.n) ? A.rec[i].a : -1L;
     bool cast = a >= 0;
     if (cast) {
       cast = A.owner[a] == (u32)i;  // the first point of this end voxel
@@ -308,6 +316,18 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     }
   }
   __syncthreads();
+  int cv[3];  // one LDS word = the 32 z-neighbours cv[2] .. cv[2]+31 of the line (cv[0] + ux, cv[1] + uy)
+  for (int k = 0; k < 3; ++k) {
+    // the end points of these slots: the box k_insert_classify recorded for its workgroup (256 slots: a superset)
+    const u64* rec = A.partial + (size_t)((blockIdx.x * RC_SLOTS) >> 8) * 8;
+    const int cam_c = (int)floor((A.cam[k] - g.org[k]) * g.res_inv), ext = k < 2 ? CUBE_XY : 32;
+    int lo = cam_c, hi = cam_c;
+    if (rec[k] <= rec[3 + k]) {  // (an empty record: min = ~0, max = 0)
+      lo = min(lo, (int)floor((dec_f64_dev(rec[k]) - g.org[k]) * g.res_inv));
+      hi = max(hi, (int)floor((dec_f64_dev(rec[3 + k]) - g.org[k]) * g.res_inv));
+    }
+    cv[k] = hi - lo < ext ? lo : (cam_c == lo ? lo : (cam_c == hi ? hi - ext + 1 : cam_c - ext / 2));
+  }
   // Every ray is walked by RC_SPLIT lanes, each doing the cells whose crossing parameter lies in its quarter
   // [q, q+1) / RC_SPLIT of the ray.  A lane reaches its starting state without walking: the tMax of an axis after j
   // steps is tMax + tDelta added j times whatever the other axes did, so it advances every axis on its own while
@@ -499,7 +519,7 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
   }
   A.rec = reinterpret_cast<InsRec*>(m->ins_rec);
   k_insert_classify<<<nb, 256, 0, m->stream>>>(g, A);
-  k_insert_raycast<<<nb, 256, 0, m->stream>>>(g, A);
+  k_insert_raycast<<<(n + RC_SLOTS - 1) / RC_SLOTS, 256, 0, m->stream>>>(g, A);
   HIPCHK(hipGetLastError());
   // the end-point box sizes the next launches: poll the stamp the fusion's second kernel writes into pinned memory
   // (a blocking stream synchronisation costs ~40 us of wake-up latency per frame)
