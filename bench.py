@@ -248,6 +248,38 @@ class GpuStreamCycle:
         self.n_clusters = self.ff.searchFrontiers()
         self.ff.commit()
 
+    def run_native(self, n, serial=False):
+        return self.prepare_native(n, serial)()
+
+    def prepare_native(self, n, serial=False):
+        """the next n frames through step() / step_serial(), issued from C++ (fuelmi_bench_stream): the same calls
+        per cycle without the interpreter between them.  Returns the callable that runs them (argument marshalling
+        stays outside the timed region)."""
+        import ctypes as C
+        from fuel_amd._lib import check
+        nf = len(self.frames)
+        idx = [(self.k + j) % nf for j in range(n)]
+        self.k += n
+        if self.frame_source == "pageable":
+            ptrs = [self.frames[i][0].ctypes.data for i in idx]
+        else:
+            ptrs = [self.ptr[self.frame_source][i] for i in idx]
+        depth = (C.c_void_p * n)(*ptrs)
+        pos = np.ascontiguousarray(np.array([self.frames[i][1] for i in idx], dtype=np.float64))
+        quat = np.ascontiguousarray(np.array([self.frames[i][2] for i in idx], dtype=np.float64))
+        cfg = self.map.depthConfig()
+        ncl, vox, sec = C.c_int(), C.c_double(), C.c_double()
+        dp = C.POINTER(C.c_double)
+
+        def run():
+            check(self.map.L.fuelmi_bench_stream(self.map.h, self.ff.h, self.dev_problem.h, n, depth, self.rows,
+                                                 self.cols, C.byref(cfg), pos.ctypes.data_as(dp), quat.ctypes.data_as(dp),
+                                                 int(serial), C.byref(ncl), C.byref(vox), C.byref(sec)))
+            self.n_clusters = ncl.value
+            self.box_vox.extend([vox.value / max(n, 1)] * n)
+            return sec.value
+        return run
+
     def finish(self):
         self.map.synchronize()
         self.ff.sync()
@@ -482,7 +514,7 @@ def main():
         map_size, n_obs, _ = WORKLOADS[args.workload]
         box = exploration_box(map_size)
         # distinct frames for every step of the run (warm-up, the two short profiling passes, timed region)
-        frames = streaming_frames(map_size, n_obs, args.warmup + 3 * args.steps + 12, seed=42 + rank)
+        frames = streaming_frames(map_size, n_obs, args.warmup + 4 * args.steps + 12, seed=42 + rank)
         rng = np.random.default_rng(1000 + 42 + rank)
         ctrl = make_trajectories(rng, args.candidates, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
         occ, n_known = None, 0
@@ -527,7 +559,9 @@ def main():
     cyc.map.profileEnable(1 << stages[dominant])
     host_loop = None
     if streaming:
-        elapsed = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
+        # the K frames are issued by the library's own C++ loop (fuelmi_bench_stream), like the full-box cycles below
+        elapsed = timed_fleet_run(cyc.prepare_native(args.steps, args.serial_stages), cyc.finish, 1, dist,
+                                  torch.cuda.synchronize)
     else:
         # the K timed cycles are issued by the library's own C++ loop (fuelmi_bench_cycles): the Python
         # interpreter's ~25 us per cycle between the seven C-ABI calls is not part of the hot path.  The
@@ -543,9 +577,13 @@ def main():
         cyc.map.profileEnable(0)
         for src in ("pinned", "pageable"):
             cyc.frame_source = src
-            t = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
+            t = timed_fleet_run(cyc.prepare_native(args.steps, args.serial_stages), cyc.finish, 1, dist,
+                                torch.cuda.synchronize)
             frame_source[src + "_host_ms_per_frame"] = 1e3 * t / args.steps
         cyc.frame_source = "device"
+        t_py = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
+        host_loop = {"native_cpp_loop_cycles_per_s": fleet_value(n_gpus, args.steps, elapsed),
+                     "python_ctypes_loop_cycles_per_s": fleet_value(n_gpus, args.steps, t_py)}
     if not streaming:
         cyc.map.profileEnable(0)
         t_py = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)

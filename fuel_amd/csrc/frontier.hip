@@ -3143,3 +3143,46 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   *n_clusters = ncl;
   return FUELMI_OK;
 }
+
+// Measurement driver for the streaming cycle (one depth frame per cycle), issued from C++ like fuelmi_bench_cycles.
+extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, int n,
+                                   const void* const* depth, int rows, int cols, const fuelmi_depth_cfg* cfg,
+                                   const double* cam_pos3, const double* cam_q4, int serial, int* n_clusters,
+                                   double* box_voxels, double* seconds) {
+  ARGCHK(m && f && n >= 0 && depth && cfg && cam_pos3 && cam_q4 && n_clusters && seconds && f->map == m);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  int rc = FUELMI_OK, ncl = 0;
+  double vox = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
+    int npts = 0;
+    if ((rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k]), rows, cols, cfg, cam_pos3 + 3 * k,
+                                     cam_q4 + 4 * k, &npts)))
+      break;
+    if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
+    if (npts > 0) {
+      int lo[3], hi[3];
+      if ((rc = fuelmi_map_get_local_bound(m, lo, hi))) break;
+      vox += (double)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+      if ((rc = fuelmi_map_inflate_local(m))) break;
+      if ((rc = fuelmi_map_update_esdf(m))) break;
+    }
+    if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
+    if (serial) {
+      HIPCHK(hipStreamSynchronize(m->stream));
+      if ((rc = fuelmi_frontier_search_begin(f))) break;
+    }
+    if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
+    if ((rc = fuelmi_frontier_commit(f, 0))) break;
+  }
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  f->tail_pending = false;
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *n_clusters = ncl;
+  if (box_voxels) *box_voxels = vox;
+  return FUELMI_OK;
+}

@@ -345,6 +345,13 @@ int fuelmi_bspline_boundary_states(fuelmi_map* m, int n_traj, int n_ctrl, int de
  * fuelmi_frontier_search_end; with `serial` != 0 the search runs after the map chain instead of beside it.
  * Both streams are drained before the clock starts and before it stops.  *n_clusters: clusters of the last
  * search; *seconds: elapsed wall time. */
+/* The streaming counterpart: n cycles of fuelmi_map_input_depth(depth[k], pose k), fuelmi_frontier_search_begin,
+ * (when the frame fused points) fuelmi_map_inflate_local + fuelmi_map_update_esdf, fuelmi_bspline_dev_eval,
+ * fuelmi_frontier_search_end, fuelmi_frontier_commit.  depth[k]: any pointer fuelmi_map_input_depth takes;
+ * cam_pos3 / cam_q4: n x 3 / n x 4 doubles; *box_voxels (may be NULL): sum of the local-bound volumes. */
+int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, int n, const void* const* depth,
+                        int rows, int cols, const fuelmi_depth_cfg* cfg, const double* cam_pos3, const double* cam_q4,
+                        int serial, int* n_clusters, double* box_voxels, double* seconds);
 int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, const double ub_min[3],
                         const double ub_max[3], int n, int serial, int* n_clusters, double* seconds);
 int fuelmi_bspline_dev_load_samples(fuelmi_bspline_dev* b, int n_points, const double* ts, const double* points,
