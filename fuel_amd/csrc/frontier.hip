@@ -2024,14 +2024,11 @@ __device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
     __syncthreads();
   }
 }
-// the last kernels of the fast chain: regroup the cells and copy them out; then one thread stamps the pinned result
-// block ("cells are in") -- frontier_tail_sync polls that word instead of paying a blocking stream synchronisation.
-// (Counting finished workgroups inside k_scatter2 instead put ~1000 same-address atomics, 15 us, into the kernel;
-// fences there -- system scope per thread, or device scope per workgroup -- wrote the L2 back thousands of times.)
+// the last kernel of the fast chain: regroups the cells and copies them out.  (Whoever needs the cell lists polls
+// the stream, frontier_tail_sync: a "cells are in" stamp from here cost more than it saved -- counting finished
+// workgroups is ~1000 same-address atomics, 15 us; fences wrote the L2 back thousands of times; a one-thread
+// stamp kernel behind this one added 4 us to the busiest stream of the plan cycle.)
 __global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) { scatter2_body(g, F); }
-__global__ void k_tail_stamp(FArgs F) {  // (the kernel boundary behind k_scatter2 is the ordering here)
-  __hip_atomic_store(&F.h_counts[14], F.var->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -2082,12 +2079,6 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
     (void)hipStreamDestroy(f->stream);
   }
   if (f->ev_dep) (void)hipEventDestroy(f->ev_dep);
-  if (f->copy_stream) {
-    (void)hipStreamSynchronize(f->copy_stream);
-    (void)hipStreamDestroy(f->copy_stream);
-  }
-  if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
-  if (f->ev_copy) (void)hipEventDestroy(f->ev_copy);
   if (f->d_stage) (void)hipFree(f->d_stage);
   for (void* p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
@@ -2186,9 +2177,6 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi_p));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
-  HIPCHK(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&f->ev_copy, hipEventDisableTiming));
 
   // ---- everything below is constant for the life of the object (the kernel chain is replayed
   // as a graph with these arguments baked in) ----
@@ -2542,7 +2530,6 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
   FDBG("k_flags_hist");
   k_scatter2<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_scatter2");
-  k_tail_stamp<<<1, 1, 0, f->stream>>>(F);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -2997,7 +2984,6 @@ extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
   HIPCHK(hipSetDevice(f->map->device));
   f->tail_pending = false;
   HIPCHK(hipStreamSynchronize(f->stream));
-  if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
@@ -3137,7 +3123,6 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
-  if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   *n_clusters = ncl;

@@ -218,9 +218,6 @@ struct fuelmi_frontier {
   u32 epoch = 0;
   hipGraphExec_t fast_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // one per tile of the menu (launch grids differ)
   int fast_menu = 0;  // menu entry of the running search
-  hipStream_t copy_stream = nullptr;  // ships the grouped cells of the fast chain to the host
-  hipEvent_t ev_tail = nullptr, ev_copy = nullptr;
-  bool copy_pending = false;
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;
@@ -272,20 +269,13 @@ int frontier_materialize_lists(fuelmi_frontier* f);
 static inline int frontier_tail_sync(const fuelmi_frontier* f) {
   if (!f->tail_pending) return FUELMI_OK;
   f->tail_pending = false;
-  if (f->fast_launched && f->F.fast) {  // the fast chain's last kernel stamps the pinned block when the cells are in
-    volatile u32* stamp = f->F.h_counts + 14;
-    const u32 want = f->h_var->epoch;
-    for (unsigned spins = 0; *stamp != want;)
-      if ((++spins & 0x3FFFu) == 0u) {
-        const hipError_t q = hipStreamQuery(f->stream);
-        if (q == hipSuccess) break;  // (everything ran: the stamp is there or the legacy path took over)
-        if (q != hipErrorNotReady) HIPCHK(q);
-      }
-    if (*stamp == want) return FUELMI_OK;
+  // poll: the tail is a few microseconds of work that has usually finished long before anybody asks, and a
+  // blocking stream synchronisation costs ~15 us of wake-up latency even then
+  for (;;) {
+    const hipError_t q = hipStreamQuery(f->stream);
+    if (q == hipSuccess) return FUELMI_OK;
+    if (q != hipErrorNotReady) HIPCHK(q);
   }
-  HIPCHK(hipStreamSynchronize(f->stream));
-  if (f->copy_pending) HIPCHK(hipStreamSynchronize(f->copy_stream));  // (the event stays armed for the next search)
-  return FUELMI_OK;
 }
 // between _search_begin and _search_end the cluster lists belong to the running search (its verdicts on
 // changed clusters are applied in _search_end): calls that would modify them are refused
