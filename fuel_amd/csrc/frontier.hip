@@ -1994,6 +1994,8 @@ __device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
   __syncthreads();
   u32* key_out = F.ms_key[1];
   u32* val_out = F.ms_val[1];
+  const bool direct = F.counts[0] <= F.hcells_direct_max;  // big lists are fetched on demand (0.5 MB over PCIe
+                                                           // per search otherwise, whether anybody reads it or not)
   for (u32 base = i0; base < i1; base += 256u) {
     for (int wv = 0; wv < 4; ++wv) wcnt[wv][threadIdx.x] = 0u;
     __syncthreads();
@@ -2017,7 +2019,7 @@ __device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
       const u32 a = F.cell_adr[i];
       key_out[pos] = kk;
       val_out[pos] = a;
-      F.h_cells[pos] = a;  // posted write over PCIe, coalesced per wave
+      if (direct) F.h_cells[pos] = a;  // posted write over PCIe, coalesced per wave
     }
     __syncthreads();
     running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
@@ -2208,6 +2210,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   F.h_rec = reinterpret_cast<KeptRec*>(F.h_counts + 16);
   F.h_part = reinterpret_cast<u32*>(F.h_rec + F.cap_kept);
   F.h_cells = F.h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
+  {
+    static const char* e = getenv("FUELMI_HCELLS_DIRECT");  // tuning hook
+    F.hcells_direct_max = e ? (u32)atol(e) : FR_HCELLS_DIRECT;
+  }
   // CCL tile = TX x TY z-lines with u32 labels in LDS (<= 48 KiB so three workgroups share a CU)
   f->TY = 16;
   f->TX = std::max(1, std::min(8, (48 * 1024) / (f->TY * g.nz * 4)));
@@ -2267,7 +2273,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
 // copy the cell lists of kept-but-still-lazy clusters out of the pinned result buffer (see frontier_keep_clusters)
 int frontier_materialize_lists(fuelmi_frontier* f) {
   if (!f->lazy_kept) return FUELMI_OK;
-  const int rc = frontier_tail_sync(f);
+  const int rc = frontier_cells_ready(f);
   if (rc) return rc;
   for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
     for (HCluster& c : *L) c.materialize();
@@ -2883,6 +2889,8 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     HIPCHK(hipStreamSynchronize(f->stream));
   }
   f->last_fin = fin;  // buffer holding the grouped cells the lazy clusters point into
+  f->cells_fetch = F.fast && !ref_order && !split_mode && nq > F.hcells_direct_max;
+  f->cells_fetch_n = ncells;
   // (the fast chain's records are complete; the legacy chain and the regrouping of the split pieces leave
   // per-chunk partial records to fold)
   const u32 nchunk = ((ref_order || F.fast) && !split_mode) ? 0u : (ncells + SZ_CH - 1) / SZ_CH;  // (records of the grouped
@@ -3043,7 +3051,7 @@ extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which
   const HCluster* c = nth(f, which, k);
   ARGCHK(c);
   if (c->lazy) {
-    int rc = frontier_tail_sync(f);
+    int rc = frontier_cells_ready(f);
     if (rc) return rc;
   }
   c->copy_to(adr);

@@ -95,6 +95,8 @@ struct FArgs {
   struct KeptRec* h_rec;  // [cap_kept]
   u32* h_part;            // like info_part
   u32* h_cells;           // [cap_q] grouped cell addresses
+  u32 hcells_direct_max;  // the fast chain writes h_cells itself only for searches of at most this many Q0 cells;
+                          // larger lists stay on the device and are fetched when somebody asks (frontier_cells_ready)
   int keys_from_slots;    // multisplit pass 0 derives (key, value) from cell_slot / slot2rank / cell_adr
   // fast path
   FVar* var_w;            // == var (the first kernel refreshes it from the pinned host copy)
@@ -115,6 +117,7 @@ struct FArgs {
 // stamp that tells the polling host "they are in" is stored after that barrier by one lane, and writes of one
 // agent reach the host in order: the stamp is a RELAXED system-scope store.  A release store here writes the
 // whole L2 back first -- 5-10 us on the critical path of every search and every fused frame.
+#define FR_HCELLS_DIRECT 32768u  // (see FArgs::hcells_direct_max)
 #define FR_DBG_SLOTS 16
 #define FR_DBG_MARK(F, blk, k)                                                                   \
   do {                                                                                           \
@@ -212,6 +215,8 @@ struct fuelmi_frontier {
   bool pending = false, search_empty = false;
   // fast path: _search_end returns as soon as the cluster records have arrived; the kernels that regroup the
   // cells and ship them to the host are still running then.  Everything that reads the cell lists waits here.
+  mutable bool cells_fetch = false;  // the grouped cells of the last search are still only on the device
+  mutable u32 cells_fetch_n = 0;
   bool lazy_kept = false;  // committed clusters whose host cell lists still sit in the pinned result buffer
   mutable bool tail_pending = false;
   bool fast_launched = false;  // the chain of the running search is the fast one
@@ -276,6 +281,16 @@ static inline int frontier_tail_sync(const fuelmi_frontier* f) {
     if (q == hipSuccess) return FUELMI_OK;
     if (q != hipErrorNotReady) HIPCHK(q);
   }
+}
+// ... and make sure the grouped cell lists are in the pinned result buffer (the lazy clusters point into it)
+static inline int frontier_cells_ready(const fuelmi_frontier* f) {
+  const int rc = frontier_tail_sync(f);
+  if (rc) return rc;
+  if (f->cells_fetch) {
+    f->cells_fetch = false;
+    HIPCHK(hipMemcpy(f->F.h_cells, f->F.ms_val[f->last_fin], (size_t)f->cells_fetch_n * sizeof(u32), hipMemcpyDeviceToHost));
+  }
+  return FUELMI_OK;
 }
 // between _search_begin and _search_end the cluster lists belong to the running search (its verdicts on
 // changed clusters are applied in _search_end): calls that would modify them are refused
