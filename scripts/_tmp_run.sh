@@ -1,8 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for k in 1 2 3; do
-python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('G400', d['value'], d['ms_per_step'], d['stage_ms'], d['stage_ms_isolated']['frontier'])"
-done
-FUELMI_HCELLS_DIRECT=100000000 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('G400 direct', d['value'], d['ms_per_step'], d['stage_ms'], d['stage_ms_isolated']['frontier'])"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ser -o s -- python bench.py --no-cpu-baseline --serial-stages > /dev/null 2>&1
+python - <<PY
+import csv
+for r in csv.DictReader(open("gpurun_out/ser/s_kernel_stats.csv")):
+    if float(r["Percentage"])>0.8: print("%-30s avg %7.1f us calls %s" % (r["Name"].split("(")[0][:30], float(r["AverageNs"])/1e3, r["Calls"]))
+PY
