@@ -1901,11 +1901,12 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   }
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
-  // the barrier waits for every thread's record stores (see the note on stamps in frontier_internal.h)
+  // the barrier orders every thread's record stores before thread 0's system-scope release (cumulative): one
+  // write-back instead of one per wave
   __syncthreads();
   FR_DBG_MARK(F, dblk, 8);
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&F.h_counts[15], F.var->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // "records are in"
+    __hip_atomic_store(&F.h_counts[15], F.var->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // "records are in"
   }
 }
 

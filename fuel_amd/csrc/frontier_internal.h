@@ -112,11 +112,10 @@ struct FArgs {
   int fast;               // the result of the last search came from the fast path
   unsigned long long* dbg;  // FUELMI_FR_TIMING: per-block phase time stamps of the fast chain's kernels (else null)
 };
-// Result words in pinned host memory (hipHostMalloc: fine-grained, written through by the device).  The data
-// stores of a workgroup are acknowledged before its barrier releases (s_waitcnt vmcnt(0) precedes s_barrier), the
-// stamp that tells the polling host "they are in" is stored after that barrier by one lane, and writes of one
-// agent reach the host in order: the stamp is a RELAXED system-scope store.  A release store here writes the
-// whole L2 back first -- 5-10 us on the critical path of every search and every fused frame.
+// Result words in pinned host memory: the data stores of a workgroup, a barrier, then ONE lane stores the stamp
+// the polling host waits for with RELEASE semantics at system scope.  (A relaxed stamp was tried -- the release
+// costs nothing measurable in these kernels -- and made a parity test flaky: stores of different waves leave
+// through different L2 channels, nothing orders them against the stamp without the release.)
 #define FR_HCELLS_DIRECT 32768u  // (see FArgs::hcells_direct_max)
 #define FR_DBG_SLOTS 16
 #define FR_DBG_MARK(F, blk, k)                                                                   \

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) k_insert_raycast(Geo g, InsertArgs A) {
     // the host is waiting for exactly these eight words (it sizes the next launches by the box): publish them
     // now, the ray walks of this block follow
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&A.h_out[7], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(&A.h_out[7], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // Only the first point of every end voxel casts a ray (~1 point in 4): compact the casters of the
   // block into LDS first, so that the walk runs with full waves and the other waves retire at once
