@@ -32,7 +32,8 @@ struct BsplineArgs {
 };
 
 struct fuelmi_bspline_dev {
-  fuelmi_map* map;
+  fuelmi_map* map;  // cleared if the map is destroyed first (then only _destroy is legal)
+  int device = 0;
   BsplineArgs a;
   std::vector<void*> allocs;
   size_t lds;
@@ -897,10 +898,21 @@ static int upload(fuelmi_bspline_dev* b, const void* src, size_t bytes, const vo
   return FUELMI_OK;
 }
 
+static void bspline_dev_orphan(void* p) { static_cast<fuelmi_bspline_dev*>(p)->map = nullptr; }  // (its work is on
+                                                                                            // the map's stream,
+                                                                                            // drained by the map)
 extern "C" void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b) {
   if (!b) return;
-  (void)hipSetDevice(b->map->device);
-  (void)hipStreamSynchronize(b->map->stream);
+  (void)hipSetDevice(b->device);
+  if (b->map) {
+    (void)hipStreamSynchronize(b->map->stream);
+    auto& deps = b->map->dependents;
+    for (size_t k = 0; k < deps.size(); ++k)
+      if (deps[k].obj == b) {
+        deps.erase(deps.begin() + (long)k);
+        break;
+      }
+  }
   for (void* p : b->allocs) (void)hipFree(p);
   delete b;
 }
@@ -922,6 +934,7 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
   HIPCHK(hipSetDevice(m->device));
   fuelmi_bspline_dev* b = new fuelmi_bspline_dev;
   b->map = m;
+  b->device = m->device;
   BsplineArgs& A = b->a;
   memset(&A, 0, sizeof(A));
   A.cfg = *cfg;
@@ -983,6 +996,7 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_cost_grad),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds));
   }
+  m->dependents.push_back({b, &bspline_dev_orphan});
   *out = b;
   return FUELMI_OK;
 }

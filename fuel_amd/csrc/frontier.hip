@@ -2073,10 +2073,24 @@ static int frontier_ensure_stage(fuelmi_frontier* f, size_t bytes) {
   return FUELMI_OK;
 }
 
+static void frontier_orphan(void* p) {  // the map is going away under a live finder
+  fuelmi_frontier* f = static_cast<fuelmi_frontier*>(p);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  f->scope.reset();
+  f->map = nullptr;
+}
 extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (!f) return;
-  (void)hipSetDevice(f->map->device);
-  (void)hipStreamSynchronize(f->map->stream);
+  (void)hipSetDevice(f->device);
+  if (f->map) {
+    (void)hipStreamSynchronize(f->map->stream);
+    auto& deps = f->map->dependents;
+    for (size_t k = 0; k < deps.size(); ++k)
+      if (deps[k].obj == f) {
+        deps.erase(deps.begin() + (long)k);
+        break;
+      }
+  }
   if (f->stream) {
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamDestroy(f->stream);
@@ -2109,6 +2123,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   HIPCHK(hipSetDevice(m->device));
   fuelmi_frontier* f = new fuelmi_frontier;
   f->map = m;
+  f->device = m->device;
   f->cfg = *cfg;
   const Geo& g = m->g;
   // first z index whose centre is NOT below min_z (reference: if (pos[2] < 0.4) continue;)
@@ -2267,6 +2282,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   // the fast path needs tiles, a cluster threshold that rules out one-seed clusters, and tile-local indices
   // that fit the 16-bit root numbers
   f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && f->tile_lds <= 150 * 1024 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
+  m->dependents.push_back({f, &frontier_orphan});
   *out = f;
   return FUELMI_OK;
 }

@@ -190,7 +190,8 @@ struct HCluster {
 };
 
 struct fuelmi_frontier {
-  fuelmi_map* map = nullptr;
+  fuelmi_map* map = nullptr;  // cleared if the map is destroyed first (then only _destroy is legal)
+  int device = 0;
   fuelmi_frontier_cfg cfg;
   int iz_min = 0;
   Plane flag, qb, sb;

@@ -88,6 +88,14 @@ struct fuelmi_map {
   Plane hit_bits, miss_bits;    // per-frame touched voxels
   u64* ins_partial = nullptr;   // per-block end-point boxes of the fusion's classify kernel
   size_t ins_partial_cap = 0;
+  // objects created on this map (frontier finders, B-spline batches): if the map is destroyed first -- garbage
+  // collectors and destructor orders do that -- each is told (its stream drained, its map pointer cleared) so that
+  // its own destroy does not touch freed memory
+  struct Dependent {
+    void* obj;
+    void (*orphan)(void*);
+  };
+  std::vector<Dependent> dependents;
   void* ins_rec = nullptr;      // per-slot records of the fusion's classify kernel (32 B each)
   size_t ins_rec_cap = 0;
   u64* ins_head = nullptr;      // [16] device; [8] = the ESDF far-output statistic (two u32, esdf.hip); [0..7]: [6] = points projected by the depth front end of the current frame

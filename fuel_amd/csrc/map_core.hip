@@ -430,6 +430,8 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  for (auto& d : m->dependents) d.orphan(d.obj);  // finders / batches that outlive their map
+  m->dependents.clear();
   for (auto& r : m->mirror)
     if (r.host) (void)hipHostUnregister(r.host);
   Plane* planes[] = {&m->occ_bits, &m->unk_bits,  &m->infl_bits, &m->tmp_bits,

@@ -169,3 +169,14 @@ def test_two_rank_rendezvous_with_real_plan_cycles():
     assert abs(e0 - e1) < 1e-9 and e0 > 0
     assert n0 > 0 and n1 > 0
     assert abs(v0 - 2 * 40 / e0) < 1e-6 * v0
+
+
+def test_map_destroyed_before_its_finder_and_batch():
+    """garbage collectors and destructor orders tear a map down before the objects created on it: their own
+    destroy calls must not touch the freed map"""
+    cyc = _build(42)
+    cyc.run_native(2)
+    cyc.finish()
+    cyc.map.close()           # first the map ...
+    cyc.ff.close()            # ... then its finder
+    cyc.dev_problem.close()   # ... and the B-spline batch
