@@ -183,7 +183,6 @@ class GpuStreamCycle:
 
     def __init__(self, map_size, box, frames, ctrl, device, dt=0.175):
         import fuel_amd
-        import torch
         self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device)
         self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100)
         self.frames = frames
@@ -194,11 +193,11 @@ class GpuStreamCycle:
         #   "pageable" -- an ordinary host array (a cv::Mat): staged through the map's pinned buffer
         stack = np.ascontiguousarray(np.stack([f[0] for f in frames]).astype(np.uint16))
         self.rows, self.cols = stack.shape[1], stack.shape[2]
-        self.dev_frames = torch.from_numpy(stack.view(np.int16)).to("cuda:%d" % device)
+        self.dev_frames = fuel_amd.DeviceBuffer(stack, device)
         self.pinned = stack.copy()
         fuel_amd._lib.check(self.map.L.fuelmi_host_register(self.pinned.ctypes.data, self.pinned.nbytes))
         fb = self.rows * self.cols * 2
-        self.ptr = {"device": [self.dev_frames.data_ptr() + i * fb for i in range(len(frames))],
+        self.ptr = {"device": [self.dev_frames.ptr + i * fb for i in range(len(frames))],
                     "pinned": [self.pinned.ctypes.data + i * fb for i in range(len(frames))]}
         self.frame_source = "device"
         self.opt = fuel_amd.BsplineOptimizer()

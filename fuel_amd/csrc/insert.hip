@@ -756,6 +756,24 @@ extern "C" int fuelmi_host_unregister(void* ptr) {
   HIPCHK(hipHostUnregister(ptr));
   return FUELMI_OK;
 }
+/* Plain device buffers for callers without a HIP runtime of their own (the tests, bench.py: frames resident in
+ * HBM before the timed region). */
+extern "C" int fuelmi_device_alloc(int device, size_t bytes, void** out) {
+  ARGCHK(out && bytes);
+  *out = nullptr;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipMalloc(out, bytes));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_device_upload(void* dst, const void* src, size_t bytes) {
+  ARGCHK(dst && src);
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_device_free(void* ptr) {
+  if (ptr) HIPCHK(hipFree(ptr));
+  return FUELMI_OK;
+}
 
 extern "C" int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stride_bytes, int n,
                                        const double camera_pos[3]) {

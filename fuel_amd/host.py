@@ -240,6 +240,29 @@ class SDFMap:
         return ms[:n.value].copy()
 
 
+class DeviceBuffer:
+    """A numpy array's bytes in device memory (fuelmi_device_alloc / _upload): .ptr is the device address."""
+
+    def __init__(self, array, device=0):
+        a = np.ascontiguousarray(array)
+        self.L = lib()
+        p = C.c_void_p()
+        check(self.L.fuelmi_device_alloc(int(device), a.nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, a.nbytes
+        check(self.L.fuelmi_device_upload(C.c_void_p(self.ptr), a.ctypes.data, a.nbytes))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.L.fuelmi_device_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class EDTEnvironment:
     """fast_planner::EDTEnvironment: distance/gradient query facade over SDFMap."""
 

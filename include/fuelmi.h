@@ -100,6 +100,10 @@ typedef struct {
  * NULL) receives proj_points_cnt.  Follow with fuelmi_map_inflate_local (local_updated_ branch). */
 int fuelmi_host_register(void* ptr, size_t bytes); /* hipHostRegister(mapped) of a frame ring; undo with _unregister */
 int fuelmi_host_unregister(void* ptr);
+/* plain device buffers for callers without a HIP runtime of their own (tests, bench.py) */
+int fuelmi_device_alloc(int device, size_t bytes, void** out);
+int fuelmi_device_upload(void* dst, const void* src, size_t bytes);
+int fuelmi_device_free(void* ptr);
 int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
                            const fuelmi_depth_cfg* cfg, const double cam_pos[3], const double cam_q_wxyz[4],
                            int* n_points);

@@ -447,3 +447,85 @@ def test_reference_order_viewpoints_exact(fa, seed, size_xy):
         _assert_exact_clusters(of, gf, which, filtered=True)
     gf.close()
     gm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# depth frames read where they lie (device memory, registered host memory) and the C++ streaming loop
+# ------------------------------------------------------------------------------------------------
+def _stream_frames(n=12, width=160, height=120):
+    from fuel_amd import synth
+    map_size = (10.0, 8.0, 4.0)
+    w = synth.World.for_map_size(map_size)
+    truth = w.world(3, 14)
+    frames = []
+    for k in range(n):
+        pose = w.camera(truth, 5, k, n, 0.9)
+        frames.append((w.depth_image(truth, pose, width, height, max_range=7.0), pose[:3].copy(),
+                       synth.World.pose_quaternion(pose)))
+    return map_size, ((-4.0, -3.0, 0.0), (4.0, 3.0, 2.2)), frames
+
+
+@pytest.mark.parametrize("where", ["device", "registered"])
+def test_depth_frames_read_in_place_give_the_same_map(fa, where):
+    """fuelmi_map_input_depth with the image in device memory / in a registered host ring (no staging copy: the
+    fusion kernels read it where it lies) == the pageable path == the oracle, bit for bit"""
+    from fuel_amd._lib import check
+    map_size, box, frames = _stream_frames()
+    s = 160 / 640.0
+    cfg_kw = dict(fx=387.229248046875 * s, fy=387.229248046875 * s, cx=321.04638671875 * s, cy=243.44969177246094 * s)
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    gcfg, ocfg = gm.depthConfig(**cfg_kw), fo.depth_cfg(**cfg_kw)
+    stack = np.ascontiguousarray(np.stack([f[0] for f in frames]).astype(np.uint16))
+    rows, cols = stack.shape[1:]
+    fb = rows * cols * 2
+    if where == "device":
+        dev = fa.DeviceBuffer(stack)
+        base = dev.ptr
+    else:
+        check(gm.L.fuelmi_host_register(stack.ctypes.data, stack.nbytes))
+        base = stack.ctypes.data
+    try:
+        for k, (img, pos, q) in enumerate(frames):
+            pts = fo.project_depth(img, pos, q, ocfg)
+            om.input_points(pts, pos)
+            assert gm.inputDepthImageAt(base + k * fb, rows, cols, pos, q, gcfg) == len(pts)
+            assert om.get_local_bound() == gm.getLocalBound()
+        gm.synchronize()
+    finally:
+        if where == "registered":
+            check(gm.L.fuelmi_host_unregister(stack.ctypes.data))
+    assert np.array_equal(gm.syncHost(occupancy=True)["occupancy"], om.occ)
+    gm.close()
+
+
+def test_cpp_streaming_loop_equals_the_call_sequence(fa):
+    """fuelmi_bench_stream (the measurement driver bench.py times) leaves the same map, clusters and costs as
+    the same frames pushed through the individual C-ABI calls"""
+    import bench
+    from fuel_amd import synth
+    map_size, n_obs, _ = bench.WORKLOADS["G200"]
+    box = bench.exploration_box(map_size)
+    frames = bench.streaming_frames(map_size, n_obs, 10, seed=5)
+    rng = np.random.default_rng(3)
+    ctrl = bench.make_trajectories(rng, 8, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
+    out = []
+    for native in (False, True):
+        cyc = bench.GpuStreamCycle(map_size, box, frames, ctrl, device=0)
+        if native:
+            cyc.run_native(len(frames))
+        else:
+            for _ in frames:
+                cyc.step()
+        cyc.finish()
+        cost, _ = cyc.dev_problem.download()
+        out.append((cyc.map.syncHost(occupancy=True, distance=True), [c.copy() for c in cyc.ff.clusters(1)], cost.copy(),
+                    cyc.n_clusters))
+        cyc.dev_problem.close()
+        cyc.ff.close()
+        cyc.map.close()
+    a, b = out
+    assert np.array_equal(a[0]["occupancy"], b[0]["occupancy"])
+    assert np.array_equal(a[0]["distance"], b[0]["distance"])
+    assert len(a[1]) == len(b[1]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert np.array_equal(a[2], b[2]) and a[3] == b[3]
