@@ -674,6 +674,13 @@ def main():
         out["frontier_path"] = dict(zip(("fast", "legacy", "fallback"), cyc.ff.stats()))
         out["cycle_hbm"] = {"algorithmic_bytes_per_cycle": cyc_bytes, "achieved": cyc_bytes * cps_per_gpu / 1e9,
                             "unit": "GB/s", "frac": cyc_bytes * cps_per_gpu / 1e9 / HBM_PEAK_GBS}
+        try:  # what a plain streaming kernel reaches on this device, beside the vendor peak used for `frac`
+            import ctypes as C
+            tri = C.c_double()
+            _lib.check(cyc.map.L.fuelmi_hbm_triad(local_rank, 1 << 30, 5, C.byref(tri)))
+            out["roofline"]["measured_triad_gbs"] = round(tri.value, 1)
+        except Exception:
+            out["roofline"]["measured_triad_gbs"] = None
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms
             out["roofline"]["isolated_frac"] = alg_bytes[dominant] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -770,6 +770,52 @@ extern "C" int fuelmi_device_upload(void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return FUELMI_OK;
 }
+/* STREAM-triad on this device, a[i] = b[i] + s * c[i] over three arrays of `bytes` each (choose >> 256 MiB so the
+ * Infinity Cache cannot hold them): the HBM bandwidth a simple kernel actually reaches, to put beside the 8 TB/s
+ * vendor peak the rooflines are quoted against. */
+__global__ void __launch_bounds__(256) k_triad(float4* __restrict__ a, const float4* __restrict__ b,
+                                                const float4* __restrict__ c, float s, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = b[i], y = c[i];
+    a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+  }
+}
+extern "C" int fuelmi_hbm_triad(int device, size_t bytes, int reps, double* gb_per_s) {
+  ARGCHK(gb_per_s && bytes >= 4096 && reps >= 1);
+  *gb_per_s = 0.0;
+  HIPCHK(hipSetDevice(device));
+  bytes &= ~(size_t)15;
+  float4 *a = nullptr, *b = nullptr, *c = nullptr;
+  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&c, bytes) != hipSuccess) {
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    (void)hipGetLastError();
+    fuelmi_set_error("fuelmi_hbm_triad: cannot allocate 3 x %zu bytes", bytes);
+    return FUELMI_EHIP;
+  }
+  (void)hipMemset(b, 0, bytes);
+  (void)hipMemset(c, 0, bytes);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  const size_t n4 = bytes / 16;
+  for (int grid : {256 * 8, 256 * 16, 256 * 32, 256 * 64, 256 * 256}) {  // the best of a few launch shapes
+    k_triad<<<grid, 256>>>(a, b, c, 0.5f, n4);  // warm-up
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < reps; ++r) k_triad<<<grid, 256>>>(a, b, c, 0.5f, n4);
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *gb_per_s = std::max(*gb_per_s, 3.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  (void)hipFree(c);
+  return FUELMI_OK;
+}
 extern "C" int fuelmi_device_free(void* ptr) {
   if (ptr) HIPCHK(hipFree(ptr));
   return FUELMI_OK;

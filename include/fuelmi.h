@@ -104,6 +104,9 @@ int fuelmi_host_unregister(void* ptr);
 int fuelmi_device_alloc(int device, size_t bytes, void** out);
 int fuelmi_device_upload(void* dst, const void* src, size_t bytes);
 int fuelmi_device_free(void* ptr);
+/* STREAM-triad over three device arrays of `bytes` each: the HBM bandwidth a plain kernel reaches on this device
+ * (reported by bench.py beside the vendor peak the rooflines are quoted against). */
+int fuelmi_hbm_triad(int device, size_t bytes, int reps, double* gb_per_s);
 int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
                            const fuelmi_depth_cfg* cfg, const double cam_pos[3], const double cam_q_wxyz[4],
                            int* n_points);
