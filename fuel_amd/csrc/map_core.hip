@@ -489,10 +489,14 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
   const int s_lo = std::max(t_lo - ryz, -m->margin_words), s_hi = std::min(t_hi + ryz, g.W - 1 + m->margin_words);
   {
     StageScope sc(m, FUELMI_K_INFLATE);
-    k_box_and<<<blocks_for(s_hi - s_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->occ_bits.p, m->tmp_bits.p,
-                                                                        s_lo, s_hi);
-    k_inflate_yz<<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, m->tmp_bits.p, m->tmp2_bits.p,
-                                                                          t_lo, t_hi);
+    // sources = occupied voxels inside the box.  A box that is the whole map needs no masking: the occupancy
+    // plane itself (zero margins included) is the source plane
+    const bool whole = b.lo[0] == 0 && b.lo[1] == 0 && b.lo[2] == 0 && b.hi[0] == g.nx - 1 && b.hi[1] == g.ny - 1 &&
+                       b.hi[2] == g.nz - 1;
+    const u64* S = whole ? m->occ_bits.p : m->tmp_bits.p;
+    if (!whole)
+      k_box_and<<<blocks_for(s_hi - s_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->occ_bits.p, m->tmp_bits.p, s_lo, s_hi);
+    k_inflate_yz<<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, S, m->tmp2_bits.p, t_lo, t_hi);
     k_inflate_x<<<((blocks_for(out_hi - out_lo + 1, 256) + 7) / 8) * 8, 256, 0, m->stream>>>(g, b, step, m->tmp2_bits.p,
                                                                              m->infl_bits.p, out_lo, out_hi);
   }
