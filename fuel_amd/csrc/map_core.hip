@@ -130,19 +130,44 @@ k_box_and(Geo g, Box3 b, const u64* __restrict__ src, u64* __restrict__ dst, int
 // the intermediate plane keeps the bits that leave [0,N) in its margins, so the reference's
 // "only the final address is range-checked" wrap quirk is preserved exactly).
 // One thread per output word; the dz loop is a funnel-shifted OR over a 128-bit window.
+// STEP > 0: the step is a compile-time constant (2 for the usual 0.199 m inflation at 0.1 m) -- all plane words of
+// the 2*STEP+1 windows are fetched before the first is used (one memory round trip instead of one per dy: the kernel
+// is a chain of dependent L2 reads otherwise); STEP == 0: any step, the loop form.
+template <int STEP>
 __global__ void __launch_bounds__(256)
 k_inflate_yz(Geo g, int step, const u64* __restrict__ S, u64* __restrict__ T, int w_lo, int w_hi) {
   int w = w_lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (w > w_hi) return;
   u64 acc = 0ull;
-  for (int dy = -step; dy <= step; ++dy) {
-    long start = 64L * w - (long)dy * g.nz - step;
-    u64 lo = plane_window(S, start);
-    u64 hi = plane_window(S, start + 64);
-    if ((lo | hi) == 0ull) continue;
-    u64 r = lo;
-    for (int k = 1; k <= 2 * step; ++k) r |= (lo >> k) | (hi << (64 - k));
-    acc |= r;
+  if (STEP > 0) {
+    u64 a[2 * STEP + 1][3];
+#pragma unroll
+    for (int i = 0; i < 2 * STEP + 1; ++i) {
+      const long start = 64L * w - (long)(i - STEP) * g.nz - STEP;
+      const long wi = start >> 6;
+      a[i][0] = S[wi], a[i][1] = S[wi + 1], a[i][2] = S[wi + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * STEP + 1; ++i) {
+      const long start = 64L * w - (long)(i - STEP) * g.nz - STEP;
+      const int sh = (int)(start & 63);
+      const u64 lo = sh ? (a[i][0] >> sh) | (a[i][1] << (64 - sh)) : a[i][0];
+      const u64 hi = sh ? (a[i][1] >> sh) | (a[i][2] << (64 - sh)) : a[i][1];
+      u64 r = lo;
+#pragma unroll
+      for (int k = 1; k <= 2 * STEP; ++k) r |= (lo >> k) | (hi << (64 - k));
+      acc |= r;
+    }
+  } else {
+    for (int dy = -step; dy <= step; ++dy) {
+      long start = 64L * w - (long)dy * g.nz - step;
+      u64 lo = plane_window(S, start);
+      u64 hi = plane_window(S, start + 64);
+      if ((lo | hi) == 0ull) continue;
+      u64 r = lo;
+      for (int k = 1; k <= 2 * step; ++k) r |= (lo >> k) | (hi << (64 - k));
+      acc |= r;
+    }
   }
   T[w] = acc;
 }
@@ -496,7 +521,10 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
     const u64* S = whole ? m->occ_bits.p : m->tmp_bits.p;
     if (!whole)
       k_box_and<<<blocks_for(s_hi - s_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->occ_bits.p, m->tmp_bits.p, s_lo, s_hi);
-    k_inflate_yz<<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, S, m->tmp2_bits.p, t_lo, t_hi);
+    if (step == 2)
+      k_inflate_yz<2><<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, S, m->tmp2_bits.p, t_lo, t_hi);
+    else
+      k_inflate_yz<0><<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, S, m->tmp2_bits.p, t_lo, t_hi);
     k_inflate_x<<<((blocks_for(out_hi - out_lo + 1, 256) + 7) / 8) * 8, 256, 0, m->stream>>>(g, b, step, m->tmp2_bits.p,
                                                                              m->infl_bits.p, out_lo, out_hi);
   }
