@@ -3008,7 +3008,7 @@ extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
   ARGCHK(f);
   HIPCHK(hipSetDevice(f->map->device));
   f->tail_pending = false;
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(stream_wait(f->stream));
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
@@ -3146,8 +3146,8 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
     if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
   }
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(stream_wait(m->stream));
+  HIPCHK(stream_wait(f->stream));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   *n_clusters = ncl;
@@ -3188,8 +3188,8 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
     if ((rc = fuelmi_frontier_commit(f, 0))) break;
   }
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(stream_wait(m->stream));
+  HIPCHK(stream_wait(f->stream));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   *n_clusters = ncl;

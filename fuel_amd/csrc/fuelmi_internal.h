@@ -162,6 +162,16 @@ struct StageScope {
     }                                                                                                           \
   } while (0)
 
+// Wait for a stream the caller is about to consume the results of: poll for a while (a blocking synchronisation
+// pays ~15 us of wake-up latency even when the work is done within microseconds), then block.
+static inline hipError_t stream_wait(hipStream_t s) {
+  for (int spins = 0; spins < 200000; ++spins) {  // ~0.2 s of polling at most
+    const hipError_t q = hipStreamQuery(s);
+    if (q != hipErrorNotReady) return q;
+  }
+  return hipStreamSynchronize(s);
+}
+
 // ---- device helpers ---------------------------------------------------------------------------
 #ifdef __HIPCC__
 __device__ __forceinline__ u64 plane_window(const u64* __restrict__ p, long bit) {

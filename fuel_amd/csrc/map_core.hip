@@ -797,7 +797,7 @@ extern "C" int fuelmi_map_query_state(fuelmi_map* m, const int* idx, int n, int*
 extern "C" int fuelmi_map_synchronize(fuelmi_map* m) {
   ARGCHK(m);
   HIPCHK(hipSetDevice(m->device));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(stream_wait(m->stream));
   return FUELMI_OK;
 }
 
