@@ -529,3 +529,18 @@ def test_cpp_streaming_loop_equals_the_call_sequence(fa):
     assert np.array_equal(a[0]["distance"], b[0]["distance"])
     assert len(a[1]) == len(b[1]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
     assert np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_device_helpers_and_triad(fa):
+    """fuelmi_device_alloc / _upload / _free round trip through a kernel that reads the buffer (a depth frame), and
+    the STREAM-triad figure bench.py reports is a plausible HBM bandwidth"""
+    import ctypes as C
+    from fuel_amd._lib import check, lib
+    L = lib()
+    t = C.c_double()
+    check(L.fuelmi_hbm_triad(0, 256 << 20, 2, C.byref(t)))
+    assert 500.0 < t.value < 20000.0, t.value
+    buf = fa.DeviceBuffer(np.arange(1024, dtype=np.uint16))
+    assert buf.ptr and buf.nbytes == 2048
+    buf.close()
+    assert buf.ptr is None
