@@ -1934,12 +1934,10 @@ __global__ void __launch_bounds__(256) k_flags_hist(Geo g, FArgs F) {
     const bool live = i < i1 && i < F.cap_q;
     u32 code = FR_UNCLAIMED;
     if (live) {
+      const u32 a = F.cell_adr[i];  // (fetched beside the tile-root id, not behind the verdict it is needed for)
       code = F.rcode[F.tgid[i]];
       F.cell_rank[i] = code < FR_KCAP ? code : NOKEY;
-      if (code != FR_UNCLAIMED) {
-        const u32 a = F.cell_adr[i];
-        atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[a >> 6]), 1ull << (a & 63));
-      }
+      if (code != FR_UNCLAIMED) atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[a >> 6]), 1ull << (a & 63));
     }
     const bool kept = code < FR_KCAP;
     u64 todo = __ballot(kept);
