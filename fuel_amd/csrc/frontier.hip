@@ -1121,22 +1121,31 @@ __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* _
 // The legacy chain above runs the cross-tile merge, the claims, the cluster sizes, the kept list and
 // its ranking on the ~10^5 CELLS through device-scope atomics: five dependent kernels (k_union ..
 // k_rank_kept, ~60 us) whose time is atomic latency.  Here a tile describes each of its local
-// components by ONE record (k_ccl_tile: size, lowest claimer inside the scan box, index sums, index box)
-// and lists the component pairs that touch across tile faces; one workgroup then does all of the above
-// on those few thousand records in its LDS (k_resolve).  The cells are visited twice more, in address
-// order: flags + per-block histogram (k_flags_hist), stable scatter into the grouped result (k_scatter2).
-//   k_pred2 -> k_scan_sums -> k_compact2 -> k_ccl_tile -> k_seed_claim -> k_resolve -> k_flags_hist
-//   -> k_scatter2
+// components by ONE record (k_tile_ccl: size, lowest claimer inside the scan box, index sums, index box,
+// cells per x-row) and lists the component pairs that touch across tile faces (k_tile_cross); one
+// workgroup then does all of the above on those few thousand records in its LDS (k_resolve).
+//
+// Round 3: no compaction anywhere.  The round-2 chain compacted the cells in address order first (predicate
+// + in-block prefix, scan of the block sums, ordered compaction) and every later kernel found a cell's
+// neighbours through rank look-ups in those tables (three dependent loads each); regrouping the cells by
+// cluster took a histogram kernel and a scatter kernel.  Now
+//   k_pred3     : predicate planes qb / sb per 64-voxel word (+ the flag reset of a fresh search)
+//   k_tile_ccl  : a tile reads its own Q0 bits, labels them run by run in LDS, writes one record per component
+//                 and the component number of every cell BY VOXEL ADDRESS (vlab, one byte per voxel)
+//   k_tile_cross: relations across tile faces + NQ seed claims, neighbours looked up in vlab
+//   k_resolve   : unions, clusters, ranks; additionally the (kept cluster x tile column) prefix matrix
+//   k_tile_out  : flags + the grouped cell list: a cell's position = offset of its cluster + cells of the cluster
+//                 in earlier tile columns (matrix) + in earlier x-rows / earlier tiles of its own column (per-row
+//                 counts of the column's components) + earlier cells of its own row of the tile
 // Capacity limits (FR_* in frontier_internal.h) are those of pathological inputs (noise-like occupancy);
 // when one is hit, or cluster_min < 1 (every NQ seed is then a cluster of its own), the search runs the
 // legacy chain instead.  Results are identical (tests run both).
 // =================================================================================================
 
-// predicate planes + in-block packed prefix (k_pred) with the per-search arguments read straight from the
-// pinned host copy (no k_load_var launch) and fuelmi_frontier_reset folded in (V.fresh)
-__global__ void __launch_bounds__(256) k_pred2(Geo g, FArgs F, const FVar* __restrict__ hvar) {
+// predicate planes with the per-search arguments read straight from the pinned host copy (no k_load_var
+// launch) and fuelmi_frontier_reset folded in (V.fresh)
+__global__ void __launch_bounds__(256) k_pred3(Geo g, FArgs F, const FVar* __restrict__ hvar) {
   __shared__ FVar s_var;
-  __shared__ u64 wsum[4];
   const int nvw = (int)(sizeof(FVar) / 4);
   if ((int)threadIdx.x < nvw) reinterpret_cast<u32*>(&s_var)[threadIdx.x] = reinterpret_cast<const u32*>(hvar)[threadIdx.x];
   __syncthreads();
@@ -1146,81 +1155,623 @@ __global__ void __launch_bounds__(256) k_pred2(Geo g, FArgs F, const FVar* __res
   }
   const FVar& V = s_var;
   if ((int)blockIdx.x >= V.nblocks) return;
-  const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = V.w0 + rel;
+  const int w = V.w0 + blockIdx.x * 256 + threadIdx.x;
+  if (w >= g.W) return;
+  u64 z0, zl, y0, yl, mq, ms;
+  word_masks(g, w, V.qreg, V.sbox, z0, zl, y0, yl, mq, ms);
+  const u64 fl = V.fresh ? 0ull : F.flag[w];
+  if (V.fresh) F.flag[w] = 0ull;
   u64 q = 0ull, s = 0ull;
-  if (w < g.W) {
-    u64 z0, zl, y0, yl, mq, ms;
-    word_masks(g, w, V.qreg, V.sbox, z0, zl, y0, yl, mq, ms);
-    const u64 fl = V.fresh ? 0ull : F.flag[w];
-    if (V.fresh) F.flag[w] = 0ull;
-    if ((mq | ms) != 0ull) {
-      u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~fl;
-      q = f1 & mq;
-      s = f1 & ms & ~mq;
-    }
-    F.qb[w] = q;
-    F.sb[w] = s;
+  if ((mq | ms) != 0ull) {
+    const u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~fl;
+    q = f1 & mq;
+    s = f1 & ms & ~mq;
   }
-  u64 packed = (u64)__popcll(q) | ((u64)__popcll(s) << 32);
-  u64 v = packed;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    u64 t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
-  if (lane == 63) wsum[wave] = v;
-  __syncthreads();
-  u64 woff = 0;
-  for (int k = 0; k < wave; ++k) woff += wsum[k];
-  u64 excl = v - packed + woff;
-  F.pref[rel] = excl;
-  if (threadIdx.x == 255) F.blocksum[blockIdx.x] = excl + packed;
+  F.qb[w] = q;
+  F.sb[w] = s;
 }
 
-// ordered compaction (k_compact without the per-cell union-find / claim state of the legacy chain).  The scan
-// of the block sums is folded in: every block adds up the sums of the blocks in front of it (a few KB from L2),
-// the last one publishes the totals -- no single-block scan kernel between the predicate and the compaction.
-__global__ void __launch_bounds__(256) k_compact2(Geo g, FArgs F) {
-  __shared__ u64 s_part[4];
-  const int nblocks = F.var->nblocks;
-  if ((int)blockIdx.x >= nblocks) return;
+// ---- tiles ----------------------------------------------------------------------------------------
+struct TileGeo {
+  int tx, ty, x0, y0, nxl, nyl, TX, TY, nseg, items;
+};
+__device__ __forceinline__ TileGeo tile_geo(const Geo& g, const FVar& V, int t) {
+  TileGeo T;
+  T.TX = V.ftx, T.TY = V.fty;
+  T.tx = t / V.nty_f, T.ty = t - T.tx * V.nty_f;
+  T.x0 = V.px0 + T.tx * T.TX, T.y0 = V.py0 + T.ty * T.TY;
+  T.nxl = min(T.TX, V.px1 - T.x0 + 1), T.nyl = min(T.TY, V.py1 - T.y0 + 1);
+  T.nseg = (g.nz + 31) >> 5;
+  T.items = T.TX * T.TY * T.nseg;
+  return T;
+}
+__device__ __forceinline__ long tile_line_adr(const Geo& g, const TileGeo& T, int line) {  // address of voxel z = 0
+  const int lx = line / T.TY, ly = line - lx * T.TY;
+  return (long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * g.nz;
+}
+
+// Bits of plane `pl` over the tile, one u32 per 32-voxel segment of every z-line (segment it = line * nseg + c),
+// and their exclusive prefix: segpre[it] = tile-local index of the first cell at / after segment it (the
+// tile-local order is the address order inside every x-row).  A thread fetches FT_PER CONSECUTIVE segments (all
+// loads in flight together), the block scans one partial per thread.  Returns the number of cells; ends with a
+// barrier.
+#define FT_PER 8
+template <int NT, bool SCAN, bool TWO = false>
+__device__ __forceinline__ u32 tile_load_bits(const Geo& g, const TileGeo& T, const u64* __restrict__ pl, u32* segb,
+                                              u32* segpre, u32* s_wsum, const u64* __restrict__ pl2 = nullptr,
+                                              u32* segb2 = nullptr, u32* lab = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u64 acc = 0ull;
-  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) acc += F.blocksum[b];
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (lane == 0) s_part[wave] = acc;
-  __syncthreads();
-  const u64 bpre = s_part[0] + s_part[1] + s_part[2] + s_part[3];  // packed (q, s) cells in front of this block
-  if (threadIdx.x == 0) {
-    F.blockscan[blockIdx.x] = bpre;
-    if ((int)blockIdx.x == nblocks - 1) {
-      const u64 run = bpre + F.blocksum[blockIdx.x];
-      u32 nq = (u32)run, ns = (u32)(run >> 32), ovf = 0u;
-      if (nq > F.cap_q) nq = F.cap_q, ovf = 1u;
-      if (ns > F.cap_s) ns = F.cap_s, ovf = 1u;
-      F.counts[0] = nq, F.counts[1] = ns, F.counts[2] = ovf, F.counts[3] = 0u, F.counts[5] = 0u;
+  const int per = (T.items + NT - 1) / NT;  // <= FT_PER (checked on the host)
+  const int it0 = threadIdx.x * per;
+  u32 b[FT_PER], b2[FT_PER];
+  u32 cnt = 0u;
+  {
+    int line = it0 / T.nseg, c = it0 - line * T.nseg;
+    int lx = line / T.TY, ly = line - lx * T.TY;
+#pragma unroll
+    for (int k = 0; k < FT_PER; ++k) {
+      b[k] = 0u, b2[k] = 0u;
+      if (k < per && it0 + k < T.items && lx < T.nxl && ly < T.nyl) {
+        const int zn = min(32, g.nz - 32 * c);
+        const long a = (long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * g.nz + 32 * c;
+        u32 v = (u32)plane_window(pl, a);
+        u32 v2 = TWO ? (u32)plane_window(pl2, a) : 0u;
+        if (zn < 32) v &= (1u << zn) - 1u, v2 &= (1u << zn) - 1u;
+        b[k] = v, b2[k] = v2;
+      }
+      if (++c == T.nseg) {
+        c = 0;
+        if (++ly == T.TY) ly = 0, ++lx;
+      }
     }
   }
-  const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = F.var->w0 + rel;
-  if (w >= g.W) return;
-  u64 q = F.qb[w], s = F.sb[w];
-  if ((q | s) == 0ull) return;
-  u64 pk = bpre + F.pref[rel];
-  u32 iq = (u32)pk, is = (u32)(pk >> 32);
-  while (q) {
-    int b = __builtin_ctzll(q);
-    q &= q - 1;
-    if (iq < F.cap_q) F.cell_adr[iq] = (u32)(64L * w + b);
-    ++iq;
+  if (TWO) {
+#pragma unroll
+    for (int k = 0; k < FT_PER; ++k)
+      if (k < per && it0 + k < T.items) segb2[it0 + k] = b2[k];
   }
-  while (s) {
-    int b = __builtin_ctzll(s);
-    s &= s - 1;
-    if (is < F.cap_s) F.seed_adr[is] = (u32)(64L * w + b);
-    ++is;
+  if (!SCAN) {  // bits only
+#pragma unroll
+    for (int k = 0; k < FT_PER; ++k)
+      if (k < per && it0 + k < T.items) segb[it0 + k] = b[k];
+    __syncthreads();
+    return 0u;
   }
+#pragma unroll
+  for (int k = 0; k < FT_PER; ++k) cnt += (u32)__popc(b[k]);
+  u32 v = cnt;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 t = (u32)__shfl_up((int)v, off, 64);
+    if (lane >= off) v += t;
+  }
+  if (lane == 63) s_wsum[wave] = v;
+  __syncthreads();
+  u32 woff = 0u, tot = 0u;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) {
+    if (k < wave) woff += s_wsum[k];
+    tot += s_wsum[k];
+  }
+  u32 run = woff + v - cnt;
+#pragma unroll
+  for (int k = 0; k < FT_PER; ++k)
+    if (k < per && it0 + k < T.items) {
+      segb[it0 + k] = b[k];
+      segpre[it0 + k] = run;
+      if (lab != nullptr && run + (u32)__popc(b[k]) <= FR_TCELL) {
+        // labels of the CCL: start of the cell's z-run inside its segment (runs are pre-joined)
+        u32 rem = b[k], l = run;
+        while (rem) {
+          const int s0 = __builtin_ctz(rem);
+          const u32 inv = ~(rem >> s0);
+          const int len = min(inv ? __builtin_ctz(inv) : 32, 32 - s0);
+          rem &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s0);
+          for (int q = 0; q < len; ++q) lab[l + (u32)q] = l;
+          l += (u32)len;
+        }
+      }
+      run += (u32)__popc(b[k]);
+    }
+  if (threadIdx.x == 0) segpre[T.items] = tot;
+  __syncthreads();
+  return tot;
+}
+
+// first run of set bits of m (m != 0): start bit, length; removes it from m
+__device__ __forceinline__ void pop_run32(u32& m, int& s, int& len) {
+  s = __builtin_ctz(m);
+  const u32 inv = ~(m >> s);
+  len = inv ? __builtin_ctz(inv) : 32;
+  len = min(len, 32 - s);
+  m &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s);
+}
+__device__ __forceinline__ void pop_run64(u64& m, int& s, int& len) {
+  s = __builtin_ctzll(m);
+  const u64 inv = ~(m >> s);
+  len = inv ? __builtin_ctzll(inv) : 64;
+  len = min(len, 64 - s);
+  m &= ~((len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s);
+}
+
+// Tile CCL.  Labels are SPARSE (one per Q0 cell of the tile, addressed through the tile-local prefix of the
+// per-segment popcounts), so a tile costs the same LDS whatever nz is.  The unit of work is the z-RUN: the cells
+// of a run share a label from the start, a run looks at each of the four lower z-lines through one 34-bit window
+// and joins every run it finds there -- a wall costs one union per line, not one per cell.
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
+  const FVar& V = *F.var;
+  if ((int)blockIdx.x >= V.ntiles_f) return;
+  const TileGeo T = tile_geo(g, V, blockIdx.x);
+  const Box3 sbox = V.sbox;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nz = g.nz, nseg = T.nseg, items = T.items, TY = T.TY;
+  u32* lab = reinterpret_cast<u32*>(smem_raw);       // [FR_TCELL] union-find over the tile-local cell indices
+  u32* segb = lab + FR_TCELL;                         // [items] Q0 bits of each 32-voxel segment
+  u32* segpre = segb + items;                         // [items + 1]
+  u32* acc = segpre + items + 1;                      // [FR_TROOT][8]: sy, sz, claim, ly, lz, hy, hz, -
+  u32* rrow = acc + FR_TROOT * 8;                     // [FR_TROOT][FR_TXS] cells per x-row
+  unsigned short* rootno = reinterpret_cast<unsigned short*>(rrow + FR_TROOT * FR_TXS);  // [FR_TCELL] at a root: its number
+  unsigned char* rcell = reinterpret_cast<unsigned char*>(rootno + FR_TCELL);            // [FR_TCELL] component number per cell
+  __shared__ u32 s_wsum[NT / 64];
+  __shared__ u32 s_nroots, s_base, s_flag;
+  __shared__ u32 s_cnt[4];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) s_nroots = 0u, s_flag = 0u, s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0u;
+  FR_DBG_MARK(F, blockIdx.x, 0);
+  const u32 total = tile_load_bits<NT, true>(g, T, F.qb, segb, segpre, s_wsum, nullptr, nullptr, lab);  // (uniform; labels too)
+  FR_DBG_MARK(F, blockIdx.x, 1);
+  if (total == 0u || total > FR_TCELL) {
+    if (threadIdx.x == 0) {
+      F.t_nroots[blockIdx.x] = 0u;
+      F.t_base[blockIdx.x] = 0u;
+      if (total > FR_TCELL) F.fctr[9] = 11u;  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
+    }
+    return;
+  }
+  for (int t = threadIdx.x; t < FR_TROOT * 8; t += NT) {
+    const int k = t & 7;
+    acc[t] = (k >= 2 && k <= 4) ? 0xFFFFFFFFu : 0u;  // claim / box minima start at +inf
+  }
+  for (int t = threadIdx.x; t < FR_TROOT * FR_TXS; t += NT) rrow[t] = 0u;  // (used behind the next barrier)
+  FR_DBG_MARK(F, blockIdx.x, 2);
+  // ---- unions: segment seams + the four lower z-lines inside the tile.  One lane per (z-line, lower line): both
+  // lines' segments (bits and tile-local prefixes) are fetched into registers in one batch of independent LDS reads,
+  // the runs are then matched in registers, and only the unions themselves go back to the LDS ----
+  {
+    const int nlines = T.TX * TY;
+    for (int j = threadIdx.x; j < 4 * nlines; j += NT) {
+      const int k = j / nlines, line = j - k * nlines, lx = line / TY, ly = line - lx * TY;
+      u32 ob[FT_PER], op[FT_PER], nb[FT_PER], npre[FT_PER];
+      u32 any = 0u;
+#pragma unroll
+      for (int c = 0; c < FT_PER; ++c) {
+        ob[c] = op[c] = 0u;
+        if (c < nseg) ob[c] = segb[line * nseg + c], op[c] = segpre[line * nseg + c];
+        any |= ob[c];
+      }
+      if (!any) continue;
+      const int nlx = lx + (k < 3 ? -1 : 0), nly = ly + (k < 3 ? k - 1 : -1);
+      const bool nvalid = nlx >= 0 && nly >= 0 && nly < TY;
+      const int nline = nlx * TY + nly;
+      u32 nany = 0u;
+#pragma unroll
+      for (int c = 0; c < FT_PER; ++c) {
+        nb[c] = npre[c] = 0u;
+        if (nvalid && c < nseg) nb[c] = segb[nline * nseg + c], npre[c] = segpre[nline * nseg + c];
+        nany |= nb[c];
+      }
+      if (k != 3 && !nany) continue;
+#pragma unroll
+      for (int c = 0; c < FT_PER; ++c) {
+        const u32 bits = ob[c];
+        if (!bits) continue;
+        if (k == 3 && (bits & 1u) && c > 0 && (ob[c > 0 ? c - 1 : 0] >> 31)) {
+          lds_union_h(lab, op[c], op[c] - 1u);
+        }
+        // the neighbour line's bits at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j)
+        const u32 nlo = c > 0 ? nb[c > 0 ? c - 1 : 0] : 0u, nhi = c + 1 < FT_PER ? nb[c + 1 < FT_PER ? c + 1 : 0] : 0u;
+        const u64 w3 = (u64)(nlo >> 31) | ((u64)nb[c] << 1) | ((u64)(nhi & 1u) << 33);
+        if (!w3) continue;
+        u32 rem = bits;
+        u32 l = op[c];
+        while (rem) {
+          int s, len;
+          pop_run32(rem, s, len);
+          u64 m = (w3 >> s) & ((1ull << (len + 2)) - 1ull);  // z - 1 .. z + len of the run
+          while (m) {
+            int jj, rl;
+            pop_run64(m, jj, rl);
+            const int q = s + jj;  // bit of w3: 0 -> last voxel of segment c - 1, 1..32 -> segment c, 33 -> first of c + 1
+            u32 ln;
+            if (q == 0)
+              ln = npre[c > 0 ? c - 1 : 0] + (u32)__popc(nlo & 0x7FFFFFFFu);
+            else if (q == 33)
+              ln = npre[c + 1 < FT_PER ? c + 1 : 0];
+            else
+              ln = npre[c] + (u32)__popc(nb[c] & ((1u << (q - 1)) - 1u));
+            lds_union_h(lab, l, ln);
+          }
+          l += (u32)len;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 3);
+  // ---- roots: dense numbers ----
+  for (u32 l = threadIdx.x; l < total; l += NT)
+    if (lab[l] == l) {
+      const u32 la = atomicAdd(&s_nroots, 1u);
+      rootno[l] = (unsigned short)min(la, 0xFFFFu);
+    }
+  __syncthreads();
+  const u32 nroots = s_nroots;
+  if (nroots > FR_TROOT) {
+    if (threadIdx.x == 0) {
+      F.fctr[9] = 12u;
+      F.t_nroots[blockIdx.x] = 0u;
+      F.t_base[blockIdx.x] = 0u;
+    }
+    return;
+  }
+  // ---- ids of the components: one contiguous range per tile inside the XCD's part of the id space (the
+  // returning atomic is issued here so that its latency hides behind the record loop) ----
+  if (threadIdx.x == 0) {
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 b = atomicAdd(&F.fctr[xcd], nroots);
+    if (b + nroots > FR_RC8) {
+      F.fctr[9] = 13u;
+      s_flag = 1u;
+    }
+    s_base = xcd * FR_RC8 + b;
+  }
+  // ---- component number of every cell ----
+  for (u32 l = threadIdx.x; l < total; l += NT) rcell[l] = (unsigned char)rootno[lds_find_h(lab, l)];
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 4);
+  // ---- per-component records.  One lane per z-LINE adds up its runs in registers (a line's cells nearly always
+  // belong to one component); a wave whose lanes all hold the same component reduces across the lanes first. ----
+  for (int line0 = 0; line0 < T.TX * TY; line0 += NT) {  // (uniform trip count: the wave reduces below)
+    const int line = line0 + threadIdx.x;
+    const bool act = line < T.TX * TY;
+    const int lx = line / TY, ly = line - lx * TY;
+    const u32 x = (u32)(T.x0 + lx), y = (u32)(T.y0 + ly);
+    const bool xy_in = (int)x >= sbox.lo[0] && (int)x <= sbox.hi[0] && (int)y >= sbox.lo[1] && (int)y <= sbox.hi[1];
+    const long la = (long)x * g.nyz + (long)y * nz;
+    u32 key = 0xFFFFFFFFu, n = 0u, sz = 0u, cl = 0xFFFFFFFFu, lz = 0xFFFFFFFFu, hz = 0u;
+    auto flush = [&]() {  // direct LDS atomics (the slow path: a second component on the line)
+      u32* r = acc + key * 8u;
+      atomicAdd(&r[0], n * y), atomicAdd(&r[1], sz), atomicMin(&r[2], cl), atomicMin(&r[3], y), atomicMin(&r[4], lz);
+      atomicMax(&r[5], y), atomicMax(&r[6], hz);
+      atomicAdd(&rrow[key * FR_TXS + (u32)lx], n);
+    };
+    for (int c = 0; act && c < nseg; ++c) {
+      const int it = line * nseg + c;
+      u32 rem = segb[it];
+      u32 l = segpre[it];
+      while (rem) {
+        int s, len;
+        pop_run32(rem, s, len);
+        const u32 k2 = (u32)rcell[l];
+        if (k2 != key) {
+          if (key != 0xFFFFFFFFu) flush();
+          key = k2, n = 0u, sz = 0u, cl = 0xFFFFFFFFu, lz = 0xFFFFFFFFu, hz = 0u;
+        }
+        const u32 z0 = (u32)(32 * c + s), z1 = z0 + (u32)len - 1u;
+        n += (u32)len;
+        sz += (u32)len * z0 + (u32)(len * (len - 1) / 2);
+        lz = min(lz, z0), hz = max(hz, z1);
+        if (xy_in) {
+          const int zc = max((int)z0, sbox.lo[2]);
+          if (zc <= min((int)z1, sbox.hi[2])) cl = min(cl, (u32)(la + zc));
+        }
+        l += (u32)len;
+      }
+    }
+    // the last (usually only) component of the line: wave-uniform -> one set of atomics per wave
+    const bool have = key != 0xFFFFFFFFu;
+    const u64 hm = __ballot(have);
+    if (hm) {
+      const u32 first = (u32)__shfl((int)key, __builtin_ctzll(hm), 64);
+      const bool uni = __ballot(have && key != first) == 0ull;
+      if (uni) {
+        u32 sy = have ? n * y : 0u, s2 = have ? sz : 0u, c2 = have ? cl : 0xFFFFFFFFu;
+        u32 ly2 = have ? y : 0xFFFFFFFFu, lz2 = have ? lz : 0xFFFFFFFFu, hy2 = have ? y : 0u, hz2 = have ? hz : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+          sy += (u32)__shfl_xor((int)sy, off, 64);
+          s2 += (u32)__shfl_xor((int)s2, off, 64);
+          c2 = min(c2, (u32)__shfl_xor((int)c2, off, 64));
+          ly2 = min(ly2, (u32)__shfl_xor((int)ly2, off, 64));
+          lz2 = min(lz2, (u32)__shfl_xor((int)lz2, off, 64));
+          hy2 = max(hy2, (u32)__shfl_xor((int)hy2, off, 64));
+          hz2 = max(hz2, (u32)__shfl_xor((int)hz2, off, 64));
+        }
+        if (lane == __builtin_ctzll(hm)) {
+          u32* r = acc + first * 8u;
+          atomicAdd(&r[0], sy), atomicAdd(&r[1], s2), atomicMin(&r[2], c2), atomicMin(&r[3], ly2), atomicMin(&r[4], lz2);
+          atomicMax(&r[5], hy2), atomicMax(&r[6], hz2);
+        }
+        if (have) atomicAdd(&rrow[key * FR_TXS + (u32)lx], n);
+      } else if (have)
+        flush();
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, blockIdx.x, 5);
+  const u32 gbase = s_base;
+  if (threadIdx.x == 0) {
+    F.t_base[blockIdx.x] = gbase;
+    F.t_nroots[blockIdx.x] = s_flag ? 0u : nroots;
+  }
+  if (s_flag) return;
+  if (threadIdx.x < nroots) {
+    const u32* r = acc + threadIdx.x * 8;
+    const u32* rw = rrow + threadIdx.x * FR_TXS;
+    TRec R;
+    u32 size = 0u, sx = 0u, lox = 0xFFFFFFFFu, hix = 0u;
+    unsigned short* grow = F.rrow + (size_t)(gbase + threadIdx.x) * FR_TXS;
+    for (int lx = 0; lx < FR_TXS; ++lx) {
+      const u32 cnt = lx < T.TX ? rw[lx] : 0u;
+      grow[lx] = (unsigned short)cnt;  // (<= TY * nz <= 32 * 256 cells)
+      if (cnt) {
+        size += cnt, sx += cnt * (u32)(T.x0 + lx);
+        lox = min(lox, (u32)(T.x0 + lx)), hix = max(hix, (u32)(T.x0 + lx));
+      }
+    }
+    R.size = size, R.sx = sx, R.sy = r[0], R.sz = r[1];
+    R.lo[0] = lox, R.lo[1] = r[3], R.lo[2] = r[4], R.hi[0] = hix, R.hi[1] = r[5], R.hi[2] = r[6];
+    R.tx = (u32)T.tx, R.own = r[2];
+    F.trec[gbase + threadIdx.x] = R;
+    F.tclaim[gbase + threadIdx.x] = r[2];
+  }
+  // ---- component number of every cell, by tile-local index (k_tile_out) and by voxel address (k_tile_cross) ----
+  {
+    unsigned char* tl = F.tlab + (size_t)blockIdx.x * FR_TCELL;
+    for (u32 l = threadIdx.x; l < total; l += NT) tl[l] = rcell[l];
+  }
+  for (int it = threadIdx.x; it < items; it += NT) {
+    u32 rem = segb[it];
+    if (!rem) continue;
+    const int line = it / nseg, c = it - line * nseg;
+    unsigned char* vl = F.vlab + tile_line_adr(g, T, line) + 32 * c;
+    u32 l = segpre[it];
+    while (rem) {
+      const int b = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      vl[b] = rcell[l++];
+    }
+  }
+  FR_DBG_MARK(F, blockIdx.x, 6);
+  if (F.dbg && threadIdx.x == 0) {
+    F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 8] = total;
+    F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 9] = s_cnt[0];
+    F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 10] = s_cnt[1];
+    F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 11] = s_cnt[2];
+    F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 12] = nroots;
+  }
+}
+
+// Joins across tile faces + seed claims, one launch after k_tile_ccl (every cell's component number is in vlab by
+// now).  The runs of the tile's lower-face lines look across the face through the same 34-bit windows as inside
+// the tile; the relation is recorded as a pair of TILE ROOTS, and a tile keeps one record per distinct pair (LDS
+// set: a surface crossing a face gives the same pair from all of its cells) -- a few thousand records per search.
+// The tile's NQ seeds claim the tile roots touching their 26-neighbourhood (atomicMin on tclaim).
+#define XC_SET 256
+#define XC_WCAP 6144  // entries of a tile's work list (beyond: processed on the spot)
+__device__ __forceinline__ void xc_insert(u32* s_set, u32* s_list, u32* s_n, u32* fctr, u32 key) {
+  u32 h = (key * 2654435761u) >> 24;
+  bool done = false;
+  for (int probe = 0; probe < XC_SET && !done; ++probe) {
+    const u32 old = atomicCAS(&s_set[h], 0xFFFFFFFFu, key);
+    if (old == 0xFFFFFFFFu) {
+      s_list[atomicAdd(s_n, 1u)] = key;
+      done = true;
+    } else if (old == key)
+      done = true;
+    h = (h + 1u) & (XC_SET - 1u);
+  }
+  if (!done) fctr[9] = 15u;  // more than XC_SET distinct root pairs around one tile
+}
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
+  FR_DBG_MARK(F, blockIdx.x, 13);  // (before the first load)
+  const FVar& V = *F.var;
+  if ((int)blockIdx.x >= V.ntiles_f) return;
+  // (no look at the chain's overflow word here: it shares a cache line with the counters k_tile_ccl just hit with
+  // atomics, and thousands of waves waiting for that line cost more than the kernel.  After an overflow the
+  // component numbers of some tile are stale: ids stay inside the padded tables, k_resolve discards everything.)
+  const TileGeo T = tile_geo(g, V, blockIdx.x);
+  const int nz = g.nz, nseg = T.nseg, TY = T.TY;
+  const int lane = threadIdx.x & 63;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32* segq = reinterpret_cast<u32*>(smem_raw);  // [items] Q0 bits of the tile
+  u32* segs = segq + T.items;                    // [items] NQ seed bits
+  // work list: (own segment, neighbour line) combinations that have something to look up -- built from LDS only,
+  // so that the global loads behind them (neighbour window, then component numbers) go out together.  An entry is
+  // the item's number: face item fs * 4 + k, or seed item 0x80000000 | it * 9 + l.
+  u32* wl = segs + T.items;                      // [XC_WCAP]
+  __shared__ u32 s_set[XC_SET];   // distinct (root, root) pairs of this tile: open addressing
+  __shared__ u32 s_list[XC_SET];  // ... in insertion order
+  __shared__ u32 s_n, s_base, s_nw;
+  __shared__ u32 s_tb[9];         // component-id base of the 3 x 3 tiles around this one
+  const int dblk = V.ntiles_f + 1 + (int)blockIdx.x;
+  FR_DBG_MARK(F, dblk, 0);
+  if (threadIdx.x < 9) {
+    const int dtx = (int)threadIdx.x / 3 - 1, dty = (int)threadIdx.x % 3 - 1;
+    const int ntx = T.tx + dtx, nty = T.ty + dty;
+    u32 b = 0u;
+    if (ntx >= 0 && ntx < V.ntx_f && nty >= 0 && nty < V.nty_f) b = F.t_base[ntx * V.nty_f + nty];
+    s_tb[threadIdx.x] = b;
+  }
+  if (threadIdx.x < XC_SET) s_set[threadIdx.x] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) s_n = 0u, s_nw = 0u;
+  tile_load_bits<NT, false, true>(g, T, F.qb, segq, nullptr, nullptr, F.sb, segs);
+  FR_DBG_MARK(F, dblk, 1);
+  auto tile_of = [&](int x, int y) -> u32 {  // which of the 3 x 3 tiles holds column (x, y)
+    const int dtx = x < T.x0 ? -1 : (x >= T.x0 + T.TX ? 1 : 0), dty = y < T.y0 ? -1 : (y >= T.y0 + TY ? 1 : 0);
+    return (u32)((dtx + 1) * 3 + dty + 1);
+  };
+  // one item: the neighbour window w3 (bit j <-> z = 32 c - 1 + j of the neighbour line) against the own bits
+  u32 k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // up to two distinct pairs wait for the wave-level de-duplication
+  auto do_item = [&](u32 bits, u32 own, int nb, u32 info, u64 w3) {
+    const int c = (int)(info & 0xFFu);
+    const u32 tb = s_tb[(info >> 8) & 0xFFu];
+    w3 &= (1ull << 34) - 1ull;
+    if (c == 0) w3 &= ~1ull;
+    const int jend = nz - 32 * c + 1;  // bit position of z = nz
+    if (jend < 34) w3 &= (1ull << jend) - 1ull;
+    if (info >> 16) {
+      // seeds: a component touching the segment's seeds is claimed by the lowest seed next to one of its cells
+      while (w3) {
+        int j, rl;
+        pop_run64(w3, j, rl);
+        const int b0 = max(j - 2, 0), b1 = min(j + rl - 1, 31);  // seeds at bits j - 2 .. j + rl - 1 touch the run
+        if (b0 > b1) continue;
+        const u32 m = bits & (((b1 - b0 + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (b1 - b0 + 1)) - 1u)) << b0);
+        if (!m) continue;
+        const u32 r = tb + (u32)F.vlab[(long)nb + j];
+        atomicMin(&F.tclaim[r], own + (u32)__builtin_ctz(m));
+      }
+      return;
+    }
+    u32 rem = bits;
+    while (rem && w3) {
+      int s, len;
+      pop_run32(rem, s, len);
+      u64 m = (w3 >> s) & ((1ull << (len + 2)) - 1ull);
+      if (!m) continue;
+      const u32 ga = s_tb[4] + (u32)F.vlab[(long)own + s];
+      while (m) {
+        int j, rl;
+        pop_run64(m, j, rl);
+        const u32 gb = tb + (u32)F.vlab[(long)nb + s + j];
+        if (gb == ga) continue;
+        const u32 key = (min(ga, gb) << 16) | max(ga, gb);
+        if (key == k0 || key == k1) continue;
+        if (k0 == 0xFFFFFFFFu)
+          k0 = key;
+        else if (k1 == 0xFFFFFFFFu)
+          k1 = key;
+        else
+          xc_insert(s_set, s_list, &s_n, F.fctr, key);  // (a third distinct pair from one lane: rare)
+      }
+    }
+  };
+  auto flush_pairs = [&]() {  // (all lanes of the wave)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const u32 kq = q ? k1 : k0;
+      const bool on = kq != 0xFFFFFFFFu;
+      u64 todo = __ballot(on);
+      while (todo) {  // one insertion per distinct pair of the wave
+        const int leader = __builtin_ctzll(todo);
+        const u32 key = (u32)__shfl((int)kq, leader, 64);
+        todo &= ~__ballot(on && kq == key);
+        if (lane == leader) xc_insert(s_set, s_list, &s_n, F.fctr, key);
+      }
+    }
+    k0 = k1 = 0xFFFFFFFFu;
+  };
+  // what an entry stands for: own bits, address of the own segment, address of the neighbour window, info word
+  auto decode = [&](u32 e, u32& bits, u32& own, int& nb, u32& info) {
+    int it, xx, yy, c;
+    if (e >> 31) {
+      const int sj = (int)(e & 0x7FFFFFFFu), l = sj % 9;
+      it = sj / 9;
+      const int line = it / nseg, lx = line / TY, ly = line - lx * TY;
+      c = it - line * nseg;
+      xx = T.x0 + lx + l / 3 - 1, yy = T.y0 + ly + l % 3 - 1;
+      bits = (xx >= V.px0 && xx <= V.px1 && yy >= V.py0 && yy <= V.py1) ? segs[it] : 0u;  // (no Q0 cells outside the tiles)
+      own = (u32)((long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * nz + 32 * c);
+      info = (u32)c | (tile_of(xx, yy) << 8) | (1u << 16);
+    } else {
+      const int k = (int)(e & 3u), fs = (int)(e >> 2), fl = fs / nseg;
+      c = fs - fl * nseg;
+      int lx = 0, ly = fl;
+      if (fl >= TY) lx = 1 + ((fl - TY) >> 1), ly = ((fl - TY) & 1) ? TY - 1 : 0;
+      xx = T.x0 + lx + (k < 3 ? -1 : 0), yy = T.y0 + ly + (k < 3 ? k - 1 : -1);
+      bits = segq[(lx * TY + ly) * nseg + c];
+      own = (u32)((long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * nz + 32 * c);
+      info = (u32)c | (tile_of(xx, yy) << 8);
+    }
+    nb = (int)((long)xx * g.nyz + (long)yy * nz + 32 * c - 1);
+  };
+  auto run_entry = [&](u32 e) {  // (list full: right away, one by one)
+    u32 bits, own, info;
+    int nb;
+    decode(e, bits, own, nb, info);
+    if (bits) do_item(bits, own, nb, info, plane_window(F.qb, (long)nb));
+  };
+  // ---- tile faces: the whole x-row 0 and, in the other x-rows, the lines ly = 0 and ly = TY - 1; an item per
+  // (face line, segment, lower z-line across the face) ----
+  const int nfl = TY + 2 * (T.nxl - 1);
+  const int fitems = nfl * nseg * 4;
+  for (int fi = threadIdx.x; fi < fitems; fi += NT) {
+    const int k = fi & 3, fs = fi >> 2, fl = fs / nseg, c = fs - fl * nseg;
+    int lx = 0, ly = fl;
+    if (fl >= TY) lx = 1 + ((fl - TY) >> 1), ly = ((fl - TY) & 1) ? TY - 1 : 0;
+    if (!segq[(lx * TY + ly) * nseg + c]) continue;
+    const int kdx = k < 3 ? -1 : 0, kdy = k < 3 ? k - 1 : -1;
+    const int xx = T.x0 + lx + kdx, yy = T.y0 + ly + kdy;
+    const bool cross = (kdx < 0 && lx == 0) || (kdy < 0 && ly == 0) || (kdy > 0 && ly == TY - 1);
+    if (!(cross && ly < T.nyl && xx >= V.px0 && yy >= V.py0 && yy <= V.py1)) continue;
+    const u32 slot = atomicAdd(&s_nw, 1u);
+    if (slot < XC_WCAP)
+      wl[slot] = (u32)fi;
+    else
+      run_entry((u32)fi);
+  }
+  // ---- NQ seeds of the tile (most tiles have none): nine items per seed segment, one per line around it (one
+  // reservation for all nine) ----
+  for (int it = threadIdx.x; it < T.items; it += NT) {
+    if (!segs[it]) continue;
+    const u32 slot0 = atomicAdd(&s_nw, 9u);
+    for (int l = 0; l < 9; ++l) {
+      const u32 e = 0x80000000u | (u32)(it * 9 + l);
+      if (slot0 + (u32)l < XC_WCAP)
+        wl[slot0 + (u32)l] = e;
+      else
+        run_entry(e);
+    }
+  }
+  flush_pairs();  // (pairs of the overflow path)
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 2);
+  // ---- the list: four items per lane and trip, their windows fetched together ----
+  const u32 nw = min(s_nw, (u32)XC_WCAP);
+  for (u32 w0 = 0; w0 < nw; w0 += 4 * NT) {
+    u32 bx[4], ox[4], ix[4];
+    int nx[4];
+    u64 wx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32 j = w0 + (u32)q * NT + threadIdx.x;
+      bx[q] = 0u, wx[q] = 0ull;
+      if (j < nw) {
+        decode(wl[j], bx[q], ox[q], nx[q], ix[q]);
+        if (bx[q]) wx[q] = plane_window(F.qb, (long)nx[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (bx[q] && wx[q]) do_item(bx[q], ox[q], nx[q], ix[q], wx[q]);
+      flush_pairs();
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 3);
+  const u32 n = s_n;
+  if (n == 0u) return;
+  const u32 xcd = blockIdx.x & 7u;
+  if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[16 + xcd], n);
+  __syncthreads();
+  const u32 base = s_base;
+  if (base + n > FR_PCAP / 8u) {
+    if (threadIdx.x == 0) F.fctr[9] = 14u;
+    return;
+  }
+  if (threadIdx.x < n) F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x] = s_list[threadIdx.x];
+  FR_DBG_MARK(F, dblk, 4);
 }
 
 // one wave-level reduction step of the per-component accumulators (sum / min / max over the lanes that share
@@ -1243,426 +1794,23 @@ __device__ __forceinline__ void cacc_reduce(CAcc& a) {
     a.hz = max(a.hz, (u32)__shfl_xor((int)a.hz, off, 64));
   }
 }
-__device__ __forceinline__ void cacc_atomic(u32* acc /* [11] in LDS */, const CAcc& a) {
-  atomicAdd(&acc[0], a.n);
-  atomicAdd(&acc[1], a.sx);
-  atomicAdd(&acc[2], a.sy);
-  atomicAdd(&acc[3], a.sz);
-  atomicMin(&acc[4], a.cl);
-  atomicMin(&acc[5], a.lx);
-  atomicMin(&acc[6], a.ly);
-  atomicMin(&acc[7], a.lz);
-  atomicMax(&acc[8], a.hx);
-  atomicMax(&acc[9], a.hy);
-  atomicMax(&acc[10], a.hz);
-}
-
-// Tile CCL.  Labels are SPARSE (one per Q0 cell of the tile, addressed through a tile-local prefix of the
-// per-segment popcounts), so a tile costs ~35 KiB of LDS whatever nz is.
-template <int NT>
-__global__ void __launch_bounds__(NT) k_ccl_tile(Geo g, FArgs F) {
-  if ((int)blockIdx.x >= F.var->ntiles_f) return;
-  const int TX = F.var->ftx, TY = F.var->fty;
-  const Box3 QR = F.var->qreg;
-  const Box3 sbox = F.var->sbox;
-  const int nty = F.var->nty_f;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int nz = g.nz, nseg = (nz + 31) >> 5;
-  const int items = TX * TY * nseg;
-  u32* lab = reinterpret_cast<u32*>(smem_raw);       // [FR_TCELL] union-find over the tile-local cell indices
-  u32* segb = lab + FR_TCELL;                         // [items] Q0 bits of each 32-voxel segment
-  u32* segpre = segb + items;                         // [items + 1] tile-local index of the first cell at/after it
-  u32* rowr = segpre + items + 1;                     // [2 * TX] compact index range of each x-row
-  u32* acc = rowr + 2 * TX;                           // [FR_TROOT][11]
-  unsigned short* rootno = reinterpret_cast<unsigned short*>(acc + FR_TROOT * 11);  // [FR_TCELL]
-  __shared__ u32 s_wsum[NT / 64];
-  __shared__ u32 s_nroots, s_base, s_flag;
-  const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
-  const int x0 = QR.lo[0] + tx * TX, y0 = QR.lo[1] + ty * TY;
-  const int nxl = min(TX, QR.hi[0] - x0 + 1), nyl = min(TY, QR.hi[1] - y0 + 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_nroots = 0u, s_flag = 0u;
-  FR_DBG_MARK(F, blockIdx.x, 0);
-  // ---- Q0 bits of the tile and their tile-local prefix ----
-  u32 run = 0u;
-  for (int it0 = 0; it0 < items; it0 += NT) {
-    const int it = it0 + threadIdx.x;
-    u32 bits = 0u;
-    if (it < items) {
-      const int line = it / nseg, c = it - line * nseg, lx = line / TY, ly = line - lx * TY;
-      const int zn = min(32, nz - 32 * c);
-      if (lx < nxl && ly < nyl) {
-        bits = (u32)plane_window(F.qb, (long)(x0 + lx) * g.nyz + (long)(y0 + ly) * nz + 32 * c);
-        if (zn < 32) bits &= (1u << zn) - 1u;
-      }
-      segb[it] = bits;
-    }
-    const u32 cnt = (u32)__popc(bits);
-    u32 v = cnt;
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 t = (u32)__shfl_up((int)v, off, 64);
-      if (lane >= off) v += t;
-    }
-    if (lane == 63) s_wsum[wave] = v;
-    __syncthreads();
-    u32 woff = 0u, tot = 0u;
-    for (int k = 0; k < NT / 64; ++k) {
-      if (k < wave) woff += s_wsum[k];
-      tot += s_wsum[k];
-    }
-    if (it < items) segpre[it] = run + woff + v - cnt;
-    run += tot;
-    __syncthreads();
-  }
-  const u32 total = run;  // uniform
-  FR_DBG_MARK(F, blockIdx.x, 1);
-  if (total == 0u) return;
-  if (total > FR_TCELL) {
-    if (threadIdx.x == 0) F.fctr[9] = 11u;  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
-    return;
-  }
-  if (threadIdx.x == 0) segpre[items] = total;
-  if ((int)threadIdx.x < 2 * TX) {
-    const int lx = threadIdx.x >> 1, hi = threadIdx.x & 1;
-    u32 rk = 0u;
-    if (lx < nxl) rk = min(rank_q(F, (long)(x0 + lx) * g.nyz + (long)(y0 + (hi ? nyl : 0)) * nz), F.cap_q);
-    rowr[threadIdx.x] = rk;
-  }
-  for (int t = threadIdx.x; t < FR_TROOT * 11; t += NT) {
-    const int k = t % 11;
-    acc[t] = (k >= 4 && k <= 7) ? 0xFFFFFFFFu : 0u;  // claim / box minima start at +inf
-  }
-  __syncthreads();
-  // ---- labels: start of the cell's z-run inside its segment (runs are pre-joined) ----
-  for (int it = threadIdx.x; it < items; it += NT) {
-    u32 bits = segb[it];
-    const u32 all = bits, base = segpre[it];
-    while (bits) {
-      const int z = __builtin_ctz(bits);
-      bits &= bits - 1;
-      const u32 below = all & ((1u << z) - 1u);
-      const u32 holes = ~all & ((1u << z) - 1u);
-      const int start = holes ? 32 - __builtin_clz(holes) : 0;
-      lab[base + (u32)__popc(below)] = base + (u32)__popc(all & ((1u << start) - 1u));
-    }
-  }
-  __syncthreads();
-  FR_DBG_MARK(F, blockIdx.x, 2);
-  // the t-th cell of the tile: compact index, address, line, z, tile-local index (x-rows of the tile are
-  // contiguous in the compact order)
-  auto locate = [&](u32 t, u32& ci, long& a, int& lx, int& ly, int& z, u32& l) {
-    lx = 0;
-    u32 tt = t;
-    for (; lx < nxl - 1; ++lx) {
-      const u32 n = rowr[2 * lx + 1] - rowr[2 * lx];
-      if (tt < n) break;
-      tt -= n;
-    }
-    ci = rowr[2 * lx] + tt;
-    a = (long)F.cell_adr[ci];
-    const int rem = (int)(a - ((long)(x0 + lx) * g.nyz + (long)y0 * nz));
-    ly = rem / nz;
-    z = rem - ly * nz;
-    const int it = (lx * TY + ly) * nseg + (z >> 5);
-    l = segpre[it] + (u32)__popc(segb[it] & ((1u << (z & 31)) - 1u));
-  };
-  auto local_of = [&](int line, int z) -> u32 {  // tile-local index of the (set) cell (line, z)
-    const int it = line * nseg + (z >> 5);
-    return segpre[it] + (u32)__popc(segb[it] & ((1u << (z & 31)) - 1u));
-  };
-  // ---- unions: segment seam + the four lower z-lines inside the tile ----
-  for (u32 t = threadIdx.x; t < total; t += NT) {
-    u32 ci, l;
-    long a;
-    int lx, ly, z;
-    locate(t, ci, a, lx, ly, z, l);
-    const int line = lx * TY + ly, c = z >> 5, zz = z & 31;
-    const bool seam = zz == 0 && c > 0 && (segb[line * nseg + c - 1] >> 31);
-    if (seam) lds_union_h(lab, l, l - 1);
-    // a cell whose z-predecessor is a cell too (same z-run) shares that cell's windows except for the voxel
-    // z + 1 of each lower line -- and that one only matters when it starts a new run there (its line's voxel z is
-    // empty): walls (long z-runs) cost one look per cell and line instead of a union
-    const bool has_prev = seam || (zz > 0 && ((segb[line * nseg + c] >> (zz - 1)) & 1u));
-    for (int k = 0; k < 4; ++k) {
-      const int nlx = lx + (k < 3 ? -1 : 0), nly = ly + (k < 3 ? k - 1 : -1);
-      if (nlx < 0 || nly < 0 || nly >= TY) continue;
-      const int nline = nlx * TY + nly;
-      const int zlo = z - 1;
-      const int s0 = max(zlo, 0) >> 5;
-      const unsigned long long w = (unsigned long long)segb[nline * nseg + s0] |
-          ((s0 + 1 < nseg) ? ((unsigned long long)segb[nline * nseg + s0 + 1] << 32) : 0ull);
-      u32 pat = (zlo >= 0) ? (u32)((w >> (zlo - 32 * s0)) & 7ull) : (u32)((w << 1) & 6ull);
-      if (z + 1 >= nz) pat &= 3u;
-      if (has_prev) pat = (pat & 6u) == 4u ? 4u : 0u;
-      if (!pat) continue;
-      const u32 ln = local_of(nline, zlo + __builtin_ctz(pat));
-      lds_union_h(lab, l, ln);
-      if (pat == 5u) lds_union_h(lab, l, ln + 1u);  // the next cell of that line sits at zlo + 2
-    }
-  }
-  __syncthreads();
-  FR_DBG_MARK(F, blockIdx.x, 3);
-  // ---- roots: dense numbers, then flat labels ----
-  for (u32 l = threadIdx.x; l < total; l += NT)
-    if (lab[l] == l) {
-      const u32 la = atomicAdd(&s_nroots, 1u);
-      rootno[l] = (unsigned short)min(la, 0xFFFFu);
-    }
-  __syncthreads();
-  const u32 nroots = s_nroots;
-  if (nroots > FR_TROOT) {
-    if (threadIdx.x == 0) F.fctr[9] = 12u;
-    return;
-  }
-  // ---- ids of the components: one contiguous range per tile inside the XCD's part of the id space (the
-  // returning atomic is issued here so that its latency hides behind the record loop) ----
-  if (threadIdx.x == 0) {
-    const u32 xcd = blockIdx.x & 7u;
-    const u32 b = atomicAdd(&F.fctr[xcd], nroots);
-    if (b + nroots > FR_RC8) {
-      F.fctr[9] = 13u;
-      s_flag = 1u;
-    }
-    s_base = xcd * FR_RC8 + b;
-  }
-  FR_DBG_MARK(F, blockIdx.x, 4);
-  // ---- per-component records (one wave-level reduction per distinct component of every 64 cells) ----
-  const u32 total_r = (total + 63u) & ~63u;
-  for (u32 t = threadIdx.x; t < total_r; t += NT) {
-    const bool live = t < total;
-    u32 key = 0u;
-    CAcc A;
-    A.n = 0u, A.sx = A.sy = A.sz = 0u, A.cl = A.lx = A.ly = A.lz = 0xFFFFFFFFu, A.hx = A.hy = A.hz = 0u;
-    if (live) {
-      u32 ci, l;
-      long a;
-      int lx, ly, z;
-      locate(t, ci, a, lx, ly, z, l);
-      key = (u32)rootno[lds_find_h(lab, l)];
-      const u32 x = (u32)(x0 + lx), y = (u32)(y0 + ly);
-      A.n = 1u, A.sx = x, A.sy = y, A.sz = (u32)z, A.lx = A.hx = x, A.ly = A.hy = y, A.lz = A.hz = (u32)z;
-      const bool inb = (int)x >= sbox.lo[0] && (int)x <= sbox.hi[0] && (int)y >= sbox.lo[1] && (int)y <= sbox.hi[1] &&
-                       z >= sbox.lo[2] && z <= sbox.hi[2];
-      A.cl = inb ? (u32)a : 0xFFFFFFFFu;
-      F.cell_rank[ci] = key;  // (scratch until k_flags_hist: the tile-local component number)
-    }
-    u64 todo = __ballot(live);
-    while (todo) {  // usually one or two components per 64 consecutive cells
-      const int leader = __builtin_ctzll(todo);
-      const u32 first = (u32)__shfl((int)key, leader, 64);
-      const bool mine = live && key == first;
-      CAcc B = A;
-      if (!mine) B.n = 0u, B.sx = B.sy = B.sz = 0u, B.cl = B.lx = B.ly = B.lz = 0xFFFFFFFFu, B.hx = B.hy = B.hz = 0u;
-      cacc_reduce(B);
-      if (lane == leader) cacc_atomic(acc + first * 11, B);
-      todo &= ~__ballot(mine);
-    }
-  }
-  __syncthreads();
-  FR_DBG_MARK(F, blockIdx.x, 5);
-  if (s_flag) return;
-  FR_DBG_MARK(F, blockIdx.x, 6);
-  const u32 gbase = s_base;
-  if (threadIdx.x < nroots) {
-    const u32* r = acc + threadIdx.x * 11;
-    TRec T;
-    T.size = r[0], T.sx = r[1], T.sy = r[2], T.sz = r[3];
-    T.lo[0] = r[5], T.lo[1] = r[6], T.lo[2] = r[7], T.hi[0] = r[8], T.hi[1] = r[9], T.hi[2] = r[10];
-    T.pad[0] = T.pad[1] = 0u;
-    F.trec[gbase + threadIdx.x] = T;
-    F.tclaim[gbase + threadIdx.x] = r[4];
-  }
-  // ---- tile-root id of every cell (k_cross joins the tiles through them) ----
-  for (u32 t = threadIdx.x; t < total; t += NT) {
-    u32 ci, l;
-    long a;
-    int lx, ly, z;
-    locate(t, ci, a, lx, ly, z, l);
-    F.tgid[ci] = (unsigned short)(gbase + F.cell_rank[ci]);
-  }
-  FR_DBG_MARK(F, blockIdx.x, 7);
-  if (F.dbg && threadIdx.x == 0) F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 8] = total;
-}
-
-// Joins across tile faces + seed claims, one launch after k_ccl_tile (every cell knows its tile root by now).
-// Blocks [0, ntiles): the cells of the tile that sit on a lower face look across it; the relation is recorded as
-// a pair of TILE ROOTS, and a tile keeps one record per distinct pair (LDS set: a surface crossing a face gives
-// the same pair from all of its cells) -- a few thousand records per search instead of one per adjacent cell
-// pair.  Blocks beyond: NQ seeds claim the tile roots touching their 26-neighbourhood (the seed half of k_claim).
-#define XC_SET 256
-__global__ void __launch_bounds__(256) k_cross(Geo g, FArgs F) {
-  if (F.fctr[9]) return;
-  const int TX = F.var->ftx, TY = F.var->fty;
-  const int ntiles = F.var->ntiles_f;
-  const int lane = threadIdx.x & 63;
-  if ((int)blockIdx.x >= ntiles) {
-    // ---- seeds: one lane per (seed, neighbour z-line) -- nine independent short chains per seed instead of one
-    // long one.  A tile root is only ever claimed by the seeds next to ITS tile (a few hundred at most), so plain
-    // atomics do here what needed wave-level aggregation on whole components.
-    const u32 ns = F.counts[1];
-    const u32 items = ns * 9u;
-    const u32 nsb = gridDim.x - (u32)ntiles;
-    for (u32 it = (blockIdx.x - (u32)ntiles) * blockDim.x + threadIdx.x; it < items; it += nsb * blockDim.x) {
-      const u32 i = it / 9u;
-      const int l = (int)(it - i * 9u);
-      const long a = F.seed_adr[i];
-      const int x = (int)(a / g.nyz);
-      const int rr = (int)(a - (long)x * g.nyz);
-      const int y = rr / g.nz, z = rr - y * g.nz;
-      const int dx = l / 3 - 1, dy = l % 3 - 1;
-      const int xx = x + dx, yy = y + dy;
-      if (xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny) continue;
-      const long nb0 = a + (long)dx * g.nyz + (long)dy * g.nz - 1;
-      u32 p = (u32)(plane_window(F.qb, nb0) & 7ull);
-      if (z == 0) p &= ~1u;
-      if (z == g.nz - 1) p &= ~4u;
-      if (!p) continue;
-      const u32 j = rank_q(F, nb0 + __builtin_ctz(p));
-      if (j >= F.cap_q) continue;
-      const u32 r = F.tgid[j];
-      if (F.tclaim[r] > (u32)a) atomicMin(&F.tclaim[r], (u32)a);
-      if (p == 5u && j + 1 < F.cap_q) {
-        const u32 r2 = F.tgid[j + 1];
-        if (r2 != r && F.tclaim[r2] > (u32)a) atomicMin(&F.tclaim[r2], (u32)a);
-      }
-    }
-    return;
-  }
-  // ---- tile faces ----
-  // Only cells on a lower face look out of the tile: the whole x-row 0 and, in the other x-rows, the lines
-  // ly = 0 and ly = TY - 1.  Each of these is a contiguous range of the compact order.
-  __shared__ u32 s_rlo[40], s_rn[40];  // face ranges: first compact index, cells
-  __shared__ u32 s_set[XC_SET];        // distinct (root, root) pairs of this tile: open addressing
-  __shared__ u32 s_list[XC_SET];       // ... in insertion order
-  __shared__ u32 s_n, s_base;
-  const Box3 QR = F.var->qreg;
-  const int nty = F.var->nty_f;
-  const int tx = blockIdx.x / nty, ty = blockIdx.x - tx * nty;
-  const int x0 = QR.lo[0] + tx * TX, y0 = QR.lo[1] + ty * TY;
-  const int nxl = min(TX, QR.hi[0] - x0 + 1), nyl = min(TY, QR.hi[1] - y0 + 1);
-  const int nz = g.nz;
-  const int nrange = 1 + 2 * (nxl - 1);
-  if ((int)threadIdx.x < 2 * nrange) {
-    // range r = 0: x-row 0, lines 0 .. nyl; r = 2 lx - 1: (lx, line 0); r = 2 lx: (lx, line TY - 1)
-    const int r = threadIdx.x >> 1, hi = threadIdx.x & 1;
-    int lx = 0, l0 = 0, l1 = nyl;
-    if (r > 0) {
-      lx = (r + 1) >> 1;
-      l0 = (r & 1) ? 0 : TY - 1;
-      l1 = l0 + 1;
-      if (l0 >= nyl) l1 = l0 = 0;  // a clipped tile has no line TY - 1 (its y-neighbour lies outside the region)
-    }
-    const u32 rk = min(rank_q(F, (long)(x0 + lx) * g.nyz + (long)(y0 + (hi ? l1 : l0)) * nz), F.cap_q);
-    if (hi)
-      s_rn[r] = rk;
-    else
-      s_rlo[r] = rk;
-  }
-  s_set[threadIdx.x] = 0xFFFFFFFFu;
-  if (threadIdx.x == 0) s_n = 0u;
-  FR_DBG_MARK(F, blockIdx.x, 9);
-  __syncthreads();
-  FR_DBG_MARK(F, blockIdx.x, 10);
-  u32 total = 0u;
-  for (int r = 0; r < nrange; ++r) total += s_rn[r] - s_rlo[r];  // (s_rn holds the END of the range)
-  if (total == 0u) return;
-  // one lane per (face cell, lower z-line): the four look-ups of a cell run side by side
-  const u32 items = total * 4u;
-  const u32 items_r = (items + 63u) & ~63u;
-  for (u32 it = threadIdx.x; it < items_r; it += blockDim.x) {
-    u32 pk[2] = {0u, 0u};
-    bool pon[2] = {false, false};
-    if (it < items) {
-      const u32 t = it >> 2;
-      const int k = (int)(it & 3u);
-      const int kdx = k < 3 ? -1 : 0, kdy = k < 3 ? k - 1 : -1;
-      int r = 0;
-      u32 tt = t;
-      for (; r < nrange - 1; ++r) {
-        const u32 n = s_rn[r] - s_rlo[r];
-        if (tt < n) break;
-        tt -= n;
-      }
-      const u32 ci = s_rlo[r] + tt;
-      const int lx = r == 0 ? 0 : (r + 1) >> 1;
-      const long a = (long)F.cell_adr[ci];
-      const int rem = (int)(a - ((long)(x0 + lx) * g.nyz + (long)y0 * nz));
-      const int ly = rem / nz, z = rem - ly * nz;
-      const int xx = x0 + lx + kdx, yy = y0 + ly + kdy;
-      const bool cross = (kdx < 0 && lx == 0) || (kdy < 0 && ly == 0) || (kdy > 0 && ly == TY - 1);
-      if (cross && xx >= 0 && yy >= 0 && yy < g.ny) {
-        const long nb0 = a + (long)kdx * g.nyz + (long)kdy * nz - 1;
-        u32 p = (u32)(plane_window(F.qb, nb0) & 7ull);
-        if (z == 0) p &= ~1u;
-        if (z == nz - 1) p &= ~4u;
-        if (p) {
-          const u32 cj = rank_q(F, nb0 + __builtin_ctz(p));
-          if (cj < F.cap_q) {
-            const u32 ga = F.tgid[ci], gb = F.tgid[cj];
-            if (gb != ga) pk[0] = (min(ga, gb) << 16) | max(ga, gb), pon[0] = true;
-            if (p == 5u && cj + 1 < F.cap_q) {  // a second run starts at z + 1: the next cell of that line
-              const u32 gc = F.tgid[cj + 1];
-              if (gc != ga) pk[1] = (min(ga, gc) << 16) | max(ga, gc), pon[1] = true;
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      u64 todo = __ballot(pon[k]);
-      while (todo) {  // one insertion per distinct pair of the wave
-        const int leader = __builtin_ctzll(todo);
-        const u32 key = (u32)__shfl((int)pk[k], leader, 64);
-        todo &= ~__ballot(pon[k] && pk[k] == key);
-        if (lane == leader) {
-          u32 h = (key * 2654435761u) >> 24;
-          bool done = false;
-          for (int probe = 0; probe < XC_SET && !done; ++probe) {
-            const u32 old = atomicCAS(&s_set[h], 0xFFFFFFFFu, key);
-            if (old == 0xFFFFFFFFu) {
-              s_list[atomicAdd(&s_n, 1u)] = key;
-              done = true;
-            } else if (old == key)
-              done = true;
-            h = (h + 1u) & (XC_SET - 1u);
-          }
-          if (!done) F.fctr[9] = 15u;  // more than XC_SET distinct root pairs around one tile
-        }
-      }
-    }
-  }
-  __syncthreads();
-  FR_DBG_MARK(F, blockIdx.x, 11);
-  const u32 n = s_n;
-  if (n == 0u) return;
-  const u32 xcd = blockIdx.x & 7u;
-  if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[16 + xcd], n);
-  __syncthreads();
-  FR_DBG_MARK(F, blockIdx.x, 12);
-  const u32 base = s_base;
-  if (base + n > FR_PCAP / 8u) {
-    if (threadIdx.x == 0) F.fctr[9] = 14u;
-    return;
-  }
-  if (threadIdx.x < n) F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x] = s_list[threadIdx.x];
-}
 
 // Everything between "tile-local components" and "kept clusters in creation order", on the tile-root records,
 // inside one workgroup: cross-tile union-find, sizes and claims per final component, clusters (a component
 // claimed by one of its own cells is a cluster; components claimed by the same NQ seed form one with it), the
 // kept list, its ranking by claimer address (= the reference's creation order), offsets of the grouped cell
-// array, per-cluster index sums / boxes -- and the result records, written straight to pinned host memory.
+// array, per-cluster index sums / boxes, the (cluster x tile column) prefix matrix k_tile_out places the cells
+// with -- and the result records, written straight to pinned host memory.
 #define RS_T 1024
 #define RS_SH 512  // seed-claimed clusters (hash slots)
 __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32* par = reinterpret_cast<u32*>(smem_raw);  // [FR_RCAP] union-find over the DENSE numbers of the tile roots
-  u32* siz = par + FR_RCAP;                     // [FR_RCAP] cells of the final component (at its root)
-  u32* clm = siz + FR_RCAP;                     // [FR_RCAP] lowest claimer address (at its root)
-  u32* rko = clm + FR_RCAP;                     // [FR_RCAP] at a root: index into the kept list | FR_NOTKEPT | FR_UNCLAIMED
+  u32* siz = par + FR_RCAP;                     // [FR_RCAP] cells of the final component (at its root); later the matrix
+  u32* clm = siz + FR_RCAP;                     // [FR_RCAP] lowest claimer address (at its root); later the matrix
+  u32* rko = clm + FR_RCAP;                     // [FR_RCAP] lowest OWN claimer (at its root), then: index into the kept list | FR_NOTKEPT | FR_UNCLAIMED
   u32* k_adr = rko + FR_RCAP;                   // [FR_KCAP] kept list: claimer address
-  u32* k_slot = k_adr + FR_KCAP;                //   slot (compact index of the claimer | nq + seed index)
+  u32* k_slot = k_adr + FR_KCAP;                //   0: claimed by an own cell, 0xFFFFFFFF: by an NQ seed
   u32* k_size = k_slot + FR_KCAP;               //   cluster size (the seed counts)
   u32* k_nq = k_size + FR_KCAP;                 //   its Q0 cells
   u32* k_rank = k_nq + FR_KCAP;                 //   rank by claimer address
@@ -1672,21 +1820,25 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   u32* h_sum = h_adr + RS_SH;                   //   cells of the components it claims
   u32* h_kept = h_sum + RS_SH;                  //   index into the kept list | FR_NOTKEPT
   unsigned long long* ksum = reinterpret_cast<unsigned long long*>(h_kept + RS_SH);  // [FR_KCAP][3] index sums
-  __shared__ u32 s_nk, s_ovf, s_nout;
+  u32* pmx = siz;                               // [nk][ntx] (FR_PMCAP = 2 FR_RCAP entries) once siz / clm are dead
+  __shared__ u32 s_nk, s_ovf, s_nout, s_nq;
+  __shared__ u32 s_fc[32];  // the chain's counters (one round trip for all of them)
   __shared__ u32 s_pre[9];  // dense number of the first tile root of every XCD range
-  const int lane = threadIdx.x & 63;
-  const u32 nq = F.counts[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntx = F.var->ntx_f;
+  if (threadIdx.x < 32) s_fc[threadIdx.x] = F.fctr[threadIdx.x];
+  const int dblk = F.var->ntiles_f;  // time stamps of this kernel go behind those of the tiles
+  FR_DBG_MARK(F, dblk, 0);
+  __syncthreads();
   if (threadIdx.x == 0) {
-    s_nk = 0u, s_ovf = F.fctr[9] | F.counts[2], s_nout = 0u;
+    s_nk = 0u, s_ovf = s_fc[9], s_nout = 0u, s_nq = 0u;
     u32 run = 0u;
     for (int k = 0; k < 8; ++k) {
       s_pre[k] = run;
-      run += min(F.fctr[k], (u32)FR_RC8);
+      run += min(s_fc[k], (u32)FR_RC8);
     }
     s_pre[8] = run;
   }
-  const int dblk = F.var->ntiles_f;  // time stamps of this kernel go behind those of the tiles
-  FR_DBG_MARK(F, dblk, 0);
   __syncthreads();
   const bool dead = s_ovf != 0u;  // an earlier kernel hit a capacity limit: report, leave everything untouched
   const u32 R = s_pre[8];         // tile roots of this search
@@ -1699,14 +1851,37 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
     return xc * FR_RC8 + (d - s_pre[xc]);
   };
   const u32 Rr = (R + RS_T - 1u) / RS_T * RS_T;
+  // the pair lists, walked as one sequence; a lane's first three pairs are fetched beside the records
+  u32 pp[9];
+  pp[0] = 0u;
+#pragma unroll
+  for (int xc = 0; xc < 8; ++xc) pp[xc + 1] = pp[xc] + min(s_fc[16 + xc], FR_PCAP / 8u);
+  auto pair_at = [&](u32 p) {
+    u32 xc = 0u;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) xc += p >= pp[k] ? 1u : 0u;
+    return F.pairs[(size_t)xc * (FR_PCAP / 8u) + (p - pp[xc])];
+  };
+  u32 pk0 = 0u, pk1 = 0u, pk2 = 0u;
+  TRec T0;  // record of tile root d = threadIdx.x (most searches have fewer than RS_T roots: read once)
+  T0.size = 0u;
   if (!dead) {
+    if (threadIdx.x < pp[8]) pk0 = pair_at(threadIdx.x);
+    if (threadIdx.x + RS_T < pp[8]) pk1 = pair_at(threadIdx.x + RS_T);
+    if (threadIdx.x + 2 * RS_T < pp[8]) pk2 = pair_at(threadIdx.x + 2 * RS_T);
+    u32 nq_part = 0u;
     for (u32 d = threadIdx.x; d < R; d += RS_T) {
       const u32 gi = gid_of(d);
+      const TRec T = F.trec[gi];
+      if (d < RS_T) T0 = T;
       par[d] = d;
-      siz[d] = F.trec[gi].size;
+      siz[d] = T.size;
       clm[d] = F.tclaim[gi];
-      rko[d] = FR_UNCLAIMED;
+      rko[d] = T.own;
+      nq_part += T.size;
     }
+    for (int off = 32; off > 0; off >>= 1) nq_part += (u32)__shfl_xor((int)nq_part, off, 64);
+    if (lane == 0 && nq_part) atomicAdd(&s_nq, nq_part);
     for (u32 i = threadIdx.x; i < RS_SH; i += RS_T) h_adr[i] = NOCLAIM, h_sum[i] = 0u, h_kept[i] = FR_NOTKEPT;
     for (u32 i = threadIdx.x; i < FR_KCAP * 6; i += RS_T) kbox[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u;
     for (u32 i = threadIdx.x; i < FR_KCAP * 3; i += RS_T) ksum[i] = 0ull;
@@ -1716,40 +1891,39 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   if (!dead) {
     // ---- cross-tile unions (one list of distinct root pairs per XCD, walked as one sequence so that all
     // lanes are busy at once) ----
-    u32 pp[9];
-    pp[0] = 0u;
-#pragma unroll
-    for (int xc = 0; xc < 8; ++xc) pp[xc + 1] = pp[xc] + min(F.fctr[16 + xc], FR_PCAP / 8u);
-    for (u32 p = threadIdx.x; p < pp[8]; p += RS_T) {
-      u32 xc = 0u;
-#pragma unroll
-      for (int k = 1; k < 8; ++k) xc += p >= pp[k] ? 1u : 0u;
-      const u32 key = F.pairs[(size_t)xc * (FR_PCAP / 8u) + (p - pp[xc])];
+    if (threadIdx.x < pp[8]) lds_union_h(par, dense_of(pk0 >> 16), dense_of(pk0 & 0xFFFFu));
+    if (threadIdx.x + RS_T < pp[8]) lds_union_h(par, dense_of(pk1 >> 16), dense_of(pk1 & 0xFFFFu));
+    if (threadIdx.x + 2 * RS_T < pp[8]) lds_union_h(par, dense_of(pk2 >> 16), dense_of(pk2 & 0xFFFFu));
+    for (u32 p = threadIdx.x + 3 * RS_T; p < pp[8]; p += RS_T) {
+      const u32 key = pair_at(p);
       lds_union_h(par, dense_of(key >> 16), dense_of(key & 0xFFFFu));
     }
   }
   __syncthreads();
   FR_DBG_MARK(F, dblk, 2);
-  // ---- flatten; cells and lowest claimer of every final component (wave-reduced per distinct root) ----
+  // ---- flatten; cells, lowest claimer and lowest own claimer of every final component (wave-reduced per
+  // distinct root) ----
   if (!dead) {
     for (u32 d0 = 0; d0 < Rr; d0 += RS_T) {
       const u32 d = d0 + threadIdx.x;
       const u32 rt = d < R ? lds_find_h(par, d) : 0u;
       const bool mov = d < R && rt != d;
-      const u32 sz = mov ? siz[d] : 0u, cl = mov ? clm[d] : NOCLAIM;
+      const u32 sz = mov ? siz[d] : 0u, cl = mov ? clm[d] : NOCLAIM, ow = mov ? rko[d] : NOCLAIM;
       u64 todo = __ballot(mov);
       while (todo) {
         const int leader = __builtin_ctzll(todo);
         const u32 first = (u32)__shfl((int)rt, leader, 64);
         const bool mine = mov && rt == first;
-        u32 s2 = mine ? sz : 0u, c2 = mine ? cl : NOCLAIM;
+        u32 s2 = mine ? sz : 0u, c2 = mine ? cl : NOCLAIM, o2 = mine ? ow : NOCLAIM;
         for (int off = 32; off > 0; off >>= 1) {
           s2 += (u32)__shfl_xor((int)s2, off, 64);
           c2 = min(c2, (u32)__shfl_xor((int)c2, off, 64));
+          o2 = min(o2, (u32)__shfl_xor((int)o2, off, 64));
         }
         if (lane == leader) {
           atomicAdd(&siz[first], s2);
           atomicMin(&clm[first], c2);
+          atomicMin(&rko[first], o2);
         }
         todo &= ~__ballot(mine);
       }
@@ -1760,19 +1934,26 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   if (!dead) {
     // (every find above ran before any sibling was re-parented by another thread's halving in a way that
     // matters: halving only ever installs ancestors; par[] is flat enough for the single look-ups below)
-    // ---- clusters: own-claimed components straight to the kept list, seed-claimed ones through the hash ----
+    // ---- clusters: own-claimed components straight to the kept list, seed-claimed ones through the hash.
+    // A component is claimed by one of its own cells iff its lowest claimer IS its lowest own claimer (seeds and
+    // Q0 cells are disjoint). ----
     for (u32 d = threadIdx.x; d < R; d += RS_T) {
-      if (lds_find_h(par, d) != d || clm[d] == NOCLAIM) continue;
-      const u32 cl = clm[d];
-      const bool own = (F.qb[cl >> 6] >> (cl & 63)) & 1ull;
-      if (own) {
+      if (lds_find_h(par, d) != d) continue;
+      const u32 cl = clm[d], ow = rko[d];
+      if (cl == NOCLAIM) {
+        rko[d] = FR_UNCLAIMED;
+        continue;
+      }
+      if (cl == ow) {
         if ((int)siz[d] > F.cluster_min) {
           const u32 e = atomicAdd(&s_nk, 1u);
           if (e < FR_KCAP) {
-            k_adr[e] = cl, k_slot[e] = rank_q(F, (long)cl), k_size[e] = siz[d], k_nq[e] = siz[d];
+            k_adr[e] = cl, k_slot[e] = 0u, k_size[e] = siz[d], k_nq[e] = siz[d];
             rko[d] = e;
-          } else
+          } else {
             s_ovf = 1u;
+            rko[d] = FR_NOTKEPT;
+          }
         } else
           rko[d] = FR_NOTKEPT;
       } else {
@@ -1787,7 +1968,10 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
           }
           h = (h + 1u) & (RS_SH - 1u);
         }
-        if (!done) s_ovf = 1u;
+        if (!done) {
+          s_ovf = 1u;
+          rko[d] = FR_NOTKEPT;
+        }
       }
     }
   }
@@ -1798,7 +1982,7 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
     if ((int)(sum + 1u) > F.cluster_min) {
       const u32 e = atomicAdd(&s_nk, 1u);
       if (e < FR_KCAP) {
-        k_adr[e] = cl, k_slot[e] = nq + rank_s(F, (long)cl), k_size[e] = sum + 1u, k_nq[e] = sum;
+        k_adr[e] = cl, k_slot[e] = 0xFFFFFFFFu, k_size[e] = sum + 1u, k_nq[e] = sum;
         h_kept[threadIdx.x] = e;
       } else
         s_ovf = 1u;
@@ -1807,7 +1991,9 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   __syncthreads();
   FR_DBG_MARK(F, dblk, 5);
   const u32 nk = min(s_nk, (u32)FR_KCAP);
-  const bool bad = dead || s_ovf != 0u;
+  const u32 nq = s_nq;
+  // (the matrix needs nk * ntx LDS words; beyond that -- hundreds of clusters on a huge map -- the legacy chain)
+  const bool bad = dead || s_ovf != 0u || (size_t)nk * (size_t)ntx > (size_t)FR_PMCAP || ntx > F.pm_stride;
   if (!bad) {
     // ---- creation order = ascending claimer address; offsets of the grouped cell array ----
     if (threadIdx.x < nk) {
@@ -1822,11 +2008,13 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
       k_off[threadIdx.x] = off;
       atomicAdd(&s_nout, k_nq[threadIdx.x]);
     }
+    // siz / clm are dead from here on: their space becomes the (rank, tile column) matrix
+    for (u32 i = threadIdx.x; i < nk * (u32)ntx; i += RS_T) pmx[i] = 0u;
   }
   __syncthreads();
   FR_DBG_MARK(F, dblk, 6);
   if (!bad) {
-    // ---- code of every tile root; index sums / boxes of the kept clusters ----
+    // ---- code of every tile root; index sums / boxes of the kept clusters; cells per (cluster, tile column) ----
     for (u32 d0 = 0; d0 < Rr; d0 += RS_T) {
       const u32 d = d0 + threadIdx.x;
       u32 e = FR_UNCLAIMED, gi = 0u;
@@ -1840,9 +2028,10 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
       CAcc A;
       A.n = 0u, A.sx = A.sy = A.sz = 0u, A.cl = A.lx = A.ly = A.lz = 0xFFFFFFFFu, A.hx = A.hy = A.hz = 0u;
       if (kept) {
-        const TRec T = F.trec[gi];
+        const TRec T = d0 == 0u ? T0 : F.trec[gi];
         A.sx = T.sx, A.sy = T.sy, A.sz = T.sz, A.lx = T.lo[0], A.ly = T.lo[1], A.lz = T.lo[2];
         A.hx = T.hi[0], A.hy = T.hi[1], A.hz = T.hi[2];
+        atomicAdd(&pmx[k_rank[e] * (u32)ntx + T.tx], T.size);
       }
       // the cluster most of the wave's roots belong to (the giant surface) is reduced across the lanes; the few
       // roots of other clusters add themselves (distinct LDS words, no contention to speak of)
@@ -1876,10 +2065,27 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   }
   __syncthreads();
   FR_DBG_MARK(F, dblk, 7);
+  if (!bad) {
+    // ---- exclusive prefix of every matrix row along the tile columns (a wave per cluster), to memory ----
+    for (u32 r = (u32)wave; r < nk; r += RS_T / 64) {
+      u32 run = 0u;
+      for (int c0 = 0; c0 < ntx; c0 += 64) {
+        const int c = c0 + lane;
+        const u32 v = c < ntx ? pmx[r * (u32)ntx + (u32)c] : 0u;
+        u32 s = v;
+        for (int off = 1; off < 64; off <<= 1) {
+          const u32 t = (u32)__shfl_up((int)s, off, 64);
+          if (lane >= off) s += t;
+        }
+        if (c < ntx) F.pm[(size_t)r * F.pm_stride + c] = run + s - v;
+        run += (u32)__shfl((int)s, 63, 64);
+      }
+    }
+  }
   if (F.dbg && threadIdx.x == 0) {
-    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 9] = F.fctr[16] + F.fctr[17] + F.fctr[18] + F.fctr[19] + F.fctr[20] + F.fctr[21] + F.fctr[22] + F.fctr[23];
+    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 9] = pp[8];
     F.dbg[(size_t)dblk * FR_DBG_SLOTS + 10] = R;
-    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 11] = F.counts[1];
+    F.dbg[(size_t)dblk * FR_DBG_SLOTS + 11] = nq;
   }
   // ---- records: device copy for the kernels that follow, pinned host copy for _search_end ----
   if (!bad && threadIdx.x < nk) {
@@ -1893,11 +2099,14 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
     F.h_rec[k_rank[e]] = r;
   }
   if (threadIdx.x == 0) {
-    F.counts[2] = bad ? 2u : 0u;  // 2: capacity of the fast path exceeded -> the host runs the legacy chain
-    F.counts[6] = dead ? F.fctr[9] : (s_ovf ? 16u : 0u);  // which one
+    const bool cap = !bad && nq > F.cap_q;  // more Q0 cells than the result arrays hold: an error, not a fallback
+    F.counts[0] = min(nq, F.cap_q);
+    F.counts[1] = 0u;
+    F.counts[2] = bad ? 2u : (cap ? 1u : 0u);  // 2: capacity of the fast path exceeded -> the host runs the legacy chain
+    F.counts[6] = dead ? F.fctr[9] : (s_ovf ? 16u : (bad ? 17u : 0u));  // which one
     F.counts[3] = bad ? 0u : nk;
     F.counts[5] = bad ? 0u : s_nout;
-    F.fctr[9] = bad ? 1u : 0u;
+    F.fctr[9] = (bad || cap) ? 1u : 0u;
   }
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
@@ -1910,130 +2119,219 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
   }
 }
 
-// flags (every claimed cell, every NQ seed), cluster rank of every cell, cells per (cluster, 256-word block).
-// One lane per CELL of the block's compact range (a lane per word left the lanes of a wall word with 30
-// dependent look-ups each).
-__global__ void __launch_bounds__(256) k_flags_hist(Geo g, FArgs F) {
-  __shared__ u32 h[FR_KCAP];
-  if ((int)blockIdx.x >= F.var->nblocks) return;
-  if (F.fctr[9]) return;
-  const u32 nkept = F.counts[3];
-  h[threadIdx.x] = 0u;
-  const int rel = blockIdx.x * 256 + threadIdx.x;
-  const int w = F.var->w0 + rel;
-  const int lane = threadIdx.x & 63;
-  if (w < g.W) {
-    const u64 sd = F.sb[w];
-    if (sd) atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[w]), sd);  // every NQ seed is flagged
-  }
-  __syncthreads();
-  const u32 i0 = (u32)F.blockscan[blockIdx.x];
-  const u32 i1 = (int)blockIdx.x + 1 < F.var->nblocks ? (u32)F.blockscan[blockIdx.x + 1] : F.counts[0];
-  for (u32 ib = i0; ib < i1; ib += 256u) {
-    const u32 i = ib + threadIdx.x;
-    const bool live = i < i1 && i < F.cap_q;
-    u32 code = FR_UNCLAIMED;
-    if (live) {
-      const u32 a = F.cell_adr[i];  // (fetched beside the tile-root id, not behind the verdict it is needed for)
-      code = F.rcode[F.tgid[i]];
-      F.cell_rank[i] = code < FR_KCAP ? code : NOKEY;
-      if (code != FR_UNCLAIMED) atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[a >> 6]), 1ull << (a & 63));
-    }
-    const bool kept = code < FR_KCAP;
-    u64 todo = __ballot(kept);
-    while (todo) {  // one LDS atomic per cluster per wave
-      const int leader = __builtin_ctzll(todo);
-      const u32 first = (u32)__shfl((int)code, leader, 64);
-      const u64 same = __ballot(kept && code == first);
-      if (lane == leader) atomicAdd(&h[first], (u32)__popcll(same));
-      todo &= ~same;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < nkept) F.whist[(size_t)threadIdx.x * F.whist_nb + blockIdx.x] = h[threadIdx.x];
-}
-
-// stable scatter of the kept cells into the grouped result (cluster by cluster in creation order, ascending
-// address inside): position = offset of the cluster + its cells in earlier blocks + its earlier cells of this
-// block.
-__device__ __forceinline__ void scatter2_body(const Geo& g, const FArgs& F) {
-  __shared__ u32 running[FR_KCAP];
-  __shared__ u32 wcnt[4][FR_KCAP];
-  if ((int)blockIdx.x >= F.var->nblocks) return;
-  if (F.fctr[9]) return;
-  const u32 nkept = F.counts[3];
-  const int nb = F.whist_nb;
+// Flags (every claimed cell, every NQ seed) and the grouped result: the kept cells cluster by cluster in creation
+// order, ascending address inside a cluster.  Address order is (x-row, y, z); a tile column's x-rows interleave the
+// column's tiles, so the position of a cell is
+//   offset of its cluster + cells of the cluster in the tile columns in front (k_resolve's matrix)
+//   + cells of the cluster in the x-rows in front inside this column, over all of its tiles
+//   + cells of the cluster in this x-row in the tiles in front (smaller y)        -- both from the per-row counts of
+//                                                                                    the column's components
+//   + cells of the cluster in front of it in this x-row of this tile (a wave walks the row in order).
+// Clusters are told apart inside a tile by a REPRESENTATIVE component (the lowest-numbered component of the tile
+// that belongs to the cluster).
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tile_out(Geo g, FArgs F) {
+  FR_DBG_MARK(F, blockIdx.x, 14);  // (before the first load)
+  const FVar& V = *F.var;
+  if ((int)blockIdx.x >= V.ntiles_f) return;
+  if (F.counts[2]) return;  // overflow (k_resolve's verdict; not the counter line the atomics went to)
+  const TileGeo T = tile_geo(g, V, blockIdx.x);
+  const int nseg = T.nseg, items = T.items, TY = T.TY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32* segb = reinterpret_cast<u32*>(smem_raw);  // [items] Q0 bits
+  u32* segpre = segb + items;                    // [items + 1]
+  u32* segs = segpre + items + 1;                // [items] seed bits
+  u32* cadr = segs + items;                      // [FR_TCELL] address of the l-th cell
+  u32* rowall = cadr + FR_TCELL;                 // [TX][FR_TROOT] cells of the representative's cluster in x-row lx, whole column
+  u32* rowpos = rowall + T.TX * FR_TROOT;        // [TX][FR_TROOT] ... in the tiles in front; then the running output position
+  u32* kmap = rowpos + T.TX * FR_TROOT;          // [FR_KCAP] cluster rank -> representative component of this tile (or 0xFFFFFFFF)
+  u32* code = kmap + FR_KCAP;                    // [FR_TROOT] rcode of the tile's components
+  unsigned short* ckey = reinterpret_cast<unsigned short*>(code + FR_TROOT);  // [FR_TCELL] per cell: representative | 0xFFFE claimed, not kept | 0xFFFF
+  __shared__ u32 s_wsum[NT / 64];
+  __shared__ u32 s_cn[64], s_cb[64], s_cp[65];  // a chunk of the column's tiles: components, id base, prefix
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // cells of this block: compact range [i0, i1)
-  const u32 i0 = (u32)F.blockscan[blockIdx.x];
-  const u32 i1 = (int)blockIdx.x + 1 < F.var->nblocks ? (u32)F.blockscan[blockIdx.x + 1] : F.counts[0];
-  if (i1 <= i0) return;
-  // first position of every cluster present in this block
-  const u32 mine = threadIdx.x < nkept ? F.whist[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
-  running[threadIdx.x] = 0u;
-  const u64 present = __ballot(mine != 0u);
-  __shared__ u64 s_present[4];
-  if (lane == 0) s_present[wave] = present;
+  const int dblk = 2 * V.ntiles_f + 2 + (int)blockIdx.x;
+  FR_DBG_MARK(F, dblk, 0);
+  const u32 nroots = F.t_nroots[blockIdx.x], gbase = F.t_base[blockIdx.x];
+  // fetched ahead, beside the bit-planes: the codes of the tile's components, the component numbers of its cells
+  // (eight consecutive cells per lane), the first 64 tiles of the column
+  const u32 my_code = threadIdx.x < nroots ? F.rcode[gbase + threadIdx.x] : FR_UNCLAIMED;
+  const u64 my_tl = reinterpret_cast<const u64*>(F.tlab + (size_t)blockIdx.x * FR_TCELL)[threadIdx.x & (FR_TCELL / 8 - 1)];
+  u32 pre_cn = 0u, pre_cb = 0u;
+  if (threadIdx.x < 64 && (int)threadIdx.x < V.nty_f) {
+    const int tt = T.tx * V.nty_f + threadIdx.x;
+    pre_cn = F.t_nroots[tt], pre_cb = F.t_base[tt];
+  }
+  const u32 total = tile_load_bits<NT, true, true>(g, T, F.qb, segb, segpre, s_wsum, F.sb, segs);  // (uniform)
+  FR_DBG_MARK(F, dblk, 1);
+  // ---- NQ seeds are flagged whatever happens to the components around them ----
+  auto or_flags = [&](long a0, u32 bits) {  // bits of the 32 voxels from address a0
+    if (!bits) return;
+    const long w = a0 >> 6;
+    const int sh = (int)(a0 & 63);
+    atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[w]), (unsigned long long)bits << sh);
+    if (sh > 32) atomicOr(reinterpret_cast<unsigned long long*>(&F.flag[w + 1]), (unsigned long long)bits >> (64 - sh));
+  };
+  if (total == 0u || nroots == 0u) {
+    for (int it = threadIdx.x; it < items; it += NT) {
+      const u32 sb = segs[it];
+      if (!sb) continue;
+      const int line = it / nseg, c = it - line * nseg;
+      or_flags(tile_line_adr(g, T, line) + 32 * c, sb);
+    }
+    return;
+  }
+  // ---- codes of the tile's components, representatives ----
+  for (int k = threadIdx.x; k < FR_KCAP; k += NT) kmap[k] = 0xFFFFFFFFu;
+  for (int k = threadIdx.x; k < T.TX * FR_TROOT; k += NT) rowall[k] = 0u, rowpos[k] = 0u;
+  if (threadIdx.x < nroots) code[threadIdx.x] = my_code;
   __syncthreads();
-  if (!(s_present[0] | s_present[1] | s_present[2] | s_present[3])) return;
-  for (int wv = 0; wv < 4; ++wv) {
-    u64 m = s_present[wv];
-    while (m) {
-      const int b = __builtin_ctzll(m);
-      m &= m - 1;
-      const u32 d = (u32)(wv * 64 + b);
-      // every wave takes the clusters d with d % 4 == its number (usually one or two clusters in all)
-      if ((int)(d & 3u) != wave) continue;
-      u32 sum = 0u;
-      for (int bb = lane; bb < (int)blockIdx.x; bb += 64) sum += F.whist[(size_t)d * nb + bb];
-      for (int off = 32; off > 0; off >>= 1) sum += (u32)__shfl_xor((int)sum, off, 64);
-      if (lane == 0) running[d] = F.krec[d].off + sum;
+  if (threadIdx.x < nroots && code[threadIdx.x] < FR_KCAP) atomicMin(&kmap[code[threadIdx.x]], threadIdx.x);
+  // ---- cells: address, key ----
+  if (threadIdx.x < FR_TCELL / 8) {  // (component number for now)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ckey[8 * threadIdx.x + q] = (unsigned short)((my_tl >> (8 * q)) & 0xFFull);
+  }
+  for (int it = threadIdx.x; it < items; it += NT) {
+    u32 rem = segb[it];
+    if (!rem) continue;
+    const int line = it / nseg, c = it - line * nseg;
+    const u32 a0 = (u32)(tile_line_adr(g, T, line) + 32 * c);
+    u32 l = segpre[it];
+    while (rem) {
+      const int b = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      cadr[l++] = a0 + (u32)b;
     }
   }
   __syncthreads();
+  for (u32 l = threadIdx.x; l < total; l += NT) {
+    const u32 cd = code[ckey[l]];
+    ckey[l] = (unsigned short)(cd < FR_KCAP ? kmap[cd] : (cd == FR_UNCLAIMED ? 0xFFFFu : 0xFFFEu));
+  }
+  FR_DBG_MARK(F, dblk, 2);
+  // ---- the column: per-row counts of every component of every tile of column tx, folded into the
+  // representatives of this tile's clusters ----
+  const int nty = V.nty_f;
+  for (int t0 = 0; t0 < nty; t0 += 64) {
+    const int nt = min(64, nty - t0);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      u32 cn = pre_cn, cb = pre_cb;
+      if (t0 > 0) {
+        cn = cb = 0u;
+        if ((int)threadIdx.x < nt) {
+          const int tt = T.tx * nty + t0 + threadIdx.x;
+          cn = F.t_nroots[tt], cb = F.t_base[tt];
+        }
+      }
+      u32 s = cn;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = (u32)__shfl_up((int)s, off, 64);
+        if (lane >= off) s += t;
+      }
+      s_cn[threadIdx.x] = cn, s_cb[threadIdx.x] = cb, s_cp[threadIdx.x] = s - cn;
+      if (threadIdx.x == 63) s_cp[64] = s;
+    }
+    __syncthreads();
+    const u32 ncomp = s_cp[64];
+    for (u32 j = threadIdx.x; j < ncomp; j += NT) {
+      int lo = 0, hi = nt - 1;  // tile of the j-th component of the chunk
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_cp[mid] <= j)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      const u32 gi = s_cb[lo] + (j - s_cp[lo]);
+      const u32 cd = F.rcode[gi];
+      if (cd >= FR_KCAP) continue;
+      const u32 rep = kmap[cd];
+      if (rep == 0xFFFFFFFFu) continue;  // a cluster this tile has no cell of
+      const uint4* rw = reinterpret_cast<const uint4*>(F.rrow + (size_t)gi * FR_TXS);
+      const uint4 r0 = rw[0], r1 = rw[1];
+      const u32 pk[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      const bool front = t0 + lo < T.ty;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const u32 c0 = pk[q] & 0xFFFFu, c1 = pk[q] >> 16;
+        if (c0 && 2 * q < T.TX) {
+          atomicAdd(&rowall[(2 * q) * FR_TROOT + rep], c0);
+          if (front) atomicAdd(&rowpos[(2 * q) * FR_TROOT + rep], c0);
+        }
+        if (c1 && 2 * q + 1 < T.TX) {
+          atomicAdd(&rowall[(2 * q + 1) * FR_TROOT + rep], c1);
+          if (front) atomicAdd(&rowpos[(2 * q + 1) * FR_TROOT + rep], c1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 3);
+  // ---- first output position of every (x-row, representative) ----
+  for (u32 j = threadIdx.x; j < nroots * (u32)T.TX; j += NT) {
+    const u32 rep = j / (u32)T.TX, lx = j - rep * (u32)T.TX;
+    const u32 cd = code[rep];
+    if (cd >= FR_KCAP || kmap[cd] != rep) continue;
+    u32 pos = F.krec[cd].off + F.pm[(size_t)cd * F.pm_stride + T.tx];
+    for (u32 q = 0; q < lx; ++q) pos += rowall[q * FR_TROOT + rep];
+    rowpos[lx * FR_TROOT + rep] += pos;
+  }
+  __syncthreads();
+  FR_DBG_MARK(F, dblk, 4);
+  // ---- the rows: a wave walks the cells of an x-row in address order, 64 at a time ----
   u32* key_out = F.ms_key[1];
   u32* val_out = F.ms_val[1];
   const bool direct = F.counts[0] <= F.hcells_direct_max;  // big lists are fetched on demand (0.5 MB over PCIe
                                                            // per search otherwise, whether anybody reads it or not)
-  for (u32 base = i0; base < i1; base += 256u) {
-    for (int wv = 0; wv < 4; ++wv) wcnt[wv][threadIdx.x] = 0u;
-    __syncthreads();
-    const u32 i = base + threadIdx.x;
-    const u32 kk = i < i1 ? F.cell_rank[i] : NOKEY;
-    const bool active = kk != NOKEY;
-    u32 lane_rank = 0u;
-    u64 todo = __ballot(active);
-    while (todo) {
-      const int leader = __builtin_ctzll(todo);
-      const u32 dl = (u32)__shfl((int)kk, leader, 64);
-      const u64 same = __ballot(active && kk == dl) & todo;
-      if (active && kk == dl) lane_rank = (u32)__popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) wcnt[wave][dl] = (u32)__popcll(same);
-      todo &= ~same;
+  for (int lx = wave; lx < T.nxl; lx += NT / 64) {
+    const u32 l0 = segpre[lx * TY * nseg], l1 = segpre[(lx + 1) * TY * nseg];
+    for (u32 lb = l0; lb < l1; lb += 64u) {
+      const u32 l = lb + (u32)lane;
+      const u32 kk = l < l1 ? (u32)ckey[l] : 0xFFFFu;
+      const bool active = kk < FR_TROOT;
+      u32 pos = 0u;
+      u64 todo = __ballot(active);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const u32 dl = (u32)__shfl((int)kk, leader, 64);
+        const u64 same = __ballot(active && kk == dl);
+        volatile u32* rp = &rowpos[(u32)lx * FR_TROOT + dl];  // (other lanes' stores must be seen: no caching in registers)
+        const u32 base = *rp;
+        if (active && kk == dl) pos = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) *rp = base + (u32)__popcll(same);
+        todo &= ~same;
+      }
+      if (active) {
+        const u32 a = cadr[l];
+        key_out[pos] = code[kk];
+        val_out[pos] = a;
+        if (direct) F.h_cells[pos] = a;  // posted write over PCIe
+      }
     }
-    __syncthreads();
-    if (active) {
-      u32 pos = running[kk] + lane_rank;
-      for (int wv = 0; wv < wave; ++wv) pos += wcnt[wv][kk];
-      const u32 a = F.cell_adr[i];
-      key_out[pos] = kk;
-      val_out[pos] = a;
-      if (direct) F.h_cells[pos] = a;  // posted write over PCIe, coalesced per wave
-    }
-    __syncthreads();
-    running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
-    __syncthreads();
   }
+  FR_DBG_MARK(F, dblk, 5);
+  // ---- flags: claimed cells + seeds, one or two atomics per 32-voxel segment ----
+  for (int it = threadIdx.x; it < items; it += NT) {
+    u32 rem = segb[it];
+    u32 fl = segs[it];
+    u32 l = segpre[it];
+    while (rem) {
+      const int b = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      if (ckey[l++] != 0xFFFFu) fl |= 1u << b;
+    }
+    if (!fl) continue;
+    const int line = it / nseg, c = it - line * nseg;
+    or_flags(tile_line_adr(g, T, line) + 32 * c, fl);
+  }  FR_DBG_MARK(F, dblk, 6);
 }
-// the last kernel of the fast chain: regroups the cells and copies them out.  (Whoever needs the cell lists polls
-// the stream, frontier_tail_sync: a "cells are in" stamp from here cost more than it saved -- counting finished
-// workgroups is ~1000 same-address atomics, 15 us; fences wrote the L2 back thousands of times; a one-thread
-// stamp kernel behind this one added 4 us to the busiest stream of the plan cycle.)
-__global__ void __launch_bounds__(256) k_scatter2(Geo g, FArgs F) { scatter2_body(g, F); }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static const int kFastMenu[4][2] = {{16, 32}, {8, 32}, {8, 16}, {4, 8}};  // tiles of the fast chain (x-rows, z-lines)
 static inline int fblocks(long n, int t, int cap = 1 << 16) {
   long b = (n + t - 1) / t;
   return (int)std::max(1L, std::min((long)cap, b));
@@ -2161,18 +2459,16 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   }
   F.kept = F.counts + 16;
   F.keys_from_slots = 1;
-  F.whist_nb = (int)(nwords / 256 + 1);
-  if ((rc = dmalloc(f, &F.tgid, F.cap_q)) || (rc = dmalloc(f, &F.trec, FR_RCAP)) || (rc = dmalloc(f, &F.tclaim, FR_RCAP)) ||
-      (rc = dmalloc(f, &F.rcode, FR_RCAP)) || (rc = dmalloc(f, &F.pairs, (size_t)FR_PCAP)) ||
-      (rc = dmalloc(f, &F.fctr, 32)) || (rc = dmalloc(f, &F.cell_rank, F.cap_q)) ||
-      (rc = dmalloc(f, &F.whist, (size_t)FR_KCAP * F.whist_nb))) {
+  if ((rc = dmalloc(f, &F.trec, FR_RCAP + 256)) || (rc = dmalloc(f, &F.tclaim, FR_RCAP + 256)) || (rc = dmalloc(f, &F.rcode, FR_RCAP + 256)) ||
+      (rc = dmalloc(f, &F.rrow, (size_t)FR_RCAP * FR_TXS)) || (rc = dmalloc(f, &F.pairs, (size_t)FR_PCAP)) ||
+      (rc = dmalloc(f, &F.fctr, 32))) {
     fuelmi_frontier_destroy(f);
     return rc;
   }
   HIPCHK(hipMemsetAsync(F.fctr, 0, 32 * sizeof(u32), m->stream));
   F.dbg = nullptr;
   if (getenv("FUELMI_FR_TIMING")) {  // dev aid: phase time stamps of the fast chain (one row per tile + one for k_resolve)
-    const size_t nrow = (size_t)((g.nx + 0) * (g.ny + 0) / 16 + 64);
+    const size_t nrow = (size_t)(3 * ((g.nx + 4) / 4) * ((g.ny + 8) / 8) + 64);
     if ((rc = dmalloc(f, &F.dbg, nrow * FR_DBG_SLOTS))) {
       fuelmi_frontier_destroy(f);
       return rc;
@@ -2256,22 +2552,48 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     }
     // fast path: sparse labels -- the tile is not bound by nz.  32 z-lines deep, 8 wide, 16 wide once that
     // still leaves >= 512 tiles (measured on 400^2 x 100 and 800^2 x 200 maps: fewer tile roots and face pairs
-    // for k_cross / k_resolve outweigh the longer tiles); FUELMI_FTILE = "TXxTY" overrides
-    // The tile of a search is picked from a menu by the size of its region (frontier_pick_tile); the launch grid
-    // and the LDS budget are those of the extremes.
+    // for k_tile_cross / k_resolve outweigh the longer tiles); FUELMI_FTILE = "TXxTY" overrides.
+    // The tile of a search is picked from a menu by the size of its region; the launch grid of a menu entry is
+    // that tile over the largest rectangle a search can cover (the Q box plus the box_max face of the scan box).
     f->FTX = f->FTY = 0;
     if (const char* e = getenv("FUELMI_FTILE")) {
       int a = 0, b = 0;
-      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && a <= 16 && b > 0 && b <= 32) f->FTX = a, f->FTY = b;
+      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && a <= FR_TXS && b > 0 && b <= 32) f->FTX = a, f->FTY = b;
     }
-    f->fast_tiles = ((qx + 3) / 4) * ((qy + 7) / 8);  // smallest tile of the menu over the whole Q box
-    if (f->FTX) f->fast_tiles = ((qx + f->FTX - 1) / f->FTX) * ((qy + f->FTY - 1) / f->FTY);
-    const size_t items = (size_t)(f->FTX ? f->FTX * f->FTY : 16 * 32) * ((g.nz + 31) / 32);
-    f->tile_lds = (FR_TCELL + 2 * items + 1 + 2 * (size_t)16 + (size_t)FR_TROOT * 11) * sizeof(u32) + FR_TCELL * sizeof(unsigned short);
-    f->tile_lds = (f->tile_lds + 15) & ~(size_t)15;
-    if (f->tile_lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_tile<512>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->tile_lds));
+    const int mtx = f->FTX ? f->FTX : 4, mty = f->FTX ? f->FTY : 8;  // smallest tile in use
+    f->fast_tiles = ((qx + 1 + mtx - 1) / mtx) * ((qy + 1 + mty - 1) / mty);
+    F.pm_stride = (qx + 1 + mtx - 1) / mtx;
+    if ((rc = dmalloc(f, &F.vlab, (size_t)g.N + 64)) || (rc = dmalloc(f, &F.tlab, (size_t)f->fast_tiles * FR_TCELL)) ||
+        (rc = dmalloc(f, &F.t_base, (size_t)f->fast_tiles)) || (rc = dmalloc(f, &F.t_nroots, (size_t)f->fast_tiles)) ||
+        (rc = dmalloc(f, &F.pm, (size_t)FR_KCAP * F.pm_stride))) {
+      fuelmi_frontier_destroy(f);
+      return rc;
+    }
+    for (int k = 0; k < 4; ++k) {
+      const size_t items = (size_t)(f->FTX ? f->FTX * f->FTY : kFastMenu[k][0] * kFastMenu[k][1]) * ((g.nz + 31) / 32);
+      f->fast_items[k] = items;
+      // k_tile_ccl: labels, bits + prefix, records, per-row counts, root numbers, component per cell
+      f->tile_lds[k] = (FR_TCELL + 2 * items + 1 + (size_t)FR_TROOT * 8 + (size_t)FR_TROOT * FR_TXS) * sizeof(u32) +
+                       FR_TCELL * sizeof(unsigned short) + FR_TCELL;
+      f->cross_lds[k] = (2 * items + (size_t)XC_WCAP) * sizeof(u32);
+      // k_tile_out: bits + prefix + seed bits, cell addresses, the two row tables, cluster map, codes, keys
+      f->out_lds[k] = (3 * items + 1 + FR_TCELL + 2 * (size_t)(f->FTX ? f->FTX : kFastMenu[k][0]) * FR_TROOT + FR_KCAP + FR_TROOT) * sizeof(u32) +
+                      FR_TCELL * sizeof(unsigned short);
+      f->tile_lds[k] = (f->tile_lds[k] + 15) & ~(size_t)15;
+      f->cross_lds[k] = (f->cross_lds[k] + 15) & ~(size_t)15;
+      f->out_lds[k] = (f->out_lds[k] + 15) & ~(size_t)15;
+    }
+    const size_t lds_max = std::max(f->tile_lds[0], f->out_lds[0]);
+    if (lds_max > 64 * 1024 && lds_max <= 150 * 1024) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<512>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->tile_lds[0]));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<512>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->out_lds[0]));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<256>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->tile_lds[0]));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<256>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->out_lds[0]));
+    }
   }
   f->resolve_lds = (4 * (size_t)FR_RCAP + 6 * (size_t)FR_KCAP + 6 * (size_t)FR_KCAP + 3 * (size_t)RS_SH) * sizeof(u32) +
                    3 * (size_t)FR_KCAP * sizeof(unsigned long long);
@@ -2279,7 +2601,9 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
                              (int)f->resolve_lds));
   // the fast path needs tiles, a cluster threshold that rules out one-seed clusters, and tile-local indices
   // that fit the 16-bit root numbers
-  f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && f->tile_lds <= 150 * 1024 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
+  // (a thread of the tile kernels fetches at most FT_PER segments: z-lines of up to 256 voxels with the largest tile)
+  f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && std::max(f->tile_lds[0], f->out_lds[0]) <= 150 * 1024 &&
+               f->fast_items[0] <= (size_t)FT_PER * 512 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
   m->dependents.push_back({f, &frontier_orphan});
   *out = f;
   return FUELMI_OK;
@@ -2528,29 +2852,47 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
 }
 
 // the fast chain (capturable); falls back to the legacy one through counts[2] == 2
-static const int kFastMenu[4][2] = {{16, 32}, {8, 32}, {8, 16}, {4, 8}};
 static int frontier_enqueue_fast(fuelmi_frontier* f) {
   const Geo& g = f->map->g;
   FArgs& F = f->F;
   const int nb_max = (g.W + 255) / 256 + 1;
-  // launch grid of the tile kernels: the chosen tile over the whole Q box (the search's region is a part of it)
-  const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 1, qy = F.qbox.hi[1] - F.qbox.lo[1] + 1;
-  const int ftx = f->FTX ? f->FTX : kFastMenu[f->fast_menu][0], fty = f->FTX ? f->FTY : kFastMenu[f->fast_menu][1];
+  // launch grid of the tile kernels: the chosen tile over the largest rectangle a search can cover
+  const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 2, qy = F.qbox.hi[1] - F.qbox.lo[1] + 2;
+  const int mk = f->FTX ? 0 : f->fast_menu;
+  const int ftx = f->FTX ? f->FTX : kFastMenu[mk][0], fty = f->FTX ? f->FTY : kFastMenu[mk][1];
   const int tiles = ((qx + ftx - 1) / ftx) * ((qy + fty - 1) / fty);
-  k_pred2<<<nb_max, 256, 0, f->stream>>>(g, F, f->h_var);
-  FDBG("k_pred2");
-  k_compact2<<<nb_max, 256, 0, f->stream>>>(g, F);
-  FDBG("k_compact2");
-  k_ccl_tile<512><<<tiles, 512, f->tile_lds, f->stream>>>(g, F);
-  FDBG("k_ccl_tile");
-  k_cross<<<tiles + 192, 256, 0, f->stream>>>(g, F);
-  FDBG("k_cross");
+  k_pred3<<<nb_max, 256, 0, f->stream>>>(g, F, f->h_var);
+  FDBG("k_pred3");
+  // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
+  static int nt3[3] = {512, 512, 512};
+  static bool nt_init = false;
+  if (!nt_init) {
+    nt_init = true;
+    if (const char* e = getenv("FUELMI_FT_THREADS")) {
+      int a = 0, b = 0, c = 0;
+      if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+        nt3[0] = a == 256 ? 256 : 512, nt3[1] = b == 256 ? 256 : 512, nt3[2] = c == 256 ? 256 : 512;
+      }
+    }
+    if (f->fast_items[0] > (size_t)FT_PER * 256) nt3[0] = nt3[1] = nt3[2] = 512;  // (a lane fetches at most FT_PER segments)
+  }
+  if (nt3[0] == 256)
+    k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F);
+  else
+    k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F);
+  FDBG("k_tile_ccl");
+  if (nt3[1] == 256)
+    k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F);
+  else
+    k_tile_cross<512><<<tiles, 512, f->cross_lds[mk], f->stream>>>(g, F);
+  FDBG("k_tile_cross");
   k_resolve<<<1, RS_T, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
-  k_flags_hist<<<nb_max, 256, 0, f->stream>>>(g, F);
-  FDBG("k_flags_hist");
-  k_scatter2<<<nb_max, 256, 0, f->stream>>>(g, F);
-  FDBG("k_scatter2");
+  if (nt3[2] == 256)
+    k_tile_out<256><<<tiles, 256, f->out_lds[mk], f->stream>>>(g, F);
+  else
+    k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
+  FDBG("k_tile_out");
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -2638,10 +2980,23 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     const int qx = hv.qreg.hi[0] - hv.qreg.lo[0] + 1, qy = hv.qreg.hi[1] - hv.qreg.lo[1] + 1;
     hv.nty = (qy + f->TY - 1) / f->TY;
     hv.ntiles = ((qx + f->TX - 1) / f->TX) * hv.nty;  // <= f->ccl_tiles (tiles of the whole Q box)
-    // tile of this search: 32 z-lines deep and 16 or 8 wide while that leaves >= 512 tiles (measured on full
+  }
+  {
+    // tiles of the fast chain: over the x/y bounding rectangle of the Q region and the scan box (NQ seeds start
+    // clusters from the box_max face, one voxel outside the Q box; seeds are flagged wherever they are).
+    // Tile of this search: 32 z-lines deep and 16 or 8 wide while that leaves >= 512 tiles (measured on full
     // 400^2 x 100 / 800^2 x 200 boxes: fewer tile roots and face pairs outweigh the longer tiles); smaller
     // tiles for small regions (a streaming search covers ~100 x 100 lines: a handful of big tiles would run
     // one after the other on a handful of CUs)
+    int p0[2], p1[2];
+    for (int k = 0; k < 2; ++k) {
+      p0[k] = hv.sbox.lo[k], p1[k] = hv.sbox.hi[k];
+      if (have_q) p0[k] = std::min(p0[k], hv.qreg.lo[k]), p1[k] = std::max(p1[k], hv.qreg.hi[k]);
+      // (never beyond what the launch grids and per-tile tables were sized for)
+      p0[k] = std::max(p0[k], F.qbox.lo[k]);
+      p1[k] = std::min(p1[k], F.qbox.hi[k] + 1);
+    }
+    const int qx = p1[0] - p0[0] + 1, qy = p1[1] - p0[1] + 1;
     int pick = 3;
     for (int k = 0; k < 4; ++k)
       if (((qx + kFastMenu[k][0] - 1) / kFastMenu[k][0]) * ((qy + kFastMenu[k][1] - 1) / kFastMenu[k][1]) >= 512) {
@@ -2652,8 +3007,10 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     int ftx = kFastMenu[pick][0], fty = kFastMenu[pick][1];
     if (f->FTX) ftx = f->FTX, fty = f->FTY;
     hv.ftx = ftx, hv.fty = fty;
-    hv.nty_f = (qy + fty - 1) / fty;
-    hv.ntiles_f = ((qx + ftx - 1) / ftx) * hv.nty_f;
+    hv.px0 = p0[0], hv.py0 = p0[1], hv.px1 = p1[0], hv.py1 = p1[1];
+    hv.ntx_f = std::max(0, (qx + ftx - 1) / ftx);
+    hv.nty_f = std::max(0, (qy + fty - 1) / fty);
+    hv.ntiles_f = hv.ntx_f * hv.nty_f;
   }
   // words to process: the x-slabs of the region plus one slab either side (neighbour look-ups of the
   // claims / unions read the Q0 plane there: it must not hold bits of an earlier search)
@@ -2783,7 +3140,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     if (F.dbg) {  // FUELMI_FR_TIMING: where the tile kernel and the resolve kernel spend their time (100 MHz ticks)
       (void)hipStreamSynchronize(f->stream);
       const int nt = f->h_var->ntiles_f;
-      std::vector<unsigned long long> d((size_t)(nt + 1) * FR_DBG_SLOTS);
+      std::vector<unsigned long long> d((size_t)(3 * (nt + 1)) * FR_DBG_SLOTS);
       (void)hipMemcpy(d.data(), F.dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       unsigned long long t0 = ~0ull, t1 = 0;
       double phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2797,35 +3154,73 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
         if (r[8] > d[(size_t)busiest * FR_DBG_SLOTS + 8]) busiest = b;
         if (r[8]) ++nonempty;
       }
-      const unsigned long long* rb = &d[(size_t)busiest * FR_DBG_SLOTS];
-      for (int k = 1; k < 8; ++k) phase[k] = rb[k] && rb[k - 1] ? (double)(rb[k] - rb[k - 1]) / 100.0 : 0.0;
-      std::fprintf(stderr, "[fr-timing] tiles %d (non-empty %d) span %.1f us; busiest tile %d (%llu cells, start +%.1f us): "
-                   "bits %.1f labels %.1f unions %.1f roots %.1f records %.1f ids %.1f pairs %.1f us\n", nt, nonempty,
-                   (double)(t1 - t0) / 100.0, busiest, rb[8], (double)(rb[0] - t0) / 100.0, phase[1], phase[2], phase[3],
-                   phase[4], phase[5], phase[6], phase[7]);
       {
-        unsigned long long c0 = ~0ull, c1 = 0;
-        double mx[3] = {0, 0, 0}, av[3] = {0, 0, 0};
+        double st_av = 0, st_mx = 0, du_av = 0, du_mx = 0;
         int cnt = 0;
         for (int b = 0; b < nt; ++b) {
           const unsigned long long* r = &d[(size_t)b * FR_DBG_SLOTS];
-          if (!r[9]) continue;
-          c0 = std::min(c0, r[9]);
-          for (int k = 10; k <= 12; ++k)
-            if (r[k]) c1 = std::max(c1, r[k]);
-          if (r[10] && r[11] && r[12]) {
-            const double ph[3] = {(double)(r[10] - r[9]) / 100.0, (double)(r[11] - r[10]) / 100.0, (double)(r[12] - r[11]) / 100.0};
-            for (int k = 0; k < 3; ++k) mx[k] = std::max(mx[k], ph[k]), av[k] += ph[k];
-            ++cnt;
-          }
+          if (!r[0] || !r[6] || r[6] < r[0]) continue;
+          const double st = (double)(r[0] - t0) / 100.0, du = (double)(r[6] - r[0]) / 100.0;
+          st_av += st, st_mx = std::max(st_mx, st), du_av += du, du_mx = std::max(du_mx, du), ++cnt;
         }
-        std::fprintf(stderr, "[fr-timing] cross: span %.1f us over %d tiles with pairs; rowr avg %.1f max %.1f, look-ups avg %.1f max %.1f, "
-                     "slot atomic avg %.1f max %.1f us\n", (double)(c1 - c0) / 100.0, cnt, av[0] / std::max(cnt, 1), mx[0],
-                     av[1] / std::max(cnt, 1), mx[1], av[2] / std::max(cnt, 1), mx[2]);
+        std::fprintf(stderr, "[fr-timing] ccl: %d tiles with cells: start avg %.1f max %.1f, duration avg %.1f max %.1f us\n", cnt,
+                     st_av / std::max(cnt, 1), st_mx, du_av / std::max(cnt, 1), du_mx);
+      }
+      const unsigned long long* rb = &d[(size_t)busiest * FR_DBG_SLOTS];
+      for (int k = 1; k < 8; ++k) phase[k] = rb[k] && rb[k - 1] ? (double)(rb[k] - rb[k - 1]) / 100.0 : 0.0;
+      std::fprintf(stderr, "[fr-timing] tiles %d (non-empty %d) span %.1f us; busiest tile %d (%llu cells, start +%.1f us): "
+                   "bits %.1f labels %.1f unions %.1f roots %.1f records %.1f write %.1f us; %llu unions, %llu find steps, %llu links, %llu roots\n", nt, nonempty,
+                   (double)(t1 - t0) / 100.0, busiest, rb[8], (double)(rb[0] - t0) / 100.0, phase[1], phase[2], phase[3],
+                   phase[4], phase[5], phase[6], rb[9], rb[10], rb[11], rb[12]);
+      for (int kern = 1; kern <= 2; ++kern) {  // k_tile_cross, k_tile_out: rows behind those of the tiles and of k_resolve
+        const int np = kern == 1 ? 4 : 6;
+        double mx[8] = {0}, av[8] = {0};
+        unsigned long long c0 = ~0ull, c1 = 0;
+        int cnt = 0;
+        for (int b = 0; b < nt; ++b) {
+          const unsigned long long* r = &d[(size_t)(kern * (nt + 1) + b) * FR_DBG_SLOTS];
+          if (!r[0] || !r[np]) continue;
+          c0 = std::min(c0, r[0]), c1 = std::max(c1, r[np]);
+          for (int k = 1; k <= np; ++k) {
+            const double ph = r[k] && r[k - 1] ? (double)(r[k] - r[k - 1]) / 100.0 : 0.0;
+            mx[k] = std::max(mx[k], ph), av[k] += ph;
+          }
+          ++cnt;
+        }
+        double st_av = 0, st_mx = 0, du_av = 0, du_mx = 0;
+        for (int b = 0; b < nt; ++b) {
+          const unsigned long long* r = &d[(size_t)(kern * (nt + 1) + b) * FR_DBG_SLOTS];
+          if (!r[0] || !r[np]) continue;
+          const double st = (double)(r[0] - c0) / 100.0, du = (double)(r[np] - r[0]) / 100.0;
+          st_av += st, st_mx = std::max(st_mx, st), du_av += du, du_mx = std::max(du_mx, du);
+        }
+        {
+          unsigned long long e0 = ~0ull;
+          double ea = 0, em = 0, la = 0, lm = 0;
+          int n2 = 0;
+          for (int b = 0; b < nt; ++b) {
+            const unsigned long long v = d[(size_t)b * FR_DBG_SLOTS + 12 + kern];
+            if (v) e0 = std::min(e0, v);
+          }
+          for (int b = 0; b < nt; ++b) {
+            const unsigned long long v = d[(size_t)b * FR_DBG_SLOTS + 12 + kern];
+            const unsigned long long* r = &d[(size_t)(kern * (nt + 1) + b) * FR_DBG_SLOTS];
+            if (!v || !r[0] || r[0] < v) continue;
+            const double e = (double)(v - e0) / 100.0, l = (double)(r[0] - v) / 100.0;
+            ea += e, em = std::max(em, e), la += l, lm = std::max(lm, l), ++n2;
+          }
+          std::fprintf(stderr, "[fr-timing]   entry avg %.1f max %.1f us after the first workgroup; entry -> first stamp avg %.1f max %.1f us\n",
+                       ea / std::max(n2, 1), em, la / std::max(n2, 1), lm);
+        }
+        std::fprintf(stderr, "[fr-timing] %s: span %.1f us over %d tiles; start avg %.1f max %.1f, duration avg %.1f max %.1f; phases avg/max:",
+                     kern == 1 ? "cross (bits, build, list, append)" : "out (bits, cells, column, first, rows, flags)",
+                     cnt ? (double)(c1 - c0) / 100.0 : 0.0, cnt, st_av / std::max(cnt, 1), st_mx, du_av / std::max(cnt, 1), du_mx);
+        for (int k = 1; k <= np; ++k) std::fprintf(stderr, " %.1f/%.1f", av[k] / std::max(cnt, 1), mx[k]);
+        std::fprintf(stderr, "\n");
       }
       const unsigned long long* rr = &d[(size_t)nt * FR_DBG_SLOTS];
       std::fprintf(stderr, "[fr-timing] resolve: init %.1f unions %.1f find %.1f reduce %.1f clusters %.1f seeds %.1f rank %.1f "
-                   "codes %.1f publish %.1f us; pairs %llu roots %llu seeds %llu\n", (rr[1] - rr[0]) / 100.0,
+                   "codes %.1f publish %.1f us; pairs %llu roots %llu cells %llu\n", (rr[1] - rr[0]) / 100.0,
                    (rr[2] - rr[1]) / 100.0, (rr[3] - rr[2]) / 100.0, (rr[4] - rr[3]) / 100.0, (rr[5] - rr[4]) / 100.0, 0.0,
                    (rr[6] - rr[5]) / 100.0, (rr[7] - rr[6]) / 100.0, (rr[8] - rr[7]) / 100.0, rr[9], rr[10], rr[11]);
     }

@@ -39,25 +39,35 @@ struct FVar {
   int pad2;
   int nty_f, ntiles_f;  // tile grid of the fast chain (its tiles are sized independently of the legacy ones)
   int ftx, fty;         // ... and its tile, chosen per search: few big tiles would serialise a small region
+  // the fast chain's tiles cover the x/y bounding rectangle of qreg and sbox (NQ seeds sit on the box_max face,
+  // one voxel outside the Q box), all z
+  int px0, py0, px1, py1;
+  int ntx_f;
+  int pad3[3];
 };
 
 // ---- fast path of the clustering chain (frontier.hip, "tile-root resolve") ---------------------------------
-// A workgroup labels one spatial tile in LDS (k_ccl_tile) and describes every tile-local component by ONE record;
+// A workgroup labels one spatial tile in LDS (k_tile_ccl) and describes every tile-local component by ONE record;
 // the cross-tile merge, the claims, the cluster sizes, the kept list and its ranking then run on those few
 // thousand records inside a single workgroup's LDS (k_resolve) instead of on the cells through global atomics.
+// No compaction of the cells in front of it: a tile finds its cells in the Q0 bit-plane, a cell's component is
+// looked up by voxel address (vlab), and the grouped output positions come from per-(component, x-row) counts.
 #define FR_RCAP 8192            // tile-local components per search (8 per-XCD ranges of FR_RC8)
 #define FR_RC8 (FR_RCAP / 8)
 #define FR_TCELL 4096           // Q0 cells per tile
-#define FR_TROOT 128            // components per tile
-#define FR_KCAP 256             // kept clusters (one 8-bit multisplit digit)
+#define FR_TROOT 128            // components per tile (they are numbered in one byte; 0xFF is free)
+#define FR_TXS 16               // x-rows per tile at most (stride of the per-row counts)
+#define FR_KCAP 256             // kept clusters
 #define FR_PCAP (1u << 18)      // cross-tile adjacency records
+#define FR_PMCAP 16384          // entries of the (kept cluster x tile column) matrix k_resolve scans in its LDS
 #define FR_UNCLAIMED 0xFFFFFFFFu  // rcode: component claimed by nobody (no flag, no cluster)
 #define FR_NOTKEPT 0xFFFFFFFEu    // rcode: claimed (flag set) but its cluster is too small
 struct TRec {  // one tile-local component
   u32 size;            // cells
   u32 sx, sy, sz;      // voxel-index sums
   u32 lo[3], hi[3];    // index box
-  u32 pad[2];
+  u32 tx;              // tile column it lives in
+  u32 own;             // lowest address among its own cells inside the scan box (NOCLAIM: none)
 };
 
 struct FArgs {
@@ -100,15 +110,18 @@ struct FArgs {
   int keys_from_slots;    // multisplit pass 0 derives (key, value) from cell_slot / slot2rank / cell_adr
   // fast path
   FVar* var_w;            // == var (the first kernel refreshes it from the pinned host copy)
-  unsigned short* tgid;   // [cap_q] tile-root id of every Q0 cell
+  unsigned char* vlab;    // [N] tile-local component number of every Q0 cell of the search (valid where qb is set)
+  unsigned char* tlab;    // [tiles][FR_TCELL] the same by tile-local cell index (coalesced source of k_tile_out)
+  u32* t_base;            // [tiles] id of the tile's component 0 (XCD range | index)
+  u32* t_nroots;          // [tiles] components of the tile
   struct TRec* trec;      // [FR_RCAP]
   u32* tclaim;            // [FR_RCAP] lowest claimer address of every tile root (own in-box cells, NQ seeds)
   u32* rcode;             // [FR_RCAP] cluster rank | FR_NOTKEPT | FR_UNCLAIMED per tile root
+  unsigned short* rrow;   // [FR_RCAP][FR_TXS] cells of the tile root in each x-row of its tile
+  u32* pm;                // [FR_KCAP][pm_stride] cells of kept cluster (by rank) in the tile columns in front of column tx
+  int pm_stride;
   u32* pairs;             // [8][FR_PCAP / 8] distinct pairs of tile roots that touch across a tile face (lo << 16 | hi)
   u32* fctr;              // [32] [0..7] roots per XCD range, [9] overflow -> legacy chain, [16..23] pairs per XCD
-  u32* cell_rank;         // [cap_q] cluster rank of the kept cells, NOKEY otherwise
-  u32* whist;             // [FR_KCAP][nb] cells per (cluster, 256-word block)
-  int whist_nb;           // row length of whist
   int fast;               // the result of the last search came from the fast path
   unsigned long long* dbg;  // FUELMI_FR_TIMING: per-block phase time stamps of the fast chain's kernels (else null)
 };
@@ -226,7 +239,8 @@ struct fuelmi_frontier {
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;
-  size_t tile_lds = 0, resolve_lds = 0;
+  size_t tile_lds[4] = {0, 0, 0, 0}, cross_lds[4] = {0, 0, 0, 0}, out_lds[4] = {0, 0, 0, 0}, fast_items[4] = {0, 0, 0, 0};
+  size_t resolve_lds = 0;  // (dynamic LDS of the fast chain's kernels, per tile of the menu)
   std::unique_ptr<StageScope> scope;
   bool dirty_all = true;    // flags / occupancy changed outside the updated-box bookkeeping
   unsigned seen_epoch = 0;  // map->occ_epoch at the last completed search

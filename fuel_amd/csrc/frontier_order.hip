@@ -24,8 +24,8 @@
 #include "frontier_internal.h"
 
 struct OrderScratch {
-  u32* key = nullptr;     // [cap_q] discovery keys
-  u32* ord_ci = nullptr;  // [cap_q + cap_kept] compact indices in BFS order
+  u32* key = nullptr;     // [N] discovery keys by voxel address (0xFFFFFFFF outside a running sweep)
+  u32* ord = nullptr;     // [cap_q + cap_kept] addresses in BFS order
   u32* off2 = nullptr;    // [cap_kept + 1]
   u32* err = nullptr;     // [4]
   u32* h_err = nullptr;   // pinned [4]
@@ -33,12 +33,11 @@ struct OrderScratch {
 
 namespace {
 
-#define NOIDX 0xFFFFFFFFu
 #define BFS_T 1024
 
 struct BArgs {
   u32* key;
-  u32* ord_ci;
+  u32* ord;
   const u32* off2;
   u32* out_adr;
   u32* out_key;
@@ -53,7 +52,19 @@ __device__ __forceinline__ void st_agent(u32* p, u32 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// member neighbours of the cell at address a, in allNeighbors order: calls fn(idx27, compact index)
+// is the Q0 cell at address a = (xx, yy, .) a member of the cluster?  (fast chain: component of the cell by
+// address -> code of the component; legacy chain: per-cell claimer slot behind the compact index)
+__device__ __forceinline__ bool is_member(const FArgs& F, long a, int xx, int yy, int slot, u32 rank) {
+  if (F.fast) {
+    const FVar& V = *F.var;
+    const int tile = ((xx - V.px0) / V.ftx) * V.nty_f + (yy - V.py0) / V.fty;
+    return F.rcode[F.t_base[tile] + (u32)F.vlab[a]] == rank;
+  }
+  const u32 cj = rank_q(F, a);
+  return cj < F.cap_q && F.cell_slot[cj] == slot;
+}
+
+// member neighbours of the cell at address a, in allNeighbors order: calls fn(idx27, address)
 template <typename Fn>
 __device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs& F, long a, int slot, u32 rank, Fn fn) {
   const int x = (int)(a / g.nyz);
@@ -73,10 +84,7 @@ __device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs&
       while (bits) {
         const int b = __builtin_ctz(bits);
         bits &= bits - 1u;
-        const u32 cj = rank_q(F, nb0 + b);
-        // member of this cluster?  (fast chain: per-cell cluster rank; legacy chain: per-cell claimer slot)
-        if (cj < F.cap_q && (F.fast ? F.cell_rank[cj] == rank : F.cell_slot[cj] == slot))
-          fn((dx + 1) * 9 + (dy + 1) * 3 + b, cj);
+        if (is_member(F, nb0 + b, xx, yy, slot, rank)) fn((dx + 1) * 9 + (dy + 1) * 3 + b, (u32)(nb0 + b));
       }
     }
   }
@@ -93,13 +101,8 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
   const u32 want = B.off2[r + 1] - base0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
-    if (seedc) {
-      st_agent(&B.ord_ci[base0], NOIDX);
-    } else {
-      const u32 c0 = rank_q(F, (long)kr.addr);
-      st_agent(&B.key[c0], 0u);
-      st_agent(&B.ord_ci[base0], c0);
-    }
+    if (!seedc) st_agent(&B.key[kr.addr], 0u);
+    st_agent(&B.ord[base0], kr.addr);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -108,11 +111,10 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
     const u32 nL = lev_hi - lev_lo;
     // ---- A: proposals ----
     for (u32 j = threadIdx.x; j < nL; j += BFS_T) {
-      const u32 ci = ld_agent(&B.ord_ci[base0 + lev_lo + j]);
-      const long a = ci == NOIDX ? (long)kr.addr : (long)F.cell_adr[ci];
+      const long a = (long)ld_agent(&B.ord[base0 + lev_lo + j]);
       const u32 kbase = (lev_lo + j) * 27u + 1u;
-      for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 cj) {
-        (void)__hip_atomic_fetch_min(&B.key[cj], kbase + (u32)idx27, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 aj) {
+        (void)__hip_atomic_fetch_min(&B.key[aj], kbase + (u32)idx27, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -125,11 +127,10 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
       u32 wmask = 0u;
       long a = 0;
       if (j < nL) {
-        const u32 ci = ld_agent(&B.ord_ci[base0 + lev_lo + j]);
-        a = ci == NOIDX ? (long)kr.addr : (long)F.cell_adr[ci];
+        a = (long)ld_agent(&B.ord[base0 + lev_lo + j]);
         const u32 kbase = (lev_lo + j) * 27u + 1u;
-        for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 cj) {
-          if (ld_agent(&B.key[cj]) == kbase + (u32)idx27) wmask |= 1u << idx27;
+        for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 aj) {
+          if (ld_agent(&B.key[aj]) == kbase + (u32)idx27) wmask |= 1u << idx27;
         });
       }
       const u32 cnt = (u32)__popc(wmask);
@@ -153,9 +154,8 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
           const int idx27 = __builtin_ctz(m);
           m &= m - 1u;
           const int dx = idx27 / 9 - 1, dy = (idx27 / 3) % 3 - 1, dz = idx27 % 3 - 1;
-          const u32 cj = rank_q(F, a + (long)dx * g.nyz + (long)dy * g.nz + dz);
           if (pos < base0 + want)
-            st_agent(&B.ord_ci[pos], cj);
+            st_agent(&B.ord[pos], (u32)(a + (long)dx * g.nyz + (long)dy * g.nz + dz));
           else
             B.err[0] = 1u;  // more cells reached than the cluster holds: cannot happen
           ++pos;
@@ -174,11 +174,12 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
     if (lev_hi > want) break;  // (error already flagged)
   }
   if (lev_hi != want && threadIdx.x == 0) B.err[1] = 1u + r;  // the sweep did not reach every cell of the cluster
-  // ordered addresses + cluster rank of every cell
+  // ordered addresses + cluster rank of every cell; the keys go back to "unset" for the next search
   for (u32 k = threadIdx.x; k < want && k < lev_hi; k += BFS_T) {
-    const u32 ci = ld_agent(&B.ord_ci[base0 + k]);
-    B.out_adr[base0 + k] = ci == NOIDX ? kr.addr : F.cell_adr[ci];
+    const u32 a = ld_agent(&B.ord[base0 + k]);
+    B.out_adr[base0 + k] = a;
     B.out_key[base0 + k] = r;
+    if (k > 0u || !seedc) B.key[a] = 0xFFFFFFFFu;
   }
 }
 
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
 void frontier_order_free(fuelmi_frontier* f) {
   OrderScratch* o = f->order;
   if (!o) return;
-  void* dev[] = {o->key, o->ord_ci, o->off2, o->err};
+  void* dev[] = {o->key, o->ord, o->off2, o->err};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (o->h_err) (void)hipHostFree(o->h_err);
@@ -203,8 +204,9 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
   if (!f->order) {
     OrderScratch* o = new OrderScratch;
     f->order = o;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->key), (size_t)F.cap_q * sizeof(u32)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->ord_ci), ((size_t)F.cap_q + F.cap_kept) * sizeof(u32)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->key), (size_t)m->g.N * sizeof(u32)));
+    HIPCHK(hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->ord), ((size_t)F.cap_q + F.cap_kept) * sizeof(u32)));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->off2), ((size_t)F.cap_kept + 1) * sizeof(u32)));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->err), 4 * sizeof(u32)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&o->h_err), 4 * sizeof(u32), hipHostMallocDefault));
@@ -221,10 +223,10 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
   }
   (void)n_out;
   HIPCHK(hipMemcpyAsync(o->off2, off2.data(), (nkept + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(o->key, 0xFF, (size_t)nq * sizeof(u32), st));
+  (void)nq;
   HIPCHK(hipMemsetAsync(o->err, 0, 4 * sizeof(u32), st));
   BArgs B;
-  B.key = o->key, B.ord_ci = o->ord_ci, B.off2 = o->off2;
+  B.key = o->key, B.ord = o->ord, B.off2 = o->off2;
   B.out_adr = F.ms_val[1 - fin], B.out_key = F.ms_key[1 - fin];
   B.nq = nq, B.err = o->err;
   k_bfs_order<<<nkept, BFS_T, 0, st>>>(m->g, F, B);
@@ -232,6 +234,7 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
   HIPCHK(hipMemcpyAsync(o->h_err, o->err, 4 * sizeof(u32), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));  // (off2 is a pageable host vector: its upload has been staged by now)
   if (o->h_err[0] || o->h_err[1]) {
+    (void)hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st);  // (a sweep that stopped half-way leaves keys behind)
     fuelmi_set_error("reference order: the level sweep of cluster %u did not match its cell set", o->h_err[1] - 1u);
     return FUELMI_EHIP;
   }
