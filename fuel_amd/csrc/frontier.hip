@@ -1258,21 +1258,26 @@ __device__ __forceinline__ u32 tile_load_bits(const Geo& g, const TileGeo& T, co
     if (k < per && it0 + k < T.items) {
       segb[it0 + k] = b[k];
       segpre[it0 + k] = run;
-      if (lab != nullptr && run + (u32)__popc(b[k]) <= FR_TCELL) {
-        // labels of the CCL: start of the cell's z-run inside its segment (runs are pre-joined)
-        u32 rem = b[k], l = run;
-        while (rem) {
-          const int s0 = __builtin_ctz(rem);
-          const u32 inv = ~(rem >> s0);
-          const int len = min(inv ? __builtin_ctz(inv) : 32, 32 - s0);
-          rem &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s0);
-          for (int q = 0; q < len; ++q) lab[l + (u32)q] = l;
-          l += (u32)len;
-        }
-      }
       run += (u32)__popc(b[k]);
     }
   if (threadIdx.x == 0) segpre[T.items] = tot;
+  if (lab != nullptr && tot <= FR_TCELL) {
+    // labels of the CCL: start of the cell's z-run inside its segment (runs are pre-joined).  Not unrolled (eight
+    // copies of the loop nest are code the instruction cache pays for): the lane re-reads what it just wrote.
+#pragma nounroll
+    for (int k = 0; k < per; ++k) {
+      if (it0 + k >= T.items) break;
+      u32 rem = segb[it0 + k], l = segpre[it0 + k];
+      while (rem) {
+        const int s0 = __builtin_ctz(rem);
+        const u32 inv = ~(rem >> s0);
+        const int len = min(inv ? __builtin_ctz(inv) : 32, 32 - s0);
+        rem &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s0);
+        for (int q = 0; q < len; ++q) lab[l + (u32)q] = l;
+        l += (u32)len;
+      }
+    }
+  }
   __syncthreads();
   return tot;
 }
@@ -1312,6 +1317,8 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
   u32* rrow = acc + FR_TROOT * 8;                     // [FR_TROOT][FR_TXS] cells per x-row
   unsigned short* rootno = reinterpret_cast<unsigned short*>(rrow + FR_TROOT * FR_TXS);  // [FR_TCELL] at a root: its number
   unsigned char* rcell = reinterpret_cast<unsigned char*>(rootno + FR_TCELL);            // [FR_TCELL] component number per cell
+  u32* plist = reinterpret_cast<u32*>(rootno);  // [FR_TPAIR] touching runs (cell << 16 | cell); shares the space of rootno + rcell, which are filled afterwards
+  static_assert((size_t)FR_TPAIR * sizeof(u32) <= FR_TCELL * sizeof(unsigned short) + FR_TCELL, "pair list does not fit");
   __shared__ u32 s_wsum[NT / 64];
   __shared__ u32 s_nroots, s_base, s_flag;
   __shared__ u32 s_cnt[4];
@@ -1334,67 +1341,117 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
   }
   for (int t = threadIdx.x; t < FR_TROOT * FR_TXS; t += NT) rrow[t] = 0u;  // (used behind the next barrier)
   FR_DBG_MARK(F, blockIdx.x, 2);
-  // ---- unions: segment seams + the four lower z-lines inside the tile.  One lane per (z-line, lower line): both
-  // lines' segments (bits and tile-local prefixes) are fetched into registers in one batch of independent LDS reads,
-  // the runs are then matched in registers, and only the unions themselves go back to the LDS ----
-  {
+  // ---- components.  (1) One lane per (z-line, lower line[, group of segments]) walks the line's segments with the
+  // neighbour line's segments c - 1, c, c + 1 sliding along in registers and matches the runs in registers: every
+  // pair of touching runs (segment seams included) goes into an LDS list (one counter atomic per wave and trip).
+  // (2) The list is then joined by HOOK + COMPRESS rounds (Shiloach-Vishkin style): both labels of a pair are read
+  // side by side and the larger root takes the smaller with a non-returning atomicMin, then every cell walks to its
+  // root; repeated until a round finds every pair joined.  Labels only ever decrease and parent < child always
+  // holds, so there are no cycles; a hook that lost a race is simply repeated in the next round.
+  // Why not a lock-free union-find inside the walk (rounds 2 and 3 tried it three ways): merging hundreds of runs
+  // into one surface makes every lane retry against the same growing tree -- measured 7 us for one union per lane --
+  // and the retry loops run under the divergence of the walk. ----
+  __shared__ u32 s_np, s_chg, s_povf;
+  if (threadIdx.x == 0) s_np = 0u, s_chg = 0u, s_povf = 0u;
+  __syncthreads();
+  auto walk_pairs = [&](auto&& fn) {  // fn(first cell of an own run, a cell of a touching run of the lower line / seam)
     const int nlines = T.TX * TY;
-    for (int j = threadIdx.x; j < 4 * nlines; j += NT) {
+    // small tiles (4 x 8 lines of 200 voxels in a streaming search): a line's segments are split over G lanes so that
+    // all waves of the workgroup have runs to walk
+    int G = 1;
+    while (4 * nlines * G < NT && 2 * G <= nseg) G *= 2;
+    const int cper = (nseg + G - 1) / G;
+    for (int jg = threadIdx.x; jg < 4 * nlines * G; jg += NT) {
+      const int grp = jg % G, j = jg / G;
+      const int c_lo = grp * cper, c_hi = min(nseg, c_lo + cper);
+      if (c_lo >= c_hi) continue;
       const int k = j / nlines, line = j - k * nlines, lx = line / TY, ly = line - lx * TY;
-      u32 ob[FT_PER], op[FT_PER], nb[FT_PER], npre[FT_PER];
-      u32 any = 0u;
-#pragma unroll
-      for (int c = 0; c < FT_PER; ++c) {
-        ob[c] = op[c] = 0u;
-        if (c < nseg) ob[c] = segb[line * nseg + c], op[c] = segpre[line * nseg + c];
-        any |= ob[c];
-      }
-      if (!any) continue;
       const int nlx = lx + (k < 3 ? -1 : 0), nly = ly + (k < 3 ? k - 1 : -1);
       const bool nvalid = nlx >= 0 && nly >= 0 && nly < TY;
-      const int nline = nlx * TY + nly;
-      u32 nany = 0u;
-#pragma unroll
-      for (int c = 0; c < FT_PER; ++c) {
-        nb[c] = npre[c] = 0u;
-        if (nvalid && c < nseg) nb[c] = segb[nline * nseg + c], npre[c] = segpre[nline * nseg + c];
-        nany |= nb[c];
-      }
-      if (k != 3 && !nany) continue;
-#pragma unroll
-      for (int c = 0; c < FT_PER; ++c) {
+      if (!nvalid && k != 3) continue;
+      const u32* ob = segb + line * nseg;
+      const u32* op = segpre + line * nseg;
+      const u32* nbp = segb + (nvalid ? nlx * TY + nly : 0) * nseg;
+      const u32* npp = segpre + (nvalid ? nlx * TY + nly : 0) * nseg;
+      u32 nlo = (nvalid && c_lo > 0) ? nbp[c_lo - 1] : 0u, nlo_pre = (nvalid && c_lo > 0) ? npp[c_lo - 1] : 0u;  // neighbour segment c - 1
+      u32 ncur = nvalid ? nbp[c_lo] : 0u, ncur_pre = nvalid ? npp[c_lo] : 0u;
+      u32 prev_own = c_lo > 0 ? ob[c_lo - 1] : 0u;
+#pragma nounroll
+      for (int c = c_lo; c < c_hi; ++c) {
+        const u32 nhi = (nvalid && c + 1 < nseg) ? nbp[c + 1] : 0u, nhi_pre = (nvalid && c + 1 < nseg) ? npp[c + 1] : 0u;
         const u32 bits = ob[c];
-        if (!bits) continue;
-        if (k == 3 && (bits & 1u) && c > 0 && (ob[c > 0 ? c - 1 : 0] >> 31)) {
-          lds_union_h(lab, op[c], op[c] - 1u);
-        }
-        // the neighbour line's bits at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j)
-        const u32 nlo = c > 0 ? nb[c > 0 ? c - 1 : 0] : 0u, nhi = c + 1 < FT_PER ? nb[c + 1 < FT_PER ? c + 1 : 0] : 0u;
-        const u64 w3 = (u64)(nlo >> 31) | ((u64)nb[c] << 1) | ((u64)(nhi & 1u) << 33);
-        if (!w3) continue;
-        u32 rem = bits;
-        u32 l = op[c];
-        while (rem) {
-          int s, len;
-          pop_run32(rem, s, len);
-          u64 m = (w3 >> s) & ((1ull << (len + 2)) - 1ull);  // z - 1 .. z + len of the run
-          while (m) {
-            int jj, rl;
-            pop_run64(m, jj, rl);
-            const int q = s + jj;  // bit of w3: 0 -> last voxel of segment c - 1, 1..32 -> segment c, 33 -> first of c + 1
-            u32 ln;
-            if (q == 0)
-              ln = npre[c > 0 ? c - 1 : 0] + (u32)__popc(nlo & 0x7FFFFFFFu);
-            else if (q == 33)
-              ln = npre[c + 1 < FT_PER ? c + 1 : 0];
-            else
-              ln = npre[c] + (u32)__popc(nb[c] & ((1u << (q - 1)) - 1u));
-            lds_union_h(lab, l, ln);
+        if (bits) {
+          const u32 base = op[c];
+          if (k == 3 && (bits & 1u) && (prev_own >> 31)) fn(base, base - 1u);
+          // the neighbour line's bits at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j)
+          const u64 w3 = (u64)(nlo >> 31) | ((u64)ncur << 1) | ((u64)(nhi & 1u) << 33);
+          u32 rem = w3 ? bits : 0u;
+          u32 l = base;
+          while (rem) {
+            int s, len;
+            pop_run32(rem, s, len);
+            u64 m = (w3 >> s) & ((1ull << (len + 2)) - 1ull);  // z - 1 .. z + len of the run
+            while (m) {
+              int jj, rl;
+              pop_run64(m, jj, rl);
+              const int q = s + jj;  // bit of w3: 0 -> last voxel of segment c - 1, 1..32 -> segment c, 33 -> first of c + 1
+              const u32 ln = q == 0 ? nlo_pre + (u32)__popc(nlo & 0x7FFFFFFFu)
+                                    : (q == 33 ? nhi_pre : ncur_pre + (u32)__popc(ncur & ((1u << (q - 1)) - 1u)));
+              fn(l, ln);
+            }
+            l += (u32)len;
           }
-          l += (u32)len;
         }
+        prev_own = bits;
+        nlo = ncur, nlo_pre = ncur_pre, ncur = nhi, ncur_pre = nhi_pre;
       }
     }
+  };
+  walk_pairs([&](u32 u, u32 v) {
+    const u64 act = __ballot(1);  // the lanes that have a pair in this trip: one counter atomic for all of them
+    const int leader = __builtin_ctzll(act);
+    u32 at = 0u;
+    if (lane == leader) at = atomicAdd(&s_np, (u32)__popcll(act));
+    at = (u32)__shfl((int)at, leader, 64) + (u32)__popcll(act & ((1ull << lane) - 1ull));
+    if (at < FR_TPAIR)
+      plist[at] = (u << 16) | v;
+    else
+      s_povf = 1u;
+  });
+  __syncthreads();
+  {
+    volatile u32* vl = lab;
+    const u32 np = min(s_np, (u32)FR_TPAIR);
+    for (;;) {
+      bool any = false;
+      for (u32 p = threadIdx.x; p < np; p += NT) {
+        const u32 pr = plist[p];
+        const u32 ru = vl[pr >> 16], rv = vl[pr & 0xFFFFu];  // (roots: the labels are flat at the start of a round)
+        if (ru != rv) {
+          atomicMin(&lab[max(ru, rv)], min(ru, rv));
+          any = true;
+        }
+      }
+      if (any) s_chg = 1u;
+      __syncthreads();
+      const bool again = s_chg != 0u;
+      __syncthreads();
+      if (!again) break;
+      if (threadIdx.x == 0) s_chg = 0u;
+      for (u32 i = threadIdx.x; i < total; i += NT) {
+        u32 r = vl[i];
+        for (;;) {
+          const u32 rr = vl[r];
+          if (rr == r) break;
+          r = rr;
+        }
+        vl[i] = r;
+      }
+      __syncthreads();
+    }
+  }
+  if (s_povf) {  // more touching pairs than the list holds (a tile of single-voxel runs): the plain union-find walk
+    walk_pairs([&](u32 u, u32 v) { lds_union_h(lab, u, v); });
   }
   __syncthreads();
   FR_DBG_MARK(F, blockIdx.x, 3);
@@ -1696,12 +1753,6 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
     }
     nb = (int)((long)xx * g.nyz + (long)yy * nz + 32 * c - 1);
   };
-  auto run_entry = [&](u32 e) {  // (list full: right away, one by one)
-    u32 bits, own, info;
-    int nb;
-    decode(e, bits, own, nb, info);
-    if (bits) do_item(bits, own, nb, info, plane_window(F.qb, (long)nb));
-  };
   // ---- tile faces: the whole x-row 0 and, in the other x-rows, the lines ly = 0 and ly = TY - 1; an item per
   // (face line, segment, lower z-line across the face) ----
   const int nfl = TY + 2 * (T.nxl - 1);
@@ -1719,7 +1770,7 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
     if (slot < XC_WCAP)
       wl[slot] = (u32)fi;
     else
-      run_entry((u32)fi);
+      F.fctr[9] = 18u;  // work list full (a tile made of seeds): the legacy chain takes the search
   }
   // ---- NQ seeds of the tile (most tiles have none): nine items per seed segment, one per line around it (one
   // reservation for all nine) ----
@@ -1731,30 +1782,31 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
       if (slot0 + (u32)l < XC_WCAP)
         wl[slot0 + (u32)l] = e;
       else
-        run_entry(e);
+        F.fctr[9] = 18u;
     }
   }
-  flush_pairs();  // (pairs of the overflow path)
   __syncthreads();
   FR_DBG_MARK(F, dblk, 2);
-  // ---- the list: four items per lane and trip, their windows fetched together ----
+  // ---- the list: two items per lane and trip, their windows fetched together ----
   const u32 nw = min(s_nw, (u32)XC_WCAP);
-  for (u32 w0 = 0; w0 < nw; w0 += 4 * NT) {
-    u32 bx[4], ox[4], ix[4];
-    int nx[4];
-    u64 wx[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const u32 j = w0 + (u32)q * NT + threadIdx.x;
-      bx[q] = 0u, wx[q] = 0ull;
-      if (j < nw) {
-        decode(wl[j], bx[q], ox[q], nx[q], ix[q]);
-        if (bx[q]) wx[q] = plane_window(F.qb, (long)nx[q]);
-      }
+  for (u32 w0 = 0; w0 < nw; w0 += 2 * NT) {
+    u32 b0 = 0u, b1 = 0u, o0 = 0u, o1 = 0u, i0 = 0u, i1 = 0u;
+    int n0 = 0, n1 = 0;
+    u64 wa = 0ull, wb = 0ull;
+    const u32 ja = w0 + threadIdx.x, jb = ja + NT;
+    if (ja < nw) {
+      decode(wl[ja], b0, o0, n0, i0);
+      if (b0) wa = plane_window(F.qb, (long)n0);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (bx[q] && wx[q]) do_item(bx[q], ox[q], nx[q], ix[q], wx[q]);
+    if (jb < nw) {
+      decode(wl[jb], b1, o1, n1, i1);
+      if (b1) wb = plane_window(F.qb, (long)n1);
+    }
+#pragma nounroll
+    for (int h = 0; h < 2; ++h) {  // (one copy of the item code)
+      const u32 bb = h ? b1 : b0;
+      const u64 ww = h ? wb : wa;
+      if (bb && ww) do_item(bb, h ? o1 : o0, h ? n1 : n0, h ? i1 : i0, ww);
       flush_pairs();
     }
   }
@@ -3038,6 +3090,8 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
       k_zero_words<<<fblocks(g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, g.W);
     f->fresh_pending = false;
   }
+  if (F.dbg)  // FUELMI_FR_TIMING: stamps of this search only
+    HIPCHK(hipMemsetAsync(F.dbg, 0, (size_t)(3 * (hv.ntiles_f + 1)) * FR_DBG_SLOTS * sizeof(unsigned long long), f->stream));
   hv.epoch = ++f->epoch;
   if (hv.epoch == 0u) hv.epoch = f->epoch = 1u;
   // pinned; read by the first kernel of the chain.  (The previous search's first kernel ran long ago -- its

@@ -55,6 +55,7 @@ struct FVar {
 #define FR_RCAP 8192            // tile-local components per search (8 per-XCD ranges of FR_RC8)
 #define FR_RC8 (FR_RCAP / 8)
 #define FR_TCELL 4096           // Q0 cells per tile
+#define FR_TPAIR 3072           // touching pairs of runs a tile lists (beyond: union-find on the spot)
 #define FR_TROOT 128            // components per tile (they are numbered in one byte; 0xFF is free)
 #define FR_TXS 16               // x-rows per tile at most (stride of the per-row counts)
 #define FR_KCAP 256             // kept clusters
