@@ -100,7 +100,7 @@ def build_inputs(workload, seed, n_traj=64):
 class GpuCycle:
     """The hot path on one GPU through the C-ABI (fuel_amd.host mirrors the reference classes)."""
 
-    def __init__(self, map_size, box, occ, ctrl, device, dt=0.175, **map_kw):
+    def __init__(self, map_size, box, occ, ctrl, device, dt=0.175, reference_order=0, **map_kw):
         import fuel_amd
         self.fa = fuel_amd
         self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device, **map_kw)
@@ -108,7 +108,7 @@ class GpuCycle:
         nv = self.map.nvox
         self.map.setLocalBound((0, 0, 0), (nv[0] - 1, nv[1] - 1, nv[2] - 1))
         self.box = box
-        self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100)
+        self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100, reference_order=reference_order)
         self.opt = fuel_amd.BsplineOptimizer()
         self.opt.setEnvironment(self.map)
         x, ptd, st, en = bspline_problem(ctrl, dt)
@@ -157,6 +157,24 @@ class GpuCycle:
         return sec.value
 
 
+def run_delivered(cyc, n):
+    """n cycles with the results delivered to host memory every cycle (fuelmi_bench_cycles_delivered): the cells of
+    every new cluster and the cost / gradient of every candidate, as the reference's callers receive them."""
+    import ctypes as C
+    from fuel_amd._lib import check
+    ncl, sec = C.c_int(), (C.c_double * 3)()
+    lo, hi = (C.c_double * 3)(*cyc.box[0]), (C.c_double * 3)(*cyc.box[1])
+    cap = 1 << 22
+    cells = np.empty(cap, dtype=np.int32)
+    nc, nvar = cyc.problem.x.shape
+    cost, grad = np.empty(nc), np.empty((nc, nvar))
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    check(cyc.map.L.fuelmi_bench_cycles_delivered(cyc.map.h, cyc.ff.h, cyc.dev_problem.h, lo, hi, int(n),
+                                                  cells.ctypes.data_as(ip), C.c_size_t(cap), cost.ctypes.data_as(dp),
+                                                  grad.ctypes.data_as(dp), C.byref(ncl), sec))
+    return sec[0], sec[1], sec[2]
+
+
 def streaming_frames(map_size, n_obs, n_frames, seed):
     """Depth frames (16UC1, 640x480) along a seeded camera path through a fresh synthetic world."""
     from fuel_amd import synth
@@ -181,10 +199,10 @@ class GpuStreamCycle:
     """BASELINE config #4: streaming depth inserts + incremental (box-local) ESDF + incremental frontier
     search on a map that starts unknown, plus the B-spline batch.  One step = one depth frame."""
 
-    def __init__(self, map_size, box, frames, ctrl, device, dt=0.175):
+    def __init__(self, map_size, box, frames, ctrl, device, dt=0.175, reference_order=0):
         import fuel_amd
         self.map = fuel_amd.SDFMap(map_size, box[0], box[1], device=device)
-        self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100)
+        self.ff = fuel_amd.FrontierFinder(self.map, cluster_min=100, reference_order=reference_order)
         self.frames = frames
         self.k = 0
         # where the depth frames live when a step hands one over (frame_source):
@@ -282,6 +300,16 @@ class GpuStreamCycle:
     def finish(self):
         self.map.synchronize()
         self.ff.sync()
+
+    def close(self):
+        """drain, release the finder / batch / map and undo the registration of the host ring"""
+        self.finish()
+        for o in (self.dev_problem, self.ff, self.map):
+            o.close()
+        if self.pinned is not None:
+            self.map.L.fuelmi_host_unregister(self.pinned.ctypes.data)
+            self.pinned = None
+        self.dev_frames = None
 
 
 def cpu_baseline_stream(map_size, box, frames, ctrl, budget_s=12.0, dt=0.175):
@@ -460,7 +488,7 @@ def timed_fleet_run(step, finish, steps, dist=None, device_sync=None, device="cu
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -483,6 +511,9 @@ def main():
                     help="B-spline candidates per cycle (BASELINE configs: 1, 64 = headline, 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--reference-order", type=int, default=0, choices=(0, 1, 2),
+                    help="fuelmi_frontier_cfg.reference_order of the finder (0 address order, 1 the reference's BFS order, "
+                         "2 auto: the reference's order for searches of <= 32768 cells); the headline uses 0")
     ap.add_argument("--serial-stages", action="store_true",
                     help="diagnostic: run the frontier scan after the ESDF chain instead of beside it")
     args = ap.parse_args()
@@ -493,17 +524,43 @@ def main():
         args.warmup = 3 if stream_wl else 20
 
     import torch
+    share = os.environ.get("FUELMI_FLEET_SHARE_DEVICE") == "1"  # N ranks on however many devices there are (tests)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: launch the N ranks here (one process per GPU, the same command the
+        # driver uses) and hand their single JSON line through
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not share:
+            raise SystemExit("bench.py --gpus %d: only %d device(s) visible (FUELMI_FLEET_SHARE_DEVICE=1 lets the ranks "
+                             "share them)" % (args.gpus, ndev))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not share:
+        raise SystemExit("rank %d has no device (%d visible; FUELMI_FLEET_SHARE_DEVICE=1 lets ranks share)" % (local_rank, ndev))
+    local_rank = local_rank % ndev  # (the device this rank uses)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:  # RCCL refuses two ranks on one device; the barrier and the max-reduce of the time run over gloo
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
     import fuel_amd
@@ -517,11 +574,11 @@ def main():
         rng = np.random.default_rng(1000 + 42 + rank)
         ctrl = make_trajectories(rng, args.candidates, 32, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
         occ, n_known = None, 0
-        cyc = GpuStreamCycle(map_size, box, frames, ctrl, device=local_rank)
+        cyc = GpuStreamCycle(map_size, box, frames, ctrl, device=local_rank, reference_order=args.reference_order)
     else:
         map_size, box, occ, ctrl, n_known = build_inputs(args.workload, seed=42 + rank, n_traj=args.candidates)
         map_kw = {"optimistic": 1} if args.workload in ("G400K", "G400E") else {}
-        cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank, **map_kw)
+        cyc = GpuCycle(map_size, box, occ, ctrl, device=local_rank, reference_order=args.reference_order, **map_kw)
     if args.serial_stages:
         cyc.step = cyc.step_serial
 
@@ -584,24 +641,46 @@ def main():
     n_launch, dom_total_ms = cyc.map.profileGet(stages[dominant])
     frame_source = None
     if streaming:
-        # the same K frames handed over from host memory instead (the map keeps growing: slightly later frames of
-        # the same path), reported beside `value`
-        frame_source = {"device_resident_ms_per_frame": 1e3 * elapsed / args.steps}
-        cyc.map.profileEnable(0)
-        for src in ("pinned", "pageable"):
-            cyc.frame_source = src
-            t = timed_fleet_run(cyc.prepare_native(args.steps, args.serial_stages), cyc.finish, 1, dist,
-                                torch.cuda.synchronize)
-            frame_source[src + "_host_ms_per_frame"] = 1e3 * t / args.steps
-        cyc.frame_source = "device"
+        # The same K frames handed over from host memory instead, each source from an IDENTICAL map state: a fresh map
+        # and finder, the same warm-up frames, the same K timed frames (the run above continues on a map that has
+        # grown, so its figure is not compared with these).  `value` stays the device-resident rate -- inputs in HBM
+        # when the timed region starts, as the bench contract asks -- and says so in `value_inputs`.
+        frame_source = {}
         t_py = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
         host_loop = {"native_cpp_loop_cycles_per_s": fleet_value(n_gpus, args.steps, elapsed),
                      "python_ctypes_loop_cycles_per_s": fleet_value(n_gpus, args.steps, t_py)}
+        for src in ("device", "pinned", "pageable"):
+            c2 = GpuStreamCycle(map_size, box, frames, ctrl, device=local_rank, reference_order=args.reference_order)
+            c2.frame_source = src
+            c2.run_native(args.warmup + 8, args.serial_stages)
+            c2.finish()
+            t = timed_fleet_run(c2.prepare_native(args.steps, args.serial_stages), c2.finish, 1, dist,
+                                torch.cuda.synchronize)
+            frame_source[{"device": "device_resident", "pinned": "pinned_host", "pageable": "pageable_host"}[src]
+                         + "_ms_per_frame"] = 1e3 * t / args.steps
+            c2.close()
+            del c2
+        frame_source["note"] = ("three fresh maps, identical warm-up and timed frames per source; `value` is the "
+                                "device-resident run of the main map (frames in HBM before the clock starts)")
+    host_delivery = None
     if not streaming:
         cyc.map.profileEnable(0)
         t_py = timed_fleet_run(cyc.step, cyc.finish, args.steps, dist, torch.cuda.synchronize)
         host_loop = {"native_cpp_loop_cycles_per_s": fleet_value(n_gpus, args.steps, elapsed),
                      "python_ctypes_loop_cycles_per_s": fleet_value(n_gpus, args.steps, t_py)}
+        # the same cycle with its results delivered to host containers every cycle (cells of every new cluster,
+        # cost + gradient of every candidate): what a drop-in caller receives, beside the device-resident `value`
+        if not args.serial_stages:
+            dsec = [0.0, 0.0, 0.0]
+
+            def _deliv():
+                dsec[:] = run_delivered(cyc, args.steps)
+            t_d = timed_fleet_run(_deliv, cyc.finish, 1, dist, torch.cuda.synchronize)
+            host_delivery = {"cycles_per_s": fleet_value(n_gpus, args.steps, t_d),
+                             "ms_per_step": 1e3 * t_d / args.steps,
+                             "cells_d2h_ms": 1e3 * dsec[1] / args.steps, "cost_grad_d2h_ms": 1e3 * dsec[2] / args.steps,
+                             "delivered": "cell lists of all new clusters (int32 addresses) + %d x %d cost/gradient doubles, "
+                                          "every cycle" % (ctrl.shape[0], ctrl.shape[1] * 3 + 1)}
     dom_ms = dom_total_ms / max(n_launch, 1)  # mean over the timed region, as the contract asks
 
     if rank == 0:
@@ -619,16 +698,18 @@ def main():
         achieved = alg_bytes[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes,
         # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/), else null
-        traffic = None
+        traffic, traffic_commit = None, None
         try:
-            pmc_file = {"G400": "r02_pmc_hbm_traffic_G400.json", "G800": "r02_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
+            pmc_file = {"G400": "r03_pmc_hbm_traffic_G400.json", "G800": "r03_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
+            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            pmc = pmc_doc["kernels"]
+            traffic_commit = pmc_doc.get("commit")
             key = {"esdf_zy": "k_esdf_zy4<", "esdf_x": "k_esdf_x4", "inflate": "k_inflate_yz",
                    "bspline": "k_bspline_cost_grad"}[dominant]
             hit = [v for k, v in pmc.items() if key in k]
             traffic = hit[0]["hbm_bytes_per_launch"]
         except Exception:
-            traffic = None
+            traffic, traffic_commit = None, None
         # The timed cycle overlaps the ESDF chain (map stream) with the frontier chain (own stream), so the
         # dominant kernel shares the CUs while it runs.  A short untimed pass with the two chains
         # serialised gives its duration in isolation (the number a kernel-level roofline usually quotes).
@@ -654,12 +735,15 @@ def main():
                                     "exploration-box frontier search, %d B-spline candidates x 32 ctrl pts"
                                     % (args.workload, nv[0], nv[1], nv[2], ctrl.shape[0])),
                        "known_voxels": int(n_known), "frontier_clusters": int(cyc.n_clusters),
+                       "reference_order": args.reference_order,
                        "parallelism": "independent map per GPU (no collective)"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_isolated": {k: round(v, 4) for k, v in iso_ms_all.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes[dominant]},
+                         "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes[dominant],
+                         # git revision the counter pass behind `traffic` was taken at (profiles/*.json carry it)
+                         "traffic_commit": traffic_commit},
         }
         # whole-cycle figure: compulsory bytes of all stages (frontier: 4 planes of the search box in, 3 out,
         # plus ~40 B per frontier cell) x cycles/s against the HBM peak
@@ -672,8 +756,8 @@ def main():
         map_chain_ms = stage_ms["inflate"] + stage_ms["esdf_zy"] + stage_ms["esdf_x"] + stage_ms["bspline"]
         map_chain_bytes = alg_bytes["inflate"] + alg_bytes["esdf_zy"] + alg_bytes["esdf_x"] + alg_bytes["bspline"]
         if stage_ms["frontier"] >= map_chain_ms:
-            crit = {"stage": "frontier chain (predicate, compaction, tile CCL, cross-tile join, resolve, flags, scatter)",
-                    "kernels": 8, "algorithmic_bytes": fr_bytes, "ms": stage_ms["frontier"]}
+            crit = {"stage": "frontier chain (predicate, tile CCL, cross-tile pairs, resolve, grouped output)",
+                    "kernels": 5, "algorithmic_bytes": fr_bytes, "ms": stage_ms["frontier"]}
         else:
             crit = {"stage": "map chain (inflate x3, ESDF z/y, ESDF x, B-spline batch)", "kernels": 6,
                     "algorithmic_bytes": map_chain_bytes, "ms": map_chain_ms}
@@ -683,6 +767,10 @@ def main():
         out["roofline"]["critical"] = crit
         if host_loop is not None:
             out["host_loop"] = host_loop
+        if host_delivery is not None:
+            out["host_delivery"] = host_delivery
+        if streaming:
+            out["value_inputs"] = "device-resident depth frames (in HBM before the timed region; see frame_source)"
         if frame_source is not None:
             out["frame_source"] = frame_source
         out["frontier_path"] = dict(zip(("fast", "legacy", "fallback"), cyc.ff.stats()))

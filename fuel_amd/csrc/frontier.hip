@@ -3333,7 +3333,10 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   u32 ncl = nkept, ncells = n_out;
   std::vector<std::vector<float>> filtered;
   const bool split_mode = f->cfg.split != 0;
-  const bool ref_order = f->cfg.reference_order != 0;
+  // reference_order 1: always; 2 ("auto", the facade's default): whenever the search kept at most FR_REFORDER_AUTO
+  // cells -- every incremental search of an exploration run -- and the canonical order for the giant ones
+  const bool ref_order = f->cfg.reference_order == 1 || (f->cfg.reference_order == 2 && n_out <= FR_REFORDER_AUTO);
+  f->ref_now = ref_order;
   int fin = nkept <= 256 ? 1 : 0;  // buffer pair holding the grouped cells of the search
   std::vector<u32> off2;
   u32 n_in = n_out;
@@ -3597,6 +3600,57 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   HIPCHK(stream_wait(f->stream));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *n_clusters = ncl;
+  return FUELMI_OK;
+}
+
+// The same cycle with its results DELIVERED to the host containers the reference's callers read
+// (fast_exploration_manager.cpp:99-114: the cluster cell lists of searchFrontiers; planner_manager.cpp:296-314: the
+// cost and gradient of every candidate): after every search the cells of all new clusters are copied into
+// cells_out (cluster after cluster, as many as fit), after every evaluation cost[C] / grad[C * nvar] are downloaded.
+// seconds3: [0] elapsed wall time, [1] of it in the cell copies, [2] in the cost / gradient download.
+extern "C" int fuelmi_bench_cycles_delivered(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch,
+                                             const double ub_min[3], const double ub_max[3], int n, int* cells_out,
+                                             size_t cells_cap, double* cost, double* grad, int* n_clusters,
+                                             double* seconds3) {
+  ARGCHK(m && f && ub_min && ub_max && n >= 0 && n_clusters && seconds3 && cells_out && f->map == m);
+  ARGCHK(!batch || (cost && grad));
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  int rc = FUELMI_OK, ncl = 0;
+  double t_cells = 0.0, t_cg = 0.0;
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
+    if ((rc = fuelmi_frontier_reset(f))) break;
+    if ((rc = fuelmi_map_set_updated_box(m, ub_min, ub_max))) break;
+    if ((rc = fuelmi_frontier_search_begin(f))) break;
+    if ((rc = fuelmi_map_inflate_local(m))) break;
+    if ((rc = fuelmi_map_update_esdf(m))) break;
+    if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
+    if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
+    const auto ta = clk::now();
+    size_t at = 0;
+    for (int c = 0; c < ncl && rc == FUELMI_OK; ++c) {
+      const int sz = fuelmi_frontier_cluster_size(f, 0, c);
+      if (sz < 0 || at + (size_t)sz > cells_cap) break;
+      rc = fuelmi_frontier_cluster_cells(f, 0, c, cells_out + at);
+      at += (size_t)sz;
+    }
+    const auto tb = clk::now();
+    if (rc == FUELMI_OK && batch) rc = fuelmi_bspline_dev_download(batch, cost, grad);
+    const auto tc = clk::now();
+    t_cells += std::chrono::duration<double>(tb - ta).count();
+    t_cg += std::chrono::duration<double>(tc - tb).count();
+  }
+  if (rc) return rc;
+  HIPCHK(stream_wait(m->stream));
+  HIPCHK(stream_wait(f->stream));
+  f->tail_pending = false;
+  seconds3[0] = std::chrono::duration<double>(clk::now() - t0).count();
+  seconds3[1] = t_cells;
+  seconds3[2] = t_cg;
   *n_clusters = ncl;
   return FUELMI_OK;
 }

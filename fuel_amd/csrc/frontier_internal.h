@@ -61,6 +61,7 @@ struct FVar {
 #define FR_KCAP 256             // kept clusters
 #define FR_PCAP (1u << 18)      // cross-tile adjacency records
 #define FR_PMCAP 16384          // entries of the (kept cluster x tile column) matrix k_resolve scans in its LDS
+#define FR_REFORDER_AUTO 32768u   // cfg.reference_order == 2: searches that keep at most this many cells use the reference's order
 #define FR_UNCLAIMED 0xFFFFFFFFu  // rcode: component claimed by nobody (no flag, no cluster)
 #define FR_NOTKEPT 0xFFFFFFFEu    // rcode: claimed (flag set) but its cluster is too small
 struct TRec {  // one tile-local component
@@ -227,6 +228,7 @@ struct fuelmi_frontier {
   size_t ccl_lds = 0;
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
   bool pending = false, search_empty = false;
+  bool ref_now = false;  // the search being collected delivers its cells in the reference's order (cfg.reference_order 1, or 2 and small)
   // fast path: _search_end returns as soon as the cluster records have arrived; the kernels that regroup the
   // cells and ship them to the host are still running then.  Everything that reads the cell lists waits here.
   mutable bool cells_fetch = false;  // the grouped cells of the last search are still only on the device

@@ -619,7 +619,7 @@ int frontier_split_run(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin
   }
   // NQ seeds that started a kept cluster are not in the grouped Q0 array: append them (in reference order
   // they already lead their cluster in the input)
-  const bool ref = f->cfg.reference_order != 0;
+  const bool ref = f->ref_now;  // (the order this search's cells arrive in: cfg.reference_order, resolved per search)
   std::vector<u32> seeds;
   for (u32 r = 0; r < nkept && !ref; ++r)
     if (F.h_rec[r].slot >= nq) {

@@ -290,7 +290,7 @@ class FrontierFinder:
         default: ascending voxel address, order-free means)."""
         self.L = lib()
         self.map = edt_or_map.sdf_map_ if isinstance(edt_or_map, EDTEnvironment) else edt_or_map
-        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split), int(reference_order))
+        cfg = FrontierCfg(cluster_min, min_z, cluster_size_xy, down_sample, int(split), int(reference_order))  # (True -> 1; pass 2 for "auto")
         h = C.c_void_p()
         check(self.L.fuelmi_frontier_create(self.map.h, C.byref(cfg), C.byref(h)))
         self.h = h

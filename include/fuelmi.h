@@ -179,7 +179,10 @@ typedef struct {
                              neighbour order :848-860), average_ as its sequential f64 sum (:374-390), VoxelGrid
                              centroids accumulated in that order (:757-774) -- so that means, filtered_cells_,
                              split pieces and viewpoints reproduce the reference bit for bit; costs one BFS
-                             level sweep per cluster on the device and host-side means */
+                             level sweep per cluster on the device and host-side means.  2 ("auto", what the C++
+                             facade uses unless told otherwise): the reference's order for every search that keeps
+                             at most 32768 cells -- the incremental searches of an exploration run -- and the
+                             address order only for giant full-box searches, where the sweep costs milliseconds */
 } fuelmi_frontier_cfg;
 
 typedef struct fuelmi_frontier fuelmi_frontier;
@@ -361,6 +364,14 @@ int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* b
                         int serial, int* n_clusters, double* box_voxels, double* seconds);
 int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, const double ub_min[3],
                         const double ub_max[3], int n, int serial, int* n_clusters, double* seconds);
+/* fuelmi_bench_cycles with the results delivered to host memory every cycle, as the reference's callers receive
+ * them (exploration_manager/src/fast_exploration_manager.cpp:99-114 reads the cell lists of searchFrontiers,
+ * plan_manage/src/planner_manager.cpp:296-314 the optimiser's cost / gradient): cells of all new clusters into
+ * cells_out (as many clusters as fit cells_cap), cost[C] and grad[C * nvar] of the batch.  seconds3: [0] elapsed,
+ * [1] spent in the cell copies, [2] in the cost / gradient download. */
+int fuelmi_bench_cycles_delivered(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, const double ub_min[3],
+                                  const double ub_max[3], int n, int* cells_out, size_t cells_cap, double* cost,
+                                  double* grad, int* n_clusters, double* seconds3);
 int fuelmi_bspline_dev_load_samples(fuelmi_bspline_dev* b, int n_points, const double* ts, const double* points,
                                     const double* derivs);
 

@@ -66,3 +66,14 @@ def test_workload_table_matches_baseline_configs():
     assert bench.WORKLOADS["G800"][0] == (80.0, 80.0, 20.0)
     lo, hi = bench.exploration_box((40.0, 40.0, 10.0))
     assert lo == (-19.0, -19.0, 0.0) and hi == (19.0, 19.0, 7.0)
+
+
+def test_bench_gpus_flag_refuses_to_run_one_gpu_silently():
+    """`python bench.py --gpus N` launches its own N ranks; with fewer devices than ranks (none here) it must say so
+    instead of quietly measuring one GPU (--gpus was parsed and ignored)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FUELMI_FLEET_SHARE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in (r.stderr + r.stdout) and "device" in (r.stderr + r.stdout)

@@ -180,3 +180,30 @@ def test_map_destroyed_before_its_finder_and_batch():
     cyc.map.close()           # first the map ...
     cyc.ff.close()            # ... then its finder
     cyc.dev_problem.close()   # ... and the B-spline batch
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` on its own (no torchrun around it) launches two ranks and prints ONE line with
+    n_gpus = 2.  On a one-GPU box the ranks share the device (FUELMI_FLEET_SHARE_DEVICE=1, rendezvous over gloo);
+    the aggregate must be in the range of what two maps sharing a device reach as threads."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FUELMI_FLEET_SHARE_DEVICE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--workload", MAP, "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["scaling"] == "weak"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--workload", MAP,
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert single["n_gpus"] == 1
+    # two ranks on ONE device: the whole-job figure is the sum over ranks -- somewhere between half and twice the
+    # single-map rate (they share the GPU); what matters is that it IS a two-rank aggregate
+    assert 0.5 * single["value"] <= out["value"] <= 2.5 * single["value"], (out["value"], single["value"])
+    print("bench --gpus 2 on one device: %.0f cycles/s vs %.0f for one rank" % (out["value"], single["value"]))
