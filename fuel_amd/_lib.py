@@ -175,6 +175,7 @@ SYMBOLS = {
     "fuelmi_bspline_dev_eval": (C.c_int, [_P]),
     "fuelmi_bspline_dev_download": (C.c_int, [_P, _dp, _dp]),
     "fuelmi_bspline_dev_optimize": (C.c_int, [_P, C.c_int, _dp, _dp, C.POINTER(C.c_int)]),
+    "fuelmi_bspline_dev_optimize_timed": (C.c_int, [_P, C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_int)]),
     "fuelmi_bspline_dev_destroy": (None, [_P]),
     "fuelmi_bspline_parameterize": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "fuelmi_bspline_boundary_states": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),

@@ -339,6 +339,7 @@ k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
 // ---------------------------------------------------------------------------------------------
 struct LbfgsArgs {
   int max_eval;
+  unsigned long long max_ticks;  // wall-clock budget of the solve in 100 MHz ticks (0: none) -- NLopt's set_maxtime
   double box_lo[3], box_hi[3];  // exploration box shrunk by 0.1 (:174-178)
   double* x_out;                // [C][nvar] best variables
   double* cost_out;             // [C]
@@ -390,11 +391,15 @@ k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsAr
     return v;
   };
   int evals = 0;
+  // the time cap is checked like NLopt does, between evaluations; the best variables seen so far are what comes back
+  // (costFunction's best_variable_, bspline_optimizer.cpp:693-707).  wall_clock64 is the 100 MHz constant clock.
+  const unsigned long long t_begin = wall_clock64();
+  auto out_of_time = [&]() { return L.max_ticks != 0ull && wall_clock64() - t_begin > L.max_ticks; };
   double f = bspline_eval(g, dist, A, c, q, gq, smem_raw);
   ++evals;
   double fbest = f;
   int hist = 0, head = 0;  // number of stored pairs, slot of the oldest
-  while (evals < L.max_eval) {
+  while (evals < L.max_eval && !out_of_time()) {
     // projected steepest-descent seed, then the two-loop recursion
     for (int i = lane; i < n; i += 64) {
       const double sv = start_val(i), lo = lb_of(i, sv), hi = ub_of(i, sv);
@@ -433,7 +438,7 @@ k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsAr
     }
     double step = hist == 0 ? 1.0 / fmax(1.0, sqrt(-gd)) : 1.0, fn = f;
     bool ok = false;
-    for (int ls = 0; ls < 20 && evals < L.max_eval; ++ls) {
+    for (int ls = 0; ls < 20 && evals < L.max_eval && !out_of_time(); ++ls) {
       for (int i = lane; i < n; i += 64) {
         const double sv = start_val(i);
         xn[i] = fmin(fmax(q[i] + step * d[i], lb_of(i, sv)), ub_of(i, sv));
@@ -557,11 +562,15 @@ k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, Lbfgs
 #pragma unroll
   for (int k = 0; k < LBFGS_MEM; ++k) rho[k] = al[k] = 0.0;
   int evals = 0;
+  // the time cap is checked like NLopt does, between evaluations; the best variables seen so far are what comes back
+  // (costFunction's best_variable_, bspline_optimizer.cpp:693-707).  wall_clock64 is the 100 MHz constant clock.
+  const unsigned long long t_begin = wall_clock64();
+  auto out_of_time = [&]() { return L.max_ticks != 0ull && wall_clock64() - t_begin > L.max_ticks; };
   double f = reg_objective<NPL>(g, dist, A, c, xs, gs, smem_raw, on, q, gq);
   ++evals;
   double fbest = f;
   int hist = 0;  // stored pairs, slot 0 the oldest
-  while (evals < L.max_eval) {
+  while (evals < L.max_eval && !out_of_time()) {
 #pragma unroll
     for (int e = 0; e < NPL; ++e) {
       const bool at_lb = q[e] <= lo[e] && gq[e] > 0, at_ub = q[e] >= hi[e] && gq[e] < 0;
@@ -601,7 +610,7 @@ k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, Lbfgs
     }
     double step = hist == 0 ? 1.0 / fmax(1.0, sqrt(-gd)) : 1.0, fn = f;
     bool ok = false;
-    for (int ls = 0; ls < 20 && evals < L.max_eval; ++ls) {
+    for (int ls = 0; ls < 20 && evals < L.max_eval && !out_of_time(); ++ls) {
 #pragma unroll
       for (int e = 0; e < NPL; ++e) xn[e] = on[e] ? fmin(fmax(q[e] + step * d[e], lo[e]), hi[e]) : 0.0;
       fn = reg_objective<NPL>(g, dist, A, c, xs, gs, smem_raw, on, xn, gn);
@@ -906,6 +915,7 @@ extern "C" void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b) {
   (void)hipSetDevice(b->device);
   if (b->map) {
     (void)hipStreamSynchronize(b->map->stream);
+    std::lock_guard<std::mutex> lk(b->map->dep_mu);
     auto& deps = b->map->dependents;
     for (size_t k = 0; k < deps.size(); ++k)
       if (deps[k].obj == b) {
@@ -996,7 +1006,10 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_cost_grad),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds));
   }
-  m->dependents.push_back({b, &bspline_dev_orphan});
+  {
+    std::lock_guard<std::mutex> lk(m->dep_mu);
+    m->dependents.push_back({b, &bspline_dev_orphan});
+  }
   *out = b;
   return FUELMI_OK;
 }
@@ -1014,6 +1027,10 @@ extern "C" int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b) {
 // objective evaluations per candidate
 extern "C" int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, double* x_out, double* cost_out,
                                            int* evals_out) {
+  return fuelmi_bspline_dev_optimize_timed(b, max_eval, -1.0, x_out, cost_out, evals_out);
+}
+extern "C" int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_eval, double max_time_s, double* x_out,
+                                                 double* cost_out, int* evals_out) {
   ARGCHK(b && max_eval >= 1 && x_out && cost_out);
   fuelmi_map* m = b->map;
   HIPCHK(hipSetDevice(m->device));
@@ -1044,6 +1061,7 @@ extern "C" int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, 
   }
   LbfgsArgs L;
   L.max_eval = max_eval;
+  L.max_ticks = max_time_s > 0.0 ? (unsigned long long)(max_time_s * 1e8) + 1ull : 0ull;
   for (int k = 0; k < 3; ++k) {  // getBox(bmin, bmax); bmin += 0.1; bmax -= 0.1  (:174-178)
     L.box_lo[k] = m->cfg.box_min[k] + 0.1;
     L.box_hi[k] = m->cfg.box_max[k] - 0.1;

@@ -256,6 +256,7 @@ __device__ __forceinline__ int line_src_up(const u64* __restrict__ infl, const u
 // the half-explored regime keeps the plain kernels.
 // ------------------------------------------------------------------------------------------------
 #define ESDF_FAR_D 8u  // statistic: an output counts as "far from sources" beyond this many voxels
+#define ESDF_NG 256    // groups of 16 x-slabs the statistic is kept for (maps wider than 4096 voxels share groups)
 static bool zy_fastrow() {  // rows of the fused z/y pass that need no sweep (all sources / no source): measured
   static const char* e = getenv("FUELMI_ZY_FASTROW");  // 400^2 x 100: 38.8 -> 37.2 us, 800^2 x 200: 188 -> 172 us
   static const bool v = e ? atoi(e) != 0 : true;
@@ -579,7 +580,7 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   const int dyi = T / G, dgi = T - dyi * G;
   // every 16th slab reports how many of its outputs are further than ESDF_FAR_D voxels from every source: the
   // host picks the FAR or the plain kernels for the NEXT update from that (esdf_update)
-  const bool sampled = stat != nullptr && (xrel & 15) == 0;
+  const bool sampled = stat != nullptr && ((x & 15) == 0 || xrel == 0);  // (absolute slabs: the statistic is kept per place)
   int n_far = 0;
   const bool z_aligned = (b.lo[2] & 3) == 0 && (b.hi[2] & 3) == 3;
   int yi = threadIdx.x / G, gi = threadIdx.x - yi * G;
@@ -608,22 +609,40 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
     }
   }
   if (sampled && (threadIdx.x & 63) == 0) {
-    atomicAdd(stat, (u32)n_far);
-    if (threadIdx.x == 0) atomicAdd(stat + 1, (u32)total);
+    u32* sg = stat + 2 * ((x >> 4) & (ESDF_NG - 1));  // group of 16 slabs this one stands for
+    atomicAdd(sg, (u32)n_far);
+    if (threadIdx.x == 0) atomicAdd(sg + 1, (u32)total);
   }
 }
 
-// The y pass of this update has counted its far outputs in stat[0..1] (device); the first workgroup of the x pass
-// hands the pair to the host (pinned, no synchronisation: esdf_update reads whatever has landed) and clears it.
-__device__ __forceinline__ void forward_stat(u32* stat, volatile u32* h_stat) {
-  if (stat != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    const u32 nf = stat[0], nt = stat[1];
-    stat[0] = 0u;
-    stat[1] = 0u;
-    if (nt) {
-      h_stat[0] = nf;
-      h_stat[1] = nt;
+// The y pass of this update has counted its far outputs per group of 16 x-slabs (stat[2 g], stat[2 g + 1]: far
+// outputs, outputs of the sampled slab); the first workgroup of the x pass hands the table to the host through
+// pinned memory and clears it.  No fence, no synchronisation (a system-scope release here makes this workgroup write
+// the L2 back while the rest of the kernel fills it: the pass went from 35 to 90 us): the table carries an epoch in
+// front and a checksum behind, the host only uses a copy whose checksum fits (esdf_use_far) and otherwise keeps what
+// it knew -- the statistic picks a kernel family, it never changes a result.
+__device__ __forceinline__ void forward_stat(u32* stat, volatile u32* h_stat_v) {
+  if (stat == nullptr || blockIdx.x != 0) return;
+  u32* h_stat = const_cast<u32*>(h_stat_v);  // (plain posted stores: nothing here waits for them)
+  __shared__ u32 s_sum;
+  if (threadIdx.x == 0) s_sum = 0u;
+  __syncthreads();
+  u32 part = 0u;
+  for (int g = threadIdx.x; g < ESDF_NG; g += blockDim.x) {
+    const uint2 p = *reinterpret_cast<const uint2*>(stat + 2 * g);  // (far outputs, outputs of the sampled slab)
+    if (p.y) {  // only the groups this update sampled cross the bus; the host keeps the others
+      *reinterpret_cast<uint2*>(h_stat + 2 * g) = p;
+      *reinterpret_cast<uint2*>(stat + 2 * g) = make_uint2(0u, 0u);
+      part += p.x * 31u + p.y + (u32)g * 0x10001u;
     }
+  }
+  if (part) atomicAdd(&s_sum, part);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 e = stat[2 * ESDF_NG] + 1u;
+    stat[2 * ESDF_NG] = e;
+    h_stat[2 * ESDF_NG] = e;
+    h_stat[2 * ESDF_NG + 1] = s_sum + e * 0x9E3779B9u;
   }
 }
 
@@ -832,13 +851,13 @@ k_esdf_x4h(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist,
   }
 }
 
-// the device and the pinned-host slots of the far-output statistic (the insert stage's little blocks have room)
+// the device and the pinned-host tables of the far-output statistic
 template <int OUT>
 static u32* esdf_stat_dev(fuelmi_map* m) {
   static const bool off = getenv("FUELMI_ESDF_NOSTAT") != nullptr;
-  return OUT == 0 && !off ? reinterpret_cast<u32*>(m->ins_head + 8) : nullptr;
+  return OUT == 0 && !off ? m->esdf_stat : nullptr;
 }
-static volatile u32* esdf_stat_host(fuelmi_map* m) { return reinterpret_cast<volatile u32*>(m->h_ins + 8); }
+static volatile u32* esdf_stat_host(fuelmi_map* m) { return m->h_esdf_stat; }
 
 template <int OUT, int P, bool FAR>
 static int launch_x4p_n(fuelmi_map* m, const Box3& b) {
@@ -899,6 +918,7 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   static const char* pad = getenv("FUELMI_ZY_LDS_PAD_KB");  // tuning: fewer workgroups per CU
   if (pad) lds += (size_t)atoi(pad) * 1024;
   if (lds > 160 * 1024) {
+    if (FAR) return -1;  // (the far-field tables do not fit beside the tile: the caller takes the plain kernel)
     fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
     return FUELMI_ELIMIT;
   }
@@ -907,7 +927,7 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   STAGE_LAUNCH(m, (k_esdf_zy4<MODE, FAR>), ((xlen + 7) / 8) * 8 * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
                m->esdf_tmp, ZC, nzc, z0a, esdf_near() | (zy_fastrow() ? 256 : 0),
-               MODE == 2 ? nullptr : reinterpret_cast<u32*>(m->ins_head + 8));
+               MODE == 2 ? nullptr : esdf_stat_dev<0>(m));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -990,7 +1010,10 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
 
 template <int MODE, bool FAR>
 static int launch_zy(fuelmi_map* m, const Box3& b) {
-  if (use_vec4(m->g, b.hi[0] - b.lo[0] + 1)) return launch_zy4<MODE, FAR>(m, b);
+  if (use_vec4(m->g, b.hi[0] - b.lo[0] + 1)) {
+    const int rc = launch_zy4<MODE, FAR>(m, b);
+    return (FAR && rc < 0) ? launch_zy4<MODE, false>(m, b) : rc;
+  }
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
   // z-chunk: LDS tile <= 16 KiB so several WGs share a CU, chunks balanced over the z extent
@@ -1039,22 +1062,52 @@ static int launch_x(fuelmi_map* m, const Box3& b) {
   return FUELMI_ELIMIT;
 }
 
-// Which kernels: the y pass of every update counts (on every 16th slab) the outputs further than ESDF_FAR_D voxels
-// from all sources, the x pass hands the count to the host.  When most outputs were far LAST time -- an explored
-// hall, optimistic_ maps -- this update runs the FAR kernels (block / line minima bound the scan), otherwise the
-// plain ones, which cost nothing extra in the half-explored maps exploration spends its time in.  Both are exact;
-// FUELMI_ESDF_FAR=0/1 pins the choice.
-static bool esdf_use_far(fuelmi_map* m) {
+// Which kernels: the y pass of every update counts, on one slab of every group of 16, the outputs further than
+// ESDF_FAR_D voxels from all sources; the x pass hands the counts to the host.  The host keeps the latest pair of
+// every group -- a statistic per PLACE, not "of the previous update" -- and an update runs the FAR kernels (block /
+// line minima bound the scan) when most outputs of the slabs it covers were far the last time they were updated:
+// an explored hall, optimistic_ maps.  A local bound that alternates between a hall and a fresh frustum therefore
+// gets the right kernels for both from the second visit on; places never seen follow the last decision.  Both
+// families are exact; FUELMI_ESDF_FAR=0/1 pins the choice.
+static bool esdf_use_far(fuelmi_map* m, const Box3& b) {
   const char* e = getenv("FUELMI_ESDF_FAR");  // (read per update: the parity tests flip it between calls)
   if (e && *e) return atoi(e) != 0;
   const volatile u32* h = esdf_stat_host(m);
-  const u32 nf = h[0], nt = h[1];
-  return nt != 0u && 2ull * nf > nt;
+  const u32 e1 = h[2 * ESDF_NG];
+  if (e1 != m->far_epoch_seen) {
+    // the groups the update behind epoch e1 sampled are the ones whose pairs changed since the copy the host holds
+    // (h_copy): the checksum covers exactly those
+    u32 tmp[2 * ESDF_NG];
+    u32 sum = 0u;
+    for (int g = 0; g < ESDF_NG; ++g) {
+      tmp[2 * g] = h[2 * g], tmp[2 * g + 1] = h[2 * g + 1];
+      if (tmp[2 * g + 1]) sum += tmp[2 * g] * 31u + tmp[2 * g + 1] + (u32)g * 0x10001u;
+    }
+    // (a mismatch means the table is still landing -- look again at the next update; a table that never fits, because
+    // an earlier one was skipped and left its marks behind, is taken as it is at the third look: it only picks kernels)
+    const bool fits = h[2 * ESDF_NG] == e1 && h[2 * ESDF_NG + 1] == sum + e1 * 0x9E3779B9u;
+    m->far_retry = (fits || e1 != m->far_epoch_tried) ? 0 : m->far_retry + 1;
+    m->far_epoch_tried = e1;
+    if (fits || m->far_retry >= 2) {
+      for (int g = 0; g < ESDF_NG; ++g)
+        if (tmp[2 * g + 1]) m->far_hist[g][0] = tmp[2 * g], m->far_hist[g][1] = tmp[2 * g + 1];
+      m->far_epoch_seen = e1;
+      volatile u32* hw = const_cast<volatile u32*>(h);
+      for (int g = 0; g < ESDF_NG; ++g) hw[2 * g + 1] = 0u;  // consumed (the next table marks its own groups)
+    }
+  }
+  unsigned long long nf = 0, nt = 0;
+  for (int g = b.lo[0] >> 4; g <= (b.hi[0] >> 4); ++g) nf += m->far_hist[g & (ESDF_NG - 1)][0], nt += m->far_hist[g & (ESDF_NG - 1)][1];
+  if (nt != 0) m->far_last = 2 * nf > nt;
+  static const bool dbg = getenv("FUELMI_ESDF_DEBUG") != nullptr;
+  if (dbg) std::fprintf(stderr, "[fuelmi] esdf regime: epoch %u (seen %u) far %llu of %llu sampled outputs -> %s kernels\n", e1,
+                        m->far_epoch_seen, nf, nt, m->far_last ? "far-field" : "plain");
+  return m->far_last;
 }
 
 int esdf_update(fuelmi_map* m) {
   const Box3& b = m->local_bound;
-  const bool far = esdf_use_far(m);
+  const bool far = esdf_use_far(m, b);
   int rc;
   {
     StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);

@@ -33,6 +33,14 @@
 #include "frontier_internal.h"
 
 // FUELMI_DEBUG_SYNC=1: synchronise and name every frontier kernel (locates device faults)
+// a finder whose map was destroyed first (garbage collectors and destructor orders do that) only accepts _destroy
+#define FRONTIER_HAS_MAP(f)                                                                        \
+  do {                                                                                             \
+    if (!(f)->map) {                                                                               \
+      fuelmi_set_error("the map of this frontier finder has been destroyed: only fuelmi_frontier_destroy is legal"); \
+      return FUELMI_EINVAL;                                                                        \
+    }                                                                                              \
+  } while (0)
 #define FDBG(name)                                                                     \
   do {                                                                                 \
     static const bool on__ = getenv("FUELMI_DEBUG_SYNC") != nullptr;                   \
@@ -2432,6 +2440,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   (void)hipSetDevice(f->device);
   if (f->map) {
     (void)hipStreamSynchronize(f->map->stream);
+    std::lock_guard<std::mutex> lk(f->map->dep_mu);
     auto& deps = f->map->dependents;
     for (size_t k = 0; k < deps.size(); ++k)
       if (deps[k].obj == f) {
@@ -2656,7 +2665,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   // (a thread of the tile kernels fetches at most FT_PER segments: z-lines of up to 256 voxels with the largest tile)
   f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && std::max(f->tile_lds[0], f->out_lds[0]) <= 150 * 1024 &&
                f->fast_items[0] <= (size_t)FT_PER * 512 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
-  m->dependents.push_back({f, &frontier_orphan});
+  {
+    std::lock_guard<std::mutex> lk(m->dep_mu);
+    m->dependents.push_back({f, &frontier_orphan});
+  }
   *out = f;
   return FUELMI_OK;
 }
@@ -2954,6 +2966,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
 // ESDF, B-spline evaluation on the map's stream) before collecting the result with _search_end.
 extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   ARGCHK(f);
+  FRONTIER_HAS_MAP(f);
   FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_search_begin");
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
@@ -3143,6 +3156,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
 extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   ARGCHK(f && n_new);
   *n_new = 0;
+  FRONTIER_HAS_MAP(f);
   if (!f->pending) {
     fuelmi_set_error("fuelmi_frontier_search_end without a matching _begin");
     return FUELMI_EINVAL;
@@ -3456,7 +3470,8 @@ extern "C" int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new) {
 
 extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
   ARGCHK(f);
-  HIPCHK(hipSetDevice(f->map->device));
+  FRONTIER_HAS_MAP(f);
+  HIPCHK(hipSetDevice(f->device));
   f->tail_pending = false;
   HIPCHK(stream_wait(f->stream));
   return FUELMI_OK;
@@ -3469,6 +3484,7 @@ extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
 
 extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   ARGCHK(f);
+  FRONTIER_HAS_MAP(f);
   FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_reset");
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
@@ -3484,6 +3500,7 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
 
 extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
   ARGCHK(f);
+  FRONTIER_HAS_MAP(f);
   FRONTIER_NOT_SEARCHING(f, "fuelmi_frontier_commit");
   auto& dst = dormant ? f->dormant : f->frontiers;
   HIPCHK(hipSetDevice(f->map->device));
@@ -3555,6 +3572,7 @@ extern "C" int fuelmi_frontier_removed_ids(const fuelmi_frontier* f, int* ids) {
 }
 extern "C" int fuelmi_frontier_get_flags(fuelmi_frontier* f, char* flags) {
   ARGCHK(f && flags);
+  FRONTIER_HAS_MAP(f);
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
   long n = m->g.N;

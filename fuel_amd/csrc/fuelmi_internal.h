@@ -96,12 +96,21 @@ struct fuelmi_map {
     void (*orphan)(void*);
   };
   std::vector<Dependent> dependents;
+  std::mutex dep_mu;  // finders / batches of a fleet are created and destroyed from different threads
   void* ins_rec = nullptr;      // per-slot records of the fusion's classify kernel (32 B each)
   size_t ins_rec_cap = 0;
   u64* ins_head = nullptr;      // [16] device; [8] = the ESDF far-output statistic (two u32, esdf.hip); [0..7]: [6] = points projected by the depth front end of the current frame
   u64* h_ins = nullptr;         // [16] pinned; [8] = the ESDF statistic as the x pass handed it over; [0..7]: end-point box [0..5], projected points [6], frame stamp [7] -- written
                                 // by the fusion's second kernel, polled by the host (no blocking stream sync)
   u64 ins_epoch = 0;
+  // ESDF far-output statistic (esdf.hip): device table [2 * 256 + 1] (pairs per group of 16 x-slabs, epoch), its
+  // pinned copy, and the host's latest pair of every group
+  u32* esdf_stat = nullptr;
+  u32* h_esdf_stat = nullptr;
+  u32 far_hist[256][2] = {};
+  u32 far_epoch_seen = 0, far_epoch_tried = 0;
+  int far_retry = 0;
+  bool far_last = false;
   signed char raycast_num = 0;
   unsigned occ_epoch = 0;  // bumped by occupancy changes that bypass the updated box (upload, resetBuffer)
 

@@ -661,17 +661,23 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
   // hipHostRegister, fuelmi_host_register) -- is read where it lies: no staging copy, and for device memory no
   // PCIe traffic inside the cycle either.  The caller keeps it unchanged until the next call on this map.
   const unsigned short* direct = nullptr;
+  bool foreign = false;  // device memory of ANOTHER GPU (a fleet in one process): copied, never dereferenced here
   {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, depth) == hipSuccess &&
         (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged) &&
-        at.devicePointer)
-      direct = reinterpret_cast<const unsigned short*>(at.devicePointer);
-    else
+        at.devicePointer) {
+      if (at.type == hipMemoryTypeDevice && at.device != m->device)
+        foreign = true;
+      else
+        direct = reinterpret_cast<const unsigned short*>(at.devicePointer);
+    } else
       (void)hipGetLastError();  // ordinary pageable memory (a cv::Mat): not an error
   }
   static const bool zero_copy = getenv("FUELMI_DEPTH_H2D") == nullptr;
-  if (!direct) {
+  if (foreign) {
+    HIPCHK(hipMemcpyAsync(d_img, depth, (size_t)rows * cols * 2, hipMemcpyDefault, m->stream));
+  } else if (!direct) {
     // (every user of the pinned staging buffer synchronises before it returns, so it is free here)
     memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
     // the fusion kernels read the (pinned) staged image over PCIe themselves -- ~0.6 MB per 640 x 480 frame, read
@@ -680,7 +686,7 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
       HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
   }
   DepthArgs D;
-  D.img = direct ? direct : ((zero_copy && !launch) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img);
+  D.img = direct ? direct : ((zero_copy && !launch && !foreign) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img);
   D.rows = rows, D.cols = cols, D.margin = margin, D.skip = skip, D.nu = nu, D.nslots = nslots;
   D.fx = c->fx, D.fy = c->fy, D.cx = c->cx, D.cy = c->cy;
   D.maxdist = c->depth_filter_maxdist, D.mindist = c->depth_filter_mindist;
@@ -785,35 +791,36 @@ extern "C" int fuelmi_hbm_triad(int device, size_t bytes, int reps, double* gb_p
   *gb_per_s = 0.0;
   HIPCHK(hipSetDevice(device));
   bytes &= ~(size_t)15;
-  float4 *a = nullptr, *b = nullptr, *c = nullptr;
-  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&c, bytes) != hipSuccess) {
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
+  struct Scratch {  // released on every way out
+    float4 *a = nullptr, *b = nullptr, *c = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      for (float4* p : {a, b, c})
+        if (p) (void)hipFree(p);
+    }
+  } S;
+  if (hipMalloc(&S.a, bytes) != hipSuccess || hipMalloc(&S.b, bytes) != hipSuccess || hipMalloc(&S.c, bytes) != hipSuccess) {
     (void)hipGetLastError();
     fuelmi_set_error("fuelmi_hbm_triad: cannot allocate 3 x %zu bytes", bytes);
     return FUELMI_EHIP;
   }
-  (void)hipMemset(b, 0, bytes);
-  (void)hipMemset(c, 0, bytes);
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipMemset(S.b, 0, bytes));
+  HIPCHK(hipMemset(S.c, 0, bytes));
+  HIPCHK(hipEventCreate(&S.e0));
+  HIPCHK(hipEventCreate(&S.e1));
   const size_t n4 = bytes / 16;
   for (int grid : {256 * 8, 256 * 16, 256 * 32, 256 * 64, 256 * 256}) {  // the best of a few launch shapes
-    k_triad<<<grid, 256>>>(a, b, c, 0.5f, n4);  // warm-up
-    HIPCHK(hipEventRecord(e0, nullptr));
-    for (int r = 0; r < reps; ++r) k_triad<<<grid, 256>>>(a, b, c, 0.5f, n4);
-    HIPCHK(hipEventRecord(e1, nullptr));
-    HIPCHK(hipEventSynchronize(e1));
+    k_triad<<<grid, 256>>>(S.a, S.b, S.c, 0.5f, n4);  // warm-up
+    HIPCHK(hipEventRecord(S.e0, nullptr));
+    for (int r = 0; r < reps; ++r) k_triad<<<grid, 256>>>(S.a, S.b, S.c, 0.5f, n4);
+    HIPCHK(hipEventRecord(S.e1, nullptr));
+    HIPCHK(hipEventSynchronize(S.e1));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventElapsedTime(&ms, S.e0, S.e1));
     *gb_per_s = std::max(*gb_per_s, 3.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(a);
-  (void)hipFree(b);
-  (void)hipFree(c);
   return FUELMI_OK;
 }
 extern "C" int fuelmi_device_free(void* ptr) {

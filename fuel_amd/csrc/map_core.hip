@@ -440,6 +440,13 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
     return fail(FUELMI_ENOMEM);
   }
   (void)hipMemsetAsync(m->ins_head, 0, 16 * sizeof(u64), m->stream);
+  if (hipMalloc(reinterpret_cast<void**>(&m->esdf_stat), (2 * 256 + 4) * sizeof(u32)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&m->h_esdf_stat), (2 * 256 + 4) * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
+    fuelmi_set_error("allocation of the ESDF statistic failed");
+    return fail(FUELMI_ENOMEM);
+  }
+  (void)hipMemsetAsync(m->esdf_stat, 0, (2 * 256 + 4) * sizeof(u32), m->stream);
+  memset(m->h_esdf_stat, 0, (2 * 256 + 4) * sizeof(u32));
   memset(m->h_ins, 0, 16 * sizeof(u64));
   if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_planes, hipEventDisableTiming) != hipSuccess ||
@@ -455,8 +462,11 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  for (auto& d : m->dependents) d.orphan(d.obj);  // finders / batches that outlive their map
-  m->dependents.clear();
+  {
+    std::lock_guard<std::mutex> lk(m->dep_mu);
+    for (auto& d : m->dependents) d.orphan(d.obj);  // finders / batches that outlive their map
+    m->dependents.clear();
+  }
   for (auto& r : m->mirror)
     if (r.host) (void)hipHostUnregister(r.host);
   Plane* planes[] = {&m->occ_bits, &m->unk_bits,  &m->infl_bits, &m->tmp_bits,
@@ -465,6 +475,8 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
     if (p->base) (void)hipFree(p->base);
   void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial, m->ins_head, m->ins_rec};
   if (m->h_ins) (void)hipHostFree(m->h_ins);
+  if (m->h_esdf_stat) (void)hipHostFree(m->h_esdf_stat);
+  if (m->esdf_stat) (void)hipFree(m->esdf_stat);
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (m->h_stage) (void)hipHostFree(m->h_stage);

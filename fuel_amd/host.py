@@ -561,15 +561,15 @@ class BsplineDeviceProblem:
         check(self.L.fuelmi_bspline_dev_download(self.h, _dp(cost), _dp(grad)))
         return cost, grad
 
-    def optimize(self, max_eval=300):
-        """BsplineOptimizer::optimize() for every candidate, on the device.
-        Returns (best_x [C][nvar], best_cost [C], evaluations [C])."""
+    def optimize(self, max_eval=300, max_time=-1.0):
+        """BsplineOptimizer::optimize() for every candidate, on the device; max_time (seconds, <= 0: none) is the
+        solver's wall-clock cap (set_maxtime).  Returns (best_x [C][nvar], best_cost [C], evaluations [C])."""
         c = self.problem.c
         nvar = c.dim * c.point_num + (1 if c.cost_function & MINTIME else 0)
         x = np.empty((c.n_traj, nvar))
         cost = np.empty(c.n_traj)
         ev = np.empty(c.n_traj, dtype=np.int32)
-        check(self.L.fuelmi_bspline_dev_optimize(self.h, int(max_eval), _dp(x), _dp(cost), _ip(ev)))
+        check(self.L.fuelmi_bspline_dev_optimize_timed(self.h, int(max_eval), float(max_time), _dp(x), _dp(cost), _ip(ev)))
         return x, cost, ev
 
     def loadSamples(self, ts, points, derivs):

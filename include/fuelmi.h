@@ -325,6 +325,12 @@ int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, double* gra
  * comparable, iterates are not.  x_out [C][nvar], cost_out [C], evals_out [C] or NULL; synchronous. */
 int fuelmi_bspline_dev_optimize(fuelmi_bspline_dev* b, int max_eval, double* x_out, double* cost_out,
                                 int* evals_out);
+/* ... with the wall-clock cap of the reference's solver as well (opt.set_maxtime(max_iteration_time_[...]),
+ * bspline_optimizer.cpp:170-172; 5 ms in exploration_manager/launch/algorithm.xml:190): a candidate's solve stops
+ * at the first evaluation boundary past max_time_s seconds of device time and returns the best variables seen so far,
+ * like costFunction keeps them (:693-707).  max_time_s <= 0: no cap. */
+int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_eval, double max_time_s, double* x_out,
+                                      double* cost_out, int* evals_out);
 void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b);
 
 /* Spline glue around the solve, batched (NonUniformBspline, bspline/src/non_uniform_bspline.cpp).

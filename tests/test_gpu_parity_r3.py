@@ -102,3 +102,113 @@ def test_config4_streaming_at_its_own_size(fa):
     fs = cyc2.ff.stats()
     assert fs[0] > 0 and fs[2] == 0, "the searches are supposed to run on the fast chain (%s)" % (fs,)
     cyc2.close()
+
+
+def test_esdf_kernel_choice_follows_the_place_not_the_previous_update(fa, monkeypatch):
+    """The local bound alternates between an explored hall (only the floor and a pillar are sources: outputs tens of
+    voxels from any source -> far-field kernels) and a half-explored region (unknown space is a source everywhere ->
+    plain kernels).  The statistic is kept per group of x-slabs, so from the second visit on each place gets its own
+    kernels -- the choice of round 2 ("whatever the previous update saw") paid the wrong family on every call.
+    Distances equal the oracle's throughout."""
+    from fuel_amd._lib import K_ESDF_ZY, K_ESDF_X
+    monkeypatch.delenv("FUELMI_ESDF_FAR", raising=False)
+    map_size = (40.0, 20.0, 6.0)
+    om = fo.OracleMap(map_size)
+    gm = fa.SDFMap(map_size)
+    nv = om.nvox
+    assert nv == (400, 200, 60)
+    occ = np.full(om.N, om.l_min).reshape(nv)       # known free ...
+    occ[:, :, 0] = om.l_max                         # ... over an occupied floor
+    occ[90:96, 100:104, 1:40] = om.l_max            # a pillar in the hall (x < 200)
+    rng = np.random.default_rng(5)
+    xs, ys, zs = np.meshgrid(np.arange(200, 400), np.arange(200), np.arange(60), indexing="ij")
+    for _ in range(60):                             # the right half: blobs of unknown space
+        c = rng.uniform([205, 5, 2], [395, 195, 55])
+        r = rng.uniform(6, 14)
+        occ[200:400][(xs - c[0]) ** 2 + (ys - c[1]) ** 2 + (zs - c[2]) ** 2 < r * r] = om.l_min - 0.01
+    om.occ[:] = occ.reshape(-1)
+    gm.uploadOccupancy(om.occ)
+    hall = ((8, 8, 0), (191, 191, 59))
+    fresh = ((208, 8, 0), (391, 191, 59))
+    gm.profileEnable((1 << K_ESDF_ZY) | (1 << K_ESDF_X))
+    ms = {"hall": [], "fresh": []}
+    for rnd in range(4):
+        for name, (lo, hi) in (("hall", hall), ("fresh", fresh)):
+            om.set_local_bound(lo, hi)
+            gm.setLocalBound(lo, hi)
+            om.inflate_local()
+            om.update_esdf()
+            gm.clearAndInflateLocalMap()
+            gm.updateESDF3d()
+            gm.synchronize()
+            sl = tuple(slice(lo[k], hi[k] + 1) for k in range(3))
+            h = gm.syncHost(distance=True, box=(lo, hi))
+            assert np.abs(np.clip(h["distance"].reshape(nv)[sl], -BIG, BIG) -
+                          np.clip(om.dist.reshape(nv)[sl], -BIG, BIG)).max() <= ESDF_TOL, (name, rnd)
+            zy, xx = gm.profileSamples(K_ESDF_ZY), gm.profileSamples(K_ESDF_X)
+            ms[name].append(zy[-1] + xx[-1])
+    print("alternating local bound, ESDF ms per update: hall %s fresh %s" %
+          (["%.3f" % v for v in ms["hall"]], ["%.3f" % v for v in ms["fresh"]]))
+    # the hall gets the far-field kernels from its second visit on; the fresh region never loses the plain ones
+    assert max(ms["hall"][1:]) < 0.8 * ms["hall"][0], ms
+    assert max(ms["fresh"][1:]) < 1.5 * ms["fresh"][0], ms
+    gm.close()
+
+
+def test_optimiser_honours_the_wall_clock_cap(fa):
+    """opt.set_maxtime(max_iteration_time_) (bspline_optimizer.cpp:170-172; 5 ms in algorithm.xml:190): a solve that
+    runs out of time stops at the next evaluation boundary and returns the best variables seen so far, as
+    costFunction keeps them (:693-707) -- fewer evaluations than the uncapped solve, a cost between the start's and the
+    uncapped result's, and variables that reproduce the returned cost."""
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    om.update_esdf()
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    cf = fa.NORMAL_PHASE | fa.MINTIME
+    rng = np.random.default_rng(12)
+    Cn, N, dt = 16, 32, 0.175
+    ctrl = helpers.make_trajectories(rng, Cn, N, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
+    x, ptd, st, en = helpers.bspline_inputs(ctrl, dt, True)
+    opt = fa.BsplineOptimizer()
+    opt.setEnvironment(gm)
+    pb = fa.BsplineBatchProblem(x, N, cf, ptd, st, en, 3, 3, dt)
+    dev = opt.deviceProblem(pb)
+    c0, _ = opt.combineCost(pb)
+    x_full, c_full, e_full = dev.optimize(max_eval=300)
+    x_gen, c_gen, e_gen = dev.optimize(max_eval=300, max_time=1.0)     # a generous cap changes nothing
+    assert np.array_equal(x_gen, x_full) and np.array_equal(e_gen, e_full)
+    x_cap, c_cap, e_cap = dev.optimize(max_eval=300, max_time=200e-6)  # ~20 evaluations' worth of device time
+    assert (e_cap >= 1).all() and e_cap.max() < e_full.max() and e_cap.sum() < 0.6 * e_full.sum(), (e_cap, e_full)
+    assert (c_cap <= c0 + 1e-9).all() and (c_cap >= c_full - 1e-9).all()
+    for c in range(Cn):
+        chk, _ = fo.bspline_cost_grad(om, x_cap[c], N, cf, ptd[c], st[c], en[c], 3, 3, dt)
+        assert abs(chk - c_cap[c]) <= 1e-6 * max(1.0, abs(chk))        # returned x <-> returned cost
+    print("optimiser evaluations: uncapped %s; capped at 200 us %s" % (e_full.tolist(), e_cap.tolist()))
+    gm.close()
+
+
+def test_finder_that_outlives_its_map_refuses_politely(fa):
+    """Garbage collectors and teardown orders destroy a map under a live finder: every entry point except _destroy
+    must then return an error instead of dereferencing the map."""
+    import ctypes as C
+    from fuel_amd._lib import lib
+    L = lib()
+    gm = fa.SDFMap((6.0, 6.0, 3.0))
+    gf = fa.FrontierFinder(gm, cluster_min=10)
+    gm.close()                      # the map goes first
+    n = C.c_int()
+    assert L.fuelmi_frontier_search(gf.h, C.byref(n)) != 0
+    assert L.fuelmi_frontier_search_begin(gf.h) != 0
+    assert L.fuelmi_frontier_reset(gf.h) != 0
+    assert L.fuelmi_frontier_commit(gf.h, 0) != 0
+    assert L.fuelmi_frontier_synchronize(gf.h) != 0
+    flags = np.empty(8, dtype=np.int8)
+    assert L.fuelmi_frontier_get_flags(gf.h, flags.ctypes.data_as(C.c_char_p)) != 0
+    assert b"destroyed" in L.fuelmi_last_error()
+    gf.close()
