@@ -1362,56 +1362,47 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
   __shared__ u32 s_np, s_chg, s_povf;
   if (threadIdx.x == 0) s_np = 0u, s_chg = 0u, s_povf = 0u;
   __syncthreads();
-  auto walk_pairs = [&](auto&& fn) {  // fn(first cell of an own run, a cell of a touching run of the lower line / seam)
-    const int nlines = T.TX * TY;
-    // small tiles (4 x 8 lines of 200 voxels in a streaming search): a line's segments are split over G lanes so that
-    // all waves of the workgroup have runs to walk
-    int G = 1;
-    while (4 * nlines * G < NT && 2 * G <= nseg) G *= 2;
-    const int cper = (nseg + G - 1) / G;
-    for (int jg = threadIdx.x; jg < 4 * nlines * G; jg += NT) {
-      const int grp = jg % G, j = jg / G;
-      const int c_lo = grp * cper, c_hi = min(nseg, c_lo + cper);
-      if (c_lo >= c_hi) continue;
-      const int k = j / nlines, line = j - k * nlines, lx = line / TY, ly = line - lx * TY;
-      const int nlx = lx + (k < 3 ? -1 : 0), nly = ly + (k < 3 ? k - 1 : -1);
-      const bool nvalid = nlx >= 0 && nly >= 0 && nly < TY;
-      if (!nvalid && k != 3) continue;
-      const u32* ob = segb + line * nseg;
-      const u32* op = segpre + line * nseg;
-      const u32* nbp = segb + (nvalid ? nlx * TY + nly : 0) * nseg;
-      const u32* npp = segpre + (nvalid ? nlx * TY + nly : 0) * nseg;
-      u32 nlo = (nvalid && c_lo > 0) ? nbp[c_lo - 1] : 0u, nlo_pre = (nvalid && c_lo > 0) ? npp[c_lo - 1] : 0u;  // neighbour segment c - 1
-      u32 ncur = nvalid ? nbp[c_lo] : 0u, ncur_pre = nvalid ? npp[c_lo] : 0u;
-      u32 prev_own = c_lo > 0 ? ob[c_lo - 1] : 0u;
-#pragma nounroll
-      for (int c = c_lo; c < c_hi; ++c) {
-        const u32 nhi = (nvalid && c + 1 < nseg) ? nbp[c + 1] : 0u, nhi_pre = (nvalid && c + 1 < nseg) ? npp[c + 1] : 0u;
-        const u32 bits = ob[c];
-        if (bits) {
-          const u32 base = op[c];
-          if (k == 3 && (bits & 1u) && (prev_own >> 31)) fn(base, base - 1u);
-          // the neighbour line's bits at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j)
-          const u64 w3 = (u64)(nlo >> 31) | ((u64)ncur << 1) | ((u64)(nhi & 1u) << 33);
-          u32 rem = w3 ? bits : 0u;
-          u32 l = base;
-          while (rem) {
-            int s, len;
-            pop_run32(rem, s, len);
-            u64 m = (w3 >> s) & ((1ull << (len + 2)) - 1ull);  // z - 1 .. z + len of the run
-            while (m) {
-              int jj, rl;
-              pop_run64(m, jj, rl);
-              const int q = s + jj;  // bit of w3: 0 -> last voxel of segment c - 1, 1..32 -> segment c, 33 -> first of c + 1
-              const u32 ln = q == 0 ? nlo_pre + (u32)__popc(nlo & 0x7FFFFFFFu)
-                                    : (q == 33 ? nhi_pre : ncur_pre + (u32)__popc(ncur & ((1u << (q - 1)) - 1u)));
-              fn(l, ln);
-            }
-            l += (u32)len;
-          }
-        }
-        prev_own = bits;
-        nlo = ncur, nlo_pre = ncur_pre, ncur = nhi, ncur_pre = nhi_pre;
+  auto walk_pairs = [&](auto&& fn) {  // fn(first cell of an own run, a cell of a touching run of a lower line / the seam)
+    // One lane per CELL: its segment by bisection over the prefix, its bit inside the segment, then one 3-bit window
+    // (z - 1, z, z + 1) per lower line.  A cell whose z-predecessor is a cell too (same run) shares that cell's
+    // windows except for the voxel z + 1 of each lower line -- and that one only matters when it starts a new run
+    // there (the line's voxel z is empty): a wall costs one look per cell and line, not one pair.
+    for (u32 l = threadIdx.x; l < total; l += NT) {
+      int lo = 0, hi = items - 1;
+      while (lo < hi) {  // last segment whose prefix is <= l and that holds cells
+        const int mid = (lo + hi + 1) >> 1;
+        if (segpre[mid] <= l)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      const int it = lo;
+      const u32 bits = segb[it];
+      u32 k = l - segpre[it], rem = bits;  // the k-th set bit
+      while (k--) rem &= rem - 1u;
+      const int zz = __builtin_ctz(rem);
+      const int line = it / nseg, c = it - line * nseg, lx = line / TY, ly = line - lx * TY;
+      const int z = 32 * c + zz;
+      const bool seam = zz == 0 && c > 0 && (segb[it - 1] >> 31);
+      const u32 own = seam ? l : lab[l];  // label node of the cell's run (its first cell inside the segment)
+      if (seam) fn(l, l - 1u);
+      const bool has_prev = seam || (zz > 0 && ((bits >> (zz - 1)) & 1u));
+      for (int q = 0; q < 4; ++q) {
+        const int nlx = lx + (q < 3 ? -1 : 0), nly = ly + (q < 3 ? q - 1 : -1);
+        if (nlx < 0 || nly < 0 || nly >= TY) continue;
+        const int nline = nlx * TY + nly;
+        const int zlo = z - 1;
+        const int s0 = max(zlo, 0) >> 5;
+        const u64 w = (u64)segb[nline * nseg + s0] | ((s0 + 1 < nseg) ? ((u64)segb[nline * nseg + s0 + 1] << 32) : 0ull);
+        u32 pat = (zlo >= 0) ? (u32)((w >> (zlo - 32 * s0)) & 7ull) : (u32)((w << 1) & 6ull);
+        if (z + 1 >= nz) pat &= 3u;
+        if (has_prev) pat = (pat & 6u) == 4u ? 4u : 0u;
+        if (!pat) continue;
+        const int zn = zlo + __builtin_ctz(pat);
+        const int nit = nline * nseg + (zn >> 5);
+        const u32 ln = segpre[nit] + (u32)__popc(segb[nit] & ((1u << (zn & 31)) - 1u));
+        fn(own, ln);
+        if (pat == 5u) fn(own, ln + 1u);  // the next cell of that line sits at zlo + 2
       }
     }
   };
