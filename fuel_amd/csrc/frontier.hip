@@ -1133,51 +1133,24 @@ __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* _
 // cells per x-row) and lists the component pairs that touch across tile faces (k_tile_cross); one
 // workgroup then does all of the above on those few thousand records in its LDS (k_resolve).
 //
-// Round 3: no compaction anywhere.  The round-2 chain compacted the cells in address order first (predicate
-// + in-block prefix, scan of the block sums, ordered compaction) and every later kernel found a cell's
-// neighbours through rank look-ups in those tables (three dependent loads each); regrouping the cells by
-// cluster took a histogram kernel and a scatter kernel.  Now
-//   k_pred3     : predicate planes qb / sb per 64-voxel word (+ the flag reset of a fresh search)
-//   k_tile_ccl  : a tile reads its own Q0 bits, labels them run by run in LDS, writes one record per component
-//                 and the component number of every cell BY VOXEL ADDRESS (vlab, one byte per voxel)
-//   k_tile_cross: relations across tile faces + NQ seed claims, neighbours looked up in vlab
+// Round 3: no compaction anywhere, and no predicate pass in front.  The round-2 chain compacted the cells in address
+// order first (predicate + in-block prefix, scan of the block sums, ordered compaction) and every later kernel found
+// a cell's neighbours through rank look-ups in those tables (three dependent loads each); regrouping the cells by
+// cluster took a histogram kernel and a scatter kernel.  Now four kernels:
+//   k_tile_ccl  : a tile evaluates the frontier predicate for its own voxels straight from the occupancy planes,
+//                 keeps the Q0 / seed bits of its 32-voxel segments in per-tile arrays (tq / ts), labels its cells run
+//                 by run in LDS, writes one record per component and the component number of every cell BY VOXEL
+//                 ADDRESS (vlab, one byte per voxel)
+//   k_tile_cross: relations across tile faces + NQ seed claims, neighbours looked up in tq / vlab
 //   k_resolve   : unions, clusters, ranks; additionally the (kept cluster x tile column) prefix matrix
 //   k_tile_out  : flags + the grouped cell list: a cell's position = offset of its cluster + cells of the cluster
 //                 in earlier tile columns (matrix) + in earlier x-rows / earlier tiles of its own column (per-row
 //                 counts of the column's components) + earlier cells of its own row of the tile
+// fuelmi_frontier_reset costs no kernel: the finder owns two flag planes and swaps to the zeroed one.
 // Capacity limits (FR_* in frontier_internal.h) are those of pathological inputs (noise-like occupancy);
 // when one is hit, or cluster_min < 1 (every NQ seed is then a cluster of its own), the search runs the
 // legacy chain instead.  Results are identical (tests run both).
 // =================================================================================================
-
-// predicate planes with the per-search arguments read straight from the pinned host copy (no k_load_var
-// launch) and fuelmi_frontier_reset folded in (V.fresh)
-__global__ void __launch_bounds__(256) k_pred3(Geo g, FArgs F, const FVar* __restrict__ hvar) {
-  __shared__ FVar s_var;
-  const int nvw = (int)(sizeof(FVar) / 4);
-  if ((int)threadIdx.x < nvw) reinterpret_cast<u32*>(&s_var)[threadIdx.x] = reinterpret_cast<const u32*>(hvar)[threadIdx.x];
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if ((int)threadIdx.x < nvw) reinterpret_cast<u32*>(F.var_w)[threadIdx.x] = reinterpret_cast<const u32*>(&s_var)[threadIdx.x];
-    if (threadIdx.x < 32) F.fctr[threadIdx.x] = 0u;
-  }
-  const FVar& V = s_var;
-  if ((int)blockIdx.x >= V.nblocks) return;
-  const int w = V.w0 + blockIdx.x * 256 + threadIdx.x;
-  if (w >= g.W) return;
-  u64 z0, zl, y0, yl, mq, ms;
-  word_masks(g, w, V.qreg, V.sbox, z0, zl, y0, yl, mq, ms);
-  const u64 fl = V.fresh ? 0ull : F.flag[w];
-  if (V.fresh) F.flag[w] = 0ull;
-  u64 q = 0ull, s = 0ull;
-  if ((mq | ms) != 0ull) {
-    const u64 f1 = f1_word(g, F.occ, F.unk, w, z0, zl, y0, yl) & ~fl;
-    q = f1 & mq;
-    s = f1 & ms & ~mq;
-  }
-  F.qb[w] = q;
-  F.sb[w] = s;
-}
 
 // ---- tiles ----------------------------------------------------------------------------------------
 struct TileGeo {
@@ -1198,55 +1171,152 @@ __device__ __forceinline__ long tile_line_adr(const Geo& g, const TileGeo& T, in
   return (long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * g.nz;
 }
 
-// Bits of plane `pl` over the tile, one u32 per 32-voxel segment of every z-line (segment it = line * nseg + c),
-// and their exclusive prefix: segpre[it] = tile-local index of the first cell at / after segment it (the
-// tile-local order is the address order inside every x-row).  A thread fetches FT_PER CONSECUTIVE segments (all
-// loads in flight together), the block scans one partial per thread.  Returns the number of cells; ends with a
-// barrier.
-#define FT_PER 8
-template <int NT, bool SCAN, bool TWO = false>
-__device__ __forceinline__ u32 tile_load_bits(const Geo& g, const TileGeo& T, const u64* __restrict__ pl, u32* segb,
-                                              u32* segpre, u32* s_wsum, const u64* __restrict__ pl2 = nullptr,
-                                              u32* segb2 = nullptr, u32* lab = nullptr) {
+#define FT_PER 8  // segments a lane of the tile kernels handles at most (tile segments / workgroup size)
+// ---- the predicate inside the tile kernel ----------------------------------------------------------------
+// Q0 and NQ-seed bits of the 32 voxels from address a = (x, y, 32 c): knownfree && isNeighborUnknown
+// (frontier_finder.cpp:862-877) && flag == 0, cut to the Q region / the scan box -- what k_pred / f1_word compute
+// per 64-voxel word, per segment here.  The seven plane windows are independent loads.
+struct SegPred {
+  u32 q, s;
+};
+// 32 bits of a plane from (signed) bit index `bit`, through 32-bit loads: the planes are little-endian u64 words, so
+// bit b of the plane is bit (b & 31) of the 32-bit word b >> 5 -- half the bytes of plane_window per window
+__device__ __forceinline__ u32 plane_window32(const u64* __restrict__ p, long bit) {
+  const u32* q = reinterpret_cast<const u32*>(p);
+  const long wi = bit >> 5;
+  const int sh = (int)(bit & 31);
+  const u32 lo = q[wi];
+  if (sh == 0) return lo;
+  return (lo >> sh) | (q[wi + 1] << (32 - sh));
+}
+__device__ __forceinline__ SegPred seg_predicate(const Geo& g, const FVar& V, const FArgs& F, int x, int y, int c) {
+  const long a = (long)x * g.nyz + (long)y * g.nz + 32 * c;
+  const int zn = min(32, g.nz - 32 * c);
+  u64 W;  // the unknown plane at z = 32 c - 1 .. 32 c + 32 (bit 0 <-> z = 32 c - 1): three 32-bit words
+  {
+    const u32* q = reinterpret_cast<const u32*>(F.unk);
+    const long wi = (a - 1) >> 5;
+    const int sh = (int)((a - 1) & 31);
+    const u64 w01 = (u64)q[wi] | ((u64)q[wi + 1] << 32);
+    W = sh ? (w01 >> sh) | ((u64)q[wi + 2] << (64 - sh)) : w01;
+  }
+  const u32 occw = plane_window32(F.occ, a);
+  const u32 ym = y > 0 ? plane_window32(F.unk, a - g.nz) : 0u, yp = y < g.ny - 1 ? plane_window32(F.unk, a + g.nz) : 0u;
+  const u32 xm = plane_window32(F.unk, a - g.nyz), xp = plane_window32(F.unk, a + g.nyz);  // (zero margins beyond the map)
+  const u32 fl = V.fresh ? 0u : plane_window32(F.flag, a);
+  u32 down = (u32)W, up = (u32)(W >> 2);
+  const u32 self_unk = (u32)(W >> 1);
+  if (c == 0) down &= ~1u;                                   // z = 0 has no lower neighbour
+  if (g.nz - 32 * c <= 32) up &= ~(1u << (zn - 1));          // z = nz - 1 (this segment's last voxel) has no upper one
+  const u32 valid = zn < 32 ? (1u << zn) - 1u : 0xFFFFFFFFu;
+  const u32 f1 = ~occw & ~self_unk & (down | up | ym | yp | xm | xp) & valid & ~fl;
+  auto zmask = [&](const Box3& b) -> u32 {
+    if (x < b.lo[0] || x > b.hi[0] || y < b.lo[1] || y > b.hi[1]) return 0u;
+    const int lo = max(32 * c, b.lo[2]) - 32 * c, hi = min(32 * c + 31, b.hi[2]) - 32 * c;
+    if (lo > hi) return 0u;
+    return ((hi - lo + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (hi - lo + 1)) - 1u)) << lo;
+  };
+  const u32 mq = zmask(V.qreg), ms = zmask(V.sbox);
+  SegPred r;
+  r.q = f1 & mq;
+  r.s = f1 & ms & ~mq;
+  return r;
+}
+
+// The tile's segments: predicate, Q0 bits + exclusive prefix + CCL labels and the seed bits in the LDS (the caller
+// copies both bit arrays into the per-tile arrays tq / ts -- what the later kernels and the neighbouring tiles read:
+// coalesced, and no 64-bit plane that tiles ending in the middle of a word would have to share).  Two segments per
+// lane and trip.
+template <int NT>
+__device__ __forceinline__ u32 tile_load_pred(const Geo& g, const TileGeo& T, const FVar& V, const FArgs& F, u32* segb,
+                                              u32* segpre, u32* s_wsum, u32* lab, u32* segs) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (T.items + NT - 1) / NT;  // <= FT_PER (checked on the host)
   const int it0 = threadIdx.x * per;
-  u32 b[FT_PER], b2[FT_PER];
   u32 cnt = 0u;
-  {
-    int line = it0 / T.nseg, c = it0 - line * T.nseg;
-    int lx = line / T.TY, ly = line - lx * T.TY;
+#pragma nounroll
+  for (int k0 = 0; k0 < per; k0 += 2) {
+    SegPred r[2];
 #pragma unroll
-    for (int k = 0; k < FT_PER; ++k) {
-      b[k] = 0u, b2[k] = 0u;
-      if (k < per && it0 + k < T.items && lx < T.nxl && ly < T.nyl) {
-        const int zn = min(32, g.nz - 32 * c);
-        const long a = (long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * g.nz + 32 * c;
-        u32 v = (u32)plane_window(pl, a);
-        u32 v2 = TWO ? (u32)plane_window(pl2, a) : 0u;
-        if (zn < 32) v &= (1u << zn) - 1u, v2 &= (1u << zn) - 1u;
-        b[k] = v, b2[k] = v2;
+    for (int h = 0; h < 2; ++h) {
+      r[h].q = r[h].s = 0u;
+      const int it = it0 + k0 + h;
+      if (k0 + h < per && it < T.items) {
+        const int line = it / T.nseg, c = it - line * T.nseg, lx = line / T.TY, ly = line - lx * T.TY;
+        if (lx < T.nxl && ly < T.nyl) r[h] = seg_predicate(g, V, F, T.x0 + lx, T.y0 + ly, c);
       }
-      if (++c == T.nseg) {
-        c = 0;
-        if (++ly == T.TY) ly = 0, ++lx;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int it = it0 + k0 + h;
+      if (k0 + h < per && it < T.items) {
+        segb[it] = r[h].q, segs[it] = r[h].s;  // (to memory later: a store in front of a barrier is a round trip)
+        cnt += (u32)__popc(r[h].q);
       }
     }
   }
-  if (TWO) {
-#pragma unroll
-    for (int k = 0; k < FT_PER; ++k)
-      if (k < per && it0 + k < T.items) segb2[it0 + k] = b2[k];
+  u32 v = cnt;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 t = (u32)__shfl_up((int)v, off, 64);
+    if (lane >= off) v += t;
   }
-  if (!SCAN) {  // bits only
+  if (lane == 63) s_wsum[wave] = v;
+  __syncthreads();
+  u32 woff = 0u, tot = 0u;
 #pragma unroll
-    for (int k = 0; k < FT_PER; ++k)
-      if (k < per && it0 + k < T.items) segb[it0 + k] = b[k];
+  for (int k = 0; k < NT / 64; ++k) {
+    if (k < wave) woff += s_wsum[k];
+    tot += s_wsum[k];
+  }
+  u32 run = woff + v - cnt;
+#pragma nounroll
+  for (int k = 0; k < per; ++k) {
+    if (it0 + k >= T.items) break;
+    u32 rem = segb[it0 + k];  // (the lane re-reads what it just wrote)
+    segpre[it0 + k] = run;
+    if (tot <= FR_TCELL) {  // labels of the CCL: start of the cell's z-run inside its segment (runs are pre-joined)
+      u32 l = run;
+      while (rem) {
+        const int s0 = __builtin_ctz(rem);
+        const u32 inv = ~(rem >> s0);
+        const int len = min(inv ? __builtin_ctz(inv) : 32, 32 - s0);
+        rem &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s0);
+        for (int q = 0; q < len; ++q) lab[l + (u32)q] = l;
+        l += (u32)len;
+      }
+    }
+    run += (u32)__popc(segb[it0 + k]);
+  }
+  if (threadIdx.x == 0) segpre[T.items] = tot;
+  __syncthreads();
+  return tot;
+}
+// a tile's own bits from the arrays (k_tile_cross, k_tile_out): coalesced, no shifting
+template <int NT, bool SCAN>
+__device__ __forceinline__ u32 tile_load_arrays(const TileGeo& T, const FArgs& F, u32* segb, u32* segpre, u32* s_wsum,
+                                                u32* segs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32* tq = F.tq + (size_t)blockIdx.x * T.items;
+  const u32* ts = F.ts + (size_t)blockIdx.x * T.items;
+  const int per = (T.items + NT - 1) / NT;
+  const int it0 = threadIdx.x * per;
+  u32 b[FT_PER], b2[FT_PER];
+#pragma unroll
+  for (int k = 0; k < FT_PER; ++k) {
+    b[k] = b2[k] = 0u;
+    if (k < per && it0 + k < T.items) b[k] = tq[it0 + k], b2[k] = ts[it0 + k];
+  }
+  u32 cnt = 0u;
+#pragma unroll
+  for (int k = 0; k < FT_PER; ++k)
+    if (k < per && it0 + k < T.items) {
+      segb[it0 + k] = b[k], segs[it0 + k] = b2[k];
+      cnt += (u32)__popc(b[k]);
+    }
+  if (!SCAN) {
     __syncthreads();
     return 0u;
   }
-#pragma unroll
-  for (int k = 0; k < FT_PER; ++k) cnt += (u32)__popc(b[k]);
   u32 v = cnt;
   for (int off = 1; off < 64; off <<= 1) {
     const u32 t = (u32)__shfl_up((int)v, off, 64);
@@ -1264,32 +1334,13 @@ __device__ __forceinline__ u32 tile_load_bits(const Geo& g, const TileGeo& T, co
 #pragma unroll
   for (int k = 0; k < FT_PER; ++k)
     if (k < per && it0 + k < T.items) {
-      segb[it0 + k] = b[k];
       segpre[it0 + k] = run;
       run += (u32)__popc(b[k]);
     }
   if (threadIdx.x == 0) segpre[T.items] = tot;
-  if (lab != nullptr && tot <= FR_TCELL) {
-    // labels of the CCL: start of the cell's z-run inside its segment (runs are pre-joined).  Not unrolled (eight
-    // copies of the loop nest are code the instruction cache pays for): the lane re-reads what it just wrote.
-#pragma nounroll
-    for (int k = 0; k < per; ++k) {
-      if (it0 + k >= T.items) break;
-      u32 rem = segb[it0 + k], l = segpre[it0 + k];
-      while (rem) {
-        const int s0 = __builtin_ctz(rem);
-        const u32 inv = ~(rem >> s0);
-        const int len = min(inv ? __builtin_ctz(inv) : 32, 32 - s0);
-        rem &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s0);
-        for (int q = 0; q < len; ++q) lab[l + (u32)q] = l;
-        l += (u32)len;
-      }
-    }
-  }
   __syncthreads();
   return tot;
 }
-
 // first run of set bits of m (m != 0): start bit, length; removes it from m
 __device__ __forceinline__ void pop_run32(u32& m, int& s, int& len) {
   s = __builtin_ctz(m);
@@ -1311,8 +1362,11 @@ __device__ __forceinline__ void pop_run64(u64& m, int& s, int& len) {
 // of a run share a label from the start, a run looks at each of the four lower z-lines through one 34-bit window
 // and joins every run it finds there -- a wall costs one union per line, not one per cell.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
-  const FVar& V = *F.var;
+__global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
+  // the chain's first kernel: the per-search arguments arrive as a KERNEL ARGUMENT (the graph node's parameters are
+  // rewritten before every launch: no memory read -- least of all one over PCIe -- stands in front of the tile's
+  // loads); workgroup 0 leaves the device copy the later kernels read
+  if (blockIdx.x == 0 && threadIdx.x == 0) *F.var_w = V;
   if ((int)blockIdx.x >= V.ntiles_f) return;
   const TileGeo T = tile_geo(g, V, blockIdx.x);
   const Box3 sbox = V.sbox;
@@ -1325,6 +1379,7 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
   u32* rrow = acc + FR_TROOT * 8;                     // [FR_TROOT][FR_TXS] cells per x-row
   unsigned short* rootno = reinterpret_cast<unsigned short*>(rrow + FR_TROOT * FR_TXS);  // [FR_TCELL] at a root: its number
   unsigned char* rcell = reinterpret_cast<unsigned char*>(rootno + FR_TCELL);            // [FR_TCELL] component number per cell
+  u32* segs = reinterpret_cast<u32*>(rcell + FR_TCELL);  // [items] NQ seed bits (on their way to the ts array)
   u32* plist = reinterpret_cast<u32*>(rootno);  // [FR_TPAIR] touching runs (cell << 16 | cell); shares the space of rootno + rcell, which are filled afterwards
   static_assert((size_t)FR_TPAIR * sizeof(u32) <= FR_TCELL * sizeof(unsigned short) + FR_TCELL, "pair list does not fit");
   __shared__ u32 s_wsum[NT / 64];
@@ -1333,7 +1388,12 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F) {
   const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_nroots = 0u, s_flag = 0u, s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0u;
   FR_DBG_MARK(F, blockIdx.x, 0);
-  const u32 total = tile_load_bits<NT, true>(g, T, F.qb, segb, segpre, s_wsum, nullptr, nullptr, lab);  // (uniform; labels too)
+  const u32 total = tile_load_pred<NT>(g, T, V, F, segb, segpre, s_wsum, lab, segs);  // (uniform; predicate, prefix, labels)
+  {  // the bit arrays of the tile, for the later kernels and the neighbours (in flight during the phases below)
+    u32* tq = F.tq + (size_t)blockIdx.x * items;
+    u32* ts = F.ts + (size_t)blockIdx.x * items;
+    for (int it = threadIdx.x; it < items; it += NT) tq[it] = segb[it], ts[it] = segs[it];
+  }
   FR_DBG_MARK(F, blockIdx.x, 1);
   if (total == 0u || total > FR_TCELL) {
     if (threadIdx.x == 0) {
@@ -1661,7 +1721,7 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
   }
   if (threadIdx.x < XC_SET) s_set[threadIdx.x] = 0xFFFFFFFFu;
   if (threadIdx.x == 0) s_n = 0u, s_nw = 0u;
-  tile_load_bits<NT, false, true>(g, T, F.qb, segq, nullptr, nullptr, F.sb, segs);
+  tile_load_arrays<NT, false>(T, F, segq, nullptr, nullptr, segs);
   FR_DBG_MARK(F, dblk, 1);
   auto tile_of = [&](int x, int y) -> u32 {  // which of the 3 x 3 tiles holds column (x, y)
     const int dtx = x < T.x0 ? -1 : (x >= T.x0 + T.TX ? 1 : 0), dty = y < T.y0 ? -1 : (y >= T.y0 + TY ? 1 : 0);
@@ -1729,8 +1789,8 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
     k0 = k1 = 0xFFFFFFFFu;
   };
   // what an entry stands for: own bits, address of the own segment, address of the neighbour window, info word
-  auto decode = [&](u32 e, u32& bits, u32& own, int& nb, u32& info) {
-    int it, xx, yy, c;
+  auto decode = [&](u32 e, u32& bits, u32& own, int& nb, u32& info, int& xx, int& yy) {
+    int it, c;
     if (e >> 31) {
       const int sj = (int)(e & 0x7FFFFFFFu), l = sj % 9;
       it = sj / 9;
@@ -1790,16 +1850,16 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
   const u32 nw = min(s_nw, (u32)XC_WCAP);
   for (u32 w0 = 0; w0 < nw; w0 += 2 * NT) {
     u32 b0 = 0u, b1 = 0u, o0 = 0u, o1 = 0u, i0 = 0u, i1 = 0u;
-    int n0 = 0, n1 = 0;
+    int n0 = 0, n1 = 0, xa = 0, ya = 0, xb = 0, yb = 0;
     u64 wa = 0ull, wb = 0ull;
     const u32 ja = w0 + threadIdx.x, jb = ja + NT;
     if (ja < nw) {
-      decode(wl[ja], b0, o0, n0, i0);
-      if (b0) wa = plane_window(F.qb, (long)n0);
+      decode(wl[ja], b0, o0, n0, i0, xa, ya);
+      if (b0) wa = q_window34(g, V, F, xa, ya, (int)(i0 & 0xFFu));
     }
     if (jb < nw) {
-      decode(wl[jb], b1, o1, n1, i1);
-      if (b1) wb = plane_window(F.qb, (long)n1);
+      decode(wl[jb], b1, o1, n1, i1, xb, yb);
+      if (b1) wb = q_window34(g, V, F, xb, yb, (int)(i1 & 0xFFu));
     }
 #pragma nounroll
     for (int h = 0; h < 2; ++h) {  // (one copy of the item code)
@@ -2154,11 +2214,11 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
     F.counts[0] = min(nq, F.cap_q);
     F.counts[1] = 0u;
     F.counts[2] = bad ? 2u : (cap ? 1u : 0u);  // 2: capacity of the fast path exceeded -> the host runs the legacy chain
-    F.counts[6] = dead ? F.fctr[9] : (s_ovf ? 16u : (bad ? 17u : 0u));  // which one
+    F.counts[6] = dead ? s_fc[9] : (s_ovf ? 16u : (bad ? 17u : 0u));  // which one
     F.counts[3] = bad ? 0u : nk;
     F.counts[5] = bad ? 0u : s_nout;
-    F.fctr[9] = (bad || cap) ? 1u : 0u;
   }
+  if (threadIdx.x < 32) F.fctr[threadIdx.x] = 0u;  // the counters of the NEXT search (its first kernel adds to them at once)
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
   // the barrier orders every thread's record stores before thread 0's system-scope release (cumulative): one
@@ -2213,7 +2273,7 @@ __global__ void __launch_bounds__(NT) k_tile_out(Geo g, FArgs F) {
     const int tt = T.tx * V.nty_f + threadIdx.x;
     pre_cn = F.t_nroots[tt], pre_cb = F.t_base[tt];
   }
-  const u32 total = tile_load_bits<NT, true, true>(g, T, F.qb, segb, segpre, s_wsum, F.sb, segs);  // (uniform)
+  const u32 total = tile_load_arrays<NT, true>(T, F, segb, segpre, s_wsum, segs);  // (uniform)
   FR_DBG_MARK(F, dblk, 1);
   // ---- NQ seeds are flagged whatever happens to the components around them ----
   auto or_flags = [&](long a0, u32 bits) {  // bits of the 32 voxels from address a0
@@ -2455,11 +2515,22 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->d_mark) (void)hipFree(f->d_mark);
   frontier_split_free(f);
   frontier_order_free(f);
-  for (hipGraphExec_t e : f->graph_exec)
-    if (e) (void)hipGraphExecDestroy(e);
-  for (hipGraphExec_t e : f->fast_exec)
-    if (e) (void)hipGraphExecDestroy(e);
-  Plane* pl[] = {&f->flag, &f->qb, &f->sb};
+  for (auto& row : f->graph_exec)
+    for (hipGraphExec_t e : row)
+      if (e) (void)hipGraphExecDestroy(e);
+  for (auto& row : f->fast_exec)
+    for (hipGraphExec_t e : row)
+      if (e) (void)hipGraphExecDestroy(e);
+  for (auto& row : f->fast_graph)
+    for (hipGraph_t gph : row)
+      if (gph) (void)hipGraphDestroy(gph);
+  if (f->zstream) {
+    (void)hipStreamSynchronize(f->zstream);
+    (void)hipStreamDestroy(f->zstream);
+  }
+  if (f->ev_zero) (void)hipEventDestroy(f->ev_zero);
+  if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
+  Plane* pl[] = {&f->flag, &f->flag2, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
   delete f;
@@ -2484,7 +2555,8 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     }
   }
   int rc;
-  if ((rc = plane_alloc(m, f->flag)) || (rc = plane_alloc(m, f->qb)) || (rc = plane_alloc(m, f->sb))) {
+  if ((rc = plane_alloc(m, f->flag)) || (rc = plane_alloc(m, f->flag2)) || (rc = plane_alloc(m, f->qb)) ||
+      (rc = plane_alloc(m, f->sb))) {
     fuelmi_frontier_destroy(f);
     return rc;
   }
@@ -2541,6 +2613,9 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi_p));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
+  HIPCHK(hipStreamCreateWithFlags(&f->zstream, hipStreamNonBlocking));  // zeroes the retired flag plane (frontier_apply_reset)
+  HIPCHK(hipEventCreateWithFlags(&f->ev_zero, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
 
   // ---- everything below is constant for the life of the object (the kernel chain is replayed
   // as a graph with these arguments baked in) ----
@@ -2621,11 +2696,14 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       fuelmi_frontier_destroy(f);
       return rc;
     }
+    size_t seg_words = 0;  // per-tile segment arrays: the largest (tiles x segments per tile) of the menu
     for (int k = 0; k < 4; ++k) {
-      const size_t items = (size_t)(f->FTX ? f->FTX * f->FTY : kFastMenu[k][0] * kFastMenu[k][1]) * ((g.nz + 31) / 32);
+      const int ftx = f->FTX ? f->FTX : kFastMenu[k][0], fty = f->FTX ? f->FTY : kFastMenu[k][1];
+      const size_t items = (size_t)(ftx * fty) * ((g.nz + 31) / 32);
+      seg_words = std::max(seg_words, (size_t)((qx + 1 + ftx - 1) / ftx) * ((qy + 1 + fty - 1) / fty) * items);
       f->fast_items[k] = items;
       // k_tile_ccl: labels, bits + prefix, records, per-row counts, root numbers, component per cell
-      f->tile_lds[k] = (FR_TCELL + 2 * items + 1 + (size_t)FR_TROOT * 8 + (size_t)FR_TROOT * FR_TXS) * sizeof(u32) +
+      f->tile_lds[k] = (FR_TCELL + 3 * items + 1 + (size_t)FR_TROOT * 8 + (size_t)FR_TROOT * FR_TXS) * sizeof(u32) +
                        FR_TCELL * sizeof(unsigned short) + FR_TCELL;
       f->cross_lds[k] = (2 * items + (size_t)XC_WCAP) * sizeof(u32);
       // k_tile_out: bits + prefix + seed bits, cell addresses, the two row tables, cluster map, codes, keys
@@ -2634,6 +2712,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       f->tile_lds[k] = (f->tile_lds[k] + 15) & ~(size_t)15;
       f->cross_lds[k] = (f->cross_lds[k] + 15) & ~(size_t)15;
       f->out_lds[k] = (f->out_lds[k] + 15) & ~(size_t)15;
+    }
+    if ((rc = dmalloc(f, &F.tq, seg_words + 64)) || (rc = dmalloc(f, &F.ts, seg_words + 64))) {
+      fuelmi_frontier_destroy(f);
+      return rc;
     }
     const size_t lds_max = std::max(f->tile_lds[0], f->out_lds[0]);
     if (lds_max > 64 * 1024 && lds_max <= 150 * 1024) {
@@ -2910,14 +2992,11 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
 static int frontier_enqueue_fast(fuelmi_frontier* f) {
   const Geo& g = f->map->g;
   FArgs& F = f->F;
-  const int nb_max = (g.W + 255) / 256 + 1;
   // launch grid of the tile kernels: the chosen tile over the largest rectangle a search can cover
   const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 2, qy = F.qbox.hi[1] - F.qbox.lo[1] + 2;
   const int mk = f->FTX ? 0 : f->fast_menu;
   const int ftx = f->FTX ? f->FTX : kFastMenu[mk][0], fty = f->FTX ? f->FTY : kFastMenu[mk][1];
   const int tiles = ((qx + ftx - 1) / ftx) * ((qy + fty - 1) / fty);
-  k_pred3<<<nb_max, 256, 0, f->stream>>>(g, F, f->h_var);
-  FDBG("k_pred3");
   // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
   static int nt3[3] = {512, 512, 512};
   static bool nt_init = false;
@@ -2932,9 +3011,9 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
     if (f->fast_items[0] > (size_t)FT_PER * 256) nt3[0] = nt3[1] = nt3[2] = 512;  // (a lane fetches at most FT_PER segments)
   }
   if (nt3[0] == 256)
-    k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F);
+    k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   else
-    k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F);
+    k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   FDBG("k_tile_ccl");
   if (nt3[1] == 256)
     k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F);
@@ -2949,6 +3028,28 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
     k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
   FDBG("k_tile_out");
   HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+// fuelmi_frontier_reset, executed: frontier_flag_ becomes all-zero by SWAPPING to the spare plane (zeroed on a side
+// stream since it was retired) -- no kernel of the search clears flags on the way, no clearing pass in front of it.
+// The plane just retired is zeroed behind everything queued on the finder's stream so far (the tail of the last
+// search still sets flags in it).  The kernel chains are captured once per plane (F.flag is a kernel argument).
+static int frontier_apply_reset(fuelmi_frontier* f) {
+  if (!f->fresh_pending) return FUELMI_OK;
+  f->fresh_pending = false;
+  if (f->zero_pending) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_zero, 0));
+  f->zero_pending = false;
+  std::swap(f->flag, f->flag2);
+  f->flag_cur ^= 1;
+  f->F.flag = f->flag.p;
+  HIPCHK(hipEventRecord(f->ev_tail, f->stream));
+  HIPCHK(hipStreamWaitEvent(f->zstream, f->ev_tail, 0));
+  const int W = f->map->g.W;
+  k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->zstream>>>(f->flag2.p, W);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev_zero, f->zstream));
+  f->zero_pending = true;
   return FUELMI_OK;
 }
 
@@ -2967,6 +3068,10 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   {
     const int rcm = frontier_materialize_lists(f);  // (the result buffer is about to be reused)
     if (rcm) return rcm;
+  }
+  {
+    const int rcr = frontier_apply_reset(f);
+    if (rcr) return rcr;
   }
   double umin[3], umax[3];
   fuelmi_map_get_updated_box(m, umin, umax, 1);
@@ -3001,13 +3106,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->pending = true;
   f->search_empty = empty;
   f->fast_launched = false;
-  if (empty) {
-    if (f->fresh_pending) {  // a reset nobody has executed yet
-      k_zero_words<<<fblocks(g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, g.W);
-      f->fresh_pending = false;
-    }
-    return FUELMI_OK;
-  }
+  if (empty) return FUELMI_OK;
 
   // Region that can hold Q0 cells: the scan box, the boxes of the clusters just dropped (their flags were
   // cleared), or the whole exploration box when flags / occupancy changed behind the updated-box
@@ -3083,17 +3182,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   hv.nblocks = (w_hi - hv.w0) / 256 + 1;
   hv.nwords = hv.nblocks * 256;
   const bool fast = f->fast_ok;
-  hv.fresh = 0;
-  if (f->fresh_pending) {
-    // fuelmi_frontier_reset: every flag an earlier search could have set lies in the words this search
-    // processes (dirty_all widened the region to the whole exploration box), so the fast chain's first kernel
-    // clears them on the way; the legacy chain gets the clearing kernel in front
-    if (fast)
-      hv.fresh = 1;
-    else
-      k_zero_words<<<fblocks(g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, g.W);
-    f->fresh_pending = false;
-  }
+  hv.fresh = 0;  // (a reset has already swapped in an all-zero flag plane, frontier_apply_reset)
   if (F.dbg)  // FUELMI_FR_TIMING: stamps of this search only
     HIPCHK(hipMemsetAsync(F.dbg, 0, (size_t)(3 * (hv.ntiles_f + 1)) * FR_DBG_SLOTS * sizeof(unsigned long long), f->stream));
   hv.epoch = ++f->epoch;
@@ -3113,7 +3202,9 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   if (fast) {
     f->fast_launched = true;
     if (no_graph) return frontier_enqueue_fast(f);
-    hipGraphExec_t& fexec = f->fast_exec[f->FTX ? 0 : f->fast_menu];
+    const int gm = f->FTX ? 0 : f->fast_menu;
+    hipGraphExec_t& fexec = f->fast_exec[gm][f->flag_cur];
+    hipGraphNode_t& knode = f->fast_k1[gm][f->flag_cur];
     if (!fexec) {
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
@@ -3121,14 +3212,44 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
       const hipError_t ec = hipStreamEndCapture(f->stream, &graph);
       if (rc2) return rc2;
       HIPCHK(ec);
+      // the node of the first kernel: its third argument (the per-search FVar) is rewritten before every launch
+      size_t nn = 0;
+      HIPCHK(hipGraphGetNodes(graph, nullptr, &nn));
+      std::vector<hipGraphNode_t> nodes(nn);
+      HIPCHK(hipGraphGetNodes(graph, nodes.data(), &nn));
+      knode = nullptr;
+      for (hipGraphNode_t nd : nodes) {
+        hipGraphNodeType ty;
+        hipKernelNodeParams kp;
+        if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+        if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) continue;
+        if (kp.func == reinterpret_cast<void*>(&k_tile_ccl<512>) || kp.func == reinterpret_cast<void*>(&k_tile_ccl<256>)) {
+          knode = nd;
+          f->fast_k1_params[gm][f->flag_cur] = kp;
+        }
+      }
+      if (!knode) {
+        (void)hipGraphDestroy(graph);
+        fuelmi_set_error("frontier search: the captured chain has no tile kernel node");
+        return FUELMI_EHIP;
+      }
       HIPCHK(hipGraphInstantiate(&fexec, graph, nullptr, nullptr, 0));
-      HIPCHK(hipGraphDestroy(graph));
+      f->fast_graph[gm][f->flag_cur] = graph;  // (kept: the node handle belongs to it)
+    }
+    {
+      hipKernelNodeParams kp = f->fast_k1_params[gm][f->flag_cur];
+      Geo g_arg = g;
+      FArgs f_arg = F;
+      void* args[3] = {&g_arg, &f_arg, f->h_var};
+      kp.kernelParams = args;
+      kp.extra = nullptr;
+      HIPCHK(hipGraphExecKernelNodeSetParams(fexec, knode, &kp));
     }
     HIPCHK(hipGraphLaunch(fexec, f->stream));
     return FUELMI_OK;
   }
   if (no_graph) return frontier_enqueue_chain(f, f->npass);
-  hipGraphExec_t& exec = f->graph_exec[f->npass - 1];
+  hipGraphExec_t& exec = f->graph_exec[f->npass - 1][f->flag_cur];
   if (!exec) {
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
@@ -3569,9 +3690,9 @@ extern "C" int fuelmi_frontier_get_flags(fuelmi_frontier* f, char* flags) {
   long n = m->g.N;
   int rc = frontier_ensure_stage(f, (size_t)n);
   if (rc) return rc;
-  if (f->fresh_pending) {
-    k_zero_words<<<fblocks(m->g.W, 256, 1024), 256, 0, f->stream>>>(f->flag.p, m->g.W);
-    f->fresh_pending = false;
+  {
+    const int rcr = frontier_apply_reset(f);
+    if (rcr) return rcr;
   }
   k_expand_flag_bits<<<fblocks(n, 256), 256, 0, f->stream>>>(f->flag.p, n, (char*)f->d_stage);
   FDBG("k_expand_flag_bits");

@@ -112,6 +112,8 @@ struct FArgs {
   int keys_from_slots;    // multisplit pass 0 derives (key, value) from cell_slot / slot2rank / cell_adr
   // fast path
   FVar* var_w;            // == var (the first kernel refreshes it from the pinned host copy)
+  u32* tq;                // [tiles][items] Q0 bits of every 32-voxel segment of every tile (segment = line * nseg + c)
+  u32* ts;                // [tiles][items] NQ seed bits, same layout
   unsigned char* vlab;    // [N] tile-local component number of every Q0 cell of the search (valid where qb is set)
   unsigned char* tlab;    // [tiles][FR_TCELL] the same by tile-local cell index (coalesced source of k_tile_out)
   u32* t_base;            // [tiles] id of the tile's component 0 (XCD range | index)
@@ -145,6 +147,23 @@ __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
   int rel = w - F.var->w0;
   u64 pk = F.blockscan[rel >> 8] + F.pref[rel];
   return (u32)pk + (u32)__popcll(F.qb[w] & ((1ull << (a & 63)) - 1ull));
+}
+// Q0 bits of z-line (xx, yy) at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j), from the tile that owns the
+// line (any tile of the search); 0 outside the tiled rectangle
+__device__ __forceinline__ u64 q_window34(const Geo& g, const FVar& V, const FArgs& F, int xx, int yy, int c) {
+  if (xx < V.px0 || xx > V.px1 || yy < V.py0 || yy > V.py1) return 0ull;
+  const int nseg = (g.nz + 31) >> 5;
+  const int tx = (xx - V.px0) / V.ftx, ty = (yy - V.py0) / V.fty;
+  const int lx = xx - V.px0 - tx * V.ftx, ly = yy - V.py0 - ty * V.fty;
+  const u32* p = F.tq + (size_t)(tx * V.nty_f + ty) * (size_t)(V.ftx * V.fty * nseg) + (size_t)(lx * V.fty + ly) * nseg + c;
+  const u32 lo = c > 0 ? p[-1] : 0u, mid = p[0], hi = c + 1 < nseg ? p[1] : 0u;
+  return (u64)(lo >> 31) | ((u64)mid << 1) | ((u64)(hi & 1u) << 33);
+}
+
+// ... and the three voxels z - 1, z, z + 1 of that line (bit 0 <-> z - 1)
+__device__ __forceinline__ u32 q_bits3(const Geo& g, const FVar& V, const FArgs& F, int xx, int yy, int z) {
+  const int c = z >> 5;
+  return (u32)(q_window34(g, V, F, xx, yy, c) >> (z - 32 * c)) & 7u;
 }
 __device__ __forceinline__ u32 rank_s(const FArgs& F, long a) {
   int w = (int)(a >> 6);
@@ -210,6 +229,11 @@ struct fuelmi_frontier {
   fuelmi_frontier_cfg cfg;
   int iz_min = 0;
   Plane flag, qb, sb;
+  Plane flag2;  // the spare flag plane (all-zero or being zeroed): a reset swaps the two
+  int flag_cur = 0;
+  hipStream_t zstream = nullptr;
+  hipEvent_t ev_zero = nullptr, ev_tail = nullptr;
+  bool zero_pending = false;
   FArgs F;
   std::vector<void*> allocs;
   std::list<HCluster> frontiers, dormant, tmp;
@@ -226,7 +250,7 @@ struct fuelmi_frontier {
   int TX = 1, TY = 16, ccl_tiles = 0;
   int FTX = 8, FTY = 16, fast_tiles = 0;  // tiles of the fast chain (sparse labels: no LDS bound from nz)
   size_t ccl_lds = 0;
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // kernel chain with 1 / 2 radix passes
+  hipGraphExec_t graph_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // kernel chain with 1 / 2 radix passes, per flag plane
   bool pending = false, search_empty = false;
   bool ref_now = false;  // the search being collected delivers its cells in the reference's order (cfg.reference_order 1, or 2 and small)
   // fast path: _search_end returns as soon as the cluster records have arrived; the kernels that regroup the
@@ -237,7 +261,10 @@ struct fuelmi_frontier {
   mutable bool tail_pending = false;
   bool fast_launched = false;  // the chain of the running search is the fast one
   u32 epoch = 0;
-  hipGraphExec_t fast_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // one per tile of the menu (launch grids differ)
+  hipGraphExec_t fast_exec[4][2] = {};  // one per tile of the menu (launch grids differ) and flag plane
+  hipGraph_t fast_graph[4][2] = {};     // ... the graphs they were instantiated from (own the node handles)
+  hipGraphNode_t fast_k1[4][2] = {};    // ... the node of the chain's first kernel (its FVar argument is rewritten per search)
+  hipKernelNodeParams fast_k1_params[4][2] = {};
   int fast_menu = 0;  // menu entry of the running search
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane

@@ -77,7 +77,8 @@ __device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs&
       const int yy = y + dy;
       if (yy < 0 || yy >= g.ny) continue;
       const long nb0 = a + (long)dx * g.nyz + (long)dy * g.nz - 1;
-      u32 bits = (u32)(plane_window(F.qb, nb0) & 7ull);
+      // (fast chain: the Q0 bits live in the per-tile segment arrays; legacy chain: in the Q0 plane)
+      u32 bits = F.fast ? q_bits3(g, *F.var, F, xx, yy, z) : (u32)(plane_window(F.qb, nb0) & 7ull);
       if (z == 0) bits &= ~1u;
       if (z == g.nz - 1) bits &= ~4u;
       if (dx == 0 && dy == 0) bits &= ~2u;
