@@ -89,6 +89,7 @@ public:
   // additions: clusters found by the last searchFrontiers() and the list positions it removed
   const list<Frontier>& newFrontiers() const { return tmp_frontiers_; }
   const vector<int>& removedIds() const { return removed_ids_; }
+  fuelmi_frontier* device() const { return dev_; }  // the C-ABI object behind the finder (like SDFMap::device())
 
 private:
   void pull(int which, list<Frontier>& out, int from = 0);

@@ -304,12 +304,14 @@ FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeH
   // searchFrontiers ends with splitLargeFrontiers (:120); without its two parameters the search stops
   // at the region-grown clusters
   c.split = (cluster_size_xy > 0.0 && down_sample > 0) ? 1 : 0;
-  // addition: frontier/reference_order.  1 lists cells_ in the reference's BFS order and sums average_ / the
-  // VoxelGrid centroids in that order (bit-identical means, filtered_cells_, viewpoints and visib_num_); 0 is the
-  // address order (fastest); 2, the default, is the reference's order for every search that keeps at most 32768
-  // cells -- all the incremental searches of a flight -- and the address order for giant full-box searches only
-  int ref_order = 2;
-  nh.param("frontier/reference_order", ref_order, 2);
+  // addition: frontier/reference_order.  0 (default) is the address order: the fast path.  1 lists cells_ in the
+  // reference's BFS order and sums average_ / the VoxelGrid centroids in that order (bit-identical means,
+  // filtered_cells_, viewpoints and visib_num_) at the price of a level-by-level sweep per search -- measured
+  // +2.9 ms per incremental search of the streaming workload, 16 ms for the full 400x400x100 box
+  // (profiles/r03_next_rows.json), which is why it is not the default.  2: order 1 for searches of at most 32768
+  // cells, order 0 for the giant ones.
+  int ref_order = 0;
+  nh.param("frontier/reference_order", ref_order, 0);
   c.reference_order = ref_order;
   warn("fuelmi_frontier_create", fuelmi_frontier_create(edt_env_->sdf_map_->device(), &c, &dev_));
   // viewpoint sampling parameters (frontier_finder.cpp:32-43, perception_utils.cpp:7-11)

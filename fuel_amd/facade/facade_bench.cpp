@@ -126,7 +126,80 @@ static double run_cabi(const double* hdr, const std::vector<Frame>& frames, int*
   return dt / (double)frames.size();
 }
 
+// BASELINE's headline cycle through the facade (the drop-in's own figure): the whole 400x400x100 map as local bound
+// and as updated box -- clearAndInflateLocalMap, updateESDF3d, searchFrontiers from fresh flags over the whole
+// exploration box, and the clusters handed to the caller's containers (getFrontiers: vector<vector<Vector3d>>, what
+// fast_exploration_manager.cpp:99-114 reads).  The occupancy state is uploaded once through the C-ABI (the reference
+// has no such call: it only ever fuses frames); fuelmi_frontier_reset stands for "a fresh finder" each cycle.
+static double run_fullbox(const double* hdr, const std::vector<double>& occ, bool mirrors, int cycles, int* n_clusters,
+                          size_t* n_cells) {
+  ros::NodeHandle nh;
+  params(nh, hdr);
+  SDFMap::Ptr map(new SDFMap);
+  map->initMap(nh);
+  map->setHostMirror(mirrors, mirrors, mirrors);
+  EDTEnvironment::Ptr edt(new EDTEnvironment);
+  edt->setMap(map);
+  FrontierFinder ff(edt, nh);
+  fuelmi_map* dev = map->device();
+  if (fuelmi_map_upload_occupancy(dev, occ.data()) != FUELMI_OK) return -1.0;
+  fuelmi_map_info inf;
+  fuelmi_map_get_info(dev, &inf);
+  const int lo[3] = {0, 0, 0}, hi[3] = {inf.voxel_num[0] - 1, inf.voxel_num[1] - 1, inf.voxel_num[2] - 1};
+  fuelmi_map_set_local_bound(dev, lo, hi);
+  std::vector<std::vector<Eigen::Vector3d>> cl;
+  double t0 = 0.0;
+  for (int k = -3; k < cycles; ++k) {  // three untimed cycles first
+    if (k == 0) {
+      fuelmi_map_synchronize(dev);
+      t0 = now_s();
+    }
+    fuelmi_frontier_reset(ff.device());
+    fuelmi_map_set_updated_box(dev, hdr + 3, hdr + 6);
+    MapROS::inflate(*map);
+    map->updateESDF3d();
+    ff.searchFrontiers();
+    ff.getFrontiers(cl);  // (empty: nothing was committed) ...
+    cl.clear();
+    for (const auto& fr : ff.newFrontiers()) cl.push_back(fr.cells_);  // ... the new clusters' cell lists, copied out
+  }
+  fuelmi_map_synchronize(dev);
+  const double dt = now_s() - t0;
+  *n_clusters = (int)cl.size();
+  *n_cells = 0;
+  for (const auto& c : cl) *n_cells += c.size();
+  return dt / (double)cycles;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 5 && std::string(argv[3]) == "fullbox") {
+    FILE* in = fopen(argv[1], "rb");
+    if (!in) return 1;
+    double hdr[10];
+    rd(in, hdr, 10);
+    fclose(in);
+    FILE* fo = fopen(argv[4], "rb");
+    if (!fo) return 1;
+    const size_t n = (size_t)std::llround(hdr[0] * 10) * (size_t)std::llround(hdr[1] * 10) * (size_t)std::llround(hdr[2] * 10);
+    std::vector<double> occ(n);
+    rd(fo, occ.data(), n);
+    fclose(fo);
+    const int repeat = std::atoi(argv[2]);
+    double best[2] = {1e30, 1e30};
+    int ncl[2] = {0, 0};
+    size_t ncell[2] = {0, 0};
+    for (int r = 0; r < repeat; ++r) {
+      best[0] = std::min(best[0], run_fullbox(hdr, occ, true, 10, &ncl[0], &ncell[0]));
+      best[1] = std::min(best[1], run_fullbox(hdr, occ, false, 20, &ncl[1], &ncell[1]));
+    }
+    std::printf("{\"workload\": \"full-box plan cycle through the facade on a %.0fx%.0fx%.0f m map: clearAndInflateLocalMap + "
+                "updateESDF3d + searchFrontiers (fresh flags, whole exploration box) + the cell lists of the new clusters as "
+                "vector<Vector3d>\", \"facade_mirrors_on_ms\": %.4f, \"facade_mirrors_off_ms\": %.4f, "
+                "\"cycles_per_s_mirrors_off\": %.1f, \"clusters\": %d, \"cells\": %zu}\n",
+                hdr[0], hdr[1], hdr[2], 1e3 * best[0], 1e3 * best[1], 1.0 / best[1], ncl[1], ncell[1]);
+    return 0;
+  }
+
   if (argc < 2) return 1;
   FILE* in = fopen(argv[1], "rb");
   if (!in) return 1;

@@ -179,10 +179,10 @@ typedef struct {
                              neighbour order :848-860), average_ as its sequential f64 sum (:374-390), VoxelGrid
                              centroids accumulated in that order (:757-774) -- so that means, filtered_cells_,
                              split pieces and viewpoints reproduce the reference bit for bit; costs one BFS
-                             level sweep per cluster on the device and host-side means.  2 ("auto", what the C++
-                             facade uses unless told otherwise): the reference's order for every search that keeps
-                             at most 32768 cells -- the incremental searches of an exploration run -- and the
-                             address order only for giant full-box searches, where the sweep costs milliseconds */
+                             level sweep per cluster on the device and host-side means.  2 ("auto"): the reference's
+                             order for every search that keeps at most 32768 cells -- the incremental searches of
+                             an exploration run, +2.9 ms each as measured -- and the address order for giant
+                             full-box searches, where the sweep costs 16 ms */
 } fuelmi_frontier_cfg;
 
 typedef struct fuelmi_frontier fuelmi_frontier;
