@@ -727,6 +727,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 bit-planes / u32 squared distances / f32 ESDF / f64 log-odds and B-spline",
             "data": "synthetic",
+            "commit": os.environ.get("FUELMI_COMMIT"),  # git revision of the code (set by scripts/collect_profiles.sh)
             "config": {"workload": ("%s: %dx%dx%d @0.1m map per GPU, streaming 640x480 depth frames from an unknown "
                                     "map: device projection + fusion, box-local inflate+ESDF (mean box %.2f M voxels), "
                                     "incremental frontier search, %d B-spline candidates x 32 ctrl pts"

@@ -22,6 +22,7 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --no-cpu-baseline`",
        "correction": "hbm_bytes = (2 * FETCH_SIZE_KiB + WRITE_SIZE_KiB) * 1024 (gfx950: FETCH_SIZE counts half of the read bytes)",
+       "commit": sys.argv[4] if len(sys.argv) > 4 else None,  # git revision of the binary the passes ran
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
