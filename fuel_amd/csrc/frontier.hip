@@ -3459,16 +3459,22 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   u32 ncl = nkept, ncells = n_out;
   std::vector<std::vector<float>> filtered;
   const bool split_mode = f->cfg.split != 0;
-  // reference_order 1: always; 2 ("auto", the facade's default): whenever the search kept at most FR_REFORDER_AUTO
-  // cells -- every incremental search of an exploration run -- and the canonical order for the giant ones
-  const bool ref_order = f->cfg.reference_order == 1 || (f->cfg.reference_order == 2 && n_out <= FR_REFORDER_AUTO);
+  // reference_order 1: always; 2 ("auto", the facade's default): whenever every cluster of the search holds at most
+  // FR_REFORDER_AUTO cells (the level sweep then runs inside LDS) -- every incremental search of an exploration
+  // run -- and the canonical order for the giant ones
+  bool ref_order = f->cfg.reference_order == 1;
+  if (f->cfg.reference_order == 2) {
+    ref_order = true;
+    for (u32 r = 0; r < nkept; ++r)
+      if (h_rec[r].size > FR_REFORDER_AUTO) ref_order = false;
+  }
   f->ref_now = ref_order;
   int fin = nkept <= 256 ? 1 : 0;  // buffer pair holding the grouped cells of the search
   std::vector<u32> off2;
   u32 n_in = n_out;
   if (ref_order || split_mode) HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
   if (ref_order) {  // cells of every cluster in expandFrontier's order (an NQ seed first), into the other pair
-    int rc = frontier_reference_order(f, nq, nkept, n_out, fin, &n_in, &off2);
+    int rc = frontier_reference_order(f, nq, nkept, n_out, fin, &n_in, &off2, !split_mode);
     if (rc) return rc;
     fin = 1 - fin;
     ncells = n_in;
@@ -3477,10 +3483,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     int rc = frontier_split_run(f, nq, nkept, n_in, fin, &ncl, &ncells, &filtered);
     if (rc) return rc;
     fin = ncl <= 256 ? 1 : 0;  // where the regrouping of the pieces ended
-  } else if (ref_order) {
-    HIPCHK(hipMemcpyAsync(F.h_cells, F.ms_val[fin], (size_t)n_in * sizeof(u32), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipStreamSynchronize(f->stream));
-  }
+  }  // (reference order without the split: the ordered cells are in h_cells already)
   f->last_fin = fin;  // buffer holding the grouped cells the lazy clusters point into
   f->cells_fetch = F.fast && !ref_order && !split_mode && nq > F.hcells_direct_max;
   f->cells_fetch_n = ncells;

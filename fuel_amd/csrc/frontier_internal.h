@@ -61,7 +61,8 @@ struct FVar {
 #define FR_KCAP 256             // kept clusters
 #define FR_PCAP (1u << 18)      // cross-tile adjacency records
 #define FR_PMCAP 16384          // entries of the (kept cluster x tile column) matrix k_resolve scans in its LDS
-#define FR_REFORDER_AUTO 32768u   // cfg.reference_order == 2: searches that keep at most this many cells use the reference's order
+#define FR_REFORDER_AUTO 26624u   // cfg.reference_order == 2: searches whose clusters all hold at most this many cells use the
+                                  // reference's order (what frontier_order.hip sweeps inside LDS)
 #define FR_UNCLAIMED 0xFFFFFFFFu  // rcode: component claimed by nobody (no flag, no cluster)
 #define FR_NOTKEPT 0xFFFFFFFEu    // rcode: claimed (flag set) but its cluster is too small
 struct TRec {  // one tile-local component
@@ -305,7 +306,7 @@ void frontier_order_free(fuelmi_frontier* f);
 // (F.ms_val[fin] / F.ms_key[fin], records F.h_rec).  out: F.ms_val[1 - fin] / F.ms_key[1 - fin] hold *n_total =
 // n_out + (clusters started by an NQ seed) cells, cluster r at h_off2[r] .. h_off2[r + 1] (host vector).
 int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin, u32* n_total,
-                             std::vector<u32>* h_off2);
+                             std::vector<u32>* h_off2, bool fetch_cells);
 // tmp cluster -> committed: materialises the host list and copies the cells into the device pool
 struct PoolPut {  // one cluster's copy into the cell pool
   u64 dst;

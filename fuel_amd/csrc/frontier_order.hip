@@ -16,34 +16,71 @@
 //      levels are larger than every key handed out before, so cells that are already placed ignore them)
 //   B  every p counts the neighbours whose final key is its own proposal (its children), a prefix sum over the
 //      level gives their positions, and they are written in neighbour order: the next level, already sorted.
-// Cost: two passes over ~26 neighbour look-ups per cell and two workgroup barriers per level; the number of
-// levels is the graph eccentricity of the start cell (hundreds for a surface that spans the map).
+// The number of levels is the graph eccentricity of the start cell (hundreds for a surface that spans the map), and
+// a level is a handful of DEPENDENT steps, so what a level costs is the latency of the memory the sweep lives in:
+//   k_bfs_nbr + k_bfs_sweep  clusters of at most BFSL_CAP cells (every cluster of an incremental search).  The part
+//                    that does not depend on the order -- which of a cell's 26 neighbours are cells of the cluster,
+//                    and where in the cluster's sorted address list they are -- is found for all cells at once by
+//                    k_bfs_nbr (a lane per cell, nine lower-bound searches side by side) and left as a 24-byte
+//                    record per cell.  k_bfs_sweep then runs the levels with the keys and the queue in LDS (and
+//                    the records too when they fit): a level is one record fetch, LDS atomics and three barriers.
+//   k_bfs_order      larger clusters: keys by voxel address in global memory, membership through the chain's own
+//                    per-voxel records; every step is a round trip to L2 (about 25 us per level).
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "frontier_internal.h"
 
 struct OrderScratch {
-  u32* key = nullptr;     // [N] discovery keys by voxel address (0xFFFFFFFF outside a running sweep)
-  u32* ord = nullptr;     // [cap_q + cap_kept] addresses in BFS order
-  u32* off2 = nullptr;    // [cap_kept + 1]
-  u32* err = nullptr;     // [4]
-  u32* h_err = nullptr;   // pinned [4]
+  u32* key = nullptr;     // [N] discovery keys by voxel address (0xFFFFFFFF outside a running sweep); allocated by the
+                          // first search that holds a cluster too large for the LDS sweep
+  u32* ord = nullptr;     // [cap_q + cap_kept] addresses in BFS order (large clusters)
+  u32* h_err = nullptr;   // pinned [4], written by the kernels
+  uint2* nbr = nullptr;   // [nbr_cap][3] neighbour records of k_bfs_nbr (grouped cells, then one per cluster for its seed)
+  size_t nbr_cap = 0;
+  u32* first = nullptr;   // [cap_kept] index of the start cell in its cluster's list
+  bool lds_attr = false;  // k_bfs_sweep may use the whole LDS of a CU
 };
 
 namespace {
 
 #define BFS_T 1024
+#define BFSL_T 256
+#define BFSL_CAP FR_REFORDER_AUTO  // cells of a cluster ordered inside LDS (6 bytes each: key, queue entry)
+#define BFSL_LDS_MAX (160u * 1024u - 64u)
 
 struct BArgs {
   u32* key;
   u32* ord;
-  const u32* off2;
+  const u32* in_adr;  // grouped cells of the search (ascending address inside a cluster), cluster r at krec[r].off
   u32* out_adr;
   u32* out_key;
   u32 nq;
+  u32 lcap;           // largest cluster of this search that k_bfs_sweep orders
+  uint2* nbr;         // neighbour records
+  u32* first;
+  u32 n_grouped;      // cells in the grouped array; record n_grouped + r belongs to the seed of cluster r
+  u32 nkept;
+  int nbr_in_lds;     // the records of a cluster fit into LDS beside its keys and its queue
   u32* err;
 };
+
+// first position of cluster r in the ordered array: the sizes of the clusters before it (a size counts the NQ seed
+// that started the cluster, the grouped array does not hold it)
+template <int T>
+__device__ __forceinline__ u32 cluster_base(const FArgs& F, u32 r, u32* s_red) {
+  u32 v = 0u;
+  for (u32 k = threadIdx.x; k < r; k += T) v += F.krec[k].size;
+  for (int off = 32; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  u32 tot = 0u;
+  for (int w = 0; w < T / 64; ++w) tot += s_red[w];
+  __syncthreads();
+  return tot;
+}
 
 __device__ __forceinline__ u32 ld_agent(const u32* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -98,8 +135,9 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
   const KeptRec kr = F.krec[r];
   const int slot = (int)kr.slot;
   const bool seedc = kr.slot >= B.nq;  // started by an NQ seed: the seed is cells_[0] but not a Q0 cell
-  const u32 base0 = B.off2[r];
-  const u32 want = B.off2[r + 1] - base0;
+  const u32 want = kr.size;
+  if (want <= BFSL_CAP) return;  // (k_bfs_sweep's)
+  const u32 base0 = cluster_base<BFS_T>(F, r, s_wave);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
     if (!seedc) st_agent(&B.key[kr.addr], 0u);
@@ -184,12 +222,243 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
   }
 }
 
+// ---- clusters that fit into LDS ----
+// What k_bfs_nbr leaves per cell: which cells of the 3 x 3 x 3 block around it are in the cluster's list (3 bits per
+// (dx, dy) line: z-1, z, z+1) and the list index of every line's first present cell.
+struct NbrSet {
+  u32 raw;                        // bits 0..26 as above; bit 27: the cell has z == 0, bit 28: z == nz - 1
+  u32 lo8;                        // index of the first present cell of line 8
+  unsigned long long lo03, lo47;  // ... of lines 0..3 and 4..7, 16 bits each (packed: a lane picks a line by a
+                                  // computed number, and an indexed array would live in scratch)
+};
+
+// the neighbours a cell proposes to: not itself, and not across the z ends of a line (bit 0 of a line at z == 0 is
+// the last cell of the previous line, bit 2 at z == nz - 1 the first of the next)
+__device__ __forceinline__ u32 nbr_valid(const NbrSet& s) {
+  u32 ok = s.raw & 0x7FFFFFFu & ~(2u << 12);
+  if (s.raw & (1u << 27)) ok &= ~0x1249249u;
+  if (s.raw & (1u << 28)) ok &= ~(0x1249249u << 2);
+  return ok;
+}
+
+// list index of neighbour idx27 = 3 * line + b
+__device__ __forceinline__ u32 nbr_index(const NbrSet& s, int idx27) {
+  const int li = idx27 / 3, b = idx27 - 3 * li;
+  const u32 below = (s.raw >> (3 * li)) & ((1u << b) - 1u);
+  const unsigned long long w = li < 4 ? s.lo03 : s.lo47;
+  const u32 first = li == 8 ? s.lo8 : (u32)(w >> (16 * (li & 3))) & 0xFFFFu;
+  return first + (u32)__popc(below);
+}
+
+__device__ __forceinline__ NbrSet find_neighbours(const Geo& g, const u32* adr, u32 n, int a) {
+  NbrSet s;
+  const int x = a / g.nyz;
+  const int rr = a - x * g.nyz;
+  const int y = rr / g.nz, z = rr - y * g.nz;
+  u32 top = 1u;
+  while (top * 2u <= n) top *= 2u;
+  if (n == 0u) top = 0u;
+  int t[9];
+  u32 lo[9];
+#pragma unroll
+  for (int li = 0; li < 9; ++li) {
+    const int dx = li / 3 - 1, dy = li % 3 - 1;
+    t[li] = a + dx * g.nyz + dy * g.nz - 1;
+    lo[li] = 0u;
+  }
+  for (u32 step = top; step > 0u; step >>= 1) {  // nine lower bounds side by side: lo = cells below t
+#pragma unroll
+    for (int li = 0; li < 9; ++li) {
+      const u32 q = lo[li] + step;
+      if (q <= n && (int)adr[q - 1u] < t[li]) lo[li] = q;
+    }
+  }
+  u32 raw = 0u;
+#pragma unroll
+  for (int li = 0; li < 9; ++li) {
+    const int dx = li / 3 - 1, dy = li % 3 - 1;
+    const bool inside = (unsigned)(x + dx) < (unsigned)g.nx && (unsigned)(y + dy) < (unsigned)g.ny;
+    u32 q = lo[li], bits = 0u;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      if (q < n && (int)adr[q] == t[li] + b) bits |= 1u << b, ++q;
+    raw |= (inside ? bits : 0u) << (3 * li);
+  }
+  if (z == 0) raw |= 1u << 27;
+  if (z == g.nz - 1) raw |= 1u << 28;
+  s.raw = raw;
+  s.lo03 = (unsigned long long)lo[0] | (unsigned long long)lo[1] << 16 | (unsigned long long)lo[2] << 32 |
+           (unsigned long long)lo[3] << 48;
+  s.lo47 = (unsigned long long)lo[4] | (unsigned long long)lo[5] << 16 | (unsigned long long)lo[6] << 32 |
+           (unsigned long long)lo[7] << 48;
+  s.lo8 = lo[8];
+  return s;
+}
+
+__device__ __forceinline__ void nbr_store(uint2* rec, const NbrSet& s) {
+  rec[0] = make_uint2(s.raw, s.lo8);
+  rec[1] = make_uint2((u32)s.lo03, (u32)(s.lo03 >> 32));
+  rec[2] = make_uint2((u32)s.lo47, (u32)(s.lo47 >> 32));
+}
+__device__ __forceinline__ NbrSet nbr_load(const uint2* rec) {
+  const uint2 a = rec[0], b = rec[1], c = rec[2];
+  NbrSet s;
+  s.raw = a.x, s.lo8 = a.y;
+  s.lo03 = (unsigned long long)b.x | (unsigned long long)b.y << 32;
+  s.lo47 = (unsigned long long)c.x | (unsigned long long)c.y << 32;
+  return s;
+}
+
+// a lane per grouped cell (then a lane per cluster for its NQ seed): the cell's neighbour record
+__global__ void __launch_bounds__(256) k_bfs_nbr(Geo g, FArgs F, BArgs B) {
+  const u32 p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= B.n_grouped + B.nkept) return;
+  u32 r;
+  bool is_seed = false;
+  if (p < B.n_grouped) {
+    u32 lo = 0u, top = 1u;  // the cluster whose range holds position p: the last with off <= p
+    while (top * 2u <= B.nkept) top *= 2u;
+    for (u32 step = top; step > 0u; step >>= 1)
+      if (lo + step < B.nkept && F.krec[lo + step].off <= p) lo += step;
+    r = lo;
+  } else {
+    r = p - B.n_grouped;
+    is_seed = true;
+  }
+  const KeptRec kr = F.krec[r];
+  if (kr.size > BFSL_CAP) return;
+  const bool seedc = kr.slot >= B.nq;
+  const u32 n = kr.size - (seedc ? 1u : 0u);
+  if (is_seed ? !seedc : p - kr.off >= n) return;
+  const u32* list = B.in_adr + kr.off;
+  const u32 a = is_seed ? kr.addr : list[p - kr.off];
+  nbr_store(B.nbr + 3 * (size_t)p, find_neighbours(g, list, n, (int)a));
+  if (is_seed)
+    B.first[r] = n;
+  else if (!seedc && a == kr.addr)
+    B.first[r] = p - kr.off;
+}
+
+// one workgroup per cluster: the level sweep.  key[i] = discovery key of cell i of the cluster's list (i == n: the NQ
+// seed, reachable by nobody), ord[k] = list index of the k-th cell of the queue.
+__global__ void __launch_bounds__(BFSL_T) k_bfs_sweep(Geo g, FArgs F, BArgs B) {
+  extern __shared__ __align__(16) u32 bfs_lds[];
+  __shared__ u32 s_wave[BFSL_T / 64];
+  const u32 r = blockIdx.x;
+  const KeptRec kr = F.krec[r];
+  const u32 want = kr.size;
+  if (want > BFSL_CAP) return;  // (k_bfs_order's)
+  const bool seedc = kr.slot >= B.nq;
+  const u32 n = want - (seedc ? 1u : 0u);
+  u32* key = bfs_lds;                                                                 // [lcap + 1]
+  uint2* tab = reinterpret_cast<uint2*>(bfs_lds + ((B.lcap + 2u) & ~1u));             // [lcap + 1][3] (optional)
+  unsigned short* ord = reinterpret_cast<unsigned short*>(
+      bfs_lds + ((B.lcap + 2u) & ~1u) + (B.nbr_in_lds ? 6u * (B.lcap + 1u) : 0u));  // [lcap + 1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2* grec = B.nbr + 3 * (size_t)kr.off;
+  const uint2* srec = B.nbr + 3 * ((size_t)B.n_grouped + r);
+  for (u32 k = threadIdx.x; k <= n; k += BFSL_T) key[k] = 0xFFFFFFFFu;
+  if (B.nbr_in_lds) {
+    for (u32 k = threadIdx.x; k < 3u * n; k += BFSL_T) tab[k] = grec[k];
+    if (seedc && threadIdx.x < 3) tab[3u * n + threadIdx.x] = srec[threadIdx.x];
+  }
+  const u32 base0 = cluster_base<BFSL_T>(F, r, s_wave);  // (barriers inside)
+  if (threadIdx.x == 0) {
+    u32 first = B.first[r];
+    if (first > n || (first == n) != seedc) B.err[2] = 1u + r, first = 0u;  // the claimer is a cell of its cluster
+    key[first] = 0u;
+    ord[0] = (unsigned short)first;
+  }
+  __syncthreads();
+  auto record = [&](u32 ci) {
+    if (B.nbr_in_lds) return nbr_load(tab + 3u * ci);
+    return nbr_load(ci < n ? grec + 3u * ci : srec);
+  };
+  u32 lev_lo = 0u, lev_hi = 1u;  // positions of the current level in the queue (uniform)
+  u32 n_lev = 0u;
+  bool bad = false;
+  while (true) {
+    const u32 nL = lev_hi - lev_lo;
+    ++n_lev;
+    NbrSet keep;  // the record of this lane's first cell of the level, fetched once for both passes
+    keep.raw = keep.lo8 = 0u, keep.lo03 = keep.lo47 = 0ull;
+    // ---- A: proposals ----
+    for (u32 j = threadIdx.x; j < nL; j += BFSL_T) {
+      const NbrSet s = record(ord[lev_lo + j]);
+      if (j < BFSL_T) keep = s;
+      const u32 kbase = (lev_lo + j) * 27u + 1u;
+      u32 m = nbr_valid(s);
+      while (m) {
+        const int idx27 = __builtin_ctz(m);
+        m &= m - 1u;
+        atomicMin(&key[nbr_index(s, idx27)], kbase + (u32)idx27);
+      }
+    }
+    __syncthreads();
+    // ---- B: children of every cell of the level, placed in (parent, neighbour) order ----
+    u32 run = 0u;
+    for (u32 c0 = 0u; c0 < nL; c0 += BFSL_T) {
+      const u32 j = c0 + threadIdx.x;
+      u32 wmask = 0u;
+      NbrSet s = keep;
+      if (j < nL) {
+        if (c0) s = record(ord[lev_lo + j]);
+        const u32 kbase = (lev_lo + j) * 27u + 1u;
+        u32 m = nbr_valid(s);
+        while (m) {
+          const int idx27 = __builtin_ctz(m);
+          m &= m - 1u;
+          if (key[nbr_index(s, idx27)] == kbase + (u32)idx27) wmask |= 1u << idx27;
+        }
+      }
+      const u32 cnt = (u32)__popc(wmask);
+      u32 v = cnt;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = (u32)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += t;
+      }
+      if (c0) __syncthreads();  // (the sums of the previous chunk have been read)
+      if (lane == 63) s_wave[wave] = v;
+      __syncthreads();
+      u32 woff = 0u, total = 0u;
+      for (int w = 0; w < BFSL_T / 64; ++w) {
+        if (w < wave) woff += s_wave[w];
+        total += s_wave[w];
+      }
+      u32 pos = lev_hi + run + woff + (v - cnt);
+      while (wmask) {
+        const int idx27 = __builtin_ctz(wmask);
+        wmask &= wmask - 1u;
+        if (pos < want)
+          ord[pos] = (unsigned short)nbr_index(s, idx27);
+        else
+          bad = true;  // more cells reached than the cluster holds: cannot happen
+        ++pos;
+      }
+      run += total;
+    }
+    __syncthreads();
+    if (run == 0u) break;
+    lev_lo = lev_hi;
+    lev_hi += run;
+    if (lev_hi > want) break;
+  }
+  if (bad) B.err[0] = 1u;
+  if (lev_hi != want && threadIdx.x == 0) B.err[1] = 1u + r;  // the sweep did not reach every cell of the cluster
+  if (threadIdx.x == 0 && r == 0u) B.err[3] = n_lev;  // (diagnostics: FUELMI_FR_TIMING)
+  for (u32 k = threadIdx.x; k < want && k < lev_hi; k += BFSL_T) {
+    const u32 ci = ord[k];
+    B.out_adr[base0 + k] = ci < n ? B.in_adr[kr.off + ci] : kr.addr;
+    B.out_key[base0 + k] = r;
+  }
+}
+
 }  // namespace
 
 void frontier_order_free(fuelmi_frontier* f) {
   OrderScratch* o = f->order;
   if (!o) return;
-  void* dev[] = {o->key, o->ord, o->off2, o->err};
+  void* dev[] = {o->key, o->ord, o->nbr, o->first};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (o->h_err) (void)hipHostFree(o->h_err);
@@ -198,45 +467,91 @@ void frontier_order_free(fuelmi_frontier* f) {
 }
 
 int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, int fin, u32* n_total,
-                             std::vector<u32>* h_off2) {
+                             std::vector<u32>* h_off2, bool fetch_cells) {
   fuelmi_map* m = f->map;
   FArgs& F = f->F;
   hipStream_t st = f->stream;
   if (!f->order) {
     OrderScratch* o = new OrderScratch;
     f->order = o;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->key), (size_t)m->g.N * sizeof(u32)));
-    HIPCHK(hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->ord), ((size_t)F.cap_q + F.cap_kept) * sizeof(u32)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->off2), ((size_t)F.cap_kept + 1) * sizeof(u32)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->err), 4 * sizeof(u32)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&o->h_err), 4 * sizeof(u32), hipHostMallocDefault));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->first), (size_t)F.cap_kept * sizeof(u32)));
   }
   OrderScratch* o = f->order;
   // cluster r occupies off2[r] .. off2[r+1]: its Q0 cells plus the NQ seed that started it, if one did
   std::vector<u32>& off2 = *h_off2;
   off2.assign(nkept + 1, 0u);
-  for (u32 r = 0; r < nkept; ++r) off2[r + 1] = off2[r] + F.h_rec[r].size;  // size counts the seed
+  u32 lcap = 0u, n_grouped = 0u;
+  bool any_big = false;
+  for (u32 r = 0; r < nkept; ++r) {
+    const u32 sz = F.h_rec[r].size;  // size counts the seed
+    off2[r + 1] = off2[r] + sz;
+    n_grouped = std::max(n_grouped, F.h_rec[r].off + sz - (F.h_rec[r].slot >= nq ? 1u : 0u));
+    if (sz <= BFSL_CAP)
+      lcap = std::max(lcap, sz);
+    else
+      any_big = true;
+  }
   const u32 total = off2[nkept];
   if (total > F.cap_q) {
     fuelmi_set_error("reference order: %u cells exceed the capacity %u", total, F.cap_q);
     return FUELMI_ELIMIT;
   }
   (void)n_out;
-  HIPCHK(hipMemcpyAsync(o->off2, off2.data(), (nkept + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
-  (void)nq;
-  HIPCHK(hipMemsetAsync(o->err, 0, 4 * sizeof(u32), st));
+  const bool timing = getenv("FUELMI_FR_TIMING") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   BArgs B;
-  B.key = o->key, B.ord = o->ord, B.off2 = o->off2;
+  B.key = o->key, B.ord = o->ord;
+  B.in_adr = F.ms_val[fin];
   B.out_adr = F.ms_val[1 - fin], B.out_key = F.ms_key[1 - fin];
-  B.nq = nq, B.err = o->err;
-  k_bfs_order<<<nkept, BFS_T, 0, st>>>(m->g, F, B);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(o->h_err, o->err, 4 * sizeof(u32), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));  // (off2 is a pageable host vector: its upload has been staged by now)
-  if (o->h_err[0] || o->h_err[1]) {
-    (void)hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st);  // (a sweep that stopped half-way leaves keys behind)
-    fuelmi_set_error("reference order: the level sweep of cluster %u did not match its cell set", o->h_err[1] - 1u);
+  B.nq = nq, B.lcap = lcap, B.err = o->h_err;
+  B.nbr = nullptr, B.first = nullptr, B.n_grouped = 0u, B.nkept = nkept, B.nbr_in_lds = 0;
+  for (int k = 0; k < 4; ++k) o->h_err[k] = 0u;  // (the kernels of the previous search are long done)
+  if (lcap) {
+    const size_t need = (size_t)n_grouped + nkept;
+    if (need > o->nbr_cap) {  // (grown by need: 24 bytes per cell of the largest search so far)
+      if (o->nbr) HIPCHK(hipFree(o->nbr));
+      o->nbr = nullptr, o->nbr_cap = 0;
+      const size_t cap = std::max<size_t>(need + need / 2, 1u << 16);
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->nbr), cap * 3 * sizeof(uint2)));
+      o->nbr_cap = cap;
+    }
+    B.nbr = o->nbr, B.first = o->first, B.n_grouped = n_grouped, B.nkept = nkept;
+    const size_t base = (((size_t)lcap + 2) & ~(size_t)1) * 4 + ((size_t)lcap + 1) * 2 + 16;
+    B.nbr_in_lds = base + ((size_t)lcap + 1) * 24 <= BFSL_LDS_MAX ? 1 : 0;
+    const size_t lds = base + (B.nbr_in_lds ? ((size_t)lcap + 1) * 24 : 0);
+    if (!o->lds_attr) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bfs_sweep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)BFSL_LDS_MAX));
+      o->lds_attr = true;
+    }
+    k_bfs_nbr<<<(u32)((need + 255) / 256), 256, 0, st>>>(m->g, F, B);
+    HIPCHK(hipGetLastError());
+    k_bfs_sweep<<<nkept, BFSL_T, lds, st>>>(m->g, F, B);
+    HIPCHK(hipGetLastError());
+  }
+  if (any_big) {
+    if (!o->key) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->key), (size_t)m->g.N * sizeof(u32)));
+      HIPCHK(hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->ord), ((size_t)F.cap_q + F.cap_kept) * sizeof(u32)));
+      B.key = o->key, B.ord = o->ord;
+    }
+    k_bfs_order<<<nkept, BFS_T, 0, st>>>(m->g, F, B);
+    HIPCHK(hipGetLastError());
+  }
+  if (fetch_cells)
+    HIPCHK(hipMemcpyAsync(F.h_cells, F.ms_val[1 - fin], (size_t)total * sizeof(u32), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (timing)
+    std::fprintf(stderr, "[fr-timing] reference order: %u clusters, %u cells, largest in LDS %u (levels of cluster 0: %u), global sweep %d: %.1f us\n",
+                 nkept, total, lcap, o->h_err[3], any_big ? 1 : 0,
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  if (o->h_err[0] || o->h_err[1] || o->h_err[2]) {
+    if (o->key)
+      (void)hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st);  // (a sweep that stopped half-way leaves keys behind)
+    fuelmi_set_error("reference order: the level sweep of cluster %u did not match its cell set",
+                     (o->h_err[1] ? o->h_err[1] : o->h_err[2]) - 1u);
     return FUELMI_EHIP;
   }
   *n_total = total;

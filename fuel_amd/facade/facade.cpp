@@ -304,14 +304,15 @@ FrontierFinder::FrontierFinder(const shared_ptr<EDTEnvironment>& edt, ros::NodeH
   // searchFrontiers ends with splitLargeFrontiers (:120); without its two parameters the search stops
   // at the region-grown clusters
   c.split = (cluster_size_xy > 0.0 && down_sample > 0) ? 1 : 0;
-  // addition: frontier/reference_order.  0 (default) is the address order: the fast path.  1 lists cells_ in the
-  // reference's BFS order and sums average_ / the VoxelGrid centroids in that order (bit-identical means,
-  // filtered_cells_, viewpoints and visib_num_) at the price of a level-by-level sweep per search -- measured
-  // +2.9 ms per incremental search of the streaming workload, 16 ms for the full 400x400x100 box
-  // (profiles/r03_next_rows.json), which is why it is not the default.  2: order 1 for searches of at most 32768
-  // cells, order 0 for the giant ones.
-  int ref_order = 0;
-  nh.param("frontier/reference_order", ref_order, 0);
+  // addition: frontier/reference_order.  1 lists cells_ in the reference's BFS order and sums average_ / the
+  // VoxelGrid centroids in that order (bit-identical means, filtered_cells_, viewpoints and visib_num_) at the price
+  // of a level-by-level sweep per search.  2 (default here): order 1 for every search whose clusters hold at most
+  // 26624 cells each -- every incremental search of an exploration run, +0.15 ... 0.6 ms as measured on the
+  // streaming workload -- and the address order for giant ones (a fresh full-box search: the sweep would cost
+  // 24 ms on the 400x400x100 map).  0 is the address order throughout: the fastest path, means equal to the last
+  // bits of a double, visib_num_ within a few cells (tests/test_golden_pillar.py asserts the bound).
+  int ref_order = 2;
+  nh.param("frontier/reference_order", ref_order, 2);
   c.reference_order = ref_order;
   warn("fuelmi_frontier_create", fuelmi_frontier_create(edt_env_->sdf_map_->device(), &c, &dev_));
   // viewpoint sampling parameters (frontier_finder.cpp:32-43, perception_utils.cpp:7-11)

@@ -179,10 +179,12 @@ typedef struct {
                              neighbour order :848-860), average_ as its sequential f64 sum (:374-390), VoxelGrid
                              centroids accumulated in that order (:757-774) -- so that means, filtered_cells_,
                              split pieces and viewpoints reproduce the reference bit for bit; costs one BFS
-                             level sweep per cluster on the device and host-side means.  2 ("auto"): the reference's
-                             order for every search that keeps at most 32768 cells -- the incremental searches of
-                             an exploration run, +2.9 ms each as measured -- and the address order for giant
-                             full-box searches, where the sweep costs 16 ms */
+                             level sweep per cluster on the device and host-side means (clusters of up to 26624
+                             cells are swept inside LDS: +0.15 ... 0.6 ms per search as measured on the streaming
+                             workload; larger ones through L2: 24 ms for the 140 k cells of a full 400x400x100
+                             box).  2 ("auto"): the reference's order for every search whose clusters all hold at
+                             most 26624 cells -- the incremental searches of an exploration run -- and the address
+                             order for the giant ones */
 } fuelmi_frontier_cfg;
 
 typedef struct fuelmi_frontier fuelmi_frontier;

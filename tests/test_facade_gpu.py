@@ -109,12 +109,12 @@ def test_facade_cycle_matches_oracle(tmp_path):
     assert np.abs(g0 - go).max() <= 1e-4
     assert f1 < f0  # the facade's solver loop decreases the reference objective
     off += 8 * ng
-    # second finder: split + viewpoints + top-viewpoint query, against the (canonical-order) oracle: the facade's
-    # default is the address order (frontier/reference_order = 0)
+    # second finder: split + viewpoints + top-viewpoint query, against the literal oracle (the reference's own BFS
+    # order): the facade's default is frontier/reference_order = 2, exact for searches of this size
     na, nd, ntop, covered = struct.unpack_from("4i", raw, off)
     off += 16
     top = np.frombuffer(raw, np.float64, 7 * ntop, off).reshape(ntop, 7)
-    of2 = fo.OracleFrontier(om, cmin, cluster_size_xy=1.0, down_sample=3, split=True, canonical_order=True)
+    of2 = fo.OracleFrontier(om, cmin, cluster_size_xy=1.0, down_sample=3, split=True)
     of2.set_viewpoint_cfg(fo.viewpoint_cfg(min_visib_num=3))
     om.set_updated_box(*ub)
     assert of2.search() > 0
