@@ -3472,10 +3472,11 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   int fin = nkept <= 256 ? 1 : 0;  // buffer pair holding the grouped cells of the search
   std::vector<u32> off2;
   u32 n_in = n_out;
-  if (ref_order || split_mode) HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
+  if (split_mode && !ref_order) HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
   if (ref_order) {  // cells of every cluster in expandFrontier's order (an NQ seed first), into the other pair
-    int rc = frontier_reference_order(f, nq, nkept, n_out, fin, &n_in, &off2, !split_mode);
-    if (rc) return rc;
+    int rc = frontier_reference_order(f, nq, nkept, n_out, fin, &n_in, &off2, !split_mode);  // (queued behind the
+    if (rc) return rc;                                                // search's tail; returns with the stream idle)
+    f->tail_pending = false;
     fin = 1 - fin;
     ncells = n_in;
   }

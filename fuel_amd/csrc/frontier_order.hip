@@ -57,6 +57,7 @@ struct BArgs {
   const u32* in_adr;  // grouped cells of the search (ascending address inside a cluster), cluster r at krec[r].off
   u32* out_adr;
   u32* out_key;
+  u32* h_out;         // pinned host copy of out_adr (nullptr: the caller does not want one)
   u32 nq;
   u32 lcap;           // largest cluster of this search that k_bfs_sweep orders
   uint2* nbr;         // neighbour records
@@ -218,6 +219,7 @@ __global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
     const u32 a = ld_agent(&B.ord[base0 + k]);
     B.out_adr[base0 + k] = a;
     B.out_key[base0 + k] = r;
+    if (B.h_out) B.h_out[base0 + k] = a;
     if (k > 0u || !seedc) B.key[a] = 0xFFFFFFFFu;
   }
 }
@@ -404,18 +406,32 @@ __global__ void __launch_bounds__(BFSL_T) k_bfs_sweep(Geo g, FArgs F, BArgs B) {
       if (j < nL) {
         if (c0) s = record(ord[lev_lo + j]);
         const u32 kbase = (lev_lo + j) * 27u + 1u;
-        u32 m = nbr_valid(s);
-        while (m) {
-          const int idx27 = __builtin_ctz(m);
-          m &= m - 1u;
-          if (key[nbr_index(s, idx27)] == kbase + (u32)idx27) wmask |= 1u << idx27;
+        const u32 ok = nbr_valid(s);
+        // all 27 keys are fetched before the first is looked at (a loop over the set bits would wait for every
+        // LDS read in turn: ~1 us of the ~3 us a level takes); absent neighbours read key[0] and are masked
+        u32 kv[27];
+#pragma unroll
+        for (int li = 0; li < 9; ++li) {
+          const u32 first = li == 8 ? s.lo8 : (u32)((li < 4 ? s.lo03 : s.lo47) >> (16 * (li & 3))) & 0xFFFFu;
+          const u32 bits = (s.raw >> (3 * li)) & 7u;
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const u32 idx = first + (u32)__popc(bits & ((1u << b) - 1u));
+            kv[3 * li + b] = key[(ok >> (3 * li + b)) & 1u ? idx : 0u];
+          }
         }
+#pragma unroll
+        for (int i27 = 0; i27 < 27; ++i27)
+          if (kv[i27] == kbase + (u32)i27) wmask |= ok & (1u << i27);
       }
       const u32 cnt = (u32)__popc(wmask);
+      // inclusive scan of the counts (<= 26 each) over the wave, one bit plane at a time: ballots and mbcnt, no
+      // cross-lane data movement
       u32 v = cnt;
-      for (int off = 1; off < 64; off <<= 1) {
-        const u32 t = (u32)__shfl_up((int)v, off, 64);
-        if (lane >= off) v += t;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const unsigned long long bal = __ballot((cnt >> b) & 1u);
+        v += (u32)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)) << b;
       }
       if (c0) __syncthreads();  // (the sums of the previous chunk have been read)
       if (lane == 63) s_wave[wave] = v;
@@ -448,8 +464,10 @@ __global__ void __launch_bounds__(BFSL_T) k_bfs_sweep(Geo g, FArgs F, BArgs B) {
   if (threadIdx.x == 0 && r == 0u) B.err[3] = n_lev;  // (diagnostics: FUELMI_FR_TIMING)
   for (u32 k = threadIdx.x; k < want && k < lev_hi; k += BFSL_T) {
     const u32 ci = ord[k];
-    B.out_adr[base0 + k] = ci < n ? B.in_adr[kr.off + ci] : kr.addr;
+    const u32 a = ci < n ? B.in_adr[kr.off + ci] : kr.addr;
+    B.out_adr[base0 + k] = a;
     B.out_key[base0 + k] = r;
+    if (B.h_out) B.h_out[base0 + k] = a;
   }
 }
 
@@ -504,6 +522,7 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
   B.key = o->key, B.ord = o->ord;
   B.in_adr = F.ms_val[fin];
   B.out_adr = F.ms_val[1 - fin], B.out_key = F.ms_key[1 - fin];
+  B.h_out = fetch_cells ? F.h_cells : nullptr;  // (written by the kernels themselves: no copy engine, no second wait)
   B.nq = nq, B.lcap = lcap, B.err = o->h_err;
   B.nbr = nullptr, B.first = nullptr, B.n_grouped = 0u, B.nkept = nkept, B.nbr_in_lds = 0;
   for (int k = 0; k < 4; ++k) o->h_err[k] = 0u;  // (the kernels of the previous search are long done)
@@ -540,9 +559,11 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
     k_bfs_order<<<nkept, BFS_T, 0, st>>>(m->g, F, B);
     HIPCHK(hipGetLastError());
   }
-  if (fetch_cells)
-    HIPCHK(hipMemcpyAsync(F.h_cells, F.ms_val[1 - fin], (size_t)total * sizeof(u32), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  for (;;) {  // (poll: a blocking synchronisation adds ~15 us of wake-up to a sweep of a few hundred)
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) HIPCHK(q);
+  }
   if (timing)
     std::fprintf(stderr, "[fr-timing] reference order: %u clusters, %u cells, largest in LDS %u (levels of cluster 0: %u), global sweep %d: %.1f us\n",
                  nkept, total, lcap, o->h_err[3], any_big ? 1 : 0,

@@ -213,4 +213,26 @@ out["full_front_end_cycle"] = {"gpu_ms": float(np.median(tg3[2:]) * 1e3),
                                "cpu_oracle_ms_with_4_of_64_solves": float(np.median(tc3[2:]) * 1e3),
                                "gpu_ms_map_search_viewpoints_solves": [round(float(v) * 1e3, 3) for v in np.median(np.array(parts3[2:]), axis=0)],
                                "active_frontiers_gpu": len(gf3.clusters(1)), "active_frontiers_cpu": len(of3.clusters(1))}
+
+# ---- what the reference's cell order costs on the incremental searches of the streaming workload (config #4) ----
+# the same 100 frames with frontier reference_order 0 (address order), 1 (always the BFS order) and 2 (BFS order
+# while every cluster fits the LDS sweep: the facade's default), each on a fresh map, issued by the C++ loop
+row = {}
+try:
+    map_size_s, n_obs_s, _ = bench.WORKLOADS["G800S"]
+    box_s = bench.exploration_box(map_size_s)
+    frames_s = bench.streaming_frames(map_size_s, n_obs_s, 124, seed=42)
+    ctrl_s = bench.make_trajectories(np.random.default_rng(1042), 64, 32, np.array(box_s[0]) + 0.5, np.array(box_s[1]) - 0.5)
+    for ro in (0, 1, 2):
+        cyc = bench.GpuStreamCycle(map_size_s, box_s, frames_s, ctrl_s, device=0, reference_order=ro)
+        cyc.run_native(20)
+        cyc.finish()
+        sec = cyc.run_native(100)
+        cyc.finish()
+        row["reference_order_%d_ms_per_frame" % ro] = round(sec / 100 * 1e3, 4)
+        cyc.close()
+    row["added_by_order_1_ms"] = round(row["reference_order_1_ms_per_frame"] - row["reference_order_0_ms_per_frame"], 4)
+    out["streaming_reference_order_cost"] = row
+except Exception as e:  # (dev aid: the other rows are still worth printing)
+    out["streaming_reference_order_cost"] = {"error": repr(e)}
 print(json.dumps(out))
