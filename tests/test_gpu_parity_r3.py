@@ -213,3 +213,37 @@ def test_finder_that_outlives_its_map_refuses_politely(fa):
     assert L.fuelmi_frontier_get_flags(gf.h, flags.ctypes.data_as(C.c_char_p)) != 0
     assert b"destroyed" in L.fuelmi_last_error()
     gf.close()
+
+
+def test_reference_order_many_clusters_and_a_large_one(fa):
+    """reference_order on the two extremes of frontier_order.hip: hundreds of tiny clusters kept by
+    cluster_min = 3 (legacy chain, two radix passes of the grouping: every cluster is swept inside LDS from the
+    neighbour records of k_bfs_nbr) and, in the same search, the map-spanning cluster of the explored world
+    (more cells than the LDS sweep holds when the map is large enough; here it exercises whichever class its
+    size falls in).  Against the LITERAL oracle: cells in expandFrontier's order, sequential means
+    (frontier_finder.cpp:123-164,374-390)."""
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    occ = om.occ.reshape(om.nvox)
+    free = np.argwhere((occ >= om.l_min - 1e-3) & (occ <= om.l_occ))
+    pick = free[np.all(free % 5 == 2, axis=1)]  # a lattice of isolated unknown voxels: separate little shells
+    occ[tuple(pick.T)] = om.l_min - 0.01
+    gm = fa.SDFMap((20.0, 20.0, 5.0), *box)
+    gm.uploadOccupancy(om.occ)
+    for cmin in (3, 0):
+        of = fo.OracleFrontier(om, cmin)
+        gf = fa.FrontierFinder(gm, cluster_min=cmin, reference_order=True)
+        om.set_updated_box(*box)
+        gm.setUpdatedBox(*box)
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g and n_o > 256
+        ca, cb = of.clusters(0), gf.clusters(0)
+        sizes = [len(c) for c in ca]
+        assert max(sizes) > 20 * min(sizes)  # (tiny shells beside the explored world's own frontier)
+        for k in range(n_o):
+            assert np.array_equal(ca[k], cb[k]), "cluster %d (%d cells): order differs" % (k, sizes[k])
+        for k in list(range(0, n_o, 41)) + [int(np.argmax(sizes))]:
+            for x, y in zip(of.cluster_info(0, k), gf.clusterInfo(0, k)):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), "cluster %d: average_/box not bit-equal" % k
+        assert np.array_equal(of.flags, gf.flags())
+        gf.close()
+    gm.close()
