@@ -1172,6 +1172,8 @@ __device__ __forceinline__ long tile_line_adr(const Geo& g, const TileGeo& T, in
 }
 
 #define FT_PER 8  // segments a lane of the tile kernels handles at most (tile segments / workgroup size)
+#define FT_TRIP 2  // segments of a lane whose plane windows are fetched side by side (4 measured no faster than 2: the fetch
+                   // is bound by the number of load instructions x cache lines they touch, not by their latency)
 // ---- the predicate inside the tile kernel ----------------------------------------------------------------
 // Q0 and NQ-seed bits of the 32 voxels from address a = (x, y, 32 c): knownfree && isNeighborUnknown
 // (frontier_finder.cpp:862-877) && flag == 0, cut to the Q region / the scan box -- what k_pred / f1_word compute
@@ -1181,13 +1183,21 @@ struct SegPred {
 };
 // 32 bits of a plane from (signed) bit index `bit`, through 32-bit loads: the planes are little-endian u64 words, so
 // bit b of the plane is bit (b & 31) of the 32-bit word b >> 5 -- half the bytes of plane_window per window
+// (both words of a window in ONE 8-byte load at 4-byte alignment -- the tile kernels are bound by how many load
+// instructions and cache-line look-ups their scattered windows cost, and two 4-byte loads look the same line up twice;
+// the word behind the last one of a plane lies in its zeroed margin)
+struct __attribute__((packed, aligned(4))) W2 {
+  u32 a, b;
+};
+struct __attribute__((packed, aligned(4))) W3 {
+  u32 a, b, c;
+};
 __device__ __forceinline__ u32 plane_window32(const u64* __restrict__ p, long bit) {
   const u32* q = reinterpret_cast<const u32*>(p);
   const long wi = bit >> 5;
   const int sh = (int)(bit & 31);
-  const u32 lo = q[wi];
-  if (sh == 0) return lo;
-  return (lo >> sh) | (q[wi + 1] << (32 - sh));
+  const W2 w = *reinterpret_cast<const W2*>(q + wi);
+  return (u32)((((u64)w.b << 32) | (u64)w.a) >> sh);
 }
 __device__ __forceinline__ SegPred seg_predicate(const Geo& g, const FVar& V, const FArgs& F, int x, int y, int c) {
   const long a = (long)x * g.nyz + (long)y * g.nz + 32 * c;
@@ -1197,13 +1207,19 @@ __device__ __forceinline__ SegPred seg_predicate(const Geo& g, const FVar& V, co
     const u32* q = reinterpret_cast<const u32*>(F.unk);
     const long wi = (a - 1) >> 5;
     const int sh = (int)((a - 1) & 31);
-    const u64 w01 = (u64)q[wi] | ((u64)q[wi + 1] << 32);
-    W = sh ? (w01 >> sh) | ((u64)q[wi + 2] << (64 - sh)) : w01;
+    const W3 w = *reinterpret_cast<const W3*>(q + wi);
+    const u64 w01 = (u64)w.a | ((u64)w.b << 32);
+    W = (w01 >> sh) | (((u64)w.c << 1) << (63 - sh));  // (no branch on sh: a load inside a branch is waited for inside it)
   }
+  // Every window is fetched unconditionally and masked afterwards: the planes carry zeroed margins of more than a
+  // slab on both sides, so the lines "before" y = 0 and "after" y = ny - 1 are addressable (they are the neighbouring
+  // slab's lines, or margin), and seven independent loads cost one round trip where seven guarded ones cost seven.
   const u32 occw = plane_window32(F.occ, a);
-  const u32 ym = y > 0 ? plane_window32(F.unk, a - g.nz) : 0u, yp = y < g.ny - 1 ? plane_window32(F.unk, a + g.nz) : 0u;
+  const u32 ym_raw = plane_window32(F.unk, a - g.nz), yp_raw = plane_window32(F.unk, a + g.nz);
   const u32 xm = plane_window32(F.unk, a - g.nyz), xp = plane_window32(F.unk, a + g.nyz);  // (zero margins beyond the map)
-  const u32 fl = V.fresh ? 0u : plane_window32(F.flag, a);
+  const u32 fl_raw = plane_window32(F.flag, a);
+  const u32 ym = y > 0 ? ym_raw : 0u, yp = y < g.ny - 1 ? yp_raw : 0u;
+  const u32 fl = V.fresh ? 0u : fl_raw;
   u32 down = (u32)W, up = (u32)(W >> 2);
   const u32 self_unk = (u32)(W >> 1);
   if (c == 0) down &= ~1u;                                   // z = 0 has no lower neighbour
@@ -1225,7 +1241,7 @@ __device__ __forceinline__ SegPred seg_predicate(const Geo& g, const FVar& V, co
 
 // The tile's segments: predicate, Q0 bits + exclusive prefix + CCL labels and the seed bits in the LDS (the caller
 // copies both bit arrays into the per-tile arrays tq / ts -- what the later kernels and the neighbouring tiles read:
-// coalesced, and no 64-bit plane that tiles ending in the middle of a word would have to share).  Two segments per
+// coalesced, and no 64-bit plane that tiles ending in the middle of a word would have to share).  FT_TRIP segments per
 // lane and trip.
 template <int NT>
 __device__ __forceinline__ u32 tile_load_pred(const Geo& g, const TileGeo& T, const FVar& V, const FArgs& F, u32* segb,
@@ -1234,20 +1250,30 @@ __device__ __forceinline__ u32 tile_load_pred(const Geo& g, const TileGeo& T, co
   const int per = (T.items + NT - 1) / NT;  // <= FT_PER (checked on the host)
   const int it0 = threadIdx.x * per;
   u32 cnt = 0u;
+  // (line, segment) of the lane's first item; the following ones by counting (a division by a run-time value is ~25
+  // instructions, and this phase is bound by instruction issue)
+  int c, lx, ly;
+  {
+    const int line = it0 / T.nseg;
+    c = it0 - line * T.nseg;
+    lx = line / T.TY;
+    ly = line - lx * T.TY;
+  }
 #pragma nounroll
-  for (int k0 = 0; k0 < per; k0 += 2) {
-    SegPred r[2];
+  for (int k0 = 0; k0 < per; k0 += FT_TRIP) {
+    SegPred r[FT_TRIP];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < FT_TRIP; ++h) {
       r[h].q = r[h].s = 0u;
       const int it = it0 + k0 + h;
-      if (k0 + h < per && it < T.items) {
-        const int line = it / T.nseg, c = it - line * T.nseg, lx = line / T.TY, ly = line - lx * T.TY;
-        if (lx < T.nxl && ly < T.nyl) r[h] = seg_predicate(g, V, F, T.x0 + lx, T.y0 + ly, c);
+      if (k0 + h < per && it < T.items && lx < T.nxl && ly < T.nyl) r[h] = seg_predicate(g, V, F, T.x0 + lx, T.y0 + ly, c);
+      if (++c == T.nseg) {
+        c = 0;
+        if (++ly == T.TY) ly = 0, ++lx;
       }
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < FT_TRIP; ++h) {
       const int it = it0 + k0 + h;
       if (k0 + h < per && it < T.items) {
         segb[it] = r[h].q, segs[it] = r[h].s;  // (to memory later: a store in front of a barrier is a round trip)

@@ -711,6 +711,7 @@ extern "C" int fuelmi_map_project_depth(fuelmi_map* m, const unsigned short* dep
                                         const double cam_q_wxyz[4], float* xyz, int cap, int* n_points) {
   ARGCHK(m && depth && cam_pos && cam_q_wxyz && n_points && depth_args_ok(cfg, rows, cols) && (cap == 0 || xyz));
   HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(m->qmu);  // (staging buffers: see fuelmi_map_input_depth)
   float* d_pts;
   DepthArgs D;
   int nslots;
@@ -741,6 +742,8 @@ extern "C" int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth
   for (int k = 0; k < 3; ++k)  // if (!map_->isInMap(camera_pos_)) return;
     if (cam_pos[k] < g.minb[k] + 1e-4 || cam_pos[k] > g.maxb[k] - 1e-4) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
+  // the staging buffers (size, host part) are shared with the host-staged queries other threads may be running
+  std::lock_guard<std::mutex> lk(m->qmu);
   StageScope sc(m, FUELMI_K_INSERT);
   float* d_pts;
   DepthArgs D;
@@ -833,5 +836,6 @@ extern "C" int fuelmi_map_input_points(fuelmi_map* m, const float* xyz, int stri
   ARGCHK(m && camera_pos && n >= 0 && stride_bytes >= 12 && (n == 0 || xyz));
   if (n == 0) return FUELMI_OK;  // reference: if (point_num == 0) return;
   HIPCHK(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lk(m->qmu);  // (staging buffers: see fuelmi_map_input_depth)
   return insert_points(m, xyz, stride_bytes, n, camera_pos);
 }

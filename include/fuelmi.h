@@ -14,6 +14,8 @@
  *   - voxel linear address: adr = x*ny*nz + y*nz + z  (plan_env/include/plan_env/sdf_map.h:145-147)
  *   - one HIP stream per map; mutators of one map must be called from one thread at a time
  *     (the reference runs them on the single ros::spin thread); different maps are independent.
+ *     Host-staged queries (dist_grad, coarse_dist, query_state, sync_host) may run from other threads
+ *     beside a mutator: they and the fusion entry points share the map's staging buffers under a per-map mutex.
  *   - all work is done by HIP kernels; there is no CPU fallback.  If no gfx950 device is
  *     usable fuelmi_map_create fails with FUELMI_ENODEV.
  */
