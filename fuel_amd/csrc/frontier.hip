@@ -1156,6 +1156,26 @@ __global__ void k_expand_flag_bits(const u64* __restrict__ bits, long n, char* _
 struct TileGeo {
   int tx, ty, x0, y0, nxl, nyl, TX, TY, nseg, items;
 };
+// What the tile kernels behind k_tile_ccl need before they can issue their bulk loads -- the per-search block, the
+// chain's overflow verdict, the tile's component count and id base -- fetched by different lanes in ONE round trip and
+// handed round through LDS.  (Read field by field from global memory, with an early return in between, this was
+// five dependent round trips at the head of every workgroup.)
+struct TilePro {
+  FVar V;
+  u32 ovf, nroots, gbase, pad;
+};
+__device__ __forceinline__ void stage_tile_pro(const FArgs& F, TilePro* sp) {
+  constexpr int NV = (int)(sizeof(FVar) / 4);
+  static_assert(sizeof(FVar) % 4 == 0 && NV + 3 <= 64, "FVar does not fit one wave's lanes");
+  const int t = threadIdx.x;
+  // (the address is selected, not the load: one load instruction, one wait)
+  const u32* src = reinterpret_cast<const u32*>(F.var) + (t < NV ? t : 0);
+  if (t == NV) src = F.counts + 2;
+  if (t == NV + 1) src = F.t_nroots + blockIdx.x;
+  if (t == NV + 2) src = F.t_base + blockIdx.x;
+  if (t < NV + 3) reinterpret_cast<u32*>(sp)[t] = *src;
+  __syncthreads();
+}
 __device__ __forceinline__ TileGeo tile_geo(const Geo& g, const FVar& V, int t) {
   TileGeo T;
   T.TX = V.ftx, T.TY = V.fty;
@@ -1717,7 +1737,9 @@ __device__ __forceinline__ void xc_insert(u32* s_set, u32* s_list, u32* s_n, u32
 template <int NT>
 __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
   FR_DBG_MARK(F, blockIdx.x, 13);  // (before the first load)
-  const FVar& V = *F.var;
+  __shared__ TilePro s_pro;
+  stage_tile_pro(F, &s_pro);
+  const FVar& V = s_pro.V;
   if ((int)blockIdx.x >= V.ntiles_f) return;
   // (no look at the chain's overflow word here: it shares a cache line with the counters k_tile_ccl just hit with
   // atomics, and thousands of waves waiting for that line cost more than the kernel.  After an overflow the
@@ -1738,16 +1760,18 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
   __shared__ u32 s_tb[9];         // component-id base of the 3 x 3 tiles around this one
   const int dblk = V.ntiles_f + 1 + (int)blockIdx.x;
   FR_DBG_MARK(F, dblk, 0);
-  if (threadIdx.x < 9) {
-    const int dtx = (int)threadIdx.x / 3 - 1, dty = (int)threadIdx.x % 3 - 1;
+  u32 tb9;  // id base of one of the 3 x 3 tiles around this one (in flight beside the tile's arrays)
+  {
+    const int t9 = (int)threadIdx.x % 9, dtx = t9 / 3 - 1, dty = t9 % 3 - 1;
     const int ntx = T.tx + dtx, nty = T.ty + dty;
-    u32 b = 0u;
-    if (ntx >= 0 && ntx < V.ntx_f && nty >= 0 && nty < V.nty_f) b = F.t_base[ntx * V.nty_f + nty];
-    s_tb[threadIdx.x] = b;
+    const bool ok = ntx >= 0 && ntx < V.ntx_f && nty >= 0 && nty < V.nty_f;
+    tb9 = F.t_base[ok ? ntx * V.nty_f + nty : (int)blockIdx.x];
+    if (!ok) tb9 = 0u;
   }
   if (threadIdx.x < XC_SET) s_set[threadIdx.x] = 0xFFFFFFFFu;
   if (threadIdx.x == 0) s_n = 0u, s_nw = 0u;
   tile_load_arrays<NT, false>(T, F, segq, nullptr, nullptr, segs);
+  if (threadIdx.x < 9) s_tb[threadIdx.x] = tb9;  // (read behind the barrier that ends the work-list phase)
   FR_DBG_MARK(F, dblk, 1);
   auto tile_of = [&](int x, int y) -> u32 {  // which of the 3 x 3 tiles holds column (x, y)
     const int dtx = x < T.x0 ? -1 : (x >= T.x0 + T.TX ? 1 : 0), dty = y < T.y0 ? -1 : (y >= T.y0 + TY ? 1 : 0);
@@ -1879,14 +1903,14 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
     int n0 = 0, n1 = 0, xa = 0, ya = 0, xb = 0, yb = 0;
     u64 wa = 0ull, wb = 0ull;
     const u32 ja = w0 + threadIdx.x, jb = ja + NT;
-    if (ja < nw) {
-      decode(wl[ja], b0, o0, n0, i0, xa, ya);
-      if (b0) wa = q_window34(g, V, F, xa, ya, (int)(i0 & 0xFFu));
-    }
-    if (jb < nw) {
-      decode(wl[jb], b1, o1, n1, i1, xb, yb);
-      if (b1) wb = q_window34(g, V, F, xb, yb, (int)(i1 & 0xFFu));
-    }
+    if (ja < nw) decode(wl[ja], b0, o0, n0, i0, xa, ya);
+    if (jb < nw) decode(wl[jb], b1, o1, n1, i1, xb, yb);
+    // (both windows unconditionally -- an idle slot looks at column (0, 0), outside the rectangle or not -- so that
+    // the six loads go out together)
+    wa = q_window34(g, V, F, xa, ya, (int)(i0 & 0xFFu));
+    wb = q_window34(g, V, F, xb, yb, (int)(i1 & 0xFFu));
+    if (!b0) wa = 0ull;
+    if (!b1) wb = 0ull;
 #pragma nounroll
     for (int h = 0; h < 2; ++h) {  // (one copy of the item code)
       const u32 bb = h ? b1 : b0;
@@ -2269,9 +2293,11 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
 template <int NT>
 __global__ void __launch_bounds__(NT) k_tile_out(Geo g, FArgs F) {
   FR_DBG_MARK(F, blockIdx.x, 14);  // (before the first load)
-  const FVar& V = *F.var;
+  __shared__ TilePro s_pro;
+  stage_tile_pro(F, &s_pro);
+  const FVar& V = s_pro.V;
   if ((int)blockIdx.x >= V.ntiles_f) return;
-  if (F.counts[2]) return;  // overflow (k_resolve's verdict; not the counter line the atomics went to)
+  if (s_pro.ovf) return;  // overflow (k_resolve's verdict; not the counter line the atomics went to)
   const TileGeo T = tile_geo(g, V, blockIdx.x);
   const int nseg = T.nseg, items = T.items, TY = T.TY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2289,15 +2315,18 @@ __global__ void __launch_bounds__(NT) k_tile_out(Geo g, FArgs F) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dblk = 2 * V.ntiles_f + 2 + (int)blockIdx.x;
   FR_DBG_MARK(F, dblk, 0);
-  const u32 nroots = F.t_nroots[blockIdx.x], gbase = F.t_base[blockIdx.x];
+  const u32 nroots = s_pro.nroots, gbase = s_pro.gbase;
   // fetched ahead, beside the bit-planes: the codes of the tile's components, the component numbers of its cells
   // (eight consecutive cells per lane), the first 64 tiles of the column
-  const u32 my_code = threadIdx.x < nroots ? F.rcode[gbase + threadIdx.x] : FR_UNCLAIMED;
+  u32 my_code = F.rcode[gbase + (threadIdx.x < nroots ? threadIdx.x : 0u)];  // (unconditional, masked)
+  if (threadIdx.x >= nroots) my_code = FR_UNCLAIMED;
   const u64 my_tl = reinterpret_cast<const u64*>(F.tlab + (size_t)blockIdx.x * FR_TCELL)[threadIdx.x & (FR_TCELL / 8 - 1)];
-  u32 pre_cn = 0u, pre_cb = 0u;
-  if (threadIdx.x < 64 && (int)threadIdx.x < V.nty_f) {
-    const int tt = T.tx * V.nty_f + threadIdx.x;
+  u32 pre_cn, pre_cb;
+  {  // (unconditional, masked: see stage_tile_pro)
+    const bool ok = threadIdx.x < 64 && (int)threadIdx.x < V.nty_f;
+    const int tt = ok ? T.tx * V.nty_f + (int)threadIdx.x : (int)blockIdx.x;
     pre_cn = F.t_nroots[tt], pre_cb = F.t_base[tt];
+    if (!ok) pre_cn = 0u, pre_cb = 0u;
   }
   const u32 total = tile_load_arrays<NT, true>(T, F, segb, segpre, s_wsum, segs);  // (uniform)
   FR_DBG_MARK(F, dblk, 1);

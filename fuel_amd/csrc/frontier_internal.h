@@ -151,14 +151,20 @@ __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
 }
 // Q0 bits of z-line (xx, yy) at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j), from the tile that owns the
 // line (any tile of the search); 0 outside the tiled rectangle
+// (branch-free: a load inside a branch is waited for inside it, and the callers issue several of these side by side --
+// coordinates outside the rectangle are clamped into it and the result masked, the segments before the first / behind
+// the last of a line read the line's own word again)
 __device__ __forceinline__ u64 q_window34(const Geo& g, const FVar& V, const FArgs& F, int xx, int yy, int c) {
-  if (xx < V.px0 || xx > V.px1 || yy < V.py0 || yy > V.py1) return 0ull;
+  const bool inside = xx >= V.px0 && xx <= V.px1 && yy >= V.py0 && yy <= V.py1;
+  const int xc = min(max(xx, V.px0), V.px1), yc = min(max(yy, V.py0), V.py1);
   const int nseg = (g.nz + 31) >> 5;
-  const int tx = (xx - V.px0) / V.ftx, ty = (yy - V.py0) / V.fty;
-  const int lx = xx - V.px0 - tx * V.ftx, ly = yy - V.py0 - ty * V.fty;
+  const int tx = (xc - V.px0) / V.ftx, ty = (yc - V.py0) / V.fty;
+  const int lx = xc - V.px0 - tx * V.ftx, ly = yc - V.py0 - ty * V.fty;
   const u32* p = F.tq + (size_t)(tx * V.nty_f + ty) * (size_t)(V.ftx * V.fty * nseg) + (size_t)(lx * V.fty + ly) * nseg + c;
-  const u32 lo = c > 0 ? p[-1] : 0u, mid = p[0], hi = c + 1 < nseg ? p[1] : 0u;
-  return (u64)(lo >> 31) | ((u64)mid << 1) | ((u64)(hi & 1u) << 33);
+  const bool has_lo = c > 0, has_hi = c + 1 < nseg;
+  const u32 lo = p[has_lo ? -1 : 0], mid = p[0], hi = p[has_hi ? 1 : 0];
+  const u64 w = (u64)(has_lo ? lo >> 31 : 0u) | ((u64)mid << 1) | ((u64)(has_hi ? hi & 1u : 0u) << 33);
+  return inside ? w : 0ull;
 }
 
 // ... and the three voxels z - 1, z, z + 1 of that line (bit 0 <-> z - 1)
