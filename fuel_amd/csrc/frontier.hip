@@ -1265,7 +1265,7 @@ __device__ __forceinline__ SegPred seg_predicate(const Geo& g, const FVar& V, co
 // lane and trip.
 template <int NT>
 __device__ __forceinline__ u32 tile_load_pred(const Geo& g, const TileGeo& T, const FVar& V, const FArgs& F, u32* segb,
-                                              u32* segpre, u32* s_wsum, u32* lab, u32* segs) {
+                                              u32* segpre, u32* s_wsum, u32* lab, u32* segs, unsigned short* cseg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (T.items + NT - 1) / NT;  // <= FT_PER (checked on the host)
   const int it0 = threadIdx.x * per;
@@ -1327,8 +1327,8 @@ __device__ __forceinline__ u32 tile_load_pred(const Geo& g, const TileGeo& T, co
         const u32 inv = ~(rem >> s0);
         const int len = min(inv ? __builtin_ctz(inv) : 32, 32 - s0);
         rem &= ~((len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << s0);
-        for (int q = 0; q < len; ++q) lab[l + (u32)q] = l;
-        l += (u32)len;
+        for (int q = 0; q < len; ++q) lab[l + (u32)q] = l, cseg[l + (u32)q] = (unsigned short)(it0 + k);  // (cell -> segment:
+        l += (u32)len;                                                         // what a bisection of the prefix would find)
       }
     }
     run += (u32)__popc(segb[it0 + k]);
@@ -1427,6 +1427,8 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
   unsigned char* rcell = reinterpret_cast<unsigned char*>(rootno + FR_TCELL);            // [FR_TCELL] component number per cell
   u32* segs = reinterpret_cast<u32*>(rcell + FR_TCELL);  // [items] NQ seed bits (on their way to the ts array)
   u32* plist = reinterpret_cast<u32*>(rootno);  // [FR_TPAIR] touching runs (cell << 16 | cell); shares the space of rootno + rcell, which are filled afterwards
+  unsigned short* cseg = reinterpret_cast<unsigned short*>(acc);  // [FR_TCELL] segment of every cell, for the pair walk; shares the space of acc + rrow, which are initialised behind it
+  static_assert((size_t)FR_TCELL * sizeof(unsigned short) <= (size_t)FR_TROOT * 8 * 4 + (size_t)FR_TROOT * FR_TXS * 4, "cell -> segment table does not fit");
   static_assert((size_t)FR_TPAIR * sizeof(u32) <= FR_TCELL * sizeof(unsigned short) + FR_TCELL, "pair list does not fit");
   __shared__ u32 s_wsum[NT / 64];
   __shared__ u32 s_nroots, s_base, s_flag;
@@ -1434,7 +1436,7 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
   const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_nroots = 0u, s_flag = 0u, s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0u;
   FR_DBG_MARK(F, blockIdx.x, 0);
-  const u32 total = tile_load_pred<NT>(g, T, V, F, segb, segpre, s_wsum, lab, segs);  // (uniform; predicate, prefix, labels)
+  const u32 total = tile_load_pred<NT>(g, T, V, F, segb, segpre, s_wsum, lab, segs, cseg);  // (uniform; predicate, prefix, labels)
   {  // the bit arrays of the tile, for the later kernels and the neighbours (in flight during the phases below)
     u32* tq = F.tq + (size_t)blockIdx.x * items;
     u32* ts = F.ts + (size_t)blockIdx.x * items;
@@ -1449,11 +1451,6 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
     }
     return;
   }
-  for (int t = threadIdx.x; t < FR_TROOT * 8; t += NT) {
-    const int k = t & 7;
-    acc[t] = (k >= 2 && k <= 4) ? 0xFFFFFFFFu : 0u;  // claim / box minima start at +inf
-  }
-  for (int t = threadIdx.x; t < FR_TROOT * FR_TXS; t += NT) rrow[t] = 0u;  // (used behind the next barrier)
   FR_DBG_MARK(F, blockIdx.x, 2);
   // ---- components.  (1) One lane per (z-line, lower line[, group of segments]) walks the line's segments with the
   // neighbour line's segments c - 1, c, c + 1 sliding along in registers and matches the runs in registers: every
@@ -1469,20 +1466,12 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
   if (threadIdx.x == 0) s_np = 0u, s_chg = 0u, s_povf = 0u;
   __syncthreads();
   auto walk_pairs = [&](auto&& fn) {  // fn(first cell of an own run, a cell of a touching run of a lower line / the seam)
-    // One lane per CELL: its segment by bisection over the prefix, its bit inside the segment, then one 3-bit window
+    // One lane per CELL: its segment from the cell -> segment table, its bit inside the segment, then one 3-bit window
     // (z - 1, z, z + 1) per lower line.  A cell whose z-predecessor is a cell too (same run) shares that cell's
     // windows except for the voxel z + 1 of each lower line -- and that one only matters when it starts a new run
     // there (the line's voxel z is empty): a wall costs one look per cell and line, not one pair.
     for (u32 l = threadIdx.x; l < total; l += NT) {
-      int lo = 0, hi = items - 1;
-      while (lo < hi) {  // last segment whose prefix is <= l and that holds cells
-        const int mid = (lo + hi + 1) >> 1;
-        if (segpre[mid] <= l)
-          lo = mid;
-        else
-          hi = mid - 1;
-      }
-      const int it = lo;
+      const int it = cseg[l];  // (written beside the labels: a bisection of the prefix here was 11 dependent LDS reads)
       const u32 bits = segb[it];
       u32 k = l - segpre[it], rem = bits;  // the k-th set bit
       while (k--) rem &= rem - 1u;
@@ -1559,6 +1548,12 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
     walk_pairs([&](u32 u, u32 v) { lds_union_h(lab, u, v); });
   }
   __syncthreads();
+  // (the cell -> segment table is dead: its space becomes the accumulators of the record phase, two barriers ahead)
+  for (int t = threadIdx.x; t < FR_TROOT * 8; t += NT) {
+    const int k = t & 7;
+    acc[t] = (k >= 2 && k <= 4) ? 0xFFFFFFFFu : 0u;  // claim / box minima start at +inf
+  }
+  for (int t = threadIdx.x; t < FR_TROOT * FR_TXS; t += NT) rrow[t] = 0u;
   FR_DBG_MARK(F, blockIdx.x, 3);
   // ---- roots: dense numbers ----
   for (u32 l = threadIdx.x; l < total; l += NT)
