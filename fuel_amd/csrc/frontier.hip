@@ -1480,9 +1480,17 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
       const int z = 32 * c + zz;
       const bool seam = zz == 0 && c > 0 && (segb[it - 1] >> 31);
       const u32 own = seam ? l : lab[l];  // label node of the cell's run (its first cell inside the segment)
-      if (seam) fn(l, l - 1u);
+      // the cell's pairs are collected in registers (slot 0: the seam, slots 1 + 2 q, 2 + 2 q: lower line q) and handed
+      // over together behind the loop, where the wave has reconverged: one list reservation per wave and trip instead
+      // of one per (cell, line) among whatever lanes happened to sit in the same iteration
+      u32 pk[9];
+      u32 nv = 0u;
+      pk[0] = (l << 16) | (l - 1u);
+      if (seam) nv |= 1u;
       const bool has_prev = seam || (zz > 0 && ((bits >> (zz - 1)) & 1u));
+#pragma unroll
       for (int q = 0; q < 4; ++q) {
+        pk[1 + 2 * q] = pk[2 + 2 * q] = 0u;
         const int nlx = lx + (q < 3 ? -1 : 0), nly = ly + (q < 3 ? q - 1 : -1);
         if (nlx < 0 || nly < 0 || nly >= TY) continue;
         const int nline = nlx * TY + nly;
@@ -1496,21 +1504,40 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
         const int zn = zlo + __builtin_ctz(pat);
         const int nit = nline * nseg + (zn >> 5);
         const u32 ln = segpre[nit] + (u32)__popc(segb[nit] & ((1u << (zn & 31)) - 1u));
-        fn(own, ln);
-        if (pat == 5u) fn(own, ln + 1u);  // the next cell of that line sits at zlo + 2
+        pk[1 + 2 * q] = (own << 16) | ln;
+        nv |= 1u << (1 + 2 * q);
+        if (pat == 5u) {  // the next cell of that line sits at zlo + 2
+          pk[2 + 2 * q] = (own << 16) | (ln + 1u);
+          nv |= 1u << (2 + 2 * q);
+        }
       }
+      fn(pk, nv);
     }
   };
-  walk_pairs([&](u32 u, u32 v) {
-    const u64 act = __ballot(1);  // the lanes that have a pair in this trip: one counter atomic for all of them
-    const int leader = __builtin_ctzll(act);
+  walk_pairs([&](const u32 (&pk)[9], u32 nv) {
+    // (all lanes of the trip arrive here together) positions by a ballot scan of the pair counts, one reservation
+    const u32 cnt = (u32)__popc(nv);
+    u32 excl = 0u, tot = 0u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {  // cnt <= 9
+      const unsigned long long bal = __ballot((cnt >> b) & 1u);
+      excl += (u32)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)) << b;
+      tot += (u32)__popcll(bal) << b;
+    }
+    if (tot == 0u) return;  // (uniform)
+    const int leader = __builtin_ctzll(__ballot(1));
     u32 at = 0u;
-    if (lane == leader) at = atomicAdd(&s_np, (u32)__popcll(act));
-    at = (u32)__shfl((int)at, leader, 64) + (u32)__popcll(act & ((1ull << lane) - 1ull));
-    if (at < FR_TPAIR)
-      plist[at] = (u << 16) | v;
-    else
-      s_povf = 1u;
+    if (lane == leader) at = atomicAdd(&s_np, tot);
+    at = (u32)__shfl((int)at, leader, 64) + excl;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if ((nv >> k) & 1u) {
+        if (at < FR_TPAIR)
+          plist[at] = pk[k];
+        else
+          s_povf = 1u;
+        ++at;
+      }
   });
   __syncthreads();
   {
@@ -1545,7 +1572,11 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
     }
   }
   if (s_povf) {  // more touching pairs than the list holds (a tile of single-voxel runs): the plain union-find walk
-    walk_pairs([&](u32 u, u32 v) { lds_union_h(lab, u, v); });
+    walk_pairs([&](const u32 (&pk)[9], u32 nv) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if ((nv >> k) & 1u) lds_union_h(lab, pk[k] >> 16, pk[k] & 0xFFFFu);
+    });
   }
   __syncthreads();
   // (the cell -> segment table is dead: its space becomes the accumulators of the record phase, two barriers ahead)
