@@ -1452,9 +1452,9 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
     return;
   }
   FR_DBG_MARK(F, blockIdx.x, 2);
-  // ---- components.  (1) One lane per (z-line, lower line[, group of segments]) walks the line's segments with the
-  // neighbour line's segments c - 1, c, c + 1 sliding along in registers and matches the runs in registers: every
-  // pair of touching runs (segment seams included) goes into an LDS list (one counter atomic per wave and trip).
+  // ---- components.  (1) One lane per CELL looks at the four lower z-lines around it through 3-bit windows of the LDS
+  // bit arrays (walk_pairs below): every pair of touching runs (segment seams included) goes into an LDS list, a
+  // cell's pairs collected in registers first (one list reservation per wave and trip).
   // (2) The list is then joined by HOOK + COMPRESS rounds (Shiloach-Vishkin style): both labels of a pair are read
   // side by side and the larger root takes the smaller with a non-returning atomicMin, then every cell walks to its
   // root; repeated until a round finds every pair joined.  Labels only ever decrease and parent < child always

@@ -1,5 +1,7 @@
 #!/bin/bash
-# dev aid: A/B of two builds on one box (fuel_amd/libfuelmi_prev.so = the previous build)
+# dev aid: A/B of two builds of libfuelmi on ONE box (boxes of the pool differ by ~10 %): copy the previous build to
+# fuel_amd/libfuelmi_prev.so, rebuild, then `gpurun -- 'bash scripts/ab_bench.sh'` -- a parity subset (KEXPR), three
+# interleaved headline runs per build, the tile-CCL phase stamps and one streaming run per build.  ~1 GPU-minute.
 timeout 300 python -m pytest tests -m gpu -x -q --timeout 120 -k "${KEXPR:-frontier or cycle or config4}" 2>&1 | tail -4
 for i in 1 2 3; do
   for L in prev new; do

@@ -1,5 +1,6 @@
 #!/bin/bash
-# dev aid (round 3): parity + G400 serial kernel stats + stamps, streaming stamps
+# dev aid: full GPU parity suite, then the frontier chain's in-kernel phase stamps (FUELMI_FR_TIMING), its kernels'
+# serialised rocprofv3 durations and the headline / streaming figures of the same box
 [ -z "$NOTEST" ] && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -${TAILN:-6}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --steps 5 --warmup 2 --serial-stages 2>&1 | grep fr-timing | tail -7 | grep -v "entry avg" | cut -c1-330
