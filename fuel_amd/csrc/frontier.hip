@@ -1665,15 +1665,8 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
       if (uni) {
         u32 sy = have ? n * y : 0u, s2 = have ? sz : 0u, c2 = have ? cl : 0xFFFFFFFFu;
         u32 ly2 = have ? y : 0xFFFFFFFFu, lz2 = have ? lz : 0xFFFFFFFFu, hy2 = have ? y : 0u, hz2 = have ? hz : 0u;
-        for (int off = 32; off > 0; off >>= 1) {
-          sy += (u32)__shfl_xor((int)sy, off, 64);
-          s2 += (u32)__shfl_xor((int)s2, off, 64);
-          c2 = min(c2, (u32)__shfl_xor((int)c2, off, 64));
-          ly2 = min(ly2, (u32)__shfl_xor((int)ly2, off, 64));
-          lz2 = min(lz2, (u32)__shfl_xor((int)lz2, off, 64));
-          hy2 = max(hy2, (u32)__shfl_xor((int)hy2, off, 64));
-          hz2 = max(hz2, (u32)__shfl_xor((int)hz2, off, 64));
-        }
+        sy = wave_add_u32(sy), s2 = wave_add_u32(s2), c2 = wave_min_u32(c2), ly2 = wave_min_u32(ly2);
+        lz2 = wave_min_u32(lz2), hy2 = wave_max_u32(hy2), hz2 = wave_max_u32(hz2);
         if (lane == __builtin_ctzll(hm)) {
           u32* r = acc + first * 8u;
           atomicAdd(&r[0], sy), atomicAdd(&r[1], s2), atomicMin(&r[2], c2), atomicMin(&r[3], ly2), atomicMin(&r[4], lz2);
@@ -1967,19 +1960,9 @@ struct CAcc {
   u32 n, sx, sy, sz, cl, lx, ly, lz, hx, hy, hz;
 };
 __device__ __forceinline__ void cacc_reduce(CAcc& a) {
-  for (int off = 32; off > 0; off >>= 1) {
-    a.n += (u32)__shfl_xor((int)a.n, off, 64);
-    a.sx += (u32)__shfl_xor((int)a.sx, off, 64);
-    a.sy += (u32)__shfl_xor((int)a.sy, off, 64);
-    a.sz += (u32)__shfl_xor((int)a.sz, off, 64);
-    a.cl = min(a.cl, (u32)__shfl_xor((int)a.cl, off, 64));
-    a.lx = min(a.lx, (u32)__shfl_xor((int)a.lx, off, 64));
-    a.ly = min(a.ly, (u32)__shfl_xor((int)a.ly, off, 64));
-    a.lz = min(a.lz, (u32)__shfl_xor((int)a.lz, off, 64));
-    a.hx = max(a.hx, (u32)__shfl_xor((int)a.hx, off, 64));
-    a.hy = max(a.hy, (u32)__shfl_xor((int)a.hy, off, 64));
-    a.hz = max(a.hz, (u32)__shfl_xor((int)a.hz, off, 64));
-  }
+  a.n = wave_add_u32(a.n), a.sx = wave_add_u32(a.sx), a.sy = wave_add_u32(a.sy), a.sz = wave_add_u32(a.sz);
+  a.cl = wave_min_u32(a.cl), a.lx = wave_min_u32(a.lx), a.ly = wave_min_u32(a.ly), a.lz = wave_min_u32(a.lz);
+  a.hx = wave_max_u32(a.hx), a.hy = wave_max_u32(a.hy), a.hz = wave_max_u32(a.hz);
 }
 
 // Everything between "tile-local components" and "kept clusters in creation order", on the tile-root records,
@@ -2067,7 +2050,7 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
       rko[d] = T.own;
       nq_part += T.size;
     }
-    for (int off = 32; off > 0; off >>= 1) nq_part += (u32)__shfl_xor((int)nq_part, off, 64);
+    nq_part = wave_add_u32(nq_part);
     if (lane == 0 && nq_part) atomicAdd(&s_nq, nq_part);
     for (u32 i = threadIdx.x; i < RS_SH; i += RS_T) h_adr[i] = NOCLAIM, h_sum[i] = 0u, h_kept[i] = FR_NOTKEPT;
     for (u32 i = threadIdx.x; i < FR_KCAP * 6; i += RS_T) kbox[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u;
@@ -2102,11 +2085,7 @@ __global__ void __launch_bounds__(RS_T) k_resolve(Geo g, FArgs F) {
         const u32 first = (u32)__shfl((int)rt, leader, 64);
         const bool mine = mov && rt == first;
         u32 s2 = mine ? sz : 0u, c2 = mine ? cl : NOCLAIM, o2 = mine ? ow : NOCLAIM;
-        for (int off = 32; off > 0; off >>= 1) {
-          s2 += (u32)__shfl_xor((int)s2, off, 64);
-          c2 = min(c2, (u32)__shfl_xor((int)c2, off, 64));
-          o2 = min(o2, (u32)__shfl_xor((int)o2, off, 64));
-        }
+        s2 = wave_add_u32(s2), c2 = wave_min_u32(c2), o2 = wave_min_u32(o2);
         if (lane == leader) {
           atomicAdd(&siz[first], s2);
           atomicMin(&clm[first], c2);

@@ -151,6 +151,30 @@ __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
 }
 // Q0 bits of z-line (xx, yy) at z = 32 c - 1 .. 32 c + 32 (bit j <-> z = 32 c - 1 + j), from the tile that owns the
 // line (any tile of the search); 0 outside the tiled rectangle
+// 64-lane reductions on the DPP data path (quads, half rows, rows, then the two row broadcasts of GFX9; the total is
+// read from lane 63 and returned to every lane).  A __shfl_xor butterfly is six trips through the LDS crossbar per
+// value; the record phases reduce 7 to 11 values at a time.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_mov(u32 old, u32 v) {
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+#define FUELMI_WAVE_RED(NAME, OP, ID)                                                        \
+  __device__ __forceinline__ u32 NAME(u32 v) {                                               \
+    v = OP(v, dpp_mov<0xB1, 0xF>(ID, v));  /* quad_perm [1,0,3,2] */                         \
+    v = OP(v, dpp_mov<0x4E, 0xF>(ID, v));  /* quad_perm [2,3,0,1] */                         \
+    v = OP(v, dpp_mov<0x141, 0xF>(ID, v)); /* row_half_mirror */                             \
+    v = OP(v, dpp_mov<0x140, 0xF>(ID, v)); /* row_mirror: every lane holds its row's value */ \
+    v = OP(v, dpp_mov<0x142, 0xA>(ID, v)); /* row_bcast15 into rows 1 and 3 */               \
+    v = OP(v, dpp_mov<0x143, 0xC>(ID, v)); /* row_bcast31 into rows 2 and 3 */               \
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);                                       \
+  }
+__device__ __forceinline__ u32 red_add_(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 red_min_(u32 a, u32 b) { return min(a, b); }
+__device__ __forceinline__ u32 red_max_(u32 a, u32 b) { return max(a, b); }
+FUELMI_WAVE_RED(wave_add_u32, red_add_, 0u)
+FUELMI_WAVE_RED(wave_min_u32, red_min_, 0xFFFFFFFFu)
+FUELMI_WAVE_RED(wave_max_u32, red_max_, 0u)
+
 // (branch-free: a load inside a branch is waited for inside it, and the callers issue several of these side by side --
 // coordinates outside the rectangle are clamped into it and the result masked, the segments before the first / behind
 // the last of a line read the line's own word again)

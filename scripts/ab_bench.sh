@@ -14,3 +14,7 @@ for L in prev new; do
   FUELMI_LIB_PATH=$P FUELMI_FR_TIMING=1 timeout 120 python bench.py --no-cpu-baseline --steps 5 --warmup 2 --serial-stages 2>&1 | grep "fr-timing\] tiles" | tail -1 | cut -c1-200
   FUELMI_LIB_PATH=$P timeout 120 python bench.py --workload G800S --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L G800S', round(d['value']), d['stage_ms']['frontier'])"
 done
+for L in prev new; do
+  P=$GRAFT_REPO_ROOT/fuel_amd/libfuelmi.so; [ $L = prev ] && P=$GRAFT_REPO_ROOT/fuel_amd/libfuelmi_prev.so
+  FUELMI_LIB_PATH=$P FUELMI_FR_TIMING=1 timeout 120 python bench.py --no-cpu-baseline --steps 5 --warmup 2 --serial-stages 2>&1 | grep "fr-timing\] resolve" | tail -1 | cut -c1-200
+done
