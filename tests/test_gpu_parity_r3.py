@@ -149,11 +149,12 @@ def test_esdf_kernel_choice_follows_the_place_not_the_previous_update(fa, monkey
             ms[name].append(zy[-1] + xx[-1])
     print("alternating local bound, ESDF ms per update: hall %s fresh %s" %
           (["%.3f" % v for v in ms["hall"]], ["%.3f" % v for v in ms["fresh"]]))
-    # the hall gets the far-field kernels from its second visit on (measured: 0.17-0.28 ms for the first visit, 0.024
-    # for the others); the fresh region never loses the plain ones (0.033 ms throughout).  Medians of the three later
-    # visits: these are event timings of 30-microsecond kernel pairs, one sample in a few hundred comes back
-    # stretched, and the statement under test is about the kernel family, not about a single launch
-    assert float(np.median(ms["hall"][1:])) < 0.5 * ms["hall"][0], ms
+    # the hall gets the far-field kernels from its second visit on (measured: 0.041 ms for the first visit with the
+    # plain kernels -- 0.17-0.28 when it is also the process's first launch of them -- and 0.023-0.024 for the others);
+    # the fresh region never loses the plain ones (0.033 ms throughout).  Medians of the three later visits: these are
+    # event timings of 30-microsecond kernel pairs, now and then one comes back stretched by a third, and the statement
+    # under test is about the kernel family, not about a single launch
+    assert float(np.median(ms["hall"][1:])) < 0.8 * ms["hall"][0], ms
     assert float(np.median(ms["fresh"][1:])) < 1.5 * ms["fresh"][0], ms
     gm.close()
 
