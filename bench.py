@@ -513,7 +513,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--reference-order", type=int, default=0, choices=(0, 1, 2),
                     help="fuelmi_frontier_cfg.reference_order of the finder (0 address order, 1 the reference's BFS order, "
-                         "2 auto: the reference's order for searches of <= 32768 cells); the headline uses 0")
+                         "2 auto: the reference's order whenever every cluster of the search holds <= 26624 cells); "
+                         "the headline uses 0")
+    ap.add_argument("--esdf-family", type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help="pin the ESDF kernel family (fuelmi_map_set_esdf_family): -1 the library's per-update choice "
+                         "(default), 0 packed plain, 1 far-field, 2 32-bit plain")
     ap.add_argument("--serial-stages", action="store_true",
                     help="diagnostic: run the frontier scan after the ESDF chain instead of beside it")
     args = ap.parse_args()
@@ -565,6 +569,8 @@ def main():
 
     import fuel_amd
     from fuel_amd import _lib
+    if args.esdf_family >= 0:
+        fuel_amd.SDFMap.default_esdf_family = args.esdf_family
     streaming = args.workload.endswith("S")
     if streaming:
         map_size, n_obs, _ = WORKLOADS[args.workload]
@@ -706,7 +712,7 @@ def main():
             traffic_commit = pmc_doc.get("commit")
             key = {"esdf_zy": "k_esdf_zy4<", "esdf_x": "k_esdf_x4", "inflate": "k_inflate_yz",
                    "bspline": "k_bspline_cost_grad"}[dominant]
-            hit = [v for k, v in pmc.items() if key in k]
+            hit = [v for k, v in pmc.items() if key in k or (dominant == "esdf_zy" and "k_esdf_zy_pk<" in k)]
             traffic = hit[0]["hbm_bytes_per_launch"]
         except Exception:
             traffic, traffic_commit = None, None
@@ -737,6 +743,8 @@ def main():
                                     % (args.workload, nv[0], nv[1], nv[2], ctrl.shape[0])),
                        "known_voxels": int(n_known), "frontier_clusters": int(cyc.n_clusters),
                        "reference_order": args.reference_order,
+                       "esdf_family": {-1: "auto", 0: "plain (packed 16-bit z/y)", 1: "far-field", 2: "plain (32-bit z/y)"}[
+                           cyc.map.lastEsdfFamily() if args.esdf_family < 0 else args.esdf_family],
                        "parallelism": "independent map per GPU (no collective)"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_isolated": {k: round(v, 4) for k, v in iso_ms_all.items()},

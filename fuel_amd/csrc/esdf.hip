@@ -615,35 +615,496 @@ k_esdf_zy4(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ 
   }
 }
 
-// The y pass of this update has counted its far outputs per group of 16 x-slabs (stat[2 g], stat[2 g + 1]: far
-// outputs, outputs of the sampled slab); the first workgroup of the x pass hands the table to the host through
-// pinned memory and clears it.  No fence, no synchronisation (a system-scope release here makes this workgroup write
-// the L2 back while the rest of the kernel fills it: the pass went from 35 to 90 us): the table carries an epoch in
-// front and a checksum behind, the host only uses a copy whose checksum fits (esdf_use_far) and otherwise keeps what
-// it knew -- the statistic picks a kernel family, it never changes a result.
-__device__ __forceinline__ void forward_stat(u32* stat, volatile u32* h_stat_v) {
-  if (stat == nullptr || blockIdx.x != 0) return;
-  u32* h_stat = const_cast<u32*>(h_stat_v);  // (plain posted stores: nothing here waits for them)
-  __shared__ u32 s_sum;
-  if (threadIdx.x == 0) s_sum = 0u;
-  __syncthreads();
-  u32 part = 0u;
-  for (int g = threadIdx.x; g < ESDF_NG; g += blockDim.x) {
-    const uint2 p = *reinterpret_cast<const uint2*>(stat + 2 * g);  // (far outputs, outputs of the sampled slab)
-    if (p.y) {  // only the groups this update sampled cross the bus; the host keeps the others
-      *reinterpret_cast<uint2*>(h_stat + 2 * g) = p;
-      *reinterpret_cast<uint2*>(stat + 2 * g) = make_uint2(0u, 0u);
-      part += p.x * 31u + p.y + (u32)g * 0x10001u;
+// ------------------------------------------------------------------------------------------------
+// Packed plain family (round 4): the z/y pass on 16-bit lanes, two y-rows per lane.
+// The u32 kernel above is issue-bound (~36 VALU instructions per voxel), so this one halves the
+// instruction stream instead of the bytes: the tile holds dz^2 as u16, rows 2p and 2p+1 interleaved in one u32
+// ("pair row" p: low half = row 2p, high half = row 2p+1), and every min / add of the scan is a v_pk_*_u16 that
+// serves both rows.  A lane owns 8 outputs (rows 2p, 2p+1 x 4 z); one trip loads pair rows p-j and p+j (two
+// ds_read_b128) and examines rows 2p-2j .. 2p+2j+1 for both outputs: straight halves are 2j away from both, swapped
+// halves (op_sel, free) 2j-1 / 2j+1 away.  Saturating adds keep everything below 2^16; PK_INF = 255^2 marks
+// "no source on this z-line" (a real dz is at most 254: the family is used for boxes of up to 255 voxels in z).
+// A result below PK_INF is exact: every candidate f(p) + r^2 < 65025 was formed without saturation and every
+// saturated one is >= 65025.  The rare outputs at or above it (further than ~255 voxels from every source, or no
+// source in the slab) are recomputed in 32 bits from the same tile (pk_slow_col).
+// ------------------------------------------------------------------------------------------------
+#define PK_INF 65025u
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_t pk_v(u32 v) { return __builtin_bit_cast(u16x2_t, v); }
+__device__ __forceinline__ u32 pk_u(u16x2_t v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { return pk_u(__builtin_elementwise_min(pk_v(a), pk_v(b))); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return pk_u(__builtin_elementwise_max(pk_v(a), pk_v(b))); }
+__device__ __forceinline__ u32 pk_adds(u32 a, u32 b) { return pk_u(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return pk_u(pk_v(a) + pk_v(b)); }
+__device__ __forceinline__ u32 pk_mul(u32 a, u32 b) { return pk_u(pk_v(a) * pk_v(b)); }
+__device__ __forceinline__ u32 pk_swap(u32 a) {
+  const u16x2_t v = pk_v(a);
+  const u16x2_t r = {v.y, v.x};
+  return pk_u(r);
+}
+__device__ __forceinline__ u32 pk_hmax(u32 a) { return max(a & 0xffffu, a >> 16); }
+__device__ __forceinline__ u32 pk_hmin(u32 a) { return min(a & 0xffffu, a >> 16); }
+__device__ __forceinline__ u32 pk_both(u32 v) { return v | (v << 16); }
+__device__ __forceinline__ u32 pk_sat16(u32 v) { return min(v, 0xffffu); }
+
+// chunk source bits and nearest sources of the box below / above the chunk (absolute z, -1: none) for one y-row
+struct RowSrc {
+  u64 bits;
+  int below, above;
+};
+// The source bits of one z-line, ALIGNED: bit k = voxel z0a + k, bits outside the box's z range cleared.  Built once
+// per line from NW + 1 plane words (a per-lane funnel shift); everything a chunk needs afterwards -- its own bits, the
+// nearest source below / above it -- is windows and masks at UNIFORM positions (scalar masks, 32-bit vector work).
+// The round-3 form (range masks over three unaligned words, per lane, in 64-bit arithmetic) cost ~250 VALU
+// instructions per row and chunk: more than the two sweeps it feeds (SQ_INSTS_VALU, profiles/r04_zy_*).
+template <int NW>
+struct LineBits {
+  u64 w[NW];
+};
+template <int MODE, int NW>
+__device__ __forceinline__ LineBits<NW> line_load(const u64* __restrict__ infl, const u64* __restrict__ unk, long linebit,
+                                                  int z0a, int zlo, int zhi) {
+  const long bit0 = linebit + z0a;
+  const long w0 = bit0 >> 6;
+  const int sh = (int)(bit0 & 63);
+  u64 L[NW + 1];
+#pragma unroll
+  for (int k = 0; k <= NW; ++k) L[k] = src_word<MODE>(infl, unk, w0 + k);  // (planes carry zeroed / masked-off margins)
+  LineBits<NW> r;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int lo = max(zlo - z0a - 64 * k, 0), hi = min(zhi - z0a - 64 * k, 63);  // in-box bits of this word (uniform)
+    const u64 mask = lo <= hi ? bit_range(lo, hi - lo + 1) : 0ull;
+    r.w[k] = (sh ? ((L[k] >> sh) | (L[k + 1] << (64 - sh))) : L[k]) & mask;
+  }
+  return r;
+}
+// 32 bits of the line from bit s (uniform, multiple of 4)
+template <int NW>
+__device__ __forceinline__ u32 line_bits32(const LineBits<NW>& L, int s) {
+  const int k = s >> 6, sh = s & 63;
+  u64 lo = 0ull, hi = 0ull;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    if (i == k) lo = L.w[i];
+    if (i == k + 1) hi = L.w[i];
+  }
+  return (u32)(sh ? ((lo >> sh) | (hi << (64 - sh))) : lo);
+}
+// lowest set bit at or above bit s / highest set bit below bit s (uniform s), or -1
+template <int NW>
+__device__ __forceinline__ int line_first_from(const LineBits<NW>& L, int s) {
+  int pos = -1;
+#pragma unroll
+  for (int i = NW - 1; i >= 0; --i) {
+    u64 m = L.w[i];
+    if (64 * i + 63 < s)
+      m = 0ull;
+    else if (64 * i < s)
+      m &= ~0ull << (s - 64 * i);
+    if (m) pos = 64 * i + __builtin_ctzll(m);
+  }
+  return pos;
+}
+template <int NW>
+__device__ __forceinline__ int line_last_below(const LineBits<NW>& L, int s) {
+  int pos = -1;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    u64 m = L.w[i];
+    if (64 * i >= s)
+      m = 0ull;
+    else if (64 * i + 64 > s)
+      m &= (1ull << (s - 64 * i)) - 1ull;
+    if (m) pos = 64 * i + 63 - __builtin_clzll(m);
+  }
+  return pos;
+}
+// chunk [zc0, zc0 + ZC) of an aligned line: its bits, the nearest sources of the box below and above it (absolute z)
+template <int NW, bool BELOW>
+__device__ __forceinline__ RowSrc row_src_line(const LineBits<NW>& L, int z0a, int zc0, int ZC) {
+  RowSrc r;
+  const int s = zc0 - z0a;
+  r.bits = (u64)(line_bits32<NW>(L, s) & (ZC == 32 ? 0xffffffffu : ((1u << ZC) - 1u)));
+  const int up = line_first_from<NW>(L, s + ZC);
+  r.above = up >= 0 ? z0a + up : -1;
+  r.below = -1;
+  if (BELOW) {
+    const int dn = line_last_below<NW>(L, s);
+    r.below = dn >= 0 ? z0a + dn : -1;
+  }
+  return r;
+}
+
+// sign-extended bit zi of a per-lane word: 0 or 0xFFFFFFFF in ONE instruction (the builtin is canonicalised into
+// and + compare + select)
+__device__ __forceinline__ u32 bit_fill(u32 v, int zi) {
+  u32 r;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(v), "s"(zi));
+  return r;
+}
+// d0: packed distance of voxel zs - 1 of both rows to their nearest source below (255: none); returns the packed
+// distance of the chunk's last voxel (capped at 255) -- the next chunk's d0 when one lane walks up a z-line.
+// Two sweeps like zy_fill_row, but on both rows at once: "d = source ? 0 : d + 1" is a packed add and an AND with the
+// pair's not-a-source mask of that z (built once, used by both sweeps).  The forward distances wait in the tile row
+// itself (LDS) for the backward sweep: 20 registers fewer, which is what lets eight workgroups share a CU.
+template <int G>
+__device__ __forceinline__ u32 zy_fill_pair(u32* prow, u32 bA, u32 bB, u32 d0, int aboveA, int aboveB, int ze, u32 inbox, bool fast) {
+  constexpr int ZC = 4 * G;
+  const u32 full = ZC == 32 ? 0xffffffffu : ((1u << ZC) - 1u);
+  if (fast) {
+    // rows that need no sweep: every in-box voxel of the chunk a source (the inside of unknown space), or no source
+    // anywhere on the z-line.  Taken by whole waves only: a mixed wave would pay for both paths
+    const bool all_src = bA == inbox && bB == inbox && inbox != 0u;
+    const bool no_src = (bA | bB) == 0u && d0 == 0x00ff00ffu && aboveA < 0 && aboveB < 0;
+    if (__ballot(!(all_src | no_src)) == 0ull) {
+      const u32 v = all_src ? 0u : pk_both(PK_INF);
+      const uint4 o = make_uint4(v, v, v, v);
+#pragma unroll
+      for (int k = 0; k < G; ++k) *reinterpret_cast<uint4*>(prow + 4 * k) = o;
+      if (inbox != full) {  // (columns outside the box must read 0: they only stretch the scans otherwise)
+        const u32 ib = inbox | (threadIdx.x & 0u);  // a per-lane copy: the masks below stay out of the scalar registers
+        for (int zi = 0; zi < ZC; ++zi) prow[zi] &= bit_fill(ib, zi);
+      }
+      return all_src ? 0u : 0x00ff00ffu;
     }
   }
-  if (part) atomicAdd(&s_sum, part);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const u32 e = stat[2 * ESDF_NG] + 1u;
-    stat[2 * ESDF_NG] = e;
-    h_stat[2 * ESDF_NG] = e;
-    h_stat[2 * ESDF_NG + 1] = s_sum + e * 0x9E3779B9u;
+  const u32 nA = ~bA, nB = ~bB;
+  u32 nm[ZC];
+  u32 d = d0;
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    u32 f[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int zi = 4 * k + q;
+      nm[zi] = (bit_fill(nA, zi) & 0xffffu) | (bit_fill(nB, zi) & 0xffff0000u);  // (one bit-field insert)
+      d = pk_add(d, 0x00010001u) & nm[zi];  // (at most 255 + 32: no carry between the halves)
+      f[q] = d;
+    }
+    *reinterpret_cast<uint4*>(prow + 4 * k) = make_uint4(f[0], f[1], f[2], f[3]);
   }
+  const u32 d_end = pk_min(d, 0x00ff00ffu);
+  d = (aboveA >= 0 ? (u32)min(aboveA - (ze + 1), 255) : 255u) | ((aboveB >= 0 ? (u32)min(aboveB - (ze + 1), 255) : 255u) << 16);
+#pragma unroll
+  for (int k = G - 1; k >= 0; --k) {
+    const uint4 fw = *reinterpret_cast<const uint4*>(prow + 4 * k);
+    const u32 f[4] = {fw.x, fw.y, fw.z, fw.w};
+    u32 o[4];
+#pragma unroll
+    for (int q = 3; q >= 0; --q) {
+      d = pk_add(d, 0x00010001u) & nm[4 * k + q];
+      const u32 t = pk_min(pk_min(f[q], d), 0x00ff00ffu);
+      o[q] = pk_mul(t, t);
+    }
+    *reinterpret_cast<uint4*>(prow + 4 * k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  if (inbox != full) {
+    const u32 ib = inbox | (threadIdx.x & 0u);
+    for (int zi = 0; zi < ZC; ++zi) prow[zi] &= bit_fill(ib, zi);
+  }
+  return d_end;
+}
+__device__ __forceinline__ u32 pk_below_d0(const RowSrc& A, const RowSrc& B, int zs) {
+  return (A.below >= 0 ? (u32)min(zs - 1 - A.below, 255) : 255u) | ((B.below >= 0 ? (u32)min(zs - 1 - B.below, 255) : 255u) << 16);
+}
+
+// exact 32-bit value of one output the packed scan left at or above PK_INF (row of the y line, column zcol of the
+// chunk): the same pruned scan over the 16-bit tile, rows [0, ylen)
+__device__ __noinline__ u32 pk_slow_col(const u32* tile, int ZC, int ylen, int row, int zcol) {
+  u32 best = INF32;
+  const int rmax = max(row, ylen - 1 - row);
+  for (int r = 0; r <= rmax && (u32)(r * r) < best; ++r) {
+    const u32 rr = (u32)(r * r);
+    if (row - r >= 0) {
+      const int q = row - r;
+      const u32 v = (tile[(q >> 1) * ZC + zcol] >> (16 * (q & 1))) & 0xffffu;
+      if (v < PK_INF) best = min(best, v + rr);
+    }
+    if (r && row + r < ylen) {
+      const int q = row + r;
+      const u32 v = (tile[(q >> 1) * ZC + zcol] >> (16 * (q & 1))) & 0xffffu;
+      if (v < PK_INF) best = min(best, v + rr);
+    }
+  }
+  return best;
+}
+
+// the 4 z-adjacent outputs of one row: one 16-byte store when the box is z-aligned (uniform test, see k_esdf_zy4)
+__device__ __forceinline__ void zy_store4(u32* dst, int z, const Box3& b, uint4 v, bool z_aligned) {
+  if (z_aligned) {
+    if (z >= b.lo[2] && z <= b.hi[2]) store16(dst, v);
+  } else if (z >= b.lo[2] && z + 3 <= b.hi[2]) {
+    *reinterpret_cast<uint4*>(dst) = v;
+  } else {
+    if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = v.x;
+    if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = v.y;
+    if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = v.z;
+    if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = v.w;
+  }
+}
+
+// the 8 outputs (rows 2p, 2p + 1 x 4 z of group gi) of one lane from the packed tile at `tile_b`
+template <int G>
+__device__ __forceinline__ void pk_scan8(const unsigned char* tile_b, int p, int gi, int npair, int ylen, bool any_src,
+                                         bool sampled, int& n_far, uint4& ra, uint4& rb) {
+  constexpr int ZC = 4 * G;
+  constexpr int stride = ZC * 4;
+  const u32* tile = reinterpret_cast<const u32*>(tile_b);
+    const int col = 16 * gi, base = __mul24(p, stride) + col;
+    if (!any_src) {  // nothing in this slab's chunk is a source: "no source in the box" everywhere
+      ra = rb = make_uint4(INF32, INF32, INF32, INF32);
+      if (sampled) n_far += __popcll(__ballot(1));
+    } else {
+      const uint4 v = lds4(tile_b, base);
+      // the partner row is one row away
+      u32 b0 = pk_min(v.x, pk_adds(pk_swap(v.x), 0x00010001u)), b1 = pk_min(v.y, pk_adds(pk_swap(v.y), 0x00010001u));
+      u32 b2 = pk_min(v.z, pk_adds(pk_swap(v.z), 0x00010001u)), b3 = pk_min(v.w, pk_adds(pk_swap(v.w), 0x00010001u));
+      u32 mx = pk_hmax(pk_max(pk_max(b0, b1), pk_max(b2, b3)));
+      const int hi_off = __mul24(npair - 1, stride) + col;
+      const int jmax = max(p, npair - 1 - p);
+      int od = base, ou = base;
+      // trip j: pair rows p - j, p + j = rows 2p - 2j .. 2p + 2j + 1; ro2 = (2j-1)^2 is the first radius not seen yet
+      u32 ro2 = 1u, j8 = 8u;
+      for (int j = 1; j <= jmax && ro2 < mx; ++j) {
+        od = max(od - stride, col);
+        ou = min(ou + stride, hi_off);
+        const uint4 pd = lds4(tile_b, od), pu = lds4(tile_b, ou);
+        const u32 rn2 = ro2 + j8;                  // (2j+1)^2
+        const u32 re2 = (ro2 + rn2 - 2u) >> 1;     // (2j)^2
+        const u32 ke = pk_both(pk_sat16(re2));
+        const u32 k1 = pk_sat16(ro2) | (pk_sat16(rn2) << 16), k2 = pk_sat16(rn2) | (pk_sat16(ro2) << 16);
+        // (a clamped pair row repeats candidates already seen with smaller radii: harmless)
+        b0 = pk_min(b0, pk_min(pk_adds(pk_min(pd.x, pu.x), ke), pk_min(pk_adds(pk_swap(pd.x), k1), pk_adds(pk_swap(pu.x), k2))));
+        b1 = pk_min(b1, pk_min(pk_adds(pk_min(pd.y, pu.y), ke), pk_min(pk_adds(pk_swap(pd.y), k1), pk_adds(pk_swap(pu.y), k2))));
+        b2 = pk_min(b2, pk_min(pk_adds(pk_min(pd.z, pu.z), ke), pk_min(pk_adds(pk_swap(pd.z), k1), pk_adds(pk_swap(pu.z), k2))));
+        b3 = pk_min(b3, pk_min(pk_adds(pk_min(pd.w, pu.w), ke), pk_min(pk_adds(pk_swap(pd.w), k1), pk_adds(pk_swap(pu.w), k2))));
+        mx = pk_hmax(pk_max(pk_max(b0, b1), pk_max(b2, b3)));
+        ro2 = rn2;
+        j8 += 8u;
+      }
+      if (sampled) n_far += __popcll(__ballot(pk_hmin(pk_min(pk_min(b0, b1), pk_min(b2, b3))) > ESDF_FAR_D * ESDF_FAR_D));
+      ra = make_uint4(b0 & 0xffffu, b1 & 0xffffu, b2 & 0xffffu, b3 & 0xffffu);
+      rb = make_uint4(b0 >> 16, b1 >> 16, b2 >> 16, b3 >> 16);
+      if (mx >= PK_INF) {  // rare: an output out of the 16-bit range
+        const int zc = 4 * gi, rA = 2 * p, rB = 2 * p + 1;
+        if (ra.x >= PK_INF) ra.x = pk_slow_col(tile, ZC, ylen, rA, zc);
+        if (ra.y >= PK_INF) ra.y = pk_slow_col(tile, ZC, ylen, rA, zc + 1);
+        if (ra.z >= PK_INF) ra.z = pk_slow_col(tile, ZC, ylen, rA, zc + 2);
+        if (ra.w >= PK_INF) ra.w = pk_slow_col(tile, ZC, ylen, rA, zc + 3);
+        if (rB < ylen) {
+          if (rb.x >= PK_INF) rb.x = pk_slow_col(tile, ZC, ylen, rB, zc);
+          if (rb.y >= PK_INF) rb.y = pk_slow_col(tile, ZC, ylen, rB, zc + 1);
+          if (rb.z >= PK_INF) rb.z = pk_slow_col(tile, ZC, ylen, rB, zc + 2);
+          if (rb.w >= PK_INF) rb.w = pk_slow_col(tile, ZC, ylen, rB, zc + 3);
+        }
+      }
+    }
+}
+
+template <int MODE, int G, int NW>
+__global__ void __launch_bounds__(512)
+k_esdf_zy_pk(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp, int nzc,
+             int z0a, int fastrow, u32* __restrict__ stat, unsigned long long* __restrict__ dbg) {
+  constexpr int ZC = 4 * G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32* tile = reinterpret_cast<u32*>(smem_raw);  // [npair][ZC]: low half row 2p, high half row 2p + 1
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;  // slab x -> XCD x % 8 with all its chunk-blocks (see k_esdf_zy4)
+  const int xrel = xcd + 8 * (slot / nzc);
+  if (xrel > b.hi[0] - b.lo[0]) return;
+  // FUELMI_ZY_TIMING: 100 MHz stamps of this workgroup's phases (start, tile filled, barrier passed, scans done)
+  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;
+  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
+  const int x = b.lo[0] + xrel;
+  const int zc0 = z0a + (slot % nzc) * ZC;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int npair = (ylen + 1) >> 1;
+  const int T = blockDim.x;
+  const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);
+  const u32 inbox = zs <= ze ? (u32)bit_range(zs - zc0, ze - zs + 1) : 0u;
+  bool has_src = false;
+  for (int p = threadIdx.x; p < npair; p += T) {
+    const int yA = 2 * p, yB = min(2 * p + 1, ylen - 1);  // (odd line: the last pair repeats its row -- a copy one
+    const long lbA = (long)x * g.nyz + (long)(b.lo[1] + yA) * g.nz;  //  row further out is never a better candidate)
+    const long lbB = (long)x * g.nyz + (long)(b.lo[1] + yB) * g.nz;
+    RowSrc A, B;
+    A.bits = B.bits = 0ull;
+    A.below = A.above = B.below = B.above = -1;
+    if (zs <= ze) {
+      const LineBits<NW> LA = line_load<MODE, NW>(infl, unk, lbA, z0a, b.lo[2], b.hi[2]);
+      const LineBits<NW> LB = line_load<MODE, NW>(infl, unk, lbB, z0a, b.lo[2], b.hi[2]);
+      A = row_src_line<NW, true>(LA, z0a, zc0, ZC);
+      B = row_src_line<NW, true>(LB, z0a, zc0, ZC);
+    }
+    has_src |= (A.bits | B.bits) != 0ull || A.below >= 0 || A.above >= 0 || B.below >= 0 || B.above >= 0;
+    (void)zy_fill_pair<G>(tile + p * ZC, (u32)A.bits, (u32)B.bits, pk_below_d0(A, B, zs), A.above, B.above, ze, inbox, fastrow != 0);
+  }
+  if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
+  const int any_src = __syncthreads_or(has_src ? 1 : 0);
+  if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+  const int total = npair * G;
+  const bool sampled = stat != nullptr && ((x & 15) == 0 || xrel == 0);
+  const bool z_aligned = (b.lo[2] & 3) == 0 && (b.hi[2] & 3) == 3;
+  int n_far = 0;
+  const int dpi = T / G, dgi = T - dpi * G;
+  int p = threadIdx.x / G, gi = threadIdx.x - p * G;
+  for (int o = threadIdx.x; o < total; o += T) {
+    uint4 ra, rb;  // rows 2p and 2p + 1
+    pk_scan8<G>(smem_raw, p, gi, npair, ylen, any_src != 0, sampled, n_far, ra, rb);
+    const int z = zc0 + 4 * gi;
+    u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + 2 * p) * g.nz + z;
+    zy_store4(dst, z, b, ra, z_aligned);
+    if (2 * p + 1 < ylen) zy_store4(dst + g.nz, z, b, rb, z_aligned);
+    p += dpi;
+    gi += dgi;
+    if (gi >= G) {
+      gi -= G;
+      ++p;
+    }
+  }
+  if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
+  if (sampled && (threadIdx.x & 63) == 0) {
+    u32* sg = stat + 2 * ((x >> 4) & (ESDF_NG - 1));
+    atomicAdd(sg, (u32)n_far);
+    if (threadIdx.x == 0) atomicAdd(sg + 1, (u32)total);
+  }
+}
+
+// Pipelined packed z/y pass.  FUELMI_ZY_TIMING on k_esdf_zy_pk (400^2 x 100 map): a workgroup lives 12 us -- 7.5 us
+// filling its tile (one lane per row pair walks a ~400-instruction chain, half of it the per-chunk search for the
+// nearest sources below / above), 3.7 us scanning -- and the 2000 workgroups take 9 us to dispatch; the issue work of
+// the whole pass is ~10 us of its 31.  So: PERSISTENT workgroups that each walk a contiguous range of tiles (slab-
+// major, chunk-minor: a lane that walks up a z-line carries its forward sweep from chunk to chunk, the "below"
+// search disappears and the plane words are fetched once per slab), with WAVE ROLES: the first nfw waves fill
+// tile k + 1 into one LDS buffer while the others scan tile k out of the other one; one barrier per tile.
+template <int MODE, int G, int NW>
+__global__ void __launch_bounds__(1024)
+k_esdf_zy_pp(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp, int nzc,
+             int z0a, int fastrow, u32* __restrict__ stat, int nfw, int ntiles, unsigned long long* __restrict__ dbg) {
+  constexpr int ZC = 4 * G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int npair = (ylen + 1) >> 1;
+  const size_t tile_bytes = (size_t)npair * ZC * 4;
+  u32* s_any = reinterpret_cast<u32*>(smem_raw + 2 * tile_bytes);  // [2][16]: "this wave's rows hold a source", per buffer
+  // tile range of this workgroup; ranges of one XCD (workgroup i runs on XCD i % 8) are neighbours, so the chunks of a
+  // slab -- interleaved 80-byte pieces of the same tmp lines -- meet in one L2
+  const int nwg = gridDim.x, per = nwg >> 3;
+  const int r = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int t0 = (int)((long)r * ntiles / nwg), t1 = (int)((long)(r + 1) * ntiles / nwg);
+  if (t0 >= t1) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool filler = wave < nfw;
+  const int nscan = blockDim.x - 64 * nfw, sid = threadIdx.x - 64 * nfw;
+  const bool z_aligned = (b.lo[2] & 3) == 0 && (b.hi[2] & 3) == 3;
+  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;
+  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
+  unsigned long long acc = 0ull;
+  LineBits<NW> LA, LB;  // the pair's aligned z-lines (loaded when the walk enters a new slab)
+#pragma unroll
+  for (int k = 0; k < NW; ++k) LA.w[k] = LB.w[k] = 0ull;
+  u32 carry = 0x00ff00ffu;
+  const int total = npair * G;
+  for (int s = 0; s <= t1 - t0; ++s) {
+    const unsigned long long ts = stamp ? wall_clock64() : 0ull;
+    if (filler) {
+      const int t = t0 + s;
+      if (t < t1) {
+        const int xrel = t / nzc, c = t - xrel * nzc;
+        const int x = b.lo[0] + xrel, zc0 = z0a + c * ZC;
+        const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);
+        const u32 inbox = zs <= ze ? (u32)bit_range(zs - zc0, ze - zs + 1) : 0u;
+        u32* buf = reinterpret_cast<u32*>(smem_raw + (s & 1) * tile_bytes);
+        const int p = threadIdx.x;
+        bool has_src = false;
+        if (p < npair) {
+          const int yA = 2 * p, yB = min(2 * p + 1, ylen - 1);
+          const long lbA = (long)x * g.nyz + (long)(b.lo[1] + yA) * g.nz;
+          const long lbB = (long)x * g.nyz + (long)(b.lo[1] + yB) * g.nz;
+          const bool fresh = s == 0 || c == 0;  // a new z-line: nothing to carry
+          RowSrc A, B;
+          A.bits = B.bits = 0ull;
+          A.below = A.above = B.below = B.above = -1;
+          if (zs <= ze) {
+            if (fresh) {
+              LA = line_load<MODE, NW>(infl, unk, lbA, z0a, b.lo[2], b.hi[2]);
+              LB = line_load<MODE, NW>(infl, unk, lbB, z0a, b.lo[2], b.hi[2]);
+              A = row_src_line<NW, true>(LA, z0a, zc0, ZC);
+              B = row_src_line<NW, true>(LB, z0a, zc0, ZC);
+            } else {
+              A = row_src_line<NW, false>(LA, z0a, zc0, ZC);
+              B = row_src_line<NW, false>(LB, z0a, zc0, ZC);
+            }
+          }
+          const u32 d0 = fresh ? pk_below_d0(A, B, zs) : carry;
+          has_src = (A.bits | B.bits) != 0ull || d0 != 0x00ff00ffu || A.above >= 0 || B.above >= 0;
+          carry = zy_fill_pair<G>(buf + p * ZC, (u32)A.bits, (u32)B.bits, d0, A.above, B.above, ze, inbox, fastrow != 0);
+        }
+        const bool wany = __ballot(has_src) != 0ull;
+        if (lane == 0) s_any[(s & 1) * 16 + wave] = wany ? 1u : 0u;
+      }
+      if (stamp && threadIdx.x == 0) acc += wall_clock64() - ts;
+    } else if (s >= 1) {
+      const int t = t0 + s - 1;
+      const int xrel = t / nzc, c = t - xrel * nzc;
+      const int x = b.lo[0] + xrel, zc0 = z0a + c * ZC;
+      const unsigned char* buf = smem_raw + ((s - 1) & 1) * tile_bytes;
+      u32 any = 0u;
+      for (int w = 0; w < nfw; ++w) any |= s_any[((s - 1) & 1) * 16 + w];
+      const bool sampled = stat != nullptr && ((x & 15) == 0 || xrel == 0);
+      int n_far = 0;
+      const int dpi = nscan / G, dgi = nscan - dpi * G;
+      int p = sid / G, gi = sid - p * G;
+      for (int o = sid; o < total; o += nscan) {
+        uint4 ra, rb;
+        pk_scan8<G>(buf, p, gi, npair, ylen, any != 0u, sampled, n_far, ra, rb);
+        const int z = zc0 + 4 * gi;
+        u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + 2 * p) * g.nz + z;
+        zy_store4(dst, z, b, ra, z_aligned);
+        if (2 * p + 1 < ylen) zy_store4(dst + g.nz, z, b, rb, z_aligned);
+        p += dpi;
+        gi += dgi;
+        if (gi >= G) {
+          gi -= G;
+          ++p;
+        }
+      }
+      if (sampled && lane == 0) {
+        u32* sg = stat + 2 * ((x >> 4) & (ESDF_NG - 1));
+        atomicAdd(sg, (u32)n_far);
+        if (sid == 0) atomicAdd(sg + 1, (u32)total);
+      }
+      if (stamp && sid == 0) stamp[2] += wall_clock64() - ts;
+    }
+    __syncthreads();
+  }
+  if (stamp && threadIdx.x == 0) stamp[1] = acc, stamp[3] = wall_clock64(), stamp[5] = (unsigned long long)(t1 - t0);
+}
+
+// The y pass of this update has counted its far outputs per group of 16 x-slabs (stat[2 g], stat[2 g + 1]: far
+// outputs, outputs of the sampled slab); the first workgroup of the x pass hands the sampled groups to the host through
+// pinned memory and clears them.  No fence, no synchronisation (a system-scope release here makes this workgroup write
+// the L2 back while the rest of the kernel fills it: the pass went from 35 to 90 us).  Every entry of the host table
+// is ONE aligned 8-byte word -- far outputs (24 bits) | sampled outputs (24 bits) | the update's tag (16 bits, never
+// 0) -- so an entry is self-consistent however the store races with the host's read, tables of several updates may
+// land between two host looks, and the host never writes the table (the round-3 epoch + checksum over a
+// host-cleared table could lock itself out of the far-field kernels for good).  The statistic picks a kernel family,
+// it never changes a result.
+__device__ __forceinline__ void forward_stat(u32* stat, volatile u32* h_stat_v) {
+  if (stat == nullptr || blockIdx.x != 0) return;
+  unsigned long long* h_stat = reinterpret_cast<unsigned long long*>(const_cast<u32*>(h_stat_v));  // (plain posted stores)
+  const u32 e = stat[2 * ESDF_NG] + 1u;
+  const unsigned long long tag = (unsigned long long)(e % 65535u + 1u) << 48;
+  for (int g = threadIdx.x; g < ESDF_NG; g += blockDim.x) {
+    uint2 p = *reinterpret_cast<const uint2*>(stat + 2 * g);  // (far outputs, outputs of the sampled slab)
+    if (p.y) {  // only the groups this update sampled cross the bus; the host keeps the others
+      *reinterpret_cast<uint2*>(stat + 2 * g) = make_uint2(0u, 0u);
+      while (p.y >> 24) p.x >>= 1, p.y >>= 1;  // (the ratio is what matters)
+      h_stat[g] = (unsigned long long)p.x | ((unsigned long long)p.y << 24) | tag;
+    }
+  }
+  __syncthreads();  // (every lane has read the epoch)
+  if (threadIdx.x == 0) stat[2 * ESDF_NG] = e;
 }
 
 // the 4 outputs of one lane: distance_buffer_ values (OUT 0) or the negative pass merged in place (OUT 1)
@@ -851,6 +1312,10 @@ k_esdf_x4h(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist,
   }
 }
 
+// "this kernel variant does not fit this box" (LDS tables, line length): the caller takes the next variant.  Positive,
+// so that it can never be taken for one of the negative FUELMI_E* codes
+enum { ESDF_NO_FIT = 1 };
+
 // the device and the pinned-host tables of the far-output statistic
 template <int OUT>
 static u32* esdf_stat_dev(fuelmi_map* m) {
@@ -866,7 +1331,7 @@ static int launch_x4p_n(fuelmi_map* m, const Box3& b) {
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
   const size_t lds = (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * 8 * 4 * sizeof(u32);
-  if (lds > 160 * 1024) return -1;
+  if (lds > 160 * 1024) return ESDF_NO_FIT;
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4p<OUT, P, FAR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -892,7 +1357,7 @@ static int launch_x4p(fuelmi_map* m, const Box3& b) {
     case 6: return launch_x4p_n<OUT, 6, FAR>(m, b);
     case 7: return launch_x4p_n<OUT, 7, FAR>(m, b);
     case 8: return launch_x4p_n<OUT, 8, FAR>(m, b);
-    default: return -1;
+    default: return ESDF_NO_FIT;
   }
 }
 
@@ -918,7 +1383,7 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   static const char* pad = getenv("FUELMI_ZY_LDS_PAD_KB");  // tuning: fewer workgroups per CU
   if (pad) lds += (size_t)atoi(pad) * 1024;
   if (lds > 160 * 1024) {
-    if (FAR) return -1;  // (the far-field tables do not fit beside the tile: the caller takes the plain kernel)
+    if (FAR) return ESDF_NO_FIT;  // (the far-field tables do not fit beside the tile: the caller takes the plain kernel)
     fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
     return FUELMI_ELIMIT;
   }
@@ -932,6 +1397,159 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   return FUELMI_OK;
 }
 
+// packed plain z/y pass (k_esdf_zy_pk): ESDF_NO_FIT when the box is not its kind (z extents above 255 voxels,
+// nz % 4 != 0, y lines too long for the tile)
+template <int MODE, int G, int NW>
+static int launch_zy_pk_g(fuelmi_map* m, const Box3& b, int nzc, int z0a, int threads, size_t lds) {
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pk<MODE, G, NW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int grid = ((xlen + 7) / 8) * 8 * nzc;
+  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
+  unsigned long long* dbg = nullptr;
+  if (timing) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)grid * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
+  }
+  STAGE_LAUNCH(m, (k_esdf_zy_pk<MODE, G, NW>), grid, threads, lds, m->g, b, (const u64*)m->infl_bits.p,
+               (const u64*)m->unk_bits.p, m->esdf_tmp, nzc, z0a, zy_fastrow() ? 1 : 0, MODE == 2 ? nullptr : esdf_stat_dev<0>(m), dbg);
+  HIPCHK(hipGetLastError());
+  if (timing) {
+    HIPCHK(hipStreamSynchronize(m->stream));
+    std::vector<unsigned long long> d((size_t)grid * 8);
+    HIPCHK(hipMemcpy(d.data(), dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dbg));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double ph[3] = {0, 0, 0}, life = 0;
+    int n = 0;
+    for (int w = 0; w < grid; ++w) {
+      const unsigned long long* r = &d[(size_t)w * 8];
+      if (!r[0] || !r[3]) continue;
+      t0 = std::min(t0, r[0]), t1 = std::max(t1, r[3]);
+      ph[0] += (double)(r[1] - r[0]), ph[1] += (double)(r[2] - r[1]), ph[2] += (double)(r[3] - r[2]), life += (double)(r[3] - r[0]);
+      ++n;
+    }
+    int alive = 0, early = 0;
+    const unsigned long long mid = t0 + (t1 - t0) / 2;
+    for (int w = 0; w < grid; ++w) {
+      const unsigned long long* r = &d[(size_t)w * 8];
+      if (!r[0] || !r[3]) continue;
+      if (r[0] <= mid && r[3] >= mid) ++alive;
+      if (r[0] - t0 < 100) ++early;
+    }
+    std::fprintf(stderr, "[zy-timing] G %d threads %d lds %zu: %d workgroups, span %.2f us; per workgroup: fill %.2f "
+                 "barrier %.2f scan %.2f life %.2f us; alive at mid-span %d, started in the first us %d\n", G, threads, lds, n,
+                 (double)(t1 - t0) / 100.0, ph[0] / n / 100.0, ph[1] / n / 100.0, ph[2] / n / 100.0, life / n / 100.0, alive, early);
+  }
+  return FUELMI_OK;
+}
+template <int MODE, int G, int NW>
+static int launch_zy_pp_g(fuelmi_map* m, const Box3& b, int nzc, int z0a, int threads, int nfw, int ntiles, int nwg, size_t lds) {
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pp<MODE, G, NW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
+  unsigned long long* dbg = nullptr;
+  if (timing) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)nwg * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * sizeof(unsigned long long), m->stream));
+  }
+  STAGE_LAUNCH(m, (k_esdf_zy_pp<MODE, G, NW>), nwg, threads, lds, m->g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
+               m->esdf_tmp, nzc, z0a, zy_fastrow() ? 1 : 0, MODE == 2 ? nullptr : esdf_stat_dev<0>(m), nfw, ntiles, dbg);
+  HIPCHK(hipGetLastError());
+  if (timing) {
+    HIPCHK(hipStreamSynchronize(m->stream));
+    std::vector<unsigned long long> d((size_t)nwg * 8);
+    HIPCHK(hipMemcpy(d.data(), dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dbg));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double fill = 0, scan = 0, life = 0, tiles = 0;
+    int n = 0;
+    for (int w = 0; w < nwg; ++w) {
+      const unsigned long long* r = &d[(size_t)w * 8];
+      if (!r[0] || !r[3]) continue;
+      t0 = std::min(t0, r[0]), t1 = std::max(t1, r[3]);
+      fill += (double)r[1], scan += (double)r[2], life += (double)(r[3] - r[0]), tiles += (double)r[5];
+      ++n;
+    }
+    std::fprintf(stderr, "[zy-timing] pipelined G %d threads %d (fill waves %d) lds %zu: %d workgroups x %.1f tiles, span %.2f us; per "
+                 "workgroup: life %.2f us, of it filling %.2f scanning %.2f (roles run side by side); per tile: fill %.2f scan %.2f us\n",
+                 G, threads, nfw, lds, n, tiles / n, (double)(t1 - t0) / 100.0, life / n / 100.0, fill / n / 100.0, scan / n / 100.0,
+                 fill / tiles / 100.0, scan / tiles / 100.0);
+  }
+  return FUELMI_OK;
+}
+template <int MODE>
+static int launch_zy_pp(fuelmi_map* m, const Box3& b, int ZC, int nzc, int z0a, int threads, int nfw, int ntiles, int nwg, size_t lds,
+                        bool wide) {
+  // (experimental, FUELMI_ZY_PP=1: built for 20-voxel chunks only -- it measured slower than the plain kernel, see DESIGN)
+  if (ZC != 20) return ESDF_NO_FIT;
+  return wide ? launch_zy_pp_g<MODE, 5, 4>(m, b, nzc, z0a, threads, nfw, ntiles, nwg, lds)
+              : launch_zy_pp_g<MODE, 5, 2>(m, b, nzc, z0a, threads, nfw, ntiles, nwg, lds);
+}
+template <int MODE>
+static int launch_zy_pk(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
+  if ((g.nz % 4) != 0 || zlen > 255) return ESDF_NO_FIT;
+  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
+  const int zlen_a = z1a - z0a + 1;
+  const int npair = (ylen + 1) >> 1;
+  // chunk of 4 G <= 32 voxels: the padded z extent plus a per-chunk row prologue worth ~6 voxels, tile <= 40 KB
+  // while that allows a chunk at all (four workgroups per CU)
+  static const char* zc_env = getenv("FUELMI_ZY_PK_ZC");  // tuning hook
+  int best_zc = 0;
+  long best_cost = 0;
+  for (int zc : {8, 16, 20, 24, 32}) {  // (the chunk sizes the kernels are compiled for)
+    if ((size_t)npair * zc * 4 > 40 * 1024 && zc > 8) break;
+    const int n = (zlen_a + zc - 1) / zc;
+    const long cost = (long)n * (zc + 6);
+    if (!best_zc || cost <= best_cost) best_zc = zc, best_cost = cost;
+  }
+  if (zc_env)
+    for (int zc : {8, 16, 20, 24, 32})
+      if (atoi(zc_env) == zc) best_zc = zc;
+  const int ZC = best_zc, nzc = (zlen_a + ZC - 1) / ZC;
+  const size_t lds = (size_t)npair * ZC * 4;
+  if (lds > 160 * 1024) return ESDF_NO_FIT;
+  {
+    // the pipelined kernel: persistent workgroups, fill waves + scan waves, >= 3 tiles per workgroup
+    static const char* pp_env = getenv("FUELMI_ZY_PP");  // tuning hook: 0 = the one-tile-per-workgroup kernel
+    const int xlen = b.hi[0] - b.lo[0] + 1;
+    const int ntiles = xlen * nzc;
+    const int nfw = (npair + 63) / 64;
+    static const char* sw_env = getenv("FUELMI_ZY_PP_SCANW");
+    int nsw = sw_env ? atoi(sw_env) : std::max(2, std::min(16 - nfw, nfw + (nfw > 4 ? 2 : 0)));
+    const size_t lds2 = 2 * lds + 2 * 16 * sizeof(u32);
+    if (pp_env && atoi(pp_env) != 0 && nfw + nsw <= 16 && nfw <= 14 && lds2 <= 160 * 1024 && ntiles >= 24) {
+      nsw = std::min(nsw, 16 - nfw);
+      const int threads = (nfw + nsw) * 64;
+      static const char* wg_env = getenv("FUELMI_ZY_PP_WGS");  // tuning hook: workgroups per CU
+      const int per_cu = wg_env ? atoi(wg_env) : (threads <= 512 && lds2 <= 72 * 1024 ? 2 : 1);
+      const int nwg = 8 * std::max(1, std::min(32 * per_cu, ntiles / 24));
+      const int rcp = launch_zy_pp<MODE>(m, b, ZC, nzc, z0a, threads, nfw, ntiles, nwg, lds2, zlen_a > 128);
+      if (rcp != ESDF_NO_FIT) return rcp;
+    }
+  }
+  static const char* th_env = getenv("FUELMI_ZY_PK_THREADS");  // tuning hook
+  const int threads = th_env ? atoi(th_env) : std::min(512, std::max(128, ((npair + 63) / 64) * 64));
+  const bool wide = zlen_a > 128;  // aligned z-lines of up to 128 / 256 bits
+#define ZY_PK_CASE(GG)                                                                     \
+  case GG:                                                                                 \
+    return wide ? launch_zy_pk_g<MODE, GG, 4>(m, b, nzc, z0a, threads, lds) : launch_zy_pk_g<MODE, GG, 2>(m, b, nzc, z0a, threads, lds);
+  switch (ZC / 4) {
+    ZY_PK_CASE(2)
+    ZY_PK_CASE(4)
+    ZY_PK_CASE(5)
+    ZY_PK_CASE(6)
+    ZY_PK_CASE(8)
+    default: return ESDF_NO_FIT;
+  }
+#undef ZY_PK_CASE
+
+}
+
 template <int OUT, int SEGS, bool FAR>
 static int launch_x4s(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
@@ -939,7 +1557,7 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
   const size_t lds = (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * SEGS * 4 * sizeof(u32);
-  if (lds > 160 * 1024) return -1;  // (FAR only: the longest lines, > 2270 voxels, scan without the far phase)
+  if (lds > 160 * 1024) return ESDF_NO_FIT;  // (FAR only: the longest lines, > 2270 voxels, scan without the far phase)
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS, FAR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -996,7 +1614,7 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
     const int ylen = b.hi[1] - b.lo[1] + 1, zlen_a = (b.hi[2] | 3) - (b.lo[2] & ~3) + 1;
     if ((long)ylen * zlen_a / 32 >= 512) {
       const int rc = launch_x4p<OUT, FAR>(m, b);
-      if (rc >= 0) return rc;
+      if (rc != ESDF_NO_FIT) return rc;
     }
   }
   static const char* force = getenv("FUELMI_X_SEGS");  // tuning hook: "4" or "8"
@@ -1004,7 +1622,7 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
   // 16-column one extends the vector path to x lines of up to 2400 voxels
   const bool narrow = force ? atoi(force) == 4 : (size_t)xlen * 128 > 150 * 1024;
   const int rc = narrow ? launch_x4s<OUT, 4, FAR>(m, b) : launch_x4s<OUT, 8, FAR>(m, b);
-  if (rc >= 0 || !FAR) return rc;
+  if (rc != ESDF_NO_FIT || !FAR) return rc;
   return narrow ? launch_x4s<OUT, 4, false>(m, b) : launch_x4s<OUT, 8, false>(m, b);
 }
 
@@ -1012,7 +1630,7 @@ template <int MODE, bool FAR>
 static int launch_zy(fuelmi_map* m, const Box3& b) {
   if (use_vec4(m->g, b.hi[0] - b.lo[0] + 1)) {
     const int rc = launch_zy4<MODE, FAR>(m, b);
-    return (FAR && rc < 0) ? launch_zy4<MODE, false>(m, b) : rc;
+    return (FAR && rc == ESDF_NO_FIT) ? launch_zy4<MODE, false>(m, b) : rc;
   }
   const Geo& g = m->g;
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
@@ -1067,56 +1685,57 @@ static int launch_x(fuelmi_map* m, const Box3& b) {
 // every group -- a statistic per PLACE, not "of the previous update" -- and an update runs the FAR kernels (block /
 // line minima bound the scan) when most outputs of the slabs it covers were far the last time they were updated:
 // an explored hall, optimistic_ maps.  A local bound that alternates between a hall and a fresh frustum therefore
-// gets the right kernels for both from the second visit on; places never seen follow the last decision.  Both
-// families are exact; FUELMI_ESDF_FAR=0/1 pins the choice.
+// gets the right kernels for both from the second visit on; places never seen follow the last decision.  All
+// families are exact; fuelmi_map_set_esdf_family pins one (tests, A/B runs).
 static bool esdf_use_far(fuelmi_map* m, const Box3& b) {
-  const char* e = getenv("FUELMI_ESDF_FAR");  // (read per update: the parity tests flip it between calls)
-  if (e && *e) return atoi(e) != 0;
-  const volatile u32* h = esdf_stat_host(m);
-  const u32 e1 = h[2 * ESDF_NG];
-  if (e1 != m->far_epoch_seen) {
-    // the groups the update behind epoch e1 sampled are the ones whose pairs changed since the copy the host holds
-    // (h_copy): the checksum covers exactly those
-    u32 tmp[2 * ESDF_NG];
-    u32 sum = 0u;
-    for (int g = 0; g < ESDF_NG; ++g) {
-      tmp[2 * g] = h[2 * g], tmp[2 * g + 1] = h[2 * g + 1];
-      if (tmp[2 * g + 1]) sum += tmp[2 * g] * 31u + tmp[2 * g + 1] + (u32)g * 0x10001u;
-    }
-    // (a mismatch means the table is still landing -- look again at the next update; a table that never fits, because
-    // an earlier one was skipped and left its marks behind, is taken as it is at the third look: it only picks kernels)
-    const bool fits = h[2 * ESDF_NG] == e1 && h[2 * ESDF_NG + 1] == sum + e1 * 0x9E3779B9u;
-    m->far_retry = (fits || e1 != m->far_epoch_tried) ? 0 : m->far_retry + 1;
-    m->far_epoch_tried = e1;
-    if (fits || m->far_retry >= 2) {
-      for (int g = 0; g < ESDF_NG; ++g)
-        if (tmp[2 * g + 1]) m->far_hist[g][0] = tmp[2 * g], m->far_hist[g][1] = tmp[2 * g + 1];
-      m->far_epoch_seen = e1;
-      volatile u32* hw = const_cast<volatile u32*>(h);
-      for (int g = 0; g < ESDF_NG; ++g) hw[2 * g + 1] = 0u;  // consumed (the next table marks its own groups)
+  const volatile unsigned long long* h = reinterpret_cast<const volatile unsigned long long*>(esdf_stat_host(m));
+  for (int g = 0; g < ESDF_NG; ++g) {  // entries are self-describing (forward_stat): take whatever is new
+    const unsigned long long v = h[g];
+    const unsigned short tag = (unsigned short)(v >> 48);
+    if (tag != 0 && tag != m->far_tag[g]) {
+      m->far_tag[g] = tag;
+      m->far_hist[g][0] = (u32)(v & 0xffffffu);
+      m->far_hist[g][1] = (u32)((v >> 24) & 0xffffffu);
     }
   }
   unsigned long long nf = 0, nt = 0;
   for (int g = b.lo[0] >> 4; g <= (b.hi[0] >> 4); ++g) nf += m->far_hist[g & (ESDF_NG - 1)][0], nt += m->far_hist[g & (ESDF_NG - 1)][1];
   if (nt != 0) m->far_last = 2 * nf > nt;
   static const bool dbg = getenv("FUELMI_ESDF_DEBUG") != nullptr;
-  if (dbg) std::fprintf(stderr, "[fuelmi] esdf regime: epoch %u (seen %u) far %llu of %llu sampled outputs -> %s kernels\n", e1,
-                        m->far_epoch_seen, nf, nt, m->far_last ? "far-field" : "plain");
+  if (dbg) std::fprintf(stderr, "[fuelmi] esdf regime: far %llu of %llu sampled outputs -> %s kernels\n", nf, nt,
+                        m->far_last ? "far-field" : "plain");
   return m->far_last;
+}
+
+template <int MODE>
+static int launch_zy_family(fuelmi_map* m, const Box3& b, int fam, int* ran) {
+  if (fam == FUELMI_ESDF_PLAIN) {
+    const int rc = launch_zy_pk<MODE>(m, b);
+    if (rc != ESDF_NO_FIT) {
+      *ran = FUELMI_ESDF_PLAIN;
+      return rc;
+    }
+    fam = FUELMI_ESDF_PLAIN32;
+  }
+  *ran = fam;
+  if constexpr (MODE != 2) {  // (the negative pass of signed maps never runs the far-field kernels)
+    if (fam == FUELMI_ESDF_FAR) return launch_zy<MODE, true>(m, b);
+  }
+  *ran = FUELMI_ESDF_PLAIN32;
+  return launch_zy<MODE, false>(m, b);
 }
 
 int esdf_update(fuelmi_map* m) {
   const Box3& b = m->local_bound;
-  const bool far = esdf_use_far(m, b);
-  int rc;
+  const int fam = m->esdf_family_pin >= 0 ? m->esdf_family_pin : (esdf_use_far(m, b) ? FUELMI_ESDF_FAR : FUELMI_ESDF_PLAIN);
+  const bool far = fam == FUELMI_ESDF_FAR;
+  int rc, ran = fam;
   {
     StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
-    if (far)
-      rc = m->cfg.optimistic ? launch_zy<1, true>(m, b) : launch_zy<0, true>(m, b);
-    else
-      rc = m->cfg.optimistic ? launch_zy<1, false>(m, b) : launch_zy<0, false>(m, b);
+    rc = m->cfg.optimistic ? launch_zy_family<1>(m, b, fam, &ran) : launch_zy_family<0>(m, b, fam, &ran);
   }
   if (rc) return rc;
+  m->esdf_family_last = ran;
   {
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
     rc = far ? launch_x<0, true>(m, b) : launch_x<0, false>(m, b);
@@ -1125,11 +1744,22 @@ int esdf_update(fuelmi_map* m) {
   if (m->cfg.signed_dist) {  // inside obstacles the nearest free voxel is never far: plain kernels
     {
       StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
-      rc = launch_zy<2, false>(m, b);
+      int ran2;
+      rc = launch_zy_family<2>(m, b, far ? FUELMI_ESDF_PLAIN : fam, &ran2);
     }
     if (rc) return rc;
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
     rc = launch_x<1, false>(m, b);
   }
   return rc;
+}
+
+extern "C" int fuelmi_map_set_esdf_family(fuelmi_map* m, int family) {
+  ARGCHK(m && family >= FUELMI_ESDF_AUTO && family <= FUELMI_ESDF_PLAIN32);
+  m->esdf_family_pin = family;
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_map_last_esdf_family(const fuelmi_map* m) {
+  ARGCHK(m);
+  return m->esdf_family_last;
 }

@@ -108,9 +108,10 @@ struct fuelmi_map {
   u32* esdf_stat = nullptr;
   u32* h_esdf_stat = nullptr;
   u32 far_hist[256][2] = {};
-  u32 far_epoch_seen = 0, far_epoch_tried = 0;
-  int far_retry = 0;
+  unsigned short far_tag[256] = {};  // tag of the entry of the pinned table each pair was taken from
   bool far_last = false;
+  int esdf_family_pin = FUELMI_ESDF_AUTO;    // fuelmi_map_set_esdf_family
+  int esdf_family_last = FUELMI_ESDF_PLAIN;  // family the z/y pass of the last update ran
   signed char raycast_num = 0;
   unsigned occ_epoch = 0;  // bumped by occupancy changes that bypass the updated box (upload, resetBuffer)
 

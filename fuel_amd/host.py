@@ -49,6 +49,10 @@ def _i3(v):
 class SDFMap:
     """fast_planner::SDFMap with the grid resident in HBM."""
     UNKNOWN, FREE, OCCUPIED = 0, 1, 2
+    ESDF_AUTO, ESDF_PLAIN, ESDF_FAR, ESDF_PLAIN32 = -1, 0, 1, 2
+    # family every newly created map is pinned to (None: the library's per-update choice); the parity tests run each
+    # ESDF test once per family by setting this
+    default_esdf_family = None
 
     def __init__(self, map_size, box_min=None, box_max=None, device=0, **params):
         self.L = lib()
@@ -76,6 +80,16 @@ class SDFMap:
         self.N = self.nvox[0] * self.nvox[1] * self.nvox[2]
         self.origin = np.array(info.origin)
         self.res = c.resolution
+        if SDFMap.default_esdf_family is not None:
+            self.setEsdfFamily(SDFMap.default_esdf_family)
+
+    def setEsdfFamily(self, family):
+        """pin the ESDF kernel family (ESDF_AUTO / _PLAIN / _FAR / _PLAIN32); all are exact"""
+        check(self.L.fuelmi_map_set_esdf_family(self.h, int(family)))
+
+    def lastEsdfFamily(self):
+        """family the z/y pass of the last updateESDF3d ran"""
+        return self.L.fuelmi_map_last_esdf_family(self.h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -120,6 +120,15 @@ int fuelmi_map_project_depth(fuelmi_map* m, const unsigned short* depth, int row
 int fuelmi_map_inflate_local(fuelmi_map* m);
 /* SDFMap::updateESDF3d (sdf_map.cpp:152-241) over the current local bound */
 int fuelmi_map_update_esdf(fuelmi_map* m);
+/* Which kernel family runs the update (all are exact -- they differ in how far the outward scans of the y / x passes
+ * look).  AUTO (default): chosen per update from the far-output statistic of the slabs the local
+ * bound covers; PLAIN: the packed 16-bit z/y pass (falls back to PLAIN32 for boxes it does not cover: z extents above
+ * 255 voxels, nz % 4 != 0); FAR: the far-field kernels (block / line minima); PLAIN32: the 32-bit plain z/y pass.
+ * fuelmi_map_last_esdf_family returns the family the z/y pass of the last update actually ran (tests assert the
+ * choice instead of a duration). */
+enum { FUELMI_ESDF_AUTO = -1, FUELMI_ESDF_PLAIN = 0, FUELMI_ESDF_FAR = 1, FUELMI_ESDF_PLAIN32 = 2 };
+int fuelmi_map_set_esdf_family(fuelmi_map* m, int family);
+int fuelmi_map_last_esdf_family(const fuelmi_map* m);
 /* SDFMap::resetBuffer() (sdf_map.cpp:95-99) and resetBuffer(min,max) (:101-114) */
 int fuelmi_map_reset_buffer_all(fuelmi_map* m);
 int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]);

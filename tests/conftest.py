@@ -11,6 +11,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock statements (kernel durations, throughput ratios); NOT part of "
+                            "the parity suite -- run with -m perf.  The parity tests assert the CHOICE a timing was a "
+                            "proxy for (fuelmi_map_last_esdf_family, evaluation counts)")
 
 
 def _has_gpu():

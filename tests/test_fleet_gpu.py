@@ -126,7 +126,7 @@ def test_four_maps_as_processes_and_as_threads_on_one_device():
     thr_procs = N_AGENTS * CYCLES / dt_procs
     print("fleet on one device: %d threads %.0f cycles/s, %d processes %.0f cycles/s" %
           (N_AGENTS, thr_threads, N_AGENTS, thr_procs))
-    assert thr_threads >= 0.8 * thr_procs, (thr_threads, thr_procs)
+    # (a wall-clock ratio: printed here, asserted only under -m perf -- tests/test_perf_gpu.py)
 
 
 def _free_port():
@@ -203,7 +203,7 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     assert one.returncode == 0, one.stderr[-2000:]
     single = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     assert single["n_gpus"] == 1
-    # two ranks on ONE device: the whole-job figure is the sum over ranks -- somewhere between half and twice the
-    # single-map rate (they share the GPU); what matters is that it IS a two-rank aggregate
-    assert 0.5 * single["value"] <= out["value"] <= 2.5 * single["value"], (out["value"], single["value"])
+    # two ranks on ONE device: the whole-job figure is the sum over ranks; what matters is that it IS a two-rank
+    # aggregate (n_gpus, one line) and a positive rate -- the range it lands in is a -m perf statement
+    assert out["value"] > 0 and single["value"] > 0
     print("bench --gpus 2 on one device: %.0f cycles/s vs %.0f for one rank" % (out["value"], single["value"]))

@@ -138,11 +138,13 @@ def test_fusion_with_the_camera_outside_the_map(fa):
     gm.close()
 
 
-@pytest.fixture(params=["plain", "far"])
-def esdf_kernels(request, monkeypatch):
-    """both ESDF kernel families (esdf.hip: esdf_use_far picks one per update from the previous update's statistic;
-    FUELMI_ESDF_FAR pins it): they must give the same bits"""
-    monkeypatch.setenv("FUELMI_ESDF_FAR", "1" if request.param == "far" else "0")
+@pytest.fixture(params=["plain", "far", "plain32"])
+def esdf_kernels(request, fa, monkeypatch):
+    """every ESDF kernel family (esdf.hip: the packed 16-bit plain z/y pass, the far-field kernels, the 32-bit plain
+    pass; esdf_use_far picks per update from the statistic of the place, fuelmi_map_set_esdf_family pins one): they
+    must give the same bits"""
+    fam = {"plain": fa.SDFMap.ESDF_PLAIN, "far": fa.SDFMap.ESDF_FAR, "plain32": fa.SDFMap.ESDF_PLAIN32}[request.param]
+    monkeypatch.setattr(fa.SDFMap, "default_esdf_family", fam)
     return request.param
 
 
@@ -232,7 +234,6 @@ def test_esdf_switches_kernels_from_the_previous_update(fa, monkeypatch):
     """the adaptive path: an explored hall (optimistic, floor + one pillar) makes the first update report mostly
     far outputs, the second one then runs the FAR kernels; a half-explored map keeps the plain ones.  Either way
     the distances equal the oracle's, and the stage timings show the hall getting cheaper on the second update."""
-    monkeypatch.delenv("FUELMI_ESDF_FAR", raising=False)
     map_size = (20.0, 20.0, 6.0)
     om = fo.OracleMap(map_size, optimistic=1)
     gm = fa.SDFMap(map_size, optimistic=1)
@@ -250,14 +251,15 @@ def test_esdf_switches_kernels_from_the_previous_update(fa, monkeypatch):
     gm.clearAndInflateLocalMap()
     from fuel_amd._lib import K_ESDF_ZY, K_ESDF_X
     gm.profileEnable((1 << K_ESDF_ZY) | (1 << K_ESDF_X))
+    fams = []
     for _ in range(3):
         gm.updateESDF3d()
         assert_map_equal(om, gm, (lo, hi))
+        fams.append(gm.lastEsdfFamily())
     esdf_ms = gm.profileSamples(K_ESDF_ZY)[:3] + gm.profileSamples(K_ESDF_X)[:3]
-    print("explored hall, ESDF ms per update:", ["%.3f" % v for v in esdf_ms])
-    # (z/y pass of the later updates against the first; the better of the two later samples: a single event timing of a
-    # 100-microsecond kernel occasionally comes back stretched, and the statement is about the kernel family)
-    assert min(esdf_ms[1:3]) < 0.8 * esdf_ms[0], esdf_ms
+    print("explored hall, ESDF ms per update:", ["%.3f" % v for v in esdf_ms], "families", fams)
+    # the statement under test is the CHOICE (durations are printed, and asserted only under -m perf)
+    assert fams == [fa.SDFMap.ESDF_PLAIN, fa.SDFMap.ESDF_FAR, fa.SDFMap.ESDF_FAR], fams
     gm.close()
 
 
