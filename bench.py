@@ -156,6 +156,16 @@ class GpuCycle:
         self.n_clusters = ncl.value
         return sec.value
 
+    def host_profile(self):
+        """mean host microseconds per cycle inside each C-ABI call of the last run_native (fuelmi_bench_host_profile)"""
+        import ctypes as C
+        out = (C.c_double * 7)()
+        from fuel_amd._lib import check
+        check(self.map.L.fuelmi_bench_host_profile(self.map.h, out))
+        keys = ("reset_and_box", "search_begin", "inflate_local", "update_esdf", "bspline_eval", "search_end",
+                "search_end_polling")
+        return {k: round(v, 2) for k, v in zip(keys, out)}
+
 
 def run_delivered(cyc, n):
     """n cycles with the results delivered to host memory every cycle (fuelmi_bench_cycles_delivered): the cells of
@@ -645,6 +655,7 @@ def main():
         elapsed = timed_fleet_run(lambda: cyc.run_native(args.steps, args.serial_stages), cyc.finish, 1, dist,
                                   torch.cuda.synchronize)
     n_launch, dom_total_ms = cyc.map.profileGet(stages[dominant])
+    host_issue = None if streaming else cyc.host_profile()  # (of the timed run)
     frame_source = None
     if streaming:
         # The same K frames handed over from host memory instead, each source from an IDENTICAL map state: a fresh map
@@ -776,6 +787,12 @@ def main():
         out["roofline"]["critical"] = crit
         if host_loop is not None:
             out["host_loop"] = host_loop
+        if host_issue is not None:
+            # what the ONE host thread that issues both streams spends per cycle inside each C-ABI call (us); everything
+            # except search_end_polling is host work on the cycle's critical path
+            host_issue["host_busy_us_per_cycle"] = round(sum(v for k, v in host_issue.items() if k != "search_end_polling")
+                                                         - host_issue["search_end_polling"], 2)
+            out["host_issue_us"] = host_issue
         if host_delivery is not None:
             out["host_delivery"] = host_delivery
         if streaming:

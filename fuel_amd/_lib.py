@@ -157,6 +157,7 @@ SYMBOLS = {
     "fuelmi_frontier_stats": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fuelmi_frontier_synchronize": (C.c_int, [_P]),
     "fuelmi_bench_cycles": (C.c_int, [_P, _P, _P, _dp, _dp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
+    "fuelmi_bench_host_profile": (C.c_int, [_P, _dp]),
     "fuelmi_bench_cycles_delivered": (C.c_int, [_P, _P, _P, _dp, _dp, C.c_int, _ip, C.c_size_t, _dp, _dp,
                                                 C.POINTER(C.c_int), _dp]),
     "fuelmi_bench_stream": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(DepthCfg),

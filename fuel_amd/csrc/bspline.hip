@@ -36,7 +36,8 @@ struct fuelmi_bspline_dev {
   int device = 0;
   BsplineArgs a;
   std::vector<void*> allocs;
-  size_t lds;
+  size_t lds;       // evaluation scratch of one wave (the solves build on it)
+  size_t lds_eval4; // ... plus the partial gradients / costs of the four-wave cost kernel
   double *opt_x = nullptr, *opt_cost = nullptr;  // fuelmi_bspline_dev_optimize outputs
   int* opt_evals = nullptr;
   double* fit_in = nullptr;  // fuelmi_bspline_dev_load_samples staging: ts | points | derivs
@@ -85,22 +86,30 @@ __device__ void load_eval_const(const BsplineArgs& A, int c, unsigned char* smem
   if (l >= 12 && l < 21) K[l] = ((A.cost_function & FUELMI_COST_END) && A.end_state) ? A.end_state[(size_t)c * 9 + (l - 12)] : 0.0;
   __syncthreads();
 }
+// NWV = waves that share one candidate: 1 (the solves: a wave per candidate walks its whole objective) or 4 (the batched
+// cost kernel: the terms of the objective are dealt to four waves -- smoothness / feasibility / distance / boundary
+// and the rest -- which evaluate side by side and add their partial costs and gradients in a fixed order; the cost
+// kernel's duration is the latency of one wave's dependent chain, and the chain is a quarter as long).
+// NWV = 4 needs 12 N + 8 more doubles of LDS behind the constants.
+template <int NWV>
 __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, const BsplineArgs& A, int c,
                                const double* x, double* grad, unsigned char* smem_raw) {
   const double* K = eval_const(A, smem_raw);
   const int N = A.N, dim = A.dim;
+  const int wv = NWV == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const bool is_sm = NWV == 1 || wv == 0, is_fe = NWV == 1 || wv == 1, is_di = NWV == 1 || wv == 2, is_mi = NWV == 1 || wv == 3;
   double* q = reinterpret_cast<double*>(smem_raw);  // [N][3]
   double* tj = q + 3 * N;                            // [N][3] 2*jerk/pt_dist      (j <= N-4)
   double* tv = tj + 3 * N;                           // [N][3] vel hinge factor    (j <= N-2)
   double* ta = tv + 3 * N;                           // [N][3] acc hinge factor    (j <= N-3)
   double* gw = ta + 3 * N;                           // [N][3] waypoint gradient scratch
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool opt_time = (A.cost_function & FUELMI_COST_MINTIME) != 0;
   const double dt = opt_time ? x[A.nvar - 1] : K[1];
   const double pt_dist = K[0];
   const fuelmi_bspline_cfg& P = A.cfg;
 
-  for (int i = lane; i < N; i += 64)
+  for (int i = threadIdx.x; i < N; i += 64 * NWV)
     for (int j = 0; j < 3; ++j) q[3 * i + j] = (j < dim) ? x[dim * i + j] : 0.0;
   __syncthreads();
 
@@ -114,18 +123,18 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
   // the ESDF corners of this lane's first control point: loads start here and are consumed in pass 2,
   // behind the arithmetic of pass 1
   DistGather G0;
-  const bool gather0 = (A.cost_function & FUELMI_COST_DISTANCE) && lane < N;
+  const bool gather0 = is_di && (A.cost_function & FUELMI_COST_DISTANCE) && lane < N;
   if (gather0) dist_gather_issue(g, dist, &q[3 * lane], G0);
 
   // ---- pass 1: per-stencil quantities ----
   for (int i = lane; i < N; i += 64) {
     for (int k = 0; k < 3; ++k) {
-      tj[3 * i + k] = 0.0;
-      tv[3 * i + k] = 0.0;
-      ta[3 * i + k] = 0.0;
-      gw[3 * i + k] = 0.0;
+      if (is_sm) tj[3 * i + k] = 0.0;
+      if (is_fe) tv[3 * i + k] = 0.0;
+      if (is_fe) ta[3 * i + k] = 0.0;
+      if (is_mi) gw[3 * i + k] = 0.0;
     }
-    if ((A.cost_function & FUELMI_COST_SMOOTHNESS) && i + 3 < N) {
+    if (is_sm && (A.cost_function & FUELMI_COST_SMOOTHNESS) && i + 3 < N) {
       double s = 0.0;
       for (int k = 0; k < 3; ++k) {
         double ji = (q[3 * (i + 3) + k] - 3 * q[3 * (i + 2) + k] + 3 * q[3 * (i + 1) + k] - q[3 * i + k]) * pt_inv;
@@ -134,7 +143,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
       }
       cost += P.ld_smooth * s;
     }
-    if (A.cost_function & FUELMI_COST_FEASIBILITY) {
+    if (is_fe && (A.cost_function & FUELMI_COST_FEASIBILITY)) {
       if (i + 1 < N) {
         for (int k = 0; k < 3; ++k) {
           double vi = (q[3 * (i + 1) + k] - q[3 * i + k]) * dt_inv;
@@ -164,7 +173,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
     }
   }
   __syncthreads();
-  if ((A.cost_function & FUELMI_COST_WAYPOINTS) && lane == 0) {
+  if (is_mi && (A.cost_function & FUELMI_COST_WAYPOINTS) && lane == 0) {
     double s = 0.0;
     for (int w = 0; w < A.n_waypt; ++w) {
       const double* wp = A.waypoints + ((size_t)c * A.n_waypt + w) * 3;
@@ -184,7 +193,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
   // ---- pass 2: per-point gradient (gather) ----
   for (int i = lane; i < N; i += 64) {
     double gq[3] = {0.0, 0.0, 0.0};
-    if (A.cost_function & FUELMI_COST_SMOOTHNESS) {
+    if (is_sm && (A.cost_function & FUELMI_COST_SMOOTHNESS)) {
       // point i sits at offset s of stencil j = i - s; weights (-1, 3, -3, 1)
       const double wgt[4] = {-1.0, 3.0, -3.0, 1.0};
       for (int s = 0; s < 4; ++s) {
@@ -193,7 +202,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
           for (int k = 0; k < 3; ++k) gq[k] += P.ld_smooth * wgt[s] * tj[3 * j + k];
       }
     }
-    if (A.cost_function & FUELMI_COST_DISTANCE) {
+    if (is_di && (A.cost_function & FUELMI_COST_DISTANCE)) {
       double dg[3];
       double d = (i == lane && gather0) ? dist_gather_finish(g, G0, dg) : dist_with_grad_dev(g, dist, &q[3 * i], dg);
       double nrm = sqrt(dot3(dg, dg));
@@ -206,7 +215,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
         for (int k = 0; k < 3; ++k) gq[k] += P.ld_dist * (2.0 * (d - P.dist0) * dg[k]);
       }
     }
-    if (A.cost_function & FUELMI_COST_FEASIBILITY) {
+    if (is_fe && (A.cost_function & FUELMI_COST_FEASIBILITY)) {
       for (int k = 0; k < 3; ++k) {
         double s = 0.0;
         if (i + 1 < N) s += -tv[3 * i + k];
@@ -223,8 +232,8 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
     // f64 divisions instead of two); the summation order of each term is the reference's ("first" is
     // q1 for START and q_1 for END).  A lane holding both roles (N < 6) takes a second pass.
     {
-      const bool is_start = (A.cost_function & FUELMI_COST_START) && i < 3;
-      const bool is_end = (A.cost_function & FUELMI_COST_END) && i >= N - 3;
+      const bool is_start = is_mi && (A.cost_function & FUELMI_COST_START) && i < 3;
+      const bool is_end = is_mi && (A.cost_function & FUELMI_COST_END) && i >= N - 3;
       for (int pass = 0; pass < 2; ++pass) {
         const bool as_end = (pass == 0) ? (!is_start && is_end) : (is_start && is_end);
         if (!(pass == 0 ? (is_start || is_end) : as_end)) continue;
@@ -260,7 +269,7 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
         }
       }
     }
-    if ((A.cost_function & FUELMI_COST_GUIDE) && i >= A.order && i < N - A.order) {
+    if (is_mi && (A.cost_function & FUELMI_COST_GUIDE) && i >= A.order && i < N - A.order) {
       const double* gp = A.guide_pts + ((size_t)c * A.n_guide + (i - A.order)) * 3;
       for (int k = 0; k < 3; ++k) {
         double d = q[3 * i + k] - gp[k];
@@ -268,9 +277,9 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
         gq[k] += P.ld_guide * 2 * d;
       }
     }
-    if (A.cost_function & FUELMI_COST_WAYPOINTS)
+    if (is_mi && (A.cost_function & FUELMI_COST_WAYPOINTS))
       for (int k = 0; k < 3; ++k) gq[k] += P.ld_waypt * gw[3 * i + k];
-    if ((A.cost_function & FUELMI_COST_VIEWCONS) && i == A.view_idx[c]) {
+    if (is_mi && (A.cost_function & FUELMI_COST_VIEWCONS) && i == A.view_idx[c]) {
       const double* p = A.view_pt + (size_t)c * 3;
       const double* dir = A.view_dir + (size_t)c * 3;
       double dn_ = sqrt(dot3(dir, dir));
@@ -293,10 +302,15 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
       }
       cost += P.ld_view * c_view;
     }
-    for (int j = 0; j < dim; ++j) grad[dim * i + j] = gq[j];
+    if (NWV == 1) {
+      for (int j = 0; j < dim; ++j) grad[dim * i + j] = gq[j];
+    } else {  // this wave's share of the point's gradient
+      double* gpart = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)N + EVAL_CONST + (size_t)wv * 3 * N;
+      for (int j = 0; j < 3; ++j) gpart[3 * i + j] = gq[j];
+    }
   }
 
-  if ((A.cost_function & FUELMI_COST_MINTIME) && lane == 0) {
+  if (is_mi && (A.cost_function & FUELMI_COST_MINTIME) && lane == 0) {
     // calcTimeCost (:504-516)
     double duration = (N - A.order) * dt;
     double cst = duration, g_t = double(N - A.order);
@@ -311,17 +325,33 @@ __device__ double bspline_eval(const Geo& g, const float* __restrict__ dist, con
   }
   cost = wave_sum(cost);
   gt = wave_sum(gt);
-  if (lane == 0 && opt_time) grad[A.nvar - 1] = gt;
-  __syncthreads();  // grad[] complete and visible to every lane
-  return cost;
+  if (NWV == 1) {
+    if (lane == 0 && opt_time) grad[A.nvar - 1] = gt;
+    __syncthreads();  // grad[] complete and visible to every lane
+    return cost;
+  }
+  // the four waves' shares, added in wave order (smoothness, feasibility, distance, the rest)
+  double* part = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)N + EVAL_CONST;
+  double* cpart = part + 12 * (size_t)N;
+  if (lane == 0) cpart[wv] = cost, cpart[4 + wv] = gt;
+  __syncthreads();
+  for (int e = threadIdx.x; e < dim * N; e += 64 * NWV) {
+    const int i = e / dim, j = e - i * dim;
+    grad[e] = ((part[3 * i + j] + part[3 * N + 3 * i + j]) + part[6 * N + 3 * i + j]) + part[9 * N + 3 * i + j];
+  }
+  if (threadIdx.x == 0 && opt_time) grad[A.nvar - 1] = ((cpart[4] + cpart[5]) + cpart[6]) + cpart[7];
+  const double total = ((cpart[0] + cpart[1]) + cpart[2]) + cpart[3];
+  __syncthreads();
+  return total;
 }
 
-__global__ void __launch_bounds__(64)
+// four waves per candidate (see bspline_eval): LDS = the evaluation scratch + 12 N + 8 doubles
+__global__ void __launch_bounds__(256)
 k_bspline_cost_grad(Geo g, const float* __restrict__ dist, BsplineArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int c = blockIdx.x;
   load_eval_const(A, c, smem_raw);
-  const double cost = bspline_eval(g, dist, A, c, A.x + (size_t)c * A.nvar, A.grad + (size_t)c * A.nvar, smem_raw);
+  const double cost = bspline_eval<4>(g, dist, A, c, A.x + (size_t)c * A.nvar, A.grad + (size_t)c * A.nvar, smem_raw);
   if (threadIdx.x == 0) A.cost[c] = cost;
 }
 
@@ -395,7 +425,7 @@ k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsAr
   // (costFunction's best_variable_, bspline_optimizer.cpp:693-707).  wall_clock64 is the 100 MHz constant clock.
   const unsigned long long t_begin = wall_clock64();
   auto out_of_time = [&]() { return L.max_ticks != 0ull && wall_clock64() - t_begin > L.max_ticks; };
-  double f = bspline_eval(g, dist, A, c, q, gq, smem_raw);
+  double f = bspline_eval<1>(g, dist, A, c, q, gq, smem_raw);
   ++evals;
   double fbest = f;
   int hist = 0, head = 0;  // number of stored pairs, slot of the oldest
@@ -444,7 +474,7 @@ k_bspline_optimize(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsAr
         xn[i] = fmin(fmax(q[i] + step * d[i], lb_of(i, sv)), ub_of(i, sv));
       }
       __syncthreads();
-      fn = bspline_eval(g, dist, A, c, xn, gn, smem_raw);
+      fn = bspline_eval<1>(g, dist, A, c, xn, gn, smem_raw);
       ++evals;
       if (fn < fbest) {  // costFunction's best_variable_ (:699-703)
         fbest = fn;
@@ -512,7 +542,7 @@ __device__ __forceinline__ double reg_objective(const Geo& g, const float* __res
   for (int e = 0; e < NPL; ++e)
     if (on[e]) xs[lane + 64 * e] = xv[e];
   __syncthreads();
-  const double fv = bspline_eval(g, dist, A, c, xs, gs, smem_raw);  // ends with a barrier
+  const double fv = bspline_eval<1>(g, dist, A, c, xs, gs, smem_raw);  // ends with a barrier
 #pragma unroll
   for (int e = 0; e < NPL; ++e) gv[e] = on[e] ? gs[lane + 64 * e] : 0.0;
   return fv;
@@ -958,7 +988,8 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
   A.order = (A.dim == 1) ? 3 : cfg->bspline_degree;  // optimize() :123-127
   A.n_guide = A.N - 2 * A.order;
   b->lds = ((size_t)A.N * 3 * 5 + EVAL_CONST) * sizeof(double);
-  if (b->lds > 160 * 1024) {
+  b->lds_eval4 = b->lds + ((size_t)A.N * 12 + 8) * sizeof(double);
+  if (b->lds_eval4 > 160 * 1024) {
     fuelmi_set_error("%d control points exceed the LDS budget", A.N);
     delete b;
     return FUELMI_ELIMIT;
@@ -1002,9 +1033,9 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
     fuelmi_bspline_dev_destroy(b);
     return rc;
   }
-  if (b->lds > 64 * 1024) {
+  if (b->lds_eval4 > 64 * 1024) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_cost_grad),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   {
     std::lock_guard<std::mutex> lk(m->dep_mu);
@@ -1018,7 +1049,7 @@ extern "C" int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b) {
   ARGCHK(b);
   HIPCHK(hipSetDevice(b->map->device));
   StageScope sc(b->map, FUELMI_K_BSPLINE);
-  k_bspline_cost_grad<<<b->a.C, 64, b->lds, b->map->stream>>>(b->map->g, b->map->dist, b->a);
+  k_bspline_cost_grad<<<b->a.C, 256, b->lds_eval4, b->map->stream>>>(b->map->g, b->map->dist, b->a);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }

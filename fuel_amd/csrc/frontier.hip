@@ -2525,6 +2525,45 @@ static int dmalloc(fuelmi_frontier* f, T** p, size_t n) {
   HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)));
   f->allocs.push_back(d);
   *p = (T*)d;
+  const char* fp = reinterpret_cast<const char*>(p), *f0 = reinterpret_cast<const char*>(&f->F);
+  if (fp >= f0 && fp < f0 + sizeof(FArgs))  // a per-search buffer of F: the other plane's set gets a twin (frontier_twin_set)
+    f->f_scratch.push_back({(size_t)(fp - f0), std::max<size_t>(n, 1) * sizeof(T)});
+  return FUELMI_OK;
+}
+// the second set of per-search buffers (see fuelmi_frontier::F2): a twin of every device buffer F points to, its own
+// per-search variables and its own pinned result block
+static int frontier_twin_set(fuelmi_frontier* f) {
+  static const bool one = getenv("FUELMI_FR_ONE_STREAM") != nullptr;  // A/B hook: the round-3 behaviour
+  if (one) return FUELMI_OK;
+  FArgs& F = f->F;
+  f->F2 = F;
+  char* f2 = reinterpret_cast<char*>(&f->F2);
+  const std::vector<fuelmi_frontier::ScratchRec> recs = f->f_scratch;  // (dmalloc below appends)
+  for (const auto& r : recs) {
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, r.bytes));
+    f->allocs.push_back(d);
+    memcpy(f2 + r.field_off, &d, sizeof(void*));
+  }
+  f->f_scratch = recs;
+  FArgs& G2 = f->F2;
+  G2.kept = G2.counts + 16;
+  HIPCHK(hipMemsetAsync(G2.fctr, 0, 32 * sizeof(u32), f->stream));
+  FVar* d_var2 = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_var2), sizeof(FVar)));
+  f->allocs.push_back(d_var2);
+  G2.var = d_var2, G2.var_w = d_var2;
+  HIPCHK(hipHostMalloc(&f->h_pin2, f->pin_bytes, hipHostMallocDefault));
+  G2.h_counts = reinterpret_cast<u32*>(f->h_pin2);
+  G2.h_rec = reinterpret_cast<KeptRec*>(G2.h_counts + 16);
+  G2.h_part = reinterpret_cast<u32*>(G2.h_rec + G2.cap_kept);
+  G2.h_cells = G2.h_part + ((size_t)G2.cap_q / SZ_CH + 2) * 10;
+  memset(f->h_pin2, 0, 64);
+  G2.flag = f->flag2.p;
+  int lo_p = 0, hi_p = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+  HIPCHK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi_p));
+  HIPCHK(hipStreamSynchronize(f->stream));
   return FUELMI_OK;
 }
 
@@ -2540,9 +2579,16 @@ static int frontier_ensure_stage(fuelmi_frontier* f, size_t bytes) {
   return FUELMI_OK;
 }
 
+// both streams of the finder (the current search's and the one the previous fresh search left its tail on)
+static hipError_t frontier_drain(const fuelmi_frontier* f) {
+  const hipError_t e = stream_wait(f->stream);
+  if (e != hipSuccess || !f->stream2) return e;
+  return stream_wait(f->stream2);
+}
 static void frontier_orphan(void* p) {  // the map is going away under a live finder
   fuelmi_frontier* f = static_cast<fuelmi_frontier*>(p);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
+  if (f->stream2) (void)hipStreamSynchronize(f->stream2);
   f->scope.reset();
   f->map = nullptr;
 }
@@ -2559,10 +2605,12 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
         break;
       }
   }
-  if (f->stream) {
-    (void)hipStreamSynchronize(f->stream);
-    (void)hipStreamDestroy(f->stream);
-  }
+  for (hipStream_t st : {f->stream, f->stream2})
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  if (f->h_pin2) (void)hipHostFree(f->h_pin2);
   if (f->ev_dep) (void)hipEventDestroy(f->ev_dep);
   if (f->d_stage) (void)hipFree(f->d_stage);
   for (void* p : f->allocs) (void)hipFree(p);
@@ -2798,6 +2846,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   // (a thread of the tile kernels fetches at most FT_PER segments: z-lines of up to 256 voxels with the largest tile)
   f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && std::max(f->tile_lds[0], f->out_lds[0]) <= 150 * 1024 &&
                f->fast_items[0] <= (size_t)FT_PER * 512 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
+  if ((rc = frontier_twin_set(f))) {
+    fuelmi_frontier_destroy(f);
+    return rc;
+  }
   {
     std::lock_guard<std::mutex> lk(m->dep_mu);
     m->dependents.push_back({f, &frontier_orphan});
@@ -2864,6 +2916,7 @@ int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
   // when somebody asks for them.  Waiting for the tail here cost ~25 us per streaming cycle.
   size_t need = 0, nlazy = 0;
   for (HCluster& c : clusters) need += c.size(), nlazy += c.lazy ? 1 : 0;
+  f->pool_dirty = true;
   int rc = pool_reserve(f, need);
   if (rc) return rc;
   std::vector<PoolPut> table;
@@ -3095,15 +3148,11 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
 // stream since it was retired) -- no kernel of the search clears flags on the way, no clearing pass in front of it.
 // The plane just retired is zeroed behind everything queued on the finder's stream so far (the tail of the last
 // search still sets flags in it).  The kernel chains are captured once per plane (F.flag is a kernel argument).
-static int frontier_apply_reset(fuelmi_frontier* f) {
-  if (!f->fresh_pending) return FUELMI_OK;
-  f->fresh_pending = false;
-  if (f->zero_pending) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_zero, 0));
-  f->zero_pending = false;
-  std::swap(f->flag, f->flag2);
-  f->flag_cur ^= 1;
-  f->F.flag = f->flag.p;
-  HIPCHK(hipEventRecord(f->ev_tail, f->stream));
+// second half of frontier_apply_reset: queue the zeroing of the retired plane on the side stream.  Off the critical
+// path: _search_begin calls it AFTER it has launched the new chain (three API calls the chain's start does not wait for)
+static int frontier_finish_reset(fuelmi_frontier* f) {
+  if (!f->zero_deferred) return FUELMI_OK;
+  f->zero_deferred = false;
   HIPCHK(hipStreamWaitEvent(f->zstream, f->ev_tail, 0));
   const int W = f->map->g.W;
   k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->zstream>>>(f->flag2.p, W);
@@ -3111,6 +3160,27 @@ static int frontier_apply_reset(fuelmi_frontier* f) {
   HIPCHK(hipEventRecord(f->ev_zero, f->zstream));
   f->zero_pending = true;
   return FUELMI_OK;
+}
+static int frontier_apply_reset(fuelmi_frontier* f, bool defer_zeroing = false) {
+  if (!f->fresh_pending) return FUELMI_OK;
+  f->fresh_pending = false;
+  HIPCHK(hipEventRecord(f->ev_tail, f->stream));  // (everything that still writes the retired plane is in front of this)
+  if (f->stream2) {
+    // the other plane's buffer set and stream: the retiring search's tail keeps running on its own stream.  (The cell
+    // pool is the one device buffer both sets share: if it was written since the last swap -- a commit -- the new
+    // stream waits for the old one.)
+    std::swap(f->stream, f->stream2);
+    std::swap(f->F, f->F2);
+    if (f->pool_dirty) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_tail, 0));
+    f->pool_dirty = false;
+  }
+  if (f->zero_pending) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_zero, 0));
+  f->zero_pending = false;
+  std::swap(f->flag, f->flag2);
+  f->flag_cur ^= 1;
+  f->F.flag = f->flag.p;
+  f->zero_deferred = true;
+  return defer_zeroing ? FUELMI_OK : frontier_finish_reset(f);
 }
 
 // searchFrontiers, first half: drops changed clusters and enqueues the whole device pipeline on the
@@ -3130,9 +3200,13 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     if (rcm) return rcm;
   }
   {
-    const int rcr = frontier_apply_reset(f);
+    const int rcr = frontier_apply_reset(f, true);
     if (rcr) return rcr;
   }
+  struct FinishReset {  // (on every exit path, behind whatever was launched)
+    fuelmi_frontier* f;
+    ~FinishReset() { (void)frontier_finish_reset(f); }
+  } finish_reset{f};
   double umin[3], umax[3];
   fuelmi_map_get_updated_box(m, umin, umax, 1);
 
@@ -3364,6 +3438,14 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     volatile u32* stamp = counts + 15;
     const u32 want = f->h_var->epoch;
     unsigned spins = 0;
+    const auto w0 = std::chrono::steady_clock::now();
+    struct WaitAcc {  // (time spent polling: the part of _search_end that is the device's, not the host's)
+      fuelmi_frontier* f;
+      std::chrono::steady_clock::time_point w0;
+      ~WaitAcc() { f->wait_us_acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count(); }
+    };
+    {
+    WaitAcc wacc{f, w0};
     while (*stamp != want) {
       if ((++spins & 0x3FFFu) == 0u) {  // every ~16k polls: has the stream died under us?
         const hipError_t q = hipStreamQuery(f->stream);
@@ -3373,6 +3455,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
           return FUELMI_EHIP;
         }
       }
+    }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     f->tail_pending = true;
@@ -3649,7 +3732,7 @@ extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
   FRONTIER_HAS_MAP(f);
   HIPCHK(hipSetDevice(f->device));
   f->tail_pending = false;
-  HIPCHK(stream_wait(f->stream));
+  HIPCHK(frontier_drain(f));
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
@@ -3773,28 +3856,49 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   ARGCHK(m && f && ub_min && ub_max && n >= 0 && n_clusters && seconds && f->map == m);
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(frontier_drain(f));
   int rc = FUELMI_OK, ncl = 0;
-  const auto t0 = std::chrono::steady_clock::now();
+  f->wait_us_acc = 0.0;
+  using clk = std::chrono::steady_clock;
+  // host time of every C-ABI call of the cycle (seven clock reads per cycle, ~0.2 us): fuelmi_bench_host_profile
+  double hp[6] = {0, 0, 0, 0, 0, 0};
+  auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  const auto t0 = clk::now();
   for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
+    const auto a0 = clk::now();
     if ((rc = fuelmi_frontier_reset(f))) break;
     if ((rc = fuelmi_map_set_updated_box(m, ub_min, ub_max))) break;
+    const auto a1 = clk::now();
     if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
+    const auto a2 = clk::now();
     if ((rc = fuelmi_map_inflate_local(m))) break;
+    const auto a3 = clk::now();
     if ((rc = fuelmi_map_update_esdf(m))) break;
+    const auto a4 = clk::now();
     if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
+    const auto a5 = clk::now();
     if (serial) {
       HIPCHK(hipStreamSynchronize(m->stream));
       if ((rc = fuelmi_frontier_search_begin(f))) break;
     }
     if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
+    const auto a6 = clk::now();
+    hp[0] += us(a0, a1), hp[1] += us(a1, a2), hp[2] += us(a2, a3), hp[3] += us(a3, a4), hp[4] += us(a4, a5), hp[5] += us(a5, a6);
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
-  HIPCHK(stream_wait(f->stream));
+  HIPCHK(frontier_drain(f));
   f->tail_pending = false;
-  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *seconds = std::chrono::duration<double>(clk::now() - t0).count();
   *n_clusters = ncl;
+  for (int q = 0; q < 6; ++q) m->bench_host_us[q] = n ? hp[q] / n : 0.0;
+  m->bench_host_us[6] = f->wait_us_acc / std::max(n, 1);
+  f->wait_us_acc = 0.0;
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_bench_host_profile(const fuelmi_map* m, double out7[7]) {
+  ARGCHK(m && out7);
+  for (int q = 0; q < 7; ++q) out7[q] = m->bench_host_us[q];
   return FUELMI_OK;
 }
 
@@ -3811,7 +3915,7 @@ extern "C" int fuelmi_bench_cycles_delivered(fuelmi_map* m, fuelmi_frontier* f, 
   ARGCHK(!batch || (cost && grad));
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(frontier_drain(f));
   int rc = FUELMI_OK, ncl = 0;
   double t_cells = 0.0, t_cg = 0.0;
   using clk = std::chrono::steady_clock;
@@ -3840,7 +3944,7 @@ extern "C" int fuelmi_bench_cycles_delivered(fuelmi_map* m, fuelmi_frontier* f, 
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
-  HIPCHK(stream_wait(f->stream));
+  HIPCHK(frontier_drain(f));
   f->tail_pending = false;
   seconds3[0] = std::chrono::duration<double>(clk::now() - t0).count();
   seconds3[1] = t_cells;
@@ -3857,7 +3961,7 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   ARGCHK(m && f && n >= 0 && depth && cfg && cam_pos3 && cam_q4 && n_clusters && seconds && f->map == m);
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(frontier_drain(f));
   int rc = FUELMI_OK, ncl = 0;
   double vox = 0.0;
   const auto t0 = std::chrono::steady_clock::now();
@@ -3884,7 +3988,7 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
-  HIPCHK(stream_wait(f->stream));
+  HIPCHK(frontier_drain(f));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   *n_clusters = ncl;

@@ -265,7 +265,21 @@ struct fuelmi_frontier {
   hipStream_t zstream = nullptr;
   hipEvent_t ev_zero = nullptr, ev_tail = nullptr;
   bool zero_pending = false;
+  bool zero_deferred = false;  // the retired plane's zeroing is still to be queued (frontier_finish_reset)
   FArgs F;
+  // A fresh search (fuelmi_frontier_reset) swaps to the OTHER flag plane -- and, with it, to the other set of every
+  // per-search buffer (F2: tile tables, records, grouped cells, pinned result block, per-search variables) and the
+  // other stream: the tail of the previous search (k_tile_out: flags + grouped cell lists, ~15-30 us) then runs BESIDE
+  // the next search's chain instead of in front of it.  Incremental searches (no reset) stay on one plane, one
+  // buffer set, one stream: their flags are a true dependency.
+  FArgs F2;
+  hipStream_t stream2 = nullptr;
+  struct ScratchRec {  // a device buffer of F (byte offset of its pointer inside FArgs, size): F2 gets a twin
+    size_t field_off, bytes;
+  };
+  std::vector<ScratchRec> f_scratch;
+  void* h_pin2 = nullptr;
+  bool pool_dirty = false;  // the cell pool was written since the last plane swap (the new stream then waits for the old one)
   std::vector<void*> allocs;
   std::list<HCluster> frontiers, dormant, tmp;
   std::vector<int> removed_ids;
@@ -300,6 +314,7 @@ struct fuelmi_frontier {
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;
+  double wait_us_acc = 0.0;  // host time spent polling for results inside _search_end (fuelmi_bench_host_profile)
   size_t tile_lds[4] = {0, 0, 0, 0}, cross_lds[4] = {0, 0, 0, 0}, out_lds[4] = {0, 0, 0, 0}, fast_items[4] = {0, 0, 0, 0};
   size_t resolve_lds = 0;  // (dynamic LDS of the fast chain's kernels, per tile of the menu)
   std::unique_ptr<StageScope> scope;

@@ -136,6 +136,7 @@ struct fuelmi_map {
   size_t h_stage_bytes = 0;
 
   // measurement
+  double bench_host_us[7] = {0, 0, 0, 0, 0, 0, 0};  // fuelmi_bench_cycles: mean host microseconds per C-ABI call
   hipEvent_t t0 = nullptr, t1 = nullptr;
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
   unsigned profile_mask = 0;

@@ -383,6 +383,10 @@ int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* b
                         int serial, int* n_clusters, double* box_voxels, double* seconds);
 int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bspline_dev* batch, const double ub_min[3],
                         const double ub_max[3], int n, int serial, int* n_clusters, double* seconds);
+/* mean HOST microseconds per cycle the last fuelmi_bench_cycles run spent inside each C-ABI call: [0] _frontier_reset +
+ * _set_updated_box, [1] _search_begin, [2] _inflate_local, [3] _update_esdf, [4] _bspline_dev_eval, [5] _search_end
+ * (of which [6] polling for the device's result). */
+int fuelmi_bench_host_profile(const fuelmi_map* m, double out7[7]);
 /* fuelmi_bench_cycles with the results delivered to host memory every cycle, as the reference's callers receive
  * them (exploration_manager/src/fast_exploration_manager.cpp:99-114 reads the cell lists of searchFrontiers,
  * plan_manage/src/planner_manager.cpp:296-314 the optimiser's cost / gradient): cells of all new clusters into
