@@ -479,6 +479,22 @@ def cpu_baseline_reference(map_size, box, occ, ctrl, budget_s=12.0, dt=0.175):
                       (len(times), "/".join("%.1f" % (1e3 * s / len(times)) for s in stage))}
 
 
+def fleet_cpu_baseline(entry, rank, world, dist, core):
+    """N > 1: every rank has timed ITS OWN single-threaded CPU baseline on its own map, pinned to its own core, all at
+    the same time -- N independent reference processes, one per core, as the reference would run a fleet
+    (exploration_node.cpp:19: one ros::spin thread per agent; SURVEY 8d, BASELINE.md 3).  Rank 0 gets the aggregate."""
+    entries = [None] * world
+    dist.all_gather_object(entries, (entry, core))
+    if rank != 0:
+        return None
+    vals = [e[0]["value"] for e in entries]
+    e0 = entries[0][0]
+    return {"value": float(sum(vals)), "unit": e0["unit"], "cores": world, "kind": e0["kind"],
+            "per_process": [round(v, 4) for v in vals], "pinned_cores": [e[1] for e in entries],
+            "sample": "%d independent single-threaded processes (one per rank, each pinned to its own core, each on its own "
+                      "map, run concurrently); value = sum of their rates.  Each: %s" % (world, e0["sample"])}
+
+
 def timed_fleet_run(step, finish, steps, dist=None, device_sync=None, device="cuda"):
     """Time exactly `steps` steps, bracketed by barrier + device sync on both sides; returns the MAX
     elapsed seconds over ranks.  No data-path collective: ranks are independent maps."""
@@ -565,6 +581,7 @@ def main():
     ndev = torch.cuda.device_count()
     if local_rank >= ndev and not share:
         raise SystemExit("rank %d has no device (%d visible; FUELMI_FLEET_SHARE_DEVICE=1 lets ranks share)" % (local_rank, ndev))
+    local_rank_raw = local_rank
     local_rank = local_rank % ndev  # (the device this rank uses)
     torch.cuda.set_device(local_rank)
     dist = None
@@ -577,6 +594,14 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
+    # 2 x ranks > cores: the host loops that poll for device results (a core each) would fight the runtime's own
+    # threads -- they yield between polls instead (read once by the library)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    if world > 1 and ncores < 2 * world:
+        os.environ.setdefault("FUELMI_POLL_YIELD", "1")
     import fuel_amd
     from fuel_amd import _lib
     if args.esdf_family >= 0:
@@ -700,6 +725,22 @@ def main():
                                           "every cycle" % (ctrl.shape[0], ctrl.shape[1] * 3 + 1)}
     dom_ms = dom_total_ms / max(n_launch, 1)  # mean over the timed region, as the contract asks
 
+    fleet_cpu = None
+    if n_gpus > 1 and not args.no_cpu_baseline:
+        # fleet-vs-fleet: every rank times the CPU path on its own map, pinned to one core, concurrently
+        cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else [0]
+        core = cores[local_rank_raw % len(cores)]
+        try:
+            os.sched_setaffinity(0, {core})
+        except Exception:
+            pass
+        dist.barrier()
+        bud = min(args.cpu_budget, 8.0)
+        if streaming:
+            mine = cpu_baseline_stream_reference(map_size, box, frames, ctrl, bud) or cpu_baseline_stream(map_size, box, frames, ctrl, bud)
+        else:
+            mine = cpu_baseline_reference(map_size, box, occ, ctrl, bud) or cpu_baseline(map_size, box, occ, ctrl, bud)
+        fleet_cpu = fleet_cpu_baseline(mine, rank, world, dist, core)
     if rank == 0:
         nv = cyc.map.nvox
         nvox = nv[0] * nv[1] * nv[2]
@@ -806,6 +847,8 @@ def main():
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms
             out["roofline"]["isolated_frac"] = alg_bytes[dominant] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if fleet_cpu is not None:
+            out["cpu_baseline"] = fleet_cpu
         if n_gpus == 1 and not args.no_cpu_baseline:
             if streaming:
                 real = cpu_baseline_stream_reference(map_size, box, frames, ctrl, args.cpu_budget)

@@ -155,6 +155,7 @@ SYMBOLS = {
     "fuelmi_frontier_destroy": (None, [_P]),
     "fuelmi_frontier_reset": (C.c_int, [_P]),
     "fuelmi_frontier_stats": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "fuelmi_frontier_order_stats": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fuelmi_frontier_synchronize": (C.c_int, [_P]),
     "fuelmi_bench_cycles": (C.c_int, [_P, _P, _P, _dp, _dp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
     "fuelmi_bench_host_profile": (C.c_int, [_P, _dp]),
@@ -174,6 +175,8 @@ SYMBOLS = {
     "fuelmi_frontier_removed_ids": (C.c_int, [_P, _ip]),
     "fuelmi_frontier_get_flags": (C.c_int, [_P, C.c_void_p]),
     "fuelmi_bspline_cost_grad": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), _dp, _dp]),
+    "fuelmi_bspline_optimize": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), C.c_int, C.c_double, _dp, _dp,
+                                C.POINTER(C.c_int)]),
     "fuelmi_bspline_dev_create": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), _PP]),
     "fuelmi_bspline_dev_eval": (C.c_int, [_P]),
     "fuelmi_bspline_dev_download": (C.c_int, [_P, _dp, _dp]),

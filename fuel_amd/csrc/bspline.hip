@@ -533,16 +533,18 @@ __device__ __forceinline__ double reg_dot(const double (&a)[NPL], const double (
   return wave_sum(s2);
 }
 // objective at register-resident variables: staged through LDS (xs in, gs out) around bspline_eval
-template <int NPL>
+template <int NPL, int NWV>
 __device__ __forceinline__ double reg_objective(const Geo& g, const float* __restrict__ dist, const BsplineArgs& A, int c,
                                                 double* xs, double* gs, unsigned char* smem_raw, const bool (&on)[NPL],
                                                 const double (&xv)[NPL], double (&gv)[NPL]) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (NWV == 1 || threadIdx.x < 64) {  // (every wave holds the same variables: one writes them)
 #pragma unroll
-  for (int e = 0; e < NPL; ++e)
-    if (on[e]) xs[lane + 64 * e] = xv[e];
+    for (int e = 0; e < NPL; ++e)
+      if (on[e]) xs[lane + 64 * e] = xv[e];
+  }
   __syncthreads();
-  const double fv = bspline_eval<1>(g, dist, A, c, xs, gs, smem_raw);  // ends with a barrier
+  const double fv = bspline_eval<NWV>(g, dist, A, c, xs, gs, smem_raw);  // ends with a barrier
 #pragma unroll
   for (int e = 0; e < NPL; ++e) gv[e] = on[e] ? gs[lane + 64 * e] : 0.0;
   return fv;
@@ -554,12 +556,18 @@ __device__ __forceinline__ double reg_objective(const Geo& g, const float* __res
 // per owned variable plus a DPP reduction, updates are register arithmetic, nothing but the objective
 // touches LDS (variables in, gradient out).  Same operations in the same order as the LDS version above
 // (which stays as the path for n > 256): identical results, ~1/3 of the time per iteration.
-template <int NPL>
-__global__ void __launch_bounds__(64)
+// NWV = 4 (round 4): FOUR wavefronts per candidate.  Every wave carries the same L-BFGS state and does the same
+// register arithmetic (identical values, so the control flow is uniform across the workgroup without any exchange);
+// what is shared out is the objective -- bspline_eval<4>: smoothness / feasibility / distance / the rest, a wave each
+// -- which is where a solve spends its time (a chain of ~100-200 dependent evaluations).
+template <int NPL, int NWV>
+__global__ void __launch_bounds__(64 * NWV)
 k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, LbfgsArgs L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int c = blockIdx.x, lane = threadIdx.x, n = A.nvar;
-  double* xs = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N + EVAL_CONST;  // variables handed to the objective
+  __shared__ int s_oot;
+  const int c = blockIdx.x, lane = threadIdx.x & 63, n = A.nvar;
+  // variables handed to the objective: behind its scratch (and behind the partial sums of the four-wave evaluation)
+  double* xs = reinterpret_cast<double*>(smem_raw) + 15 * (size_t)A.N + EVAL_CONST + (NWV == 1 ? 0 : 12 * (size_t)A.N + 8);
   load_eval_const(A, blockIdx.x, smem_raw);
   double* gs = xs + n;                                                  // its gradient
   const double* x0 = A.x + (size_t)c * n;
@@ -595,8 +603,16 @@ k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, Lbfgs
   // the time cap is checked like NLopt does, between evaluations; the best variables seen so far are what comes back
   // (costFunction's best_variable_, bspline_optimizer.cpp:693-707).  wall_clock64 is the 100 MHz constant clock.
   const unsigned long long t_begin = wall_clock64();
-  auto out_of_time = [&]() { return L.max_ticks != 0ull && wall_clock64() - t_begin > L.max_ticks; };
-  double f = reg_objective<NPL>(g, dist, A, c, xs, gs, smem_raw, on, q, gq);
+  auto out_of_time = [&]() {
+    if (L.max_ticks == 0ull) return false;
+    if (NWV == 1) return wall_clock64() - t_begin > L.max_ticks;
+    if (threadIdx.x == 0) s_oot = wall_clock64() - t_begin > L.max_ticks ? 1 : 0;  // (one clock for the whole workgroup)
+    __syncthreads();
+    const bool o = s_oot != 0;
+    __syncthreads();
+    return o;
+  };
+  double f = reg_objective<NPL, NWV>(g, dist, A, c, xs, gs, smem_raw, on, q, gq);
   ++evals;
   double fbest = f;
   int hist = 0;  // stored pairs, slot 0 the oldest
@@ -643,7 +659,7 @@ k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, Lbfgs
     for (int ls = 0; ls < 20 && evals < L.max_eval && !out_of_time(); ++ls) {
 #pragma unroll
       for (int e = 0; e < NPL; ++e) xn[e] = on[e] ? fmin(fmax(q[e] + step * d[e], lo[e]), hi[e]) : 0.0;
-      fn = reg_objective<NPL>(g, dist, A, c, xs, gs, smem_raw, on, xn, gn);
+      fn = reg_objective<NPL, NWV>(g, dist, A, c, xs, gs, smem_raw, on, xn, gn);
       ++evals;
       if (fn < fbest) {  // costFunction's best_variable_ (:699-703)
         fbest = fn;
@@ -692,6 +708,7 @@ k_bspline_optimize_r(Geo g, const float* __restrict__ dist, BsplineArgs A, Lbfgs
     f = fn;
     if (sqrt(ss) <= 1e-5 * sqrt(xx)) break;  // xtol_rel 1e-5
   }
+  if (NWV > 1 && threadIdx.x >= 64) return;  // (every wave holds the result: one writes it)
 #pragma unroll
   for (int e = 0; e < NPL; ++e)
     if (on[e]) L.x_out[(size_t)c * n + lane + 64 * e] = best[e];
@@ -957,10 +974,8 @@ extern "C" void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b) {
   delete b;
 }
 
-extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
-                                         const fuelmi_bspline_batch* in, fuelmi_bspline_dev** out) {
-  ARGCHK(m && cfg && in && out);
-  *out = nullptr;
+// checks a batch description and derives the sizes combineCost / optimize() work with (pointers stay null)
+static int bspline_args_init(const fuelmi_bspline_cfg* cfg, const fuelmi_bspline_batch* in, BsplineArgs& A) {
   ARGCHK(in->dim >= 1 && in->dim <= 3 && in->point_num >= 4 && in->n_traj >= 1);
   ARGCHK(in->x && in->pt_dist);
   const int cf = in->cost_function;
@@ -971,11 +986,6 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
   ARGCHK(!(cf & FUELMI_COST_GUIDE) || in->guide_pts);
   ARGCHK(!(cf & FUELMI_COST_WAYPOINTS) || (in->n_waypt >= 0 && (in->n_waypt == 0 || (in->waypoints && in->waypt_idx))));
   ARGCHK(!(cf & FUELMI_COST_VIEWCONS) || (in->view_pt && in->view_dir && in->view_idx));
-  HIPCHK(hipSetDevice(m->device));
-  fuelmi_bspline_dev* b = new fuelmi_bspline_dev;
-  b->map = m;
-  b->device = m->device;
-  BsplineArgs& A = b->a;
   memset(&A, 0, sizeof(A));
   A.cfg = *cfg;
   A.cost_function = cf;
@@ -987,6 +997,27 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
   A.nvar = opt_time ? A.dim * A.N + 1 : A.dim * A.N;
   A.order = (A.dim == 1) ? 3 : cfg->bspline_degree;  // optimize() :123-127
   A.n_guide = A.N - 2 * A.order;
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
+                                         const fuelmi_bspline_batch* in, fuelmi_bspline_dev** out) {
+  ARGCHK(m && cfg && in && out);
+  *out = nullptr;
+  BsplineArgs A0;
+  {
+    const int rca = bspline_args_init(cfg, in, A0);
+    if (rca) return rca;
+  }
+  const int cf = in->cost_function;
+  const bool opt_time = (cf & FUELMI_COST_MINTIME) != 0;
+  HIPCHK(hipSetDevice(m->device));
+  fuelmi_bspline_dev* b = new fuelmi_bspline_dev;
+  b->map = m;
+  b->device = m->device;
+  BsplineArgs& A = b->a;
+  A = A0;
+  (void)opt_time;
   b->lds = ((size_t)A.N * 3 * 5 + EVAL_CONST) * sizeof(double);
   b->lds_eval4 = b->lds + ((size_t)A.N * 12 + 8) * sizeof(double);
   if (b->lds_eval4 > 160 * 1024) {
@@ -1069,7 +1100,7 @@ extern "C" int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_
   const size_t C = (size_t)A.C, n = (size_t)A.nvar;
   static const bool lds_path = getenv("FUELMI_OPT_LDS") != nullptr;  // tuning hook: force the LDS-state kernel
   const int npl = lds_path ? 0 : (n <= 128 ? 2 : (n <= 256 ? 4 : 0));  // register-state kernel up to 256 variables
-  const size_t lds_opt = npl ? b->lds + 2 * n * sizeof(double)
+  const size_t lds_opt = npl ? b->lds_eval4 + 2 * n * sizeof(double)
                              : b->lds + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
   if (lds_opt > 160 * 1024) {
     fuelmi_set_error("%d variables exceed the LDS budget of the device optimiser", (int)n);
@@ -1101,9 +1132,9 @@ extern "C" int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_
   {
     StageScope sc(m, FUELMI_K_BSPLINE);
     if (npl == 2)
-      k_bspline_optimize_r<2><<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+      k_bspline_optimize_r<2, 4><<<A.C, 256, lds_opt, m->stream>>>(m->g, m->dist, A, L);
     else if (npl == 4)
-      k_bspline_optimize_r<4><<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+      k_bspline_optimize_r<4, 4><<<A.C, 256, lds_opt, m->stream>>>(m->g, m->dist, A, L);
     else
       k_bspline_optimize<<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
     HIPCHK(hipGetLastError());
@@ -1123,30 +1154,128 @@ extern "C" int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, 
   HIPCHK(hipMemcpyAsync(cost, b->a.cost, (size_t)b->a.C * sizeof(double), hipMemcpyDeviceToHost, b->map->stream));
   HIPCHK(hipMemcpyAsync(grad, b->a.grad, (size_t)b->a.C * b->a.nvar * sizeof(double), hipMemcpyDeviceToHost,
                         b->map->stream));
-  HIPCHK(hipStreamSynchronize(b->map->stream));
+  HIPCHK(stream_wait(b->map->stream));  // (polls: a blocking synchronisation adds its wake-up latency to a 50 KB copy)
+  return FUELMI_OK;
+}
+
+// One-shot calls (what the reference's callers make: combineCost / optimize() of ONE trajectory at a time,
+// plan_manage/src/planner_manager.cpp:296-314) on a query slot of the map: the batch is packed into the slot's pinned
+// block and read by the kernel in place, the kernel writes its results there, the caller polls the slot's event.  No
+// hipMalloc / hipFree (round 3: ~10 allocations and a device-draining free per call, ~2.5 ms per solve), no copy
+// engine, nothing on the map's own stream; concurrent callers get different slots.
+// max_eval == 0: cost + gradient (out_a = cost [C], out_b = grad [C][nvar]); > 0: whole solves (out_a = cost_out [C],
+// out_b = x_out [C][nvar], evals [C] or null).
+static int bspline_oneshot(fuelmi_map* m, const fuelmi_bspline_cfg* cfg, const fuelmi_bspline_batch* in, int max_eval,
+                           double max_time_s, double* out_a, double* out_b, int* evals) {
+  ARGCHK(m && cfg && in && out_a && out_b);
+  BsplineArgs A;
+  {
+    const int rca = bspline_args_init(cfg, in, A);
+    if (rca) return rca;
+  }
+  HIPCHK(hipSetDevice(m->device));
+  const int cf = A.cost_function;
+  const size_t C = (size_t)A.C, n = (size_t)A.nvar;
+  struct Piece {
+    const void* src;
+    size_t bytes;
+    const void** dst;
+  };
+  const Piece pieces[] = {
+      {in->x, C * n * sizeof(double), (const void**)&A.x},
+      {in->pt_dist, C * sizeof(double), (const void**)&A.pt_dist},
+      {in->knot_span, in->knot_span ? C * sizeof(double) : 0, (const void**)&A.knot_span},
+      {in->time_lb, in->time_lb ? C * sizeof(double) : 0, (const void**)&A.time_lb},
+      {in->start_state, (cf & FUELMI_COST_START) ? C * 9 * sizeof(double) : 0, (const void**)&A.start_state},
+      {in->end_state, (cf & FUELMI_COST_END) ? C * 9 * sizeof(double) : 0, (const void**)&A.end_state},
+      {in->guide_pts, ((cf & FUELMI_COST_GUIDE) && A.n_guide > 0) ? C * A.n_guide * 3 * sizeof(double) : 0, (const void**)&A.guide_pts},
+      {in->waypoints, A.n_waypt > 0 ? C * A.n_waypt * 3 * sizeof(double) : 0, (const void**)&A.waypoints},
+      {in->waypt_idx, A.n_waypt > 0 ? C * A.n_waypt * sizeof(int) : 0, (const void**)&A.waypt_idx},
+      {in->view_pt, (cf & FUELMI_COST_VIEWCONS) ? C * 3 * sizeof(double) : 0, (const void**)&A.view_pt},
+      {in->view_dir, (cf & FUELMI_COST_VIEWCONS) ? C * 3 * sizeof(double) : 0, (const void**)&A.view_dir},
+      {in->view_idx, (cf & FUELMI_COST_VIEWCONS) ? C * sizeof(int) : 0, (const void**)&A.view_idx},
+  };
+  size_t in_bytes = 0;
+  for (const Piece& p : pieces) in_bytes += (p.bytes + 15) & ~(size_t)15;
+  const size_t out_bytes = ((C * sizeof(double) + 15) & ~(size_t)15) + ((C * n * sizeof(double) + 15) & ~(size_t)15) +
+                           ((C * sizeof(int) + 15) & ~(size_t)15);
+  const size_t lds_eval = ((size_t)A.N * 3 * 5 + EVAL_CONST) * sizeof(double);
+  QuerySlotGuard q;
+  {
+    const int rcq = q.acquire(m, in_bytes + out_bytes);
+    if (rcq) return rcq;
+  }
+  unsigned char* at = q.s->pin;
+  for (const Piece& p : pieces) {
+    *p.dst = nullptr;
+    if (!p.bytes || !p.src) continue;
+    memcpy(at, p.src, p.bytes);
+    *p.dst = at;
+    at += (p.bytes + 15) & ~(size_t)15;
+  }
+  double* o_a = reinterpret_cast<double*>(q.s->pin + in_bytes);
+  double* o_b = reinterpret_cast<double*>(q.s->pin + in_bytes + ((C * sizeof(double) + 15) & ~(size_t)15));
+  int* o_e = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(o_b) + ((C * n * sizeof(double) + 15) & ~(size_t)15));
+  if (max_eval <= 0) {
+    const size_t lds4 = lds_eval + ((size_t)A.N * 12 + 8) * sizeof(double);
+    if (lds4 > 160 * 1024) {
+      fuelmi_set_error("%d control points exceed the LDS budget", A.N);
+      return FUELMI_ELIMIT;
+    }
+    if (lds4 > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_cost_grad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+    A.cost = o_a, A.grad = o_b;
+    k_bspline_cost_grad<<<A.C, 256, lds4, q.s->st>>>(m->g, m->dist, A);
+  } else {
+    static const bool lds_path = getenv("FUELMI_OPT_LDS") != nullptr;
+    const int npl = lds_path ? 0 : (n <= 128 ? 2 : (n <= 256 ? 4 : 0));
+    const size_t lds_opt = npl ? lds_eval + ((size_t)A.N * 12 + 8) * sizeof(double) + 2 * n * sizeof(double)
+                               : lds_eval + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
+    if (lds_opt > 160 * 1024) {
+      fuelmi_set_error("%d variables exceed the LDS budget of the device optimiser", (int)n);
+      return FUELMI_ELIMIT;
+    }
+    if (lds_opt > 64 * 1024 && !npl)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_optimize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds_opt));
+    LbfgsArgs L;
+    L.max_eval = max_eval;
+    L.max_ticks = max_time_s > 0.0 ? (unsigned long long)(max_time_s * 1e8) + 1ull : 0ull;
+    for (int k = 0; k < 3; ++k) {
+      L.box_lo[k] = m->cfg.box_min[k] + 0.1;
+      L.box_hi[k] = m->cfg.box_max[k] - 0.1;
+    }
+    L.x_out = o_b, L.cost_out = o_a, L.evals_out = o_e;
+    if (npl == 2)
+      k_bspline_optimize_r<2, 4><<<A.C, 256, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
+    else if (npl == 4)
+      k_bspline_optimize_r<4, 4><<<A.C, 256, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
+    else
+      k_bspline_optimize<<<A.C, 64, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(q.finish());
+  memcpy(out_a, o_a, C * sizeof(double));
+  memcpy(out_b, o_b, C * n * sizeof(double));
+  if (evals && max_eval > 0) memcpy(evals, o_e, C * sizeof(int));
   return FUELMI_OK;
 }
 
 extern "C" int fuelmi_bspline_cost_grad(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
                                         const fuelmi_bspline_batch* batch, double* cost, double* grad) {
-  fuelmi_bspline_dev* b = nullptr;
-  int rc = fuelmi_bspline_dev_create(m, cfg, batch, &b);
-  if (rc) return rc;
-  rc = fuelmi_bspline_dev_eval(b);
-  if (rc == FUELMI_OK) rc = fuelmi_bspline_dev_download(b, cost, grad);
-  fuelmi_bspline_dev_destroy(b);
-  return rc;
+  ARGCHK(cost && grad);
+  return bspline_oneshot(m, cfg, batch, 0, -1.0, cost, grad, nullptr);
+}
+extern "C" int fuelmi_bspline_optimize(fuelmi_map* m, const fuelmi_bspline_cfg* cfg, const fuelmi_bspline_batch* batch,
+                                       int max_eval, double max_time_s, double* x_out, double* cost_out, int* evals_out) {
+  ARGCHK(max_eval >= 1 && x_out && cost_out);
+  return bspline_oneshot(m, cfg, batch, max_eval, max_time_s, cost_out, x_out, evals_out);
 }
 
 // ---- spline glue entry points ----
 namespace {
-struct DevBuf {  // scoped device scratch of the one-shot calls
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-};
-int fit_launch(fuelmi_map* m, const FitArgs& F) {
+int fit_launch(fuelmi_map* m, const FitArgs& F, hipStream_t st = nullptr) {
   const size_t lds = fit_lds(F.K, F.degree);
   if (lds > 160 * 1024) {
     fuelmi_set_error("%d samples exceed the LDS budget of the spline fit", F.K);
@@ -1155,7 +1284,7 @@ int fit_launch(fuelmi_map* m, const FitArgs& F) {
   if (lds > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bspline_fit), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  k_bspline_fit<<<F.C, 64, lds, m->stream>>>(F);
+  k_bspline_fit<<<F.C, 64, lds, st ? st : m->stream>>>(F);
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -1174,12 +1303,15 @@ extern "C" int fuelmi_bspline_parameterize(fuelmi_map* m, int n_traj, int n_poin
   const size_t C = (size_t)n_traj, K = (size_t)n_points, n = K + degree - 1;
   const size_t b_ts = C * sizeof(double), b_pts = C * K * 3 * sizeof(double), b_der = C * 12 * sizeof(double),
                b_ctrl = C * n * 3 * sizeof(double);
-  DevBuf buf;
-  HIPCHK(hipMalloc(&buf.p, b_ts + b_pts + b_der + b_ctrl));
-  unsigned char* d = static_cast<unsigned char*>(buf.p);
-  HIPCHK(hipMemcpyAsync(d, ts, b_ts, hipMemcpyHostToDevice, m->stream));
-  HIPCHK(hipMemcpyAsync(d + b_ts, points, b_pts, hipMemcpyHostToDevice, m->stream));
-  HIPCHK(hipMemcpyAsync(d + b_ts + b_pts, derivs, b_der, hipMemcpyHostToDevice, m->stream));
+  QuerySlotGuard q;  // (inputs read and results written in the slot's pinned block: no allocation, no copies)
+  {
+    const int rcq = q.acquire(m, b_ts + b_pts + b_der + b_ctrl);
+    if (rcq) return rcq;
+  }
+  unsigned char* d = q.s->pin;
+  memcpy(d, ts, b_ts);
+  memcpy(d + b_ts, points, b_pts);
+  memcpy(d + b_ts + b_pts, derivs, b_der);
   FitArgs F;
   memset(&F, 0, sizeof(F));
   F.C = n_traj, F.K = n_points, F.degree = degree;
@@ -1188,10 +1320,10 @@ extern "C" int fuelmi_bspline_parameterize(fuelmi_map* m, int n_traj, int n_poin
   F.derivs = reinterpret_cast<double*>(d + b_ts + b_pts);
   F.ctrl = reinterpret_cast<double*>(d + b_ts + b_pts + b_der);
   F.stride = (long)(n * 3);
-  const int rc = fit_launch(m, F);
+  const int rc = fit_launch(m, F, q.s->st);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(ctrl, F.ctrl, b_ctrl, hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(q.finish());
+  memcpy(ctrl, F.ctrl, b_ctrl);
   return FUELMI_OK;
 }
 
@@ -1209,19 +1341,22 @@ extern "C" int fuelmi_bspline_boundary_states(fuelmi_map* m, int n_traj, int n_c
     fuelmi_set_error("%d control points exceed the LDS budget", n_ctrl);
     return FUELMI_ELIMIT;
   }
-  DevBuf buf;
-  HIPCHK(hipMalloc(&buf.p, b_ts + b_ctrl + b_s + b_e));
-  unsigned char* d = static_cast<unsigned char*>(buf.p);
-  HIPCHK(hipMemcpyAsync(d, ts, b_ts, hipMemcpyHostToDevice, m->stream));
-  HIPCHK(hipMemcpyAsync(d + b_ts, ctrl, b_ctrl, hipMemcpyHostToDevice, m->stream));
+  QuerySlotGuard q;
+  {
+    const int rcq = q.acquire(m, b_ts + b_ctrl + b_s + b_e);
+    if (rcq) return rcq;
+  }
+  unsigned char* d = q.s->pin;
+  memcpy(d, ts, b_ts);
+  memcpy(d + b_ts, ctrl, b_ctrl);
   double* d_s = reinterpret_cast<double*>(d + b_ts + b_ctrl);
   double* d_e = reinterpret_cast<double*>(d + b_ts + b_ctrl + b_s);
-  k_bspline_boundary<<<n_traj, 64, lds, m->stream>>>(n_ctrl, degree, reinterpret_cast<double*>(d),
-                                                      reinterpret_cast<double*>(d + b_ts), ks, ke, d_s, d_e);
+  k_bspline_boundary<<<n_traj, 64, lds, q.s->st>>>(n_ctrl, degree, reinterpret_cast<double*>(d),
+                                                    reinterpret_cast<double*>(d + b_ts), ks, ke, d_s, d_e);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(start, d_s, b_s, hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipMemcpyAsync(end, d_e, b_e, hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(q.finish());
+  memcpy(start, d_s, b_s);
+  memcpy(end, d_e, b_e);
   return FUELMI_OK;
 }
 

@@ -2530,6 +2530,16 @@ static int dmalloc(fuelmi_frontier* f, T** p, size_t n) {
     f->f_scratch.push_back({(size_t)(fp - f0), std::max<size_t>(n, 1) * sizeof(T)});
   return FUELMI_OK;
 }
+// priority of the finder's streams: the highest by default (a chain of short latency-bound kernels beside the wide
+// ESDF passes); FUELMI_FR_PRIO = "high" | "normal" | "low" for A/B runs
+static int frontier_stream_priority() {
+  int lo_p = 0, hi_p = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) return 0;
+  static const char* e = getenv("FUELMI_FR_PRIO");
+  if (e && !strcmp(e, "normal")) return 0;
+  if (e && !strcmp(e, "low")) return lo_p;
+  return hi_p;
+}
 // the second set of per-search buffers (see fuelmi_frontier::F2): a twin of every device buffer F points to, its own
 // per-search variables and its own pinned result block
 static int frontier_twin_set(fuelmi_frontier* f) {
@@ -2560,9 +2570,7 @@ static int frontier_twin_set(fuelmi_frontier* f) {
   G2.h_cells = G2.h_part + ((size_t)G2.cap_q / SZ_CH + 2) * 10;
   memset(f->h_pin2, 0, 64);
   G2.flag = f->flag2.p;
-  int lo_p = 0, hi_p = 0;
-  HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-  HIPCHK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi_p));
+  HIPCHK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, frontier_stream_priority()));
   HIPCHK(hipStreamSynchronize(f->stream));
   return FUELMI_OK;
 }
@@ -2646,6 +2654,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
 
 extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* cfg, fuelmi_frontier** out) {
   ARGCHK(m && cfg && out);
+  ARGCHK(cfg->reference_order >= 0 && cfg->reference_order <= 2);
   *out = nullptr;
   HIPCHK(hipSetDevice(m->device));
   fuelmi_frontier* f = new fuelmi_frontier;
@@ -2716,9 +2725,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   {
     // the scan is a chain of short latency-bound kernels and is the critical path of a plan cycle:
     // give its stream the highest priority so the wide ESDF kernels of the map stream fill in around it
-    int lo_p = 0, hi_p = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-    HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi_p));
+    HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, frontier_stream_priority()));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&f->zstream, hipStreamNonBlocking));  // zeroes the retired flag plane (frontier_apply_reset)
@@ -3446,7 +3453,9 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     };
     {
     WaitAcc wacc{f, w0};
+    const bool yld = poll_yields();
     while (*stamp != want) {
+      if (yld) std::this_thread::yield();
       if ((++spins & 0x3FFFu) == 0u) {  // every ~16k polls: has the stream died under us?
         const hipError_t q = hipStreamQuery(f->stream);
         if (q != hipErrorNotReady && q != hipSuccess) HIPCHK(q);
@@ -3612,6 +3621,16 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       if (h_rec[r].size > FR_REFORDER_AUTO) ref_order = false;
   }
   f->ref_now = ref_order;
+  // never silent: which order this search delivers is part of its result -- fuelmi_frontier_order_stats
+  f->order_last = ref_order ? 1 : 0;
+  if (ref_order)
+    ++f->n_order_ref;
+  else if (f->cfg.reference_order == 2) {
+    ++f->n_order_fallback;
+    u32 big = 0;
+    for (u32 r = 0; r < nkept; ++r) big = std::max(big, h_rec[r].size);
+    f->order_fallback_cells = big;
+  }
   int fin = nkept <= 256 ? 1 : 0;  // buffer pair holding the grouped cells of the search
   std::vector<u32> off2;
   u32 n_in = n_out;
@@ -3738,6 +3757,11 @@ extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
 extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
   ARGCHK(f && out3);
   out3[0] = f->n_fast, out3[1] = f->n_legacy, out3[2] = f->n_fallback;
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_frontier_order_stats(const fuelmi_frontier* f, int out4[4]) {
+  ARGCHK(f && out4);
+  out4[0] = f->order_last, out4[1] = f->n_order_ref, out4[2] = f->n_order_fallback, out4[3] = (int)f->order_fallback_cells;
   return FUELMI_OK;
 }
 

@@ -314,6 +314,11 @@ struct fuelmi_frontier {
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;
+  // cell order of the searches (fuelmi_frontier_order_stats): what the last one delivered (0 address order, 1 the
+  // reference's BFS order), how many delivered the reference's, how many wanted it (cfg.reference_order == 2) and fell
+  // back to the address order because a cluster exceeded FR_REFORDER_AUTO cells, and that cluster's size
+  int order_last = 0, n_order_ref = 0, n_order_fallback = 0;
+  u32 order_fallback_cells = 0;
   double wait_us_acc = 0.0;  // host time spent polling for results inside _search_end (fuelmi_bench_host_profile)
   size_t tile_lds[4] = {0, 0, 0, 0}, cross_lds[4] = {0, 0, 0, 0}, out_lds[4] = {0, 0, 0, 0}, fast_items[4] = {0, 0, 0, 0};
   size_t resolve_lds = 0;  // (dynamic LDS of the fast chain's kernels, per tile of the menu)

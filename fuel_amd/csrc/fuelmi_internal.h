@@ -7,7 +7,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
+#include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -135,6 +139,25 @@ struct fuelmi_map {
   void* h_stage = nullptr;  // pinned
   size_t h_stage_bytes = 0;
 
+  // Read-only queries (getDistWithGrad, the one-shot B-spline calls: combineCost / optimize of ONE trajectory, the
+  // spline glue) run on QUERY SLOTS: a side stream, two events and a pinned block each, taken from a pool -- so that
+  // the <= 10 optimiser threads of topoReplan (plan_manage/src/planner_manager.cpp:446-453) and the visualisation
+  // thread (exploration_manager/src/fast_exploration_fsm.cpp:122) neither queue behind the mutators on the map's
+  // stream nor behind each other, and no call allocates or frees device memory (hipFree drains the device).  Inputs
+  // are packed into the pinned block and read by the kernel in place; results are written there by the kernel; the
+  // caller polls the slot's event.  A slot's stream is ordered behind what the map's stream held when the call began.
+  struct QuerySlot {
+    hipStream_t st = nullptr;
+    hipEvent_t ev_dep = nullptr, ev_done = nullptr;
+    unsigned char* pin = nullptr;
+    size_t pin_cap = 0;
+    bool busy = false;
+  };
+  std::vector<std::unique_ptr<QuerySlot>> qslots;
+  std::mutex qs_mu;
+  std::condition_variable qs_cv;
+  std::mutex prof_mu;  // the stage-profile log (StageScope) is shared by every thread that launches on this map
+
   // measurement
   double bench_host_us[7] = {0, 0, 0, 0, 0, 0, 0};  // fuelmi_bench_cycles: mean host microseconds per C-ABI call
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -148,6 +171,15 @@ struct fuelmi_map {
 };
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
+// a query slot with at least `bytes` of pinned memory, its stream ordered behind the map's; released (and waited for)
+// by the guard
+struct QuerySlotGuard {
+  fuelmi_map* m = nullptr;
+  fuelmi_map::QuerySlot* s = nullptr;
+  int acquire(fuelmi_map* m_, size_t bytes);
+  hipError_t finish();  // record + poll the slot's completion event
+  ~QuerySlotGuard();
+};
 int plane_alloc(fuelmi_map* m, Plane& pl);  // zeroed, with margins
 
 // stage profiling helpers: bracket a launch sequence belonging to `stage`
@@ -175,10 +207,18 @@ struct StageScope {
 
 // Wait for a stream the caller is about to consume the results of: poll for a while (a blocking synchronisation
 // pays ~15 us of wake-up latency even when the work is done within microseconds), then block.
+// FUELMI_POLL_YIELD=1 (bench.py sets it when a fleet has fewer than two host cores per rank): polling loops hand the
+// core back between looks instead of spinning on it
+static inline bool poll_yields() {
+  static const bool v = getenv("FUELMI_POLL_YIELD") != nullptr && atoi(getenv("FUELMI_POLL_YIELD")) != 0;
+  return v;
+}
 static inline hipError_t stream_wait(hipStream_t s) {
+  const bool yld = poll_yields();
   for (int spins = 0; spins < 200000; ++spins) {  // ~0.2 s of polling at most
     const hipError_t q = hipStreamQuery(s);
     if (q != hipErrorNotReady) return q;
+    if (yld) std::this_thread::yield();
   }
   return hipStreamSynchronize(s);
 }

@@ -39,6 +39,7 @@ extern "C" int fuelmi_device_count(void) {
 StageScope::StageScope(fuelmi_map* m_, int stage_, hipStream_t stream, bool kernel_timed) : m(m_), stage(stage_) {
   st = stream ? stream : m->stream;
   if (!(m->profile_mask & (1u << stage))) return;
+  std::lock_guard<std::mutex> lk(m->prof_mu);
   ProfileSlot& s = m->prof[stage];
   if (s.used + 2 > s.ev.size()) {
     size_t old = s.ev.size();
@@ -60,6 +61,63 @@ StageScope::~StageScope() {
     (void)hipEventRecord(m->kev[1], st);
     m->kev[0] = m->kev[1] = nullptr;
   }
+}
+
+int QuerySlotGuard::acquire(fuelmi_map* m_, size_t bytes) {
+  m = m_;
+  {
+    std::unique_lock<std::mutex> lk(m->qs_mu);
+    for (;;) {
+      for (auto& q : m->qslots)
+        if (!q->busy) {
+          s = q.get();
+          break;
+        }
+      if (s) break;
+      if (m->qslots.size() < 32) {
+        m->qslots.emplace_back(new fuelmi_map::QuerySlot);
+        s = m->qslots.back().get();
+        break;
+      }
+      m->qs_cv.wait(lk);
+    }
+    s->busy = true;
+  }
+  if (!s->st) {
+    HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+  }
+  if (bytes > s->pin_cap) {
+    if (s->pin) HIPCHK(hipHostFree(s->pin));
+    s->pin = nullptr, s->pin_cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 64 * 1024);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->pin), want, hipHostMallocDefault));
+    s->pin_cap = want;
+  }
+  // behind everything the map's stream holds now (an ESDF update the caller has just queued, say)
+  HIPCHK(hipEventRecord(s->ev_dep, m->stream));
+  HIPCHK(hipStreamWaitEvent(s->st, s->ev_dep, 0));
+  return FUELMI_OK;
+}
+hipError_t QuerySlotGuard::finish() {
+  hipError_t e = hipEventRecord(s->ev_done, s->st);
+  if (e != hipSuccess) return e;
+  const bool yld = poll_yields();
+  for (long spins = 0;; ++spins) {  // poll: a blocking wait costs ~15 us of wake-up for a 10-us kernel
+    e = hipEventQuery(s->ev_done);
+    if (e != hipErrorNotReady) return e;
+    if (yld || spins > 2000000) std::this_thread::yield();
+  }
+}
+QuerySlotGuard::~QuerySlotGuard() {
+  if (!s) return;
+  (void)hipStreamSynchronize(s->st);  // (an error path may leave work behind: the pinned block is about to be reused)
+  {
+    std::lock_guard<std::mutex> lk(m->qs_mu);
+    s->busy = false;
+  }
+  m->qs_cv.notify_one();
 }
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes) {
@@ -184,6 +242,66 @@ k_inflate_x(Geo g, Box3 b, int step, const u64* __restrict__ T, u64* __restrict_
   long a0 = 64L * w;
   if (a0 + 64 > g.N) acc &= bit_range(0, (int)(g.N - a0));
   infl[w] = (infl[w] & ~box_mask_word(g, w, b)) | acc;
+}
+
+// The same inflation in ONE launch (round 4).  The two kernels above move 10 MB and take 12 us on the 400^2 x 100 map:
+// two launches, a boundary and a plane written and read back in between, each a chain of dependent window loads.
+// Here a workgroup owns 256 output words; for each of the 2*STEP+1 x offsets it stages the source words its outputs
+// can reach (256 + the y/z reach), box-masked, in LDS, dilates them in z there (shifts of the linear bit string across
+// word boundaries), and every lane then ORs the (2*STEP+1)^2 (dx, dy) windows of its word out of LDS.  Same bits as
+// the factored form: out[a] = OR S[a - dx*ny*nz - dy*nz + dz], S = occupied & box on the linear address string, only
+// the final address range-checked (the reference's wrap quirk, sdf_map.cpp:453-458).
+template <int STEP, bool WHOLE>
+__global__ void __launch_bounds__(256)
+k_inflate_fused(Geo g, Box3 b, const u64* __restrict__ occ_bits, u64* __restrict__ infl, int w_lo, int w_hi, int margin) {
+  constexpr int NR = 2 * STEP + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ry = (STEP * (g.nz + 1) + 63) / 64 + 1;  // y/z reach of an output word, in words
+  const int RW = 256 + 2 * ry + 2;                   // words staged per x offset (+ the funnels' second word)
+  u64* raw = reinterpret_cast<u64*>(smem_raw);       // [NR][RW + 2]  (one more word either side for the z dilation)
+  u64* sz = raw + (size_t)NR * (RW + 2);             // [NR][RW]
+  const int w0 = w_lo + blockIdx.x * 256;
+  for (int it = threadIdx.x; it < NR * (RW + 2); it += 256) {
+    const int r = it / (RW + 2), k = it - r * (RW + 2);
+    const long start = 64L * w0 - (long)(r - STEP) * g.nyz;
+    const long wi = (start >> 6) - ry - 1 + k;
+    u64 v = 0ull;
+    if (wi >= -margin && wi < (long)g.W + margin) {
+      v = occ_bits[wi];
+      if (!WHOLE) v = (wi >= 0 && wi < g.W) ? (v & box_mask_word(g, (int)wi, b)) : 0ull;
+    }
+    raw[it] = v;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < NR * RW; it += 256) {
+    const int r = it / RW, k = it - r * RW;
+    const u64* q = raw + (size_t)r * (RW + 2) + k;  // q[0], q[1], q[2] = words wi - 1, wi, wi + 1 of range word k
+    const u64 s0 = q[0], s1 = q[1], s2 = q[2];
+    u64 zd = s1;
+#pragma unroll
+    for (int d = 1; d <= STEP; ++d) zd |= (s1 >> d) | (s2 << (64 - d)) | (s1 << d) | (s0 >> (64 - d));
+    sz[it] = zd;
+  }
+  __syncthreads();
+  const int w = w0 + threadIdx.x;
+  if (w > w_hi) return;
+  u64 acc = 0ull;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const long start = 64L * w0 - (long)(r - STEP) * g.nyz;
+    const int shx = (int)(start & 63);
+    const u64* row = sz + (size_t)r * RW;
+#pragma unroll
+    for (int dy = -STEP; dy <= STEP; ++dy) {
+      const int rel = 64 * ((int)threadIdx.x + ry) + shx - dy * g.nz;  // bit position relative to the staged range
+      const int kw = rel >> 6, sh = rel & 63;
+      const u64 lo = row[kw], hi = row[kw + 1];
+      acc |= sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    }
+  }
+  const long a0 = 64L * w;
+  if (a0 + 64 > g.N) acc &= bit_range(0, (int)(g.N - a0));
+  infl[w] = WHOLE ? acc : ((infl[w] & ~box_mask_word(g, w, b)) | acc);
 }
 
 // virtual ceiling (sdf_map.cpp:464-471): occupancy_buffer_[x,y,ceil_id] = clamp_max_log
@@ -475,6 +593,13 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
     if (p->base) (void)hipFree(p->base);
   void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial, m->ins_head, m->ins_rec};
   if (m->h_ins) (void)hipHostFree(m->h_ins);
+  for (auto& q : m->qslots) {
+    if (q->st) (void)hipStreamSynchronize(q->st), (void)hipStreamDestroy(q->st);
+    if (q->ev_dep) (void)hipEventDestroy(q->ev_dep);
+    if (q->ev_done) (void)hipEventDestroy(q->ev_done);
+    if (q->pin) (void)hipHostFree(q->pin);
+  }
+  m->qslots.clear();
   if (m->h_esdf_stat) (void)hipHostFree(m->h_esdf_stat);
   if (m->esdf_stat) (void)hipFree(m->esdf_stat);
   for (void* b : bufs)
@@ -530,6 +655,16 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
     // plane itself (zero margins included) is the source plane
     const bool whole = b.lo[0] == 0 && b.lo[1] == 0 && b.lo[2] == 0 && b.hi[0] == g.nx - 1 && b.hi[1] == g.ny - 1 &&
                        b.hi[2] == g.nz - 1;
+    static const bool two_pass = getenv("FUELMI_INFLATE_2PASS") != nullptr;  // A/B hook: the factored kernels
+    const int ry = (step * (g.nz + 1) + 63) / 64 + 1;
+    const size_t lds_f = (size_t)(2 * step + 1) * (2 * (size_t)(256 + 2 * ry + 2) + 2) * sizeof(u64);
+    if (step == 2 && !two_pass && lds_f <= 64 * 1024) {
+      const int nb = blocks_for(out_hi - out_lo + 1, 256);
+      if (whole)
+        k_inflate_fused<2, true><<<nb, 256, lds_f, m->stream>>>(g, b, m->occ_bits.p, m->infl_bits.p, out_lo, out_hi, m->margin_words);
+      else
+        k_inflate_fused<2, false><<<nb, 256, lds_f, m->stream>>>(g, b, m->occ_bits.p, m->infl_bits.p, out_lo, out_hi, m->margin_words);
+    } else {
     const u64* S = whole ? m->occ_bits.p : m->tmp_bits.p;
     if (!whole)
       k_box_and<<<blocks_for(s_hi - s_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->occ_bits.p, m->tmp_bits.p, s_lo, s_hi);
@@ -539,6 +674,7 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
       k_inflate_yz<0><<<blocks_for(t_hi - t_lo + 1, 256), 256, 0, m->stream>>>(g, step, S, m->tmp2_bits.p, t_lo, t_hi);
     k_inflate_x<<<((blocks_for(out_hi - out_lo + 1, 256) + 7) / 8) * 8, 256, 0, m->stream>>>(g, b, step, m->tmp2_bits.p,
                                                                              m->infl_bits.p, out_lo, out_hi);
+    }
   }
   if (m->cfg.virtual_ceil_height > -0.5) {
     int ceil_id = (int)std::floor((m->cfg.virtual_ceil_height - g.org[2]) * g.res_inv);
@@ -751,19 +887,20 @@ extern "C" int fuelmi_map_dist_grad(fuelmi_map* m, const double* pos, int n, dou
   ARGCHK(m && n >= 0 && (n == 0 || (pos && dist && grad)));
   if (n == 0) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lk(m->qmu);
-  size_t in_b = (size_t)n * 3 * sizeof(double), out_b = (size_t)n * 4 * sizeof(double);
-  int rc = map_ensure_stage(m, in_b + out_b, 0);
+  // re-entrant: a query slot -- own side stream, positions and results in its pinned block
+  const size_t in_b = (size_t)n * 3 * sizeof(double), out_b = (size_t)n * 4 * sizeof(double);
+  QuerySlotGuard q;
+  const int rc = q.acquire(m, in_b + out_b);
   if (rc) return rc;
-  double* d_pos = (double*)m->d_stage;
-  double* d_d = d_pos + (size_t)n * 3;
-  double* d_g = d_d + n;
-  HIPCHK(hipMemcpyAsync(d_pos, pos, in_b, hipMemcpyHostToDevice, m->stream));
-  k_dist_grad<<<blocks_for(n, 128), 128, 0, m->stream>>>(m->g, m->dist, d_pos, n, d_d, d_g);
+  double* h_pos = reinterpret_cast<double*>(q.s->pin);
+  double* h_d = h_pos + (size_t)n * 3;
+  double* h_g = h_d + n;
+  memcpy(h_pos, pos, in_b);
+  k_dist_grad<<<blocks_for(n, 128), 128, 0, q.s->st>>>(m->g, m->dist, h_pos, n, h_d, h_g);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipMemcpyAsync(grad, d_g, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(q.finish());
+  memcpy(dist, h_d, (size_t)n * sizeof(double));
+  memcpy(grad, h_g, (size_t)n * 3 * sizeof(double));
   return FUELMI_OK;
 }
 
@@ -771,17 +908,17 @@ extern "C" int fuelmi_map_coarse_dist(fuelmi_map* m, const double* pos, int n, d
   ARGCHK(m && n >= 0 && (n == 0 || (pos && dist)));
   if (n == 0) return FUELMI_OK;
   HIPCHK(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lk(m->qmu);
-  size_t in_b = (size_t)n * 3 * sizeof(double);
-  int rc = map_ensure_stage(m, in_b + (size_t)n * sizeof(double), 0);
+  const size_t in_b = (size_t)n * 3 * sizeof(double);
+  QuerySlotGuard q;
+  const int rc = q.acquire(m, in_b + (size_t)n * sizeof(double));
   if (rc) return rc;
-  double* d_pos = (double*)m->d_stage;
-  double* d_d = d_pos + (size_t)n * 3;
-  HIPCHK(hipMemcpyAsync(d_pos, pos, in_b, hipMemcpyHostToDevice, m->stream));
-  k_coarse_dist<<<blocks_for(n, 128), 128, 0, m->stream>>>(m->g, m->dist, d_pos, n, d_d);
+  double* h_pos = reinterpret_cast<double*>(q.s->pin);
+  double* h_d = h_pos + (size_t)n * 3;
+  memcpy(h_pos, pos, in_b);
+  k_coarse_dist<<<blocks_for(n, 128), 128, 0, q.s->st>>>(m->g, m->dist, h_pos, n, h_d);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(q.finish());
+  memcpy(dist, h_d, (size_t)n * sizeof(double));
   return FUELMI_OK;
 }
 

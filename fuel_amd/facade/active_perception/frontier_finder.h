@@ -99,6 +99,7 @@ private:
   int cluster_min_;
   double resolution_, min_candidate_dist_;
   bool have_viewpoints_;  // frontier/candidate_* and perception_utils/* were all given
+  bool order_fallback_logged_ = false;  // the first address-order fallback of reference_order = 2 has been reported
   vector<int> removed_ids_;
   list<Frontier> frontiers_, dormant_frontiers_, tmp_frontiers_;
   list<Frontier>::iterator first_new_ftr_;  // first cluster appended by the last computeFrontiersToVisit()

@@ -385,6 +385,18 @@ void FrontierFinder::pull(int which, list<Frontier>& out, int from) {
 void FrontierFinder::searchFrontiers() {
   int n_new = 0;
   warn("fuelmi_frontier_search", fuelmi_frontier_search(dev_, &n_new));
+  {
+    // frontier/reference_order = 2 answers per search: say so the first time a search is delivered in the address
+    // order instead of the reference's (a cluster too large for the in-LDS level sweep) -- never silently
+    int os[4] = {0, 0, 0, 0};
+    if (fuelmi_frontier_order_stats(dev_, os) == 0 && os[2] > 0 && !order_fallback_logged_) {
+      order_fallback_logged_ = true;
+      std::fprintf(stderr, "[fuelmi facade] FrontierFinder: search delivered in ascending-address cell order, not the "
+                   "reference's BFS order: a cluster of %d cells exceeds the in-LDS level sweep (frontier/reference_order = 2; "
+                   "set it to 1 to pay for the order on every search).  Further fallbacks are counted, not logged: "
+                   "fuelmi_frontier_order_stats.\n", os[3]);
+    }
+  }
   pull(0, tmp_frontiers_);
   removed_ids_.resize(fuelmi_frontier_removed_count(dev_));
   if (!removed_ids_.empty()) fuelmi_frontier_removed_ids(dev_, removed_ids_.data());
@@ -754,17 +766,14 @@ void BsplineOptimizer::optimize() {
   fuelmi_bspline_batch b;
   BatchStore S;
   FUELMI_FILL_BATCH(b, S, q)
-  fuelmi_bspline_dev* dev = nullptr;
-  int rc = fuelmi_bspline_dev_create(edt_environment_->sdf_map_->device(), &cfg_, &b, &dev);
-  warn("fuelmi_bspline_dev_create", rc);
-  if (rc) return;
+  // one call on a query slot of the map: no device allocation, own side stream -- the ten optimiser threads of
+  // topoReplan (planner_manager.cpp:446-453) solve side by side
   best_variable_.assign(n, 0.0);
   double cost = 0.0;
   int evals = 0;
-  rc = fuelmi_bspline_dev_optimize_timed(dev, std::max(1, max_iteration_num_[max_num_id_]),
+  const int rc = fuelmi_bspline_optimize(edt_environment_->sdf_map_->device(), &cfg_, &b, std::max(1, max_iteration_num_[max_num_id_]),
                                          max_iteration_time_[max_time_id_], best_variable_.data(), &cost, &evals);
-  warn("fuelmi_bspline_dev_optimize_timed", rc);
-  fuelmi_bspline_dev_destroy(dev);
+  warn("fuelmi_bspline_optimize", rc);
   comb_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   if (rc) return;
   iter_num_ = evals;

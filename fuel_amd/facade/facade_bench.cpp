@@ -16,6 +16,10 @@
 #include <active_perception/frontier_finder.h>
 #include <active_perception/graph_node.h>
 #include <active_perception/perception_utils.h>
+#include <bspline_opt/bspline_optimizer.h>
+
+#include <algorithm>
+#include <thread>
 
 namespace fast_planner {
 double ViewNode::computeCost(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2, const double& y1, const double& y2,
@@ -173,6 +177,116 @@ static double run_fullbox(const double* hdr, const std::vector<double>& occ, boo
   return dt / (double)cycles;
 }
 
+// The per-candidate path the reference actually calls (plan_manage/src/planner_manager.cpp:296-314: optimize() of ONE
+// trajectory; bspline_optimizer.cpp:693-707 -> combineCost per evaluation): median latency of BsplineOptimizer::optimize
+// and of one combineCost through the facade on the map of the full-box run, and the same solve from ten threads at
+// once on ONE map (topoReplan, planner_manager.cpp:446-453).  out: [0] optimize ms, [1] combineCost us,
+// [2] wall ms for 10 concurrent solves, [3] evaluations of the solve.
+static void run_candidate(const double* hdr, const std::vector<double>& occ, double out[4]) {
+  ros::NodeHandle nh;
+  params(nh, hdr);
+  auto& P = nh.num;
+  P["optimization/ld_smooth"] = 20.0, P["optimization/ld_dist"] = 10.0, P["optimization/ld_feasi"] = 2.0;
+  P["optimization/ld_start"] = 100.0, P["optimization/ld_end"] = 0.5, P["optimization/ld_guide"] = 1.5;
+  P["optimization/ld_waypt"] = 0.3, P["optimization/ld_view"] = 0.0, P["optimization/ld_time"] = 1.0;
+  P["optimization/dist0"] = 0.7, P["optimization/max_vel"] = 2.0, P["optimization/max_acc"] = 2.0;
+  P["optimization/dlmin"] = 0.0, P["optimization/wnl"] = 1.0;
+  for (int i = 1; i <= 4; ++i) {
+    P["optimization/max_iteration_num" + std::to_string(i)] = 300;   // algorithm.xml:184-191
+    P["optimization/max_iteration_time" + std::to_string(i)] = 0.005;
+  }
+  P["manager/bspline_degree"] = 3;
+  SDFMap::Ptr map(new SDFMap);
+  map->initMap(nh);
+  EDTEnvironment::Ptr edt(new EDTEnvironment);
+  edt->setMap(map);
+  fuelmi_map* dev = map->device();
+  if (fuelmi_map_upload_occupancy(dev, occ.data()) != FUELMI_OK) return;
+  fuelmi_map_info inf;
+  fuelmi_map_get_info(dev, &inf);
+  const int lo[3] = {0, 0, 0}, hi[3] = {inf.voxel_num[0] - 1, inf.voxel_num[1] - 1, inf.voxel_num[2] - 1};
+  fuelmi_map_set_local_bound(dev, lo, hi);
+  MapROS::inflate(*map);
+  map->updateESDF3d();
+  fuelmi_map_synchronize(dev);
+  const int N = 32;
+  auto make = [&](int seed, Eigen::MatrixXd& ctrl, std::vector<Eigen::Vector3d>& st) {
+    ctrl = Eigen::MatrixXd(N, 3);
+    const double x0 = hdr[3] + 2.0 + 0.37 * seed, y0 = hdr[4] + 3.0 + 0.61 * seed;
+    for (int i = 0; i < N; ++i) {
+      ctrl(i, 0) = x0 + 6.0 * i / (N - 1.0), ctrl(i, 1) = y0 + 0.3 * std::sin(0.7 * i + seed), ctrl(i, 2) = 1.0 + 0.1 * std::cos(0.5 * i);
+    }
+    st = {Eigen::Vector3d(ctrl(0, 0), ctrl(0, 1), ctrl(0, 2)), Eigen::Vector3d(0.5, 0, 0), Eigen::Vector3d(0, 0, 0)};
+  };
+  const int cf = BsplineOptimizer::NORMAL_PHASE | BsplineOptimizer::MINTIME;
+  BsplineOptimizer opt;
+  opt.setParam(nh);
+  opt.setEnvironment(edt);
+  std::vector<double> t_opt, t_cc;
+  int evals = 0;
+  for (int r = 0; r < 24; ++r) {
+    Eigen::MatrixXd ctrl;
+    std::vector<Eigen::Vector3d> st, en = {Eigen::Vector3d(0, 0, 0)};
+    make(r % 6, ctrl, st);
+    en[0] = Eigen::Vector3d(ctrl(N - 1, 0), ctrl(N - 1, 1), ctrl(N - 1, 2));
+    double dt = 0.175;
+    opt.setBoundaryStates(st, en);
+    const double a = now_s();
+    opt.optimize(ctrl, dt, cf, 1, 1);
+    if (r >= 4) t_opt.push_back(now_s() - a);
+    (void)evals;
+  }
+  {
+    Eigen::MatrixXd ctrl;
+    std::vector<Eigen::Vector3d> st, en = {Eigen::Vector3d(0, 0, 0)};
+    make(1, ctrl, st);
+    double dt = 0.175;
+    opt.setBoundaryStates(st, en);
+    opt.optimize(ctrl, dt, cf, 1, 1);  // (leaves dim_/point_num_/pt_dist_ set for combineCost)
+    std::vector<double> x(3 * N + 1), g;
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < 3; ++k) x[3 * i + k] = ctrl(i, k);
+    x[3 * N] = dt;
+    opt.setBoundaryStates(st, en);
+    double c = 0;
+    for (int r = 0; r < 60; ++r) {
+      const double a = now_s();
+      opt.combineCost(x, g, c);
+      if (r >= 10) t_cc.push_back(now_s() - a);
+    }
+  }
+  std::sort(t_opt.begin(), t_opt.end());
+  std::sort(t_cc.begin(), t_cc.end());
+  out[0] = 1e3 * t_opt[t_opt.size() / 2];
+  out[1] = 1e6 * t_cc[t_cc.size() / 2];
+  // ten optimisers, ten threads, one map
+  std::vector<std::unique_ptr<BsplineOptimizer>> opts;
+  for (int k = 0; k < 10; ++k) {
+    opts.emplace_back(new BsplineOptimizer);
+    opts.back()->setParam(nh);
+    opts.back()->setEnvironment(edt);
+  }
+  double best = 1e30;
+  for (int r = 0; r < 5; ++r) {
+    std::vector<std::thread> th;
+    const double a = now_s();
+    for (int k = 0; k < 10; ++k)
+      th.emplace_back([&, k] {
+        Eigen::MatrixXd ctrl;
+        std::vector<Eigen::Vector3d> st, en = {Eigen::Vector3d(0, 0, 0)};
+        make(k % 6, ctrl, st);
+        en[0] = Eigen::Vector3d(ctrl(N - 1, 0), ctrl(N - 1, 1), ctrl(N - 1, 2));
+        double dt = 0.175;
+        opts[k]->setBoundaryStates(st, en);
+        opts[k]->optimize(ctrl, dt, cf, 1, 1);
+      });
+    for (auto& t : th) t.join();
+    best = std::min(best, now_s() - a);
+  }
+  out[2] = 1e3 * best;
+  out[3] = 0.0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 5 && std::string(argv[3]) == "fullbox") {
     FILE* in = fopen(argv[1], "rb");
@@ -194,11 +308,17 @@ int main(int argc, char** argv) {
       best[0] = std::min(best[0], run_fullbox(hdr, occ, true, 10, &ncl[0], &ncell[0]));
       best[1] = std::min(best[1], run_fullbox(hdr, occ, false, 20, &ncl[1], &ncell[1]));
     }
+    double cand[4] = {0, 0, 0, 0};
+    run_candidate(hdr, occ, cand);
     std::printf("{\"workload\": \"full-box plan cycle through the facade on a %.0fx%.0fx%.0f m map: clearAndInflateLocalMap + "
                 "updateESDF3d + searchFrontiers (fresh flags, whole exploration box) + the cell lists of the new clusters as "
                 "vector<Vector3d>\", \"facade_mirrors_on_ms\": %.4f, \"facade_mirrors_off_ms\": %.4f, "
-                "\"cycles_per_s_mirrors_off\": %.1f, \"clusters\": %d, \"cells\": %zu}\n",
-                hdr[0], hdr[1], hdr[2], 1e3 * best[0], 1e3 * best[1], 1.0 / best[1], ncl[1], ncell[1]);
+                "\"cycles_per_s_mirrors_off\": %.1f, \"clusters\": %d, \"cells\": %zu, "
+                "\"per_candidate\": {\"what\": \"BsplineOptimizer::optimize (one 32-point trajectory, NORMAL_PHASE|MINTIME, "
+                "max 300 evaluations / 5 ms) and one combineCost through the facade, medians; ten optimisers on ten threads on "
+                "ONE map, wall time for the ten solves\", \"optimize_ms\": %.4f, \"combine_cost_us\": %.2f, "
+                "\"ten_threads_ten_solves_ms\": %.4f}}\n",
+                hdr[0], hdr[1], hdr[2], 1e3 * best[0], 1e3 * best[1], 1.0 / best[1], ncl[1], ncell[1], cand[0], cand[1], cand[2]);
     return 0;
   }
 

@@ -350,6 +350,13 @@ class FrontierFinder:
         check(self.L.fuelmi_frontier_stats(self.h, o))
         return tuple(o)
 
+    def orderStats(self):
+        """(order of the last search: 0 address / 1 reference BFS, searches in the reference's order, mode-2 searches
+        that fell back to the address order, cells of the cluster that forced the last fallback)"""
+        o = (C.c_int * 4)()
+        check(self.L.fuelmi_frontier_order_stats(self.h, o))
+        return tuple(o)
+
     def clusters(self, which=0):
         out = []
         cnt = self.L.fuelmi_frontier_count(self.h, which)
@@ -518,6 +525,16 @@ class BsplineOptimizer:
         check(self.L.fuelmi_bspline_cost_grad(self._map().h, C.byref(self.cfg), C.byref(problem.c),
                                               _dp(cost), _dp(grad)))
         return cost, grad
+
+    def optimize(self, problem, max_eval=300, max_time=-1.0):
+        """BsplineOptimizer::optimize() for the C trajectories of `problem` in ONE call (fuelmi_bspline_optimize: a
+        query slot of the map -- no device allocation, re-entrant).  Returns (x [C, nvar], cost [C], evals [C])."""
+        x = np.empty((problem.C, problem.nvar))
+        cost = np.empty(problem.C)
+        ev = np.empty(problem.C, dtype=np.int32)
+        check(self.L.fuelmi_bspline_optimize(self._map().h, C.byref(self.cfg), C.byref(problem.c), int(max_eval),
+                                             float(max_time), _dp(x), _dp(cost), _ip(ev)))
+        return x, cost, ev
 
     def deviceProblem(self, problem):
         return BsplineDeviceProblem(self, problem)

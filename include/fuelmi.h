@@ -208,6 +208,12 @@ int fuelmi_frontier_reset(fuelmi_frontier* f);
 /* diagnostics: searches answered by the fast clustering chain [0], by the legacy chain [1], and searches that
  * started on the fast chain and fell back because an input exceeded one of its capacities [2] */
 int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]);
+/* the cell order the searches delivered (cfg.reference_order is a request; mode 2 answers per search): [0] the last
+ * search's order -- 0 ascending address, 1 the reference's BFS order --, [1] searches that delivered the reference's
+ * order, [2] searches of a mode-2 finder that fell back to the address order because a cluster was too large for the
+ * in-LDS level sweep, [3] cells of the largest cluster of the last such search.  A caller that needs the reference's
+ * bits checks [0] after fuelmi_frontier_search_end (the facade logs the first fallback). */
+int fuelmi_frontier_order_stats(const fuelmi_frontier* f, int out4[4]);
 /* waits for everything queued on the finder's stream.  fuelmi_frontier_search_end returns as soon as the cluster
  * records have arrived; the regrouping of the cells and their copy to the host finish behind it (calls that read
  * cell lists wait by themselves) */
@@ -322,6 +328,15 @@ typedef struct {
 
 int fuelmi_bspline_cost_grad(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
                              const fuelmi_bspline_batch* batch, double* cost, double* grad);
+
+/* BsplineOptimizer::optimize() (bspline_optimizer.cpp:165-253) as ONE call for a batch given in host arrays -- what
+ * the reference's callers do one trajectory at a time (plan_manage/src/planner_manager.cpp:296-314).  Like
+ * fuelmi_bspline_cost_grad it runs on a query slot of the map (own side stream, inputs and results in the slot's pinned
+ * block): no device allocation, re-entrant, concurrent callers do not queue behind each other or behind the map's
+ * mutators.  Semantics of the solve: fuelmi_bspline_dev_optimize_timed.  x_out [C][nvar], cost_out [C], evals_out [C]
+ * or NULL. */
+int fuelmi_bspline_optimize(fuelmi_map* m, const fuelmi_bspline_cfg* cfg, const fuelmi_bspline_batch* batch,
+                            int max_eval, double max_time_s, double* x_out, double* cost_out, int* evals_out);
 
 /* Device-resident variant for benchmarking / optimiser loops: upload once, evaluate many times
  * without host copies.  Handles are owned by the map. */

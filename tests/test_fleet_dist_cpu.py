@@ -77,3 +77,33 @@ def test_bench_gpus_flag_refuses_to_run_one_gpu_silently():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "--gpus 2" in (r.stderr + r.stdout) and "device" in (r.stderr + r.stdout)
+
+
+def _baseline_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    mine = {"value": 2.0 + rank, "unit": "cycles/s", "cores": 1, "kind": "reference", "sample": "stub of rank %d" % rank}
+    out = bench.fleet_cpu_baseline(mine, rank, world, dist, core=10 + rank)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fleet_cpu_baseline_is_the_sum_of_one_pinned_process_per_rank():
+    """N > 1 bench lines carry a cpu_baseline too: N single-threaded reference processes, one per
+    core, run concurrently; rank 0 reports their summed rate with cores = N."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_baseline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    b = res[0]
+    assert b["value"] == 5.0 and b["cores"] == 2 and b["kind"] == "reference"
+    assert b["per_process"] == [2.0, 3.0] and b["pinned_cores"] == [10, 11]

@@ -191,13 +191,17 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["FUELMI_FLEET_SHARE_DEVICE"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-           "--workload", MAP, "--no-cpu-baseline"]
+           "--workload", MAP, "--cpu-budget", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["scaling"] == "weak"
+    # the N > 1 line carries the fleet-vs-fleet CPU baseline: one single-threaded process per rank, pinned, summed
+    cb = out["cpu_baseline"]
+    assert cb["cores"] == 2 and len(cb["per_process"]) == 2 and abs(cb["value"] - sum(cb["per_process"])) < 1e-3
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--workload", MAP,
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]

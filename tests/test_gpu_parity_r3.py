@@ -251,3 +251,49 @@ def test_reference_order_many_clusters_and_a_large_one(fa):
         assert np.array_equal(of.flags, gf.flags())
         gf.close()
     gm.close()
+
+
+def test_reference_order_auto_reports_the_order_it_delivered(fa):
+    """cfg.reference_order = 2 ("auto", the facade's default) answers per search -- and says which way
+    (fuelmi_frontier_order_stats; VERDICT r3: the fallback used to be silent).  A search whose clusters all fit the
+    in-LDS level sweep delivers the reference's BFS order, bit for bit; a search holding a cluster above the limit
+    (26 624 cells) delivers ascending addresses, counts the fallback and names the cluster's size."""
+    from fuel_amd._lib import lib
+    import ctypes as C
+    # (a) small clusters: the reference's order
+    om, _, _, box = helpers.explored_oracle_map((9.0, 7.0, 4.0), 14, 25)
+    gm = fa.SDFMap((9.0, 7.0, 4.0), *box)
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 10)
+    gf = fa.FrontierFinder(gm, cluster_min=10, reference_order=2)
+    om.set_updated_box(*box)
+    gm.setUpdatedBox(*box)
+    assert of.search() == gf.searchFrontiers() > 0
+    for a, b in zip(of.clusters(0), gf.clusters(0)):
+        assert np.array_equal(a, b), "auto mode on small clusters must deliver expandFrontier's order"
+    assert gf.orderStats() == (1, 1, 0, 0)
+    gf.close()
+    gm.close()
+    # (b) a map-spanning cluster: the address order, reported
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    gm = fa.SDFMap((20.0, 20.0, 5.0), *box)
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100, reference_order=2)
+    om.set_updated_box(*box)
+    gm.setUpdatedBox(*box)
+    assert of.search() == gf.searchFrontiers() > 0
+    ca, cb = of.clusters(0), gf.clusters(0)
+    big = max(len(c) for c in ca)
+    assert big > 26624, "the fixture is supposed to hold a cluster above the LDS sweep's limit (%d)" % big
+    for a, b in zip(ca, cb):
+        assert np.array_equal(np.sort(a), b), "the fallback is the ascending-address order of the same cells"
+    last, n_ref, n_fallback, cells = gf.orderStats()
+    assert (last, n_ref, n_fallback, cells) == (0, 0, 1, big)
+    gf.close()
+    # an invalid mode is refused, not treated as 0 (ADVICE r3)
+    L = lib()
+    cfg = fa._lib.FrontierCfg(100, 0.4, -1.0, -1, 0, 3)
+    h = C.c_void_p()
+    assert L.fuelmi_frontier_create(gm.h, C.byref(cfg), C.byref(h)) != 0
+    gm.close()
