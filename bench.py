@@ -722,7 +722,10 @@ def main():
                              "ms_per_step": 1e3 * t_d / args.steps,
                              "cells_d2h_ms": 1e3 * dsec[1] / args.steps, "cost_grad_d2h_ms": 1e3 * dsec[2] / args.steps,
                              "delivered": "cell lists of all new clusters (int32 addresses) + %d x %d cost/gradient doubles, "
-                                          "every cycle" % (ctrl.shape[0], ctrl.shape[1] * 3 + 1)}
+                                          "every cycle, consumed one cycle behind the device: cycle k - 1's cells are copied "
+                                          "from the retired buffer set (fuelmi_frontier_keep_previous) and its costs / gradients "
+                                          "from the pinned slot the kernel wrote while cycle k runs"
+                                          % (ctrl.shape[0], ctrl.shape[1] * 3 + 1)}
     dom_ms = dom_total_ms / max(n_launch, 1)  # mean over the timed region, as the contract asks
 
     fleet_cpu = None

@@ -166,10 +166,12 @@ SYMBOLS = {
     "fuelmi_frontier_search": (C.c_int, [_P, _ip]),
     "fuelmi_frontier_search_begin": (C.c_int, [_P]),
     "fuelmi_frontier_search_end": (C.c_int, [_P, _ip]),
+    "fuelmi_frontier_keep_previous": (C.c_int, [_P, C.c_int]),
     "fuelmi_frontier_commit": (C.c_int, [_P, C.c_int]),
     "fuelmi_frontier_count": (C.c_int, [_P, C.c_int]),
     "fuelmi_frontier_cluster_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "fuelmi_frontier_cluster_cells": (C.c_int, [_P, C.c_int, C.c_int, _ip]),
+    "fuelmi_frontier_cluster_centres": (C.c_int, [_P, C.c_int, C.c_int, _dp]),
     "fuelmi_frontier_cluster_info": (C.c_int, [_P, C.c_int, C.c_int, _dp]),
     "fuelmi_frontier_removed_count": (C.c_int, [_P]),
     "fuelmi_frontier_removed_ids": (C.c_int, [_P, _ip]),
@@ -179,6 +181,8 @@ SYMBOLS = {
                                 C.POINTER(C.c_int)]),
     "fuelmi_bspline_dev_create": (C.c_int, [_P, C.POINTER(BsplineCfg), C.POINTER(BsplineBatch), _PP]),
     "fuelmi_bspline_dev_eval": (C.c_int, [_P]),
+    "fuelmi_bspline_dev_eval_pinned": (C.c_int, [_P, C.c_int]),
+    "fuelmi_bspline_dev_collect": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "fuelmi_bspline_dev_download": (C.c_int, [_P, _dp, _dp]),
     "fuelmi_bspline_dev_optimize": (C.c_int, [_P, C.c_int, _dp, _dp, C.POINTER(C.c_int)]),
     "fuelmi_bspline_dev_optimize_timed": (C.c_int, [_P, C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_int)]),

@@ -40,6 +40,10 @@ struct fuelmi_bspline_dev {
   size_t lds_eval4; // ... plus the partial gradients / costs of the four-wave cost kernel
   double *opt_x = nullptr, *opt_cost = nullptr;  // fuelmi_bspline_dev_optimize outputs
   int* opt_evals = nullptr;
+  // fuelmi_bspline_dev_eval_pinned: two pinned result slots (cost [C] | grad [C][nvar]) the cost kernel writes
+  // directly, and the event behind each launch
+  double* pin_out[2] = {nullptr, nullptr};
+  hipEvent_t ev_out[2] = {nullptr, nullptr};
   double* fit_in = nullptr;  // fuelmi_bspline_dev_load_samples staging: ts | points | derivs
   size_t fit_cap = 0;
 };
@@ -971,6 +975,10 @@ extern "C" void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b) {
       }
   }
   for (void* p : b->allocs) (void)hipFree(p);
+  for (int k = 0; k < 2; ++k) {
+    if (b->pin_out[k]) (void)hipHostFree(b->pin_out[k]);
+    if (b->ev_out[k]) (void)hipEventDestroy(b->ev_out[k]);
+  }
   delete b;
 }
 
@@ -1082,6 +1090,43 @@ extern "C" int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b) {
   StageScope sc(b->map, FUELMI_K_BSPLINE);
   k_bspline_cost_grad<<<b->a.C, 256, b->lds_eval4, b->map->stream>>>(b->map->g, b->map->dist, b->a);
   HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
+// The evaluation with its results DELIVERED: the kernel writes cost and gradient straight into one of two pinned host
+// slots (posted PCIe writes of ~50 KB, no copy engine, no blocking synchronisation); _collect waits for that launch
+// only and copies the slot out.  A caller that works in cycles evaluates into slot k & 1 and collects cycle k - 1's
+// slot while cycle k runs.
+extern "C" int fuelmi_bspline_dev_eval_pinned(fuelmi_bspline_dev* b, int slot) {
+  ARGCHK(b && (slot == 0 || slot == 1));
+  HIPCHK(hipSetDevice(b->map->device));
+  const size_t C = (size_t)b->a.C, n = (size_t)b->a.nvar;
+  if (!b->pin_out[slot]) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&b->pin_out[slot]), (C + C * n) * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&b->ev_out[slot], hipEventDisableTiming));
+  }
+  BsplineArgs A = b->a;
+  A.cost = b->pin_out[slot];
+  A.grad = b->pin_out[slot] + C;
+  {
+    StageScope sc(b->map, FUELMI_K_BSPLINE);
+    k_bspline_cost_grad<<<A.C, 256, b->lds_eval4, b->map->stream>>>(b->map->g, b->map->dist, A);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(b->ev_out[slot], b->map->stream));
+  return FUELMI_OK;
+}
+extern "C" int fuelmi_bspline_dev_collect(fuelmi_bspline_dev* b, int slot, double* cost, double* grad) {
+  ARGCHK(b && (slot == 0 || slot == 1) && cost && grad && b->pin_out[slot]);
+  HIPCHK(hipSetDevice(b->map->device));
+  for (;;) {
+    const hipError_t q = hipEventQuery(b->ev_out[slot]);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) HIPCHK(q);
+  }
+  const size_t C = (size_t)b->a.C, n = (size_t)b->a.nvar;
+  memcpy(cost, b->pin_out[slot], C * sizeof(double));
+  memcpy(grad, b->pin_out[slot] + C, C * n * sizeof(double));
   return FUELMI_OK;
 }
 

@@ -2646,6 +2646,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   }
   if (f->ev_zero) (void)hipEventDestroy(f->ev_zero);
   if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
+  if (f->ev_prev) (void)hipEventDestroy(f->ev_prev);
   Plane* pl[] = {&f->flag, &f->flag2, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
@@ -2731,6 +2732,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   HIPCHK(hipStreamCreateWithFlags(&f->zstream, hipStreamNonBlocking));  // zeroes the retired flag plane (frontier_apply_reset)
   HIPCHK(hipEventCreateWithFlags(&f->ev_zero, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&f->ev_prev, hipEventDisableTiming));
 
   // ---- everything below is constant for the life of the object (the kernel chain is replayed
   // as a graph with these arguments baked in) ----
@@ -3773,11 +3775,34 @@ extern "C" int fuelmi_frontier_reset(fuelmi_frontier* f) {
   HIPCHK(hipSetDevice(m->device));
   f->frontiers.clear();
   f->dormant.clear();
+  f->prev.clear();
+  if (f->keep_prev && f->stream2 && !f->fresh_pending && !f->tmp.empty()) {
+    // the new clusters of the last search stay readable as list 3 (see fuelmi_frontier::prev): their cells are in
+    // the buffer set this reset retires.  Whatever still has to happen to them -- the search's tail, the copy of a
+    // large grouped cell list to the pinned block -- is queued on the retiring stream now and waited for by whoever
+    // reads list 3, not here
+    f->prev.swap(f->tmp);
+    if (f->cells_fetch) {
+      f->cells_fetch = false;
+      HIPCHK(hipMemcpyAsync(f->F.h_cells, f->F.ms_val[f->last_fin], (size_t)f->cells_fetch_n * sizeof(u32), hipMemcpyDeviceToHost,
+                            f->stream));
+    }
+    HIPCHK(hipEventRecord(f->ev_prev, f->stream));
+    f->prev_pending = true;
+    f->tail_pending = false;
+  }
   f->tmp.clear();
   f->removed_ids.clear();
   f->dirty_all = true;
   f->pool_used = 0;
   f->fresh_pending = true;  // executed by the next search (folded into its first kernel) or by whoever reads the flags
+  return FUELMI_OK;
+}
+
+extern "C" int fuelmi_frontier_keep_previous(fuelmi_frontier* f, int on) {
+  ARGCHK(f);
+  f->keep_prev = on != 0;
+  if (!on) f->prev.clear();
   return FUELMI_OK;
 }
 
@@ -3794,7 +3819,7 @@ extern "C" int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant) {
 }
 
 static const std::list<HCluster>* pick(const fuelmi_frontier* f, int which) {
-  return which == 0 ? &f->tmp : (which == 1 ? &f->frontiers : (which == 2 ? &f->dormant : nullptr));
+  return which == 0 ? &f->tmp : (which == 1 ? &f->frontiers : (which == 2 ? &f->dormant : (which == 3 ? &f->prev : nullptr)));
 }
 static const HCluster* nth(const fuelmi_frontier* f, int which, int k) {
   const std::list<HCluster>* L = pick(f, which);
@@ -3818,10 +3843,57 @@ extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which
   const HCluster* c = nth(f, which, k);
   ARGCHK(c);
   if (c->lazy) {
-    int rc = frontier_cells_ready(f);
+    int rc = which == 3 ? frontier_prev_ready(f) : frontier_cells_ready(f);
     if (rc) return rc;
   }
   c->copy_to(adr);
+  return FUELMI_OK;
+}
+// Frontier::cells_ as the reference's callers hold them: the voxel CENTRES of cluster k, three doubles per cell (the
+// layout of a vector<Eigen::Vector3d>), decoded by the library straight out of the pinned result block into the
+// caller's storage -- no intermediate address list, and no division per cell: consecutive cells of a list mostly share
+// a z-line (ascending addresses) or neighbour one (BFS order), so the line's base address is carried along.
+extern "C" int fuelmi_frontier_cluster_centres(const fuelmi_frontier* f, int which, int k, double* xyz) {
+  ARGCHK(f && xyz);
+  const HCluster* c = nth(f, which, k);
+  ARGCHK(c);
+  if (c->lazy) {
+    int rc = which == 3 ? frontier_prev_ready(f) : frontier_cells_ready(f);
+    if (rc) return rc;
+  }
+  if (!f->map) {
+    fuelmi_set_error("fuelmi_frontier_cluster_centres: the map of this finder has been destroyed");
+    return FUELMI_EINVAL;
+  }
+  const Geo& g = f->map->g;
+  const size_t n = c->size();
+  // (a cluster started by an NQ seed keeps the seed apart from its sorted list: materialise the merged order first)
+  std::vector<int> merged;
+  const int* adr = nullptr;
+  if (c->lazy && c->lazy_seed < 0)
+    adr = c->lazy;
+  else if (!c->lazy)
+    adr = c->cells.data();
+  else {
+    merged.resize(n);
+    c->copy_to(merged.data());
+    adr = merged.data();
+  }
+  const double res = g.res, ox = g.org[0], oy = g.org[1], oz = g.org[2];
+  unsigned lb = 0xFFFFFFFFu;  // address of z = 0 of the current z-line
+  double cx = 0.0, cy = 0.0;
+  const unsigned nz = (unsigned)g.nz, nyz = (unsigned)g.nyz;
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned a = (unsigned)adr[i];
+    unsigned z = a - lb;
+    if (z >= nz) {  // another line
+      const unsigned x = a / nyz, r = a - x * nyz, y = r / nz;
+      z = r - y * nz;
+      lb = a - z;
+      cx = (x + 0.5) * res + ox, cy = (y + 0.5) * res + oy;
+    }
+    xyz[3 * i] = cx, xyz[3 * i + 1] = cy, xyz[3 * i + 2] = (z + 0.5) * res + oz;
+  }
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_cluster_filtered_size(const fuelmi_frontier* f, int which, int k) {
@@ -3943,29 +4015,46 @@ extern "C" int fuelmi_bench_cycles_delivered(fuelmi_map* m, fuelmi_frontier* f, 
   int rc = FUELMI_OK, ncl = 0;
   double t_cells = 0.0, t_cg = 0.0;
   using clk = std::chrono::steady_clock;
+  const bool kept = f->keep_prev;
+  (void)fuelmi_frontier_keep_previous(f, 1);
+  // Results are consumed one cycle behind the device: while cycle k runs, the host copies out what cycle k - 1 found
+  // -- its cluster cells from the retired buffer set (list 3), its costs and gradients from the pinned slot the
+  // B-spline kernel wrote them to.  Every cycle's results are delivered (the last one's after the loop); nothing
+  // blocks on a copy engine.
+  auto deliver = [&](int cyc, int ncl_of) -> int {
+    const auto ta = clk::now();
+    size_t at = 0;
+    int r2 = FUELMI_OK;
+    const int which = cyc < 0 ? 0 : 3;  // (the last cycle has not been retired: its clusters are still list 0)
+    const int cnt = fuelmi_frontier_count(f, which);
+    for (int c = 0; c < cnt && c < ncl_of && r2 == FUELMI_OK; ++c) {
+      const int sz = fuelmi_frontier_cluster_size(f, which, c);
+      if (sz < 0 || at + (size_t)sz > cells_cap) break;
+      r2 = fuelmi_frontier_cluster_cells(f, which, c, cells_out + at);
+      at += (size_t)sz;
+    }
+    const auto tb = clk::now();
+    if (r2 == FUELMI_OK && batch) r2 = fuelmi_bspline_dev_collect(batch, (cyc < 0 ? n - 1 : cyc) & 1, cost, grad);
+    const auto tc = clk::now();
+    t_cells += std::chrono::duration<double>(tb - ta).count();
+    t_cg += std::chrono::duration<double>(tc - tb).count();
+    return r2;
+  };
   const auto t0 = clk::now();
+  int ncl_prev = 0;
   for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
-    if ((rc = fuelmi_frontier_reset(f))) break;
+    if ((rc = fuelmi_frontier_reset(f))) break;  // (retires cycle k - 1's clusters to list 3)
     if ((rc = fuelmi_map_set_updated_box(m, ub_min, ub_max))) break;
     if ((rc = fuelmi_frontier_search_begin(f))) break;
     if ((rc = fuelmi_map_inflate_local(m))) break;
     if ((rc = fuelmi_map_update_esdf(m))) break;
-    if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
+    if (batch && (rc = fuelmi_bspline_dev_eval_pinned(batch, k & 1))) break;
+    if (k > 0 && (rc = deliver(k - 1, ncl_prev))) break;
     if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
-    const auto ta = clk::now();
-    size_t at = 0;
-    for (int c = 0; c < ncl && rc == FUELMI_OK; ++c) {
-      const int sz = fuelmi_frontier_cluster_size(f, 0, c);
-      if (sz < 0 || at + (size_t)sz > cells_cap) break;
-      rc = fuelmi_frontier_cluster_cells(f, 0, c, cells_out + at);
-      at += (size_t)sz;
-    }
-    const auto tb = clk::now();
-    if (rc == FUELMI_OK && batch) rc = fuelmi_bspline_dev_download(batch, cost, grad);
-    const auto tc = clk::now();
-    t_cells += std::chrono::duration<double>(tb - ta).count();
-    t_cg += std::chrono::duration<double>(tc - tb).count();
+    ncl_prev = ncl;
   }
+  if (rc == FUELMI_OK && n > 0) rc = deliver(-1, ncl_prev);
+  (void)fuelmi_frontier_keep_previous(f, kept ? 1 : 0);
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
   HIPCHK(frontier_drain(f));

@@ -282,6 +282,13 @@ struct fuelmi_frontier {
   bool pool_dirty = false;  // the cell pool was written since the last plane swap (the new stream then waits for the old one)
   std::vector<void*> allocs;
   std::list<HCluster> frontiers, dormant, tmp;
+  // which = 3: the new clusters of the search BEFORE the last fuelmi_frontier_reset.  Their cell lists sit in the
+  // retired buffer set (see F2), which nothing touches until the next reset -- a caller that works in cycles reads
+  // cycle k - 1's cells while cycle k runs on the device (fuelmi_bench_cycles_delivered does).
+  std::list<HCluster> prev;
+  hipEvent_t ev_prev = nullptr;  // the retired search's tail (and the copy of its grouped cells to the host) have completed
+  bool prev_pending = false;
+  bool keep_prev = false;  // fuelmi_frontier_keep_previous
   std::vector<int> removed_ids;
   hipStream_t stream = nullptr;  // frontier work runs beside the map's own stream
   hipEvent_t ev_dep = nullptr;
@@ -378,6 +385,16 @@ static inline int frontier_tail_sync(const fuelmi_frontier* f) {
   }
 }
 // ... and make sure the grouped cell lists are in the pinned result buffer (the lazy clusters point into it)
+static inline int frontier_prev_ready(const fuelmi_frontier* f) {
+  if (!f->prev_pending) return FUELMI_OK;
+  for (;;) {
+    const hipError_t q = hipEventQuery(f->ev_prev);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) HIPCHK(q);
+  }
+  const_cast<fuelmi_frontier*>(f)->prev_pending = false;
+  return FUELMI_OK;
+}
 static inline int frontier_cells_ready(const fuelmi_frontier* f) {
   const int rc = frontier_tail_sync(f);
   if (rc) return rc;

@@ -369,6 +369,23 @@ class FrontierFinder:
             out.append(a)
         return out
 
+    def clusterCentres(self, which=0):
+        """cells_ of every cluster as voxel centres ([n, 3] doubles each), decoded by the library"""
+        out = []
+        cnt = self.L.fuelmi_frontier_count(self.h, which)
+        if cnt < 0:
+            check(cnt)
+        for k in range(cnt):
+            n = self.L.fuelmi_frontier_cluster_size(self.h, which, k)
+            a = np.empty((n, 3))
+            check(self.L.fuelmi_frontier_cluster_centres(self.h, which, k, _dp(a)))
+            out.append(a)
+        return out
+
+    def keepPrevious(self, on=True):
+        """fuelmi_frontier_keep_previous: a reset keeps the retired search's new clusters readable as list 3"""
+        check(self.L.fuelmi_frontier_keep_previous(self.h, int(bool(on))))
+
     @staticmethod
     def viewpointConfig(rmin=1.5, rmax=2.5, rnum=3, dphi=15 * 3.1415926 / 180.0, clearance=0.21, min_visib_num=15,
                         min_candidate_dist=0.75, min_view_finish_fraction=0.2, top_angle=0.56125,
@@ -585,6 +602,15 @@ class BsplineDeviceProblem:
 
     def eval(self):
         check(self.L.fuelmi_bspline_dev_eval(self.h))
+
+    def evalPinned(self, slot):
+        check(self.L.fuelmi_bspline_dev_eval_pinned(self.h, int(slot)))
+
+    def collect(self, slot):
+        cost = np.empty(self.problem.C)
+        grad = np.empty((self.problem.C, self.problem.nvar))
+        check(self.L.fuelmi_bspline_dev_collect(self.h, int(slot), _dp(cost), _dp(grad)))
+        return cost, grad
 
     def download(self):
         cost = np.empty(self.problem.C)

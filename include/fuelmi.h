@@ -257,14 +257,24 @@ int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new);
  * _is_covered and a second _begin return FUELMI_EINVAL until _end has been called. */
 int fuelmi_frontier_search_begin(fuelmi_frontier* f);
 int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new);
+/* Pipelined delivery for callers that work in cycles (fresh search every cycle): with keep_previous on,
+ * fuelmi_frontier_reset does not discard the new clusters of the search it retires -- they become list 3 and stay
+ * readable (size / cells / centres / info) until the NEXT reset: their cell lists live in the buffer set the reset
+ * retires, which nothing touches for a whole cycle.  Reading list 3 waits only for that search's own tail, so cycle
+ * k - 1's cells are copied out while cycle k runs on the device. */
+int fuelmi_frontier_keep_previous(fuelmi_frontier* f, int on);
 /* move tmp_frontiers_ into frontiers_ (dormant=0) or dormant_frontiers_ (dormant=1) */
 int fuelmi_frontier_commit(fuelmi_frontier* f, int dormant);
-/* which: 0 tmp_frontiers_, 1 frontiers_, 2 dormant_frontiers_ */
+/* which: 0 tmp_frontiers_, 1 frontiers_, 2 dormant_frontiers_, 3 the new clusters of the search before the last reset
+ * (fuelmi_frontier_keep_previous) */
 int fuelmi_frontier_count(const fuelmi_frontier* f, int which);
 int fuelmi_frontier_cluster_size(const fuelmi_frontier* f, int which, int k);
 /* cells of cluster k as linear voxel addresses, ascending (the reference keeps BFS order;
  * the SET is identical) */
 int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which, int k, int* adr);
+/* the same cells as voxel CENTRES, xyz[3 * size] doubles (the storage of the reference's vector<Vector3d> cells_,
+ * frontier_finder.h:27): indexToPos of every cell (sdf_map.h:137-140), same order as _cluster_cells */
+int fuelmi_frontier_cluster_centres(const fuelmi_frontier* f, int which, int k, double* xyz);
 /* average_[3], box_min_[3], box_max_[3] (computeFrontierInfo) */
 int fuelmi_frontier_cluster_info(const fuelmi_frontier* f, int which, int k, double out9[9]);
 int fuelmi_frontier_removed_count(const fuelmi_frontier* f);
@@ -345,6 +355,10 @@ int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg* cfg,
                               const fuelmi_bspline_batch* batch, fuelmi_bspline_dev** out);
 int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b);             /* async on the map's stream */
 int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, double* grad);
+/* the evaluation with its results delivered to one of two pinned host slots by the kernel itself (slot 0 / 1);
+ * _collect waits for that launch only and copies cost [C] / grad [C][nvar] out */
+int fuelmi_bspline_dev_eval_pinned(fuelmi_bspline_dev* b, int slot);
+int fuelmi_bspline_dev_collect(fuelmi_bspline_dev* b, int slot, double* cost, double* grad);
 /* BsplineOptimizer::optimize() (bspline_optimizer.cpp:165-253) for every candidate of the batch on the
  * device: start point and bounds as the reference sets them up (control points clamped into the
  * exploration box shrunk by 0.1, +-10 around the start, knot span in [0,5]), at most max_eval objective
