@@ -845,7 +845,9 @@ __device__ __forceinline__ void zy_store4(u32* dst, int z, const Box3& b, uint4 
 }
 
 // the 8 outputs (rows 2p, 2p + 1 x 4 z of group gi) of one lane from the packed tile at `tile_b`
-template <int G>
+// TILE_SLOW: outputs at or above PK_INF are recomputed from the tile itself (z/y pass: the tile holds every finite value
+// exactly); false: they are left to the caller (x pass: PK_INF in its tile may stand for a larger finite value)
+template <int G, bool TILE_SLOW = true>
 __device__ __forceinline__ void pk_scan8(const unsigned char* tile_b, int p, int gi, int npair, int ylen, bool any_src,
                                          bool sampled, int& n_far, uint4& ra, uint4& rb) {
   constexpr int ZC = 4 * G;
@@ -886,7 +888,7 @@ __device__ __forceinline__ void pk_scan8(const unsigned char* tile_b, int p, int
       if (sampled) n_far += __popcll(__ballot(pk_hmin(pk_min(pk_min(b0, b1), pk_min(b2, b3))) > ESDF_FAR_D * ESDF_FAR_D));
       ra = make_uint4(b0 & 0xffffu, b1 & 0xffffu, b2 & 0xffffu, b3 & 0xffffu);
       rb = make_uint4(b0 >> 16, b1 >> 16, b2 >> 16, b3 >> 16);
-      if (mx >= PK_INF) {  // rare: an output out of the 16-bit range
+      if (TILE_SLOW && mx >= PK_INF) {  // rare: an output out of the 16-bit range
         const int zc = 4 * gi, rA = 2 * p, rB = 2 * p + 1;
         if (ra.x >= PK_INF) ra.x = pk_slow_col(tile, ZC, ylen, rA, zc);
         if (ra.y >= PK_INF) ra.y = pk_slow_col(tile, ZC, ylen, rA, zc + 1);
@@ -1569,6 +1571,142 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
+// ------------------------------------------------------------------------------------------------
+// Packed x pass (round 4): the same two-rows-per-lane 16-bit scan as k_esdf_zy_pk, over x.  The tile holds
+// min(tmp, PK_INF) of x-rows 2p / 2p + 1 in the halves of one u32 (half the LDS of the 32-bit tile: 25 KB for 400 rows
+// x 32 columns, so eight 256-thread workgroups share a CU and all 1250 column tiles of the 400^2 x 100 map are resident
+// at once), a lane owns 8 outputs.  An output the packed scan leaves at or above PK_INF -- further than ~255 voxels
+// from every source, or a column without any -- is recomputed in 32 bits from the y-pass result in global memory
+// (x_slow_col); a column tile without a finite value at all answers "no source" without scanning.
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ u32 x_slow_col(const u32* __restrict__ col, long row_stride, int xlen, int row) {
+  u32 best = INF32;
+  const int rmax = max(row, xlen - 1 - row);
+  for (int r = 0; r <= rmax && (u32)__mul24(r, r) < best; ++r) {
+    const u32 rr = (u32)__mul24(r, r);
+    if (row - r >= 0) {
+      const u32 v = col[(long)(row - r) * row_stride];
+      if (v < INF32) best = min(best, v + rr);
+    }
+    if (r && row + r < xlen) {
+      const u32 v = col[(long)(row + r) * row_stride];
+      if (v < INF32) best = min(best, v + rr);
+    }
+  }
+  return best;
+}
+__device__ __forceinline__ u32 pk_pack_sat(u32 lo, u32 hi) { return min(lo, PK_INF) | (min(hi, PK_INF) << 16); }
+
+template <int OUT>
+__global__ void __launch_bounds__(512)
+k_esdf_x_pk(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, u32* stat,
+            volatile u32* h_stat) {
+  constexpr int SEGS = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  forward_stat(stat, h_stat);
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [npx][SEGS] of uint4: halves = x-rows 2p, 2p + 1
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int npx = (xlen + 1) >> 1;
+  const int ncol = ylen * zlen_a;
+  const int T = blockDim.x;
+  const int total = npx * SEGS;
+  const float resf = (float)g.res;
+  __shared__ u32 s_colfin;  // bit c: column c of the tile holds a finite value
+  if (threadIdx.x == 0) s_colfin = 0u;
+  __syncthreads();
+  u32 finbits = 0u;
+  for (int o = threadIdx.x; o < total; o += T) {
+    const int p = o >> 3, seg = o & 7;
+    const int col = blockIdx.x * (4 * SEGS) + seg * 4;
+    uint4 pk = make_uint4(pk_both(PK_INF), pk_both(PK_INF), pk_both(PK_INF), pk_both(PK_INF));
+    if (col < ncol) {
+      const int yy = col / zlen_a;
+      const long coloff = (long)(b.lo[1] + yy) * g.nz + z0a + (col - yy * zlen_a);
+      const u32* src = tmp + (long)(b.lo[0] + 2 * p) * g.nyz + coloff;
+      const uint4 va = *reinterpret_cast<const uint4*>(src);
+      // (odd line: the last pair repeats its row -- a copy one row further out is never a better candidate)
+      const uint4 vb = *reinterpret_cast<const uint4*>(2 * p + 1 < xlen ? src + g.nyz : src);
+      pk = make_uint4(pk_pack_sat(va.x, vb.x), pk_pack_sat(va.y, vb.y), pk_pack_sat(va.z, vb.z), pk_pack_sat(va.w, vb.w));
+      const u32 f4 = (min(va.x, vb.x) < INF32 ? 1u : 0u) | (min(va.y, vb.y) < INF32 ? 2u : 0u) | (min(va.z, vb.z) < INF32 ? 4u : 0u) |
+                     (min(va.w, vb.w) < INF32 ? 8u : 0u);
+      finbits |= f4 << (4 * seg);
+    }
+    tile[o] = pk;
+  }
+  if (finbits) atomicOr(&s_colfin, finbits);
+  __syncthreads();
+  const u32 colfin = s_colfin;
+  const int any_src = colfin != 0u;
+  if (any_src && colfin != 0xFFFFFFFFu) {
+    // columns without any finite value (no source on the whole x line): they answer "no source" below; in the tile they
+    // read 0 so that they do not stretch the shared scan loop of the lane's other columns
+    for (int o = threadIdx.x; o < total; o += T) {
+      const u32 f4 = (colfin >> (4 * (o & 7))) & 15u;
+      if (f4 != 15u) {
+        uint4 v = tile[o];
+        if (!(f4 & 1u)) v.x = 0u;
+        if (!(f4 & 2u)) v.y = 0u;
+        if (!(f4 & 4u)) v.z = 0u;
+        if (!(f4 & 8u)) v.w = 0u;
+        tile[o] = v;
+      }
+    }
+    __syncthreads();
+  }
+  int n_far = 0;
+  for (int o = threadIdx.x; o < total; o += T) {
+    const int p = o >> 3, seg = o & 7;
+    const int col = blockIdx.x * (4 * SEGS) + seg * 4;
+    if (col >= ncol) continue;
+    uint4 ra, rb;
+    pk_scan8<SEGS, false>(smem_raw, p, seg, npx, xlen, any_src != 0, false, n_far, ra, rb);
+    const int yy = col / zlen_a;
+    const int z = z0a + (col - yy * zlen_a);
+    const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
+    if (any_src) {
+      const u32 f4 = (colfin >> (4 * seg)) & 15u;
+      u32* pa = &ra.x;
+      u32* pb = &rb.x;
+      if (f4 != 15u) {
+        for (int k = 0; k < 4; ++k)
+          if (!((f4 >> k) & 1u)) pa[k] = pb[k] = INF32;
+      }
+      if (max(max4(ra.x, ra.y, ra.z, ra.w), max4(rb.x, rb.y, rb.z, rb.w)) >= PK_INF) {
+        // rare: recompute the outputs out of the 16-bit range from the y-pass result itself
+        const u32* cb = tmp + (long)b.lo[0] * g.nyz + coloff;
+        for (int k = 0; k < 4; ++k) {
+          if (pa[k] >= PK_INF && pa[k] < INF32) pa[k] = x_slow_col(cb + k, g.nyz, xlen, 2 * p);
+          if (2 * p + 1 < xlen && pb[k] >= PK_INF && pb[k] < INF32) pb[k] = x_slow_col(cb + k, g.nyz, xlen, 2 * p + 1);
+        }
+      }
+    }
+    float* dst = dist + (long)(b.lo[0] + 2 * p) * g.nyz + coloff;
+    x_store4<OUT>(dst, z, b.lo[2], b.hi[2], ra, resf);
+    if (2 * p + 1 < xlen) x_store4<OUT>(dst + g.nyz, z, b.lo[2], b.hi[2], rb, resf);
+  }
+}
+template <int OUT>
+static int launch_x_pk(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
+  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
+  const int zlen_a = z1a - z0a + 1;
+  const int npx = (xlen + 1) >> 1;
+  const size_t lds = (size_t)npx * 8 * 16;
+  if ((g.nz % 4) != 0 || lds > 150 * 1024) return ESDF_NO_FIT;  // (x lines of up to 2400 voxels; longer ones: the 32-bit kernels)
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x_pk<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               150 * 1024));  // (the kernel also holds a few bytes of static LDS)
+  const int ncol = ylen * zlen_a;
+  static const char* th_env = getenv("FUELMI_X_PK_THREADS");  // tuning hook
+  const int threads = th_env ? atoi(th_env) : 256;
+  STAGE_LAUNCH(m, (k_esdf_x_pk<OUT>), (ncol + 31) / 32, threads, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a,
+               esdf_stat_dev<OUT>(m), esdf_stat_host(m));
+  HIPCHK(hipGetLastError());
+  return FUELMI_OK;
+}
+
 template <int OUT>
 static int launch_x4h(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
@@ -1738,7 +1876,10 @@ int esdf_update(fuelmi_map* m) {
   m->esdf_family_last = ran;
   {
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
-    rc = far ? launch_x<0, true>(m, b) : launch_x<0, false>(m, b);
+    static const bool x32 = getenv("FUELMI_X_PK") != nullptr && atoi(getenv("FUELMI_X_PK")) == 0;  // A/B hook
+    rc = ESDF_NO_FIT;
+    if (ran == FUELMI_ESDF_PLAIN && !x32) rc = launch_x_pk<0>(m, b);  // the packed family: both passes on 16-bit lanes
+    if (rc == ESDF_NO_FIT) rc = far ? launch_x<0, true>(m, b) : launch_x<0, false>(m, b);
   }
   if (rc) return rc;
   if (m->cfg.signed_dist) {  // inside obstacles the nearest free voxel is never far: plain kernels
