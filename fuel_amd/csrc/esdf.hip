@@ -972,117 +972,6 @@ k_esdf_zy_pk(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict_
   }
 }
 
-// Pipelined packed z/y pass.  FUELMI_ZY_TIMING on k_esdf_zy_pk (400^2 x 100 map): a workgroup lives 12 us -- 7.5 us
-// filling its tile (one lane per row pair walks a ~400-instruction chain, half of it the per-chunk search for the
-// nearest sources below / above), 3.7 us scanning -- and the 2000 workgroups take 9 us to dispatch; the issue work of
-// the whole pass is ~10 us of its 31.  So: PERSISTENT workgroups that each walk a contiguous range of tiles (slab-
-// major, chunk-minor: a lane that walks up a z-line carries its forward sweep from chunk to chunk, the "below"
-// search disappears and the plane words are fetched once per slab), with WAVE ROLES: the first nfw waves fill
-// tile k + 1 into one LDS buffer while the others scan tile k out of the other one; one barrier per tile.
-template <int MODE, int G, int NW>
-__global__ void __launch_bounds__(1024)
-k_esdf_zy_pp(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp, int nzc,
-             int z0a, int fastrow, u32* __restrict__ stat, int nfw, int ntiles, unsigned long long* __restrict__ dbg) {
-  constexpr int ZC = 4 * G;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int ylen = b.hi[1] - b.lo[1] + 1;
-  const int npair = (ylen + 1) >> 1;
-  const size_t tile_bytes = (size_t)npair * ZC * 4;
-  u32* s_any = reinterpret_cast<u32*>(smem_raw + 2 * tile_bytes);  // [2][16]: "this wave's rows hold a source", per buffer
-  // tile range of this workgroup; ranges of one XCD (workgroup i runs on XCD i % 8) are neighbours, so the chunks of a
-  // slab -- interleaved 80-byte pieces of the same tmp lines -- meet in one L2
-  const int nwg = gridDim.x, per = nwg >> 3;
-  const int r = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int t0 = (int)((long)r * ntiles / nwg), t1 = (int)((long)(r + 1) * ntiles / nwg);
-  if (t0 >= t1) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool filler = wave < nfw;
-  const int nscan = blockDim.x - 64 * nfw, sid = threadIdx.x - 64 * nfw;
-  const bool z_aligned = (b.lo[2] & 3) == 0 && (b.hi[2] & 3) == 3;
-  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;
-  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
-  unsigned long long acc = 0ull;
-  LineBits<NW> LA, LB;  // the pair's aligned z-lines (loaded when the walk enters a new slab)
-#pragma unroll
-  for (int k = 0; k < NW; ++k) LA.w[k] = LB.w[k] = 0ull;
-  u32 carry = 0x00ff00ffu;
-  const int total = npair * G;
-  for (int s = 0; s <= t1 - t0; ++s) {
-    const unsigned long long ts = stamp ? wall_clock64() : 0ull;
-    if (filler) {
-      const int t = t0 + s;
-      if (t < t1) {
-        const int xrel = t / nzc, c = t - xrel * nzc;
-        const int x = b.lo[0] + xrel, zc0 = z0a + c * ZC;
-        const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);
-        const u32 inbox = zs <= ze ? (u32)bit_range(zs - zc0, ze - zs + 1) : 0u;
-        u32* buf = reinterpret_cast<u32*>(smem_raw + (s & 1) * tile_bytes);
-        const int p = threadIdx.x;
-        bool has_src = false;
-        if (p < npair) {
-          const int yA = 2 * p, yB = min(2 * p + 1, ylen - 1);
-          const long lbA = (long)x * g.nyz + (long)(b.lo[1] + yA) * g.nz;
-          const long lbB = (long)x * g.nyz + (long)(b.lo[1] + yB) * g.nz;
-          const bool fresh = s == 0 || c == 0;  // a new z-line: nothing to carry
-          RowSrc A, B;
-          A.bits = B.bits = 0ull;
-          A.below = A.above = B.below = B.above = -1;
-          if (zs <= ze) {
-            if (fresh) {
-              LA = line_load<MODE, NW>(infl, unk, lbA, z0a, b.lo[2], b.hi[2]);
-              LB = line_load<MODE, NW>(infl, unk, lbB, z0a, b.lo[2], b.hi[2]);
-              A = row_src_line<NW, true>(LA, z0a, zc0, ZC);
-              B = row_src_line<NW, true>(LB, z0a, zc0, ZC);
-            } else {
-              A = row_src_line<NW, false>(LA, z0a, zc0, ZC);
-              B = row_src_line<NW, false>(LB, z0a, zc0, ZC);
-            }
-          }
-          const u32 d0 = fresh ? pk_below_d0(A, B, zs) : carry;
-          has_src = (A.bits | B.bits) != 0ull || d0 != 0x00ff00ffu || A.above >= 0 || B.above >= 0;
-          carry = zy_fill_pair<G>(buf + p * ZC, (u32)A.bits, (u32)B.bits, d0, A.above, B.above, ze, inbox, fastrow != 0);
-        }
-        const bool wany = __ballot(has_src) != 0ull;
-        if (lane == 0) s_any[(s & 1) * 16 + wave] = wany ? 1u : 0u;
-      }
-      if (stamp && threadIdx.x == 0) acc += wall_clock64() - ts;
-    } else if (s >= 1) {
-      const int t = t0 + s - 1;
-      const int xrel = t / nzc, c = t - xrel * nzc;
-      const int x = b.lo[0] + xrel, zc0 = z0a + c * ZC;
-      const unsigned char* buf = smem_raw + ((s - 1) & 1) * tile_bytes;
-      u32 any = 0u;
-      for (int w = 0; w < nfw; ++w) any |= s_any[((s - 1) & 1) * 16 + w];
-      const bool sampled = stat != nullptr && ((x & 15) == 0 || xrel == 0);
-      int n_far = 0;
-      const int dpi = nscan / G, dgi = nscan - dpi * G;
-      int p = sid / G, gi = sid - p * G;
-      for (int o = sid; o < total; o += nscan) {
-        uint4 ra, rb;
-        pk_scan8<G>(buf, p, gi, npair, ylen, any != 0u, sampled, n_far, ra, rb);
-        const int z = zc0 + 4 * gi;
-        u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + 2 * p) * g.nz + z;
-        zy_store4(dst, z, b, ra, z_aligned);
-        if (2 * p + 1 < ylen) zy_store4(dst + g.nz, z, b, rb, z_aligned);
-        p += dpi;
-        gi += dgi;
-        if (gi >= G) {
-          gi -= G;
-          ++p;
-        }
-      }
-      if (sampled && lane == 0) {
-        u32* sg = stat + 2 * ((x >> 4) & (ESDF_NG - 1));
-        atomicAdd(sg, (u32)n_far);
-        if (sid == 0) atomicAdd(sg + 1, (u32)total);
-      }
-      if (stamp && sid == 0) stamp[2] += wall_clock64() - ts;
-    }
-    __syncthreads();
-  }
-  if (stamp && threadIdx.x == 0) stamp[1] = acc, stamp[3] = wall_clock64(), stamp[5] = (unsigned long long)(t1 - t0);
-}
-
 // The y pass of this update has counted its far outputs per group of 16 x-slabs (stat[2 g], stat[2 g + 1]: far
 // outputs, outputs of the sampled slab); the first workgroup of the x pass hands the sampled groups to the host through
 // pinned memory and clears them.  No fence, no synchronisation (a system-scope release here makes this workgroup write
@@ -1446,50 +1335,6 @@ static int launch_zy_pk_g(fuelmi_map* m, const Box3& b, int nzc, int z0a, int th
   }
   return FUELMI_OK;
 }
-template <int MODE, int G, int NW>
-static int launch_zy_pp_g(fuelmi_map* m, const Box3& b, int nzc, int z0a, int threads, int nfw, int ntiles, int nwg, size_t lds) {
-  if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pp<MODE, G, NW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
-  unsigned long long* dbg = nullptr;
-  if (timing) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)nwg * 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)nwg * 8 * sizeof(unsigned long long), m->stream));
-  }
-  STAGE_LAUNCH(m, (k_esdf_zy_pp<MODE, G, NW>), nwg, threads, lds, m->g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
-               m->esdf_tmp, nzc, z0a, zy_fastrow() ? 1 : 0, MODE == 2 ? nullptr : esdf_stat_dev<0>(m), nfw, ntiles, dbg);
-  HIPCHK(hipGetLastError());
-  if (timing) {
-    HIPCHK(hipStreamSynchronize(m->stream));
-    std::vector<unsigned long long> d((size_t)nwg * 8);
-    HIPCHK(hipMemcpy(d.data(), dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(dbg));
-    unsigned long long t0 = ~0ull, t1 = 0;
-    double fill = 0, scan = 0, life = 0, tiles = 0;
-    int n = 0;
-    for (int w = 0; w < nwg; ++w) {
-      const unsigned long long* r = &d[(size_t)w * 8];
-      if (!r[0] || !r[3]) continue;
-      t0 = std::min(t0, r[0]), t1 = std::max(t1, r[3]);
-      fill += (double)r[1], scan += (double)r[2], life += (double)(r[3] - r[0]), tiles += (double)r[5];
-      ++n;
-    }
-    std::fprintf(stderr, "[zy-timing] pipelined G %d threads %d (fill waves %d) lds %zu: %d workgroups x %.1f tiles, span %.2f us; per "
-                 "workgroup: life %.2f us, of it filling %.2f scanning %.2f (roles run side by side); per tile: fill %.2f scan %.2f us\n",
-                 G, threads, nfw, lds, n, tiles / n, (double)(t1 - t0) / 100.0, life / n / 100.0, fill / n / 100.0, scan / n / 100.0,
-                 fill / tiles / 100.0, scan / tiles / 100.0);
-  }
-  return FUELMI_OK;
-}
-template <int MODE>
-static int launch_zy_pp(fuelmi_map* m, const Box3& b, int ZC, int nzc, int z0a, int threads, int nfw, int ntiles, int nwg, size_t lds,
-                        bool wide) {
-  // (experimental, FUELMI_ZY_PP=1: built for 20-voxel chunks only -- it measured slower than the plain kernel, see DESIGN)
-  if (ZC != 20) return ESDF_NO_FIT;
-  return wide ? launch_zy_pp_g<MODE, 5, 4>(m, b, nzc, z0a, threads, nfw, ntiles, nwg, lds)
-              : launch_zy_pp_g<MODE, 5, 2>(m, b, nzc, z0a, threads, nfw, ntiles, nwg, lds);
-}
 template <int MODE>
 static int launch_zy_pk(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
@@ -1515,25 +1360,6 @@ static int launch_zy_pk(fuelmi_map* m, const Box3& b) {
   const int ZC = best_zc, nzc = (zlen_a + ZC - 1) / ZC;
   const size_t lds = (size_t)npair * ZC * 4;
   if (lds > 160 * 1024) return ESDF_NO_FIT;
-  {
-    // the pipelined kernel: persistent workgroups, fill waves + scan waves, >= 3 tiles per workgroup
-    static const char* pp_env = getenv("FUELMI_ZY_PP");  // tuning hook: 0 = the one-tile-per-workgroup kernel
-    const int xlen = b.hi[0] - b.lo[0] + 1;
-    const int ntiles = xlen * nzc;
-    const int nfw = (npair + 63) / 64;
-    static const char* sw_env = getenv("FUELMI_ZY_PP_SCANW");
-    int nsw = sw_env ? atoi(sw_env) : std::max(2, std::min(16 - nfw, nfw + (nfw > 4 ? 2 : 0)));
-    const size_t lds2 = 2 * lds + 2 * 16 * sizeof(u32);
-    if (pp_env && atoi(pp_env) != 0 && nfw + nsw <= 16 && nfw <= 14 && lds2 <= 160 * 1024 && ntiles >= 24) {
-      nsw = std::min(nsw, 16 - nfw);
-      const int threads = (nfw + nsw) * 64;
-      static const char* wg_env = getenv("FUELMI_ZY_PP_WGS");  // tuning hook: workgroups per CU
-      const int per_cu = wg_env ? atoi(wg_env) : (threads <= 512 && lds2 <= 72 * 1024 ? 2 : 1);
-      const int nwg = 8 * std::max(1, std::min(32 * per_cu, ntiles / 24));
-      const int rcp = launch_zy_pp<MODE>(m, b, ZC, nzc, z0a, threads, nfw, ntiles, nwg, lds2, zlen_a > 128);
-      if (rcp != ESDF_NO_FIT) return rcp;
-    }
-  }
   static const char* th_env = getenv("FUELMI_ZY_PK_THREADS");  // tuning hook
   const int threads = th_env ? atoi(th_env) : std::min(512, std::max(128, ((npair + 63) / 64) * 64));
   const bool wide = zlen_a > 128;  // aligned z-lines of up to 128 / 256 bits

@@ -2647,6 +2647,10 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->ev_zero) (void)hipEventDestroy(f->ev_zero);
   if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
   if (f->ev_prev) (void)hipEventDestroy(f->ev_prev);
+  if (f->ev_planes_read) {
+    if (f->map && f->map->planes_read_ev == f->ev_planes_read) f->map->planes_read_ev = nullptr;
+    (void)hipEventDestroy(f->ev_planes_read);
+  }
   Plane* pl[] = {&f->flag, &f->flag2, &f->qb, &f->sb};
   for (Plane* p : pl)
     if (p->base) (void)hipFree(p->base);
@@ -2733,6 +2737,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   HIPCHK(hipEventCreateWithFlags(&f->ev_zero, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_prev, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&f->ev_planes_read, hipEventDisableTiming));
 
   // ---- everything below is constant for the life of the object (the kernel chain is replayed
   // as a graph with these arguments baked in) ----
@@ -2836,14 +2841,12 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     }
     const size_t lds_max = std::max(f->tile_lds[0], f->out_lds[0]);
     if (lds_max > 64 * 1024 && lds_max <= 150 * 1024) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<512>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->tile_lds[0]));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<512>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->out_lds[0]));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<256>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->tile_lds[0]));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<256>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->out_lds[0]));
+      // (the attribute belongs to the FUNCTION, not to this finder: always the kernels' ceiling, so that a second
+      // finder with a shorter map cannot lower it under a taller finder's launches -- ADVICE r3)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
   }
   f->resolve_lds = (4 * (size_t)FR_RCAP + 6 * (size_t)FR_KCAP + 6 * (size_t)FR_KCAP + 3 * (size_t)RS_SH) * sizeof(u32) +
@@ -2853,6 +2856,15 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   // the fast path needs tiles, a cluster threshold that rules out one-seed clusters, and tile-local indices
   // that fit the 16-bit root numbers
   // (a thread of the tile kernels fetches at most FT_PER segments: z-lines of up to 256 voxels with the largest tile)
+  // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
+  f->ft_threads[0] = f->ft_threads[1] = f->ft_threads[2] = 512;
+  if (const char* e = getenv("FUELMI_FT_THREADS")) {
+    int a = 0, b2 = 0, c = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3)
+      f->ft_threads[0] = a == 256 ? 256 : 512, f->ft_threads[1] = b2 == 256 ? 256 : 512, f->ft_threads[2] = c == 256 ? 256 : 512;
+  }
+  if (f->fast_items[0] > (size_t)FT_PER * 256)  // (a lane fetches at most FT_PER segments)
+    f->ft_threads[0] = f->ft_threads[1] = f->ft_threads[2] = 512;
   f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && std::max(f->tile_lds[0], f->out_lds[0]) <= 150 * 1024 &&
                f->fast_items[0] <= (size_t)FT_PER * 512 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
   if ((rc = frontier_twin_set(f))) {
@@ -2869,12 +2881,34 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
 
 // copy the cell lists of kept-but-still-lazy clusters out of the pinned result buffer (see frontier_keep_clusters)
 int frontier_materialize_lists(fuelmi_frontier* f) {
+  // (the name is round 2's: the lists are no longer copied out here -- see HCluster::dev_only)
   if (!f->lazy_kept) return FUELMI_OK;
-  const int rc = frontier_cells_ready(f);
-  if (rc) return rc;
   for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
-    for (HCluster& c : *L) c.materialize();
+    for (HCluster& c : *L)
+      if (c.lazy) {
+        c.dev_n = (u32)c.size();
+        c.lazy = nullptr;
+        c.lazy_n = 0;
+        c.dev_only = true;
+      }
   f->lazy_kept = false;
+  return FUELMI_OK;
+}
+// the host list of a cluster that lives in the device pool only: fetched when somebody asks for it
+static int frontier_fetch_cluster(const fuelmi_frontier* f, const HCluster* cc) {
+  HCluster* c = const_cast<HCluster*>(cc);
+  if (!c->dev_only) return FUELMI_OK;
+  HIPCHK(hipStreamSynchronize(f->stream));  // (the copy into the pool is queued on the finder's stream)
+  std::vector<int> v(c->dev_n);
+  if (c->dev_n) HIPCHK(hipMemcpy(v.data(), f->pool + c->pool_off, (size_t)c->dev_n * sizeof(int), hipMemcpyDeviceToHost));
+  if (c->lazy_seed >= 0 && !v.empty()) {  // the NQ seed travels behind the sorted cells: back into address order
+    const int seed = v.back();
+    v.pop_back();
+    v.insert(std::lower_bound(v.begin(), v.end(), seed), seed);
+  }
+  c->cells.swap(v);
+  c->lazy_seed = -1;
+  c->dev_only = false;
   return FUELMI_OK;
 }
 
@@ -2896,7 +2930,11 @@ static int pool_reserve(fuelmi_frontier* f, size_t need) {
     if (rcm) return rcm;
   }
   for (std::list<HCluster>* L : {&f->frontiers, &f->dormant})
-    for (HCluster& c : *L) live += c.cells.size();
+    for (HCluster& c : *L) {
+      const int rcf = frontier_fetch_cluster(f, &c);  // (the pool is about to be rebuilt from the host lists)
+      if (rcf) return rcf;
+      live += c.cells.size();
+    }
   HIPCHK(hipStreamSynchronize(f->stream));
   if (live > f->pool_cap / 2 || !f->pool) {
     size_t cap = std::max<size_t>(1u << 20, f->pool_cap);
@@ -2935,12 +2973,19 @@ int frontier_keep_clusters(fuelmi_frontier* f, std::list<HCluster>& clusters) {
       if ((rc = pool_upload(f, c))) return rc;
       continue;
     }
-    PoolPut e;
-    e.dst = f->pool_used;
-    e.src = (u32)(c.lazy - reinterpret_cast<const int*>(f->F.h_cells));
-    e.n = (u32)c.lazy_n;
-    e.seed = c.lazy_seed;
-    table.push_back(e);
+    // one workgroup per table entry: a large cluster (the growing surface of a streaming run reaches 20 k cells) is
+    // cut into pieces of 2048 cells -- one workgroup walking it alone was 13 us of every frame's frontier stream
+    const u32 src0 = (u32)(c.lazy - reinterpret_cast<const int*>(f->F.h_cells)), ncell = (u32)c.lazy_n;
+    for (u32 at = 0; at < ncell || at == 0; at += 2048u) {
+      PoolPut e;
+      e.dst = f->pool_used + at;
+      e.src = src0 + at;
+      e.n = std::min(2048u, ncell - at);
+      e.seed = at + 2048u >= ncell ? c.lazy_seed : -1;  // (the seed goes behind the last piece)
+      e.pad = 0;
+      table.push_back(e);
+      if (ncell == 0) break;
+    }
     c.pool_off = f->pool_used;
     f->pool_used += c.size();
     f->lazy_kept = true;
@@ -3111,7 +3156,7 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
 }
 
 // the fast chain (capturable); falls back to the legacy one through counts[2] == 2
-static int frontier_enqueue_fast(fuelmi_frontier* f) {
+static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   const Geo& g = f->map->g;
   FArgs& F = f->F;
   // launch grid of the tile kernels: the chosen tile over the largest rectangle a search can cover
@@ -3120,23 +3165,19 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
   const int ftx = f->FTX ? f->FTX : kFastMenu[mk][0], fty = f->FTX ? f->FTY : kFastMenu[mk][1];
   const int tiles = ((qx + ftx - 1) / ftx) * ((qy + fty - 1) / fty);
   // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
-  static int nt3[3] = {512, 512, 512};
-  static bool nt_init = false;
-  if (!nt_init) {
-    nt_init = true;
-    if (const char* e = getenv("FUELMI_FT_THREADS")) {
-      int a = 0, b = 0, c = 0;
-      if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
-        nt3[0] = a == 256 ? 256 : 512, nt3[1] = b == 256 ? 256 : 512, nt3[2] = c == 256 ? 256 : 512;
-      }
-    }
-    if (f->fast_items[0] > (size_t)FT_PER * 256) nt3[0] = nt3[1] = nt3[2] = 512;  // (a lane fetches at most FT_PER segments)
-  }
+  const int* nt3 = f->ft_threads;  // (per finder, fixed at creation: ADVICE r3 -- a process-wide static took the first finder's)
   if (nt3[0] == 256)
     k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   else
     k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   FDBG("k_tile_ccl");
+  // the tile CCL (and the changed-cluster test in front of it) is the last reader of the map's occupancy planes: a
+  // fusion queued behind this point may start as soon as it is done (direct launches only -- inside a captured graph
+  // the event is recorded behind the whole chain by the caller)
+  if (!capturing) {
+    HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
+    f->map->planes_read_ev = f->ev_planes_read;
+  }
   if (nt3[1] == 256)
     k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F);
   else
@@ -3247,6 +3288,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     if (lo > hi) empty = true;
   }
   f->pending = true;
+  f->fusion_at_begin = m->fusion_count;
   f->search_empty = empty;
   f->fast_launched = false;
   if (empty) return FUELMI_OK;
@@ -3341,17 +3383,34 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   // The chain is ~23 dependent launches whose arguments never change (everything per-search sits
   // behind F.var): replay it as a hipGraph -- the host-side launch cost of the individual kernels
   // (~6 us each) was longer than the kernels themselves.
-  static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || getenv("FUELMI_DEBUG_SYNC") != nullptr;
+  // Round 4: the fast chain's four kernels are launched DIRECTLY by default.  Replaying them as a hipGraph cost the
+  // host less but reached the device ~10 us later; since a fresh search runs beside the previous one's tail that
+  // latency is on the cycle's critical path (same-box A/B, profiles/r04_tuning_*: direct >= graph on the full-box
+  // cycle and on the streaming one), and only direct launches can mark the point behind which the next depth frame
+  // may be fused.  FUELMI_FR_GRAPH=1 brings the graph back; the legacy chain (~23 launches) stays a graph.
+  static const bool dbg_sync = getenv("FUELMI_DEBUG_SYNC") != nullptr;
+  static const bool fast_graph = getenv("FUELMI_FR_GRAPH") != nullptr && atoi(getenv("FUELMI_FR_GRAPH")) != 0 && !dbg_sync;
+  static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || dbg_sync;
+  struct PlanesRead {  // on every path below: whatever was queued, the planes are free behind it
+    fuelmi_frontier* f;
+    bool done = false;
+    ~PlanesRead() {
+      if (!done && f->map && hipEventRecord(f->ev_planes_read, f->stream) == hipSuccess) f->map->planes_read_ev = f->ev_planes_read;
+    }
+  } planes_read{f};
   if (fast) {
     f->fast_launched = true;
-    if (no_graph) return frontier_enqueue_fast(f);
+    if (!fast_graph) {
+      planes_read.done = true;
+      return frontier_enqueue_fast(f, false);
+    }
     const int gm = f->FTX ? 0 : f->fast_menu;
     hipGraphExec_t& fexec = f->fast_exec[gm][f->flag_cur];
     hipGraphNode_t& knode = f->fast_k1[gm][f->flag_cur];
     if (!fexec) {
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
-      const int rc2 = frontier_enqueue_fast(f);
+      const int rc2 = frontier_enqueue_fast(f, true);
       const hipError_t ec = hipStreamEndCapture(f->stream, &graph);
       if (rc2) return rc2;
       HIPCHK(ec);
@@ -3559,6 +3618,12 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
                    (rr[6] - rr[5]) / 100.0, (rr[7] - rr[6]) / 100.0, (rr[8] - rr[7]) / 100.0, rr[9], rr[10], rr[11]);
     }
     ++f->n_fast;
+    if (counts[2] == 2u && m->fusion_count != f->fusion_at_begin) {
+      fuelmi_set_error("frontier search: the fast chain overflowed AFTER the map was fused again (a frame queued between "
+                       "_search_begin and _search_end): the occupancy this search was about is gone -- call _search_end before the next fusion "
+                       "on inputs this noisy");
+      return FUELMI_ELIMIT;
+    }
     if (counts[2] == 2u) {
       // a capacity of the fast path was exceeded (noise-like input): nothing was modified; run the legacy chain
       --f->n_fast;
@@ -3846,6 +3911,10 @@ extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which
     int rc = which == 3 ? frontier_prev_ready(f) : frontier_cells_ready(f);
     if (rc) return rc;
   }
+  {
+    const int rcf = frontier_fetch_cluster(f, c);
+    if (rcf) return rcf;
+  }
   c->copy_to(adr);
   return FUELMI_OK;
 }
@@ -3864,6 +3933,10 @@ extern "C" int fuelmi_frontier_cluster_centres(const fuelmi_frontier* f, int whi
   if (!f->map) {
     fuelmi_set_error("fuelmi_frontier_cluster_centres: the map of this finder has been destroyed");
     return FUELMI_EINVAL;
+  }
+  {
+    const int rcf = frontier_fetch_cluster(f, c);
+    if (rcf) return rcf;
   }
   const Geo& g = f->map->g;
   const size_t n = c->size();
@@ -4078,11 +4151,14 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   int rc = FUELMI_OK, ncl = 0;
   double vox = 0.0;
   const auto t0 = std::chrono::steady_clock::now();
+  // Frame k + 1 is fused while the search of frame k is still running: the search reads the occupancy planes only in
+  // its first kernels, the fusion waits for those ON THE DEVICE (map_wait_plane_readers), and the host's wait for the
+  // fused frame's box (which the next search needs) falls beside the chain instead of in front of it.  Same calls,
+  // same arguments, same results as the frame-by-frame order (serial != 0 keeps that order for diagnostics).
+  int npts = 0;
+  if (n > 0)
+    rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[0]), rows, cols, cfg, cam_pos3, cam_q4, &npts);
   for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
-    int npts = 0;
-    if ((rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k]), rows, cols, cfg, cam_pos3 + 3 * k,
-                                     cam_q4 + 4 * k, &npts)))
-      break;
     if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
     if (npts > 0) {
       int lo[3], hi[3];
@@ -4092,12 +4168,23 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
       if ((rc = fuelmi_map_update_esdf(m))) break;
     }
     if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
+    int npts_next = 0;
     if (serial) {
       HIPCHK(hipStreamSynchronize(m->stream));
       if ((rc = fuelmi_frontier_search_begin(f))) break;
+    } else if (k + 1 < n) {
+      if ((rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k + 1]), rows, cols, cfg, cam_pos3 + 3 * (k + 1),
+                                       cam_q4 + 4 * (k + 1), &npts_next)))
+        break;
     }
     if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
     if ((rc = fuelmi_frontier_commit(f, 0))) break;
+    if (serial && k + 1 < n) {
+      if ((rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k + 1]), rows, cols, cfg, cam_pos3 + 3 * (k + 1),
+                                       cam_q4 + 4 * (k + 1), &npts_next)))
+        break;
+    }
+    npts = npts_next;
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));

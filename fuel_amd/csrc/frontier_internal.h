@@ -230,7 +230,12 @@ struct HCluster {
   const int* lazy = nullptr;
   u32 lazy_n = 0;
   int lazy_seed = -1;  // NQ seed address to merge in, or -1
-  size_t size() const { return lazy ? (size_t)lazy_n + (lazy_seed >= 0 ? 1u : 0u) : cells.size(); }
+  // A committed cluster whose pinned result buffer has been handed to the next search keeps its cells in the finder's
+  // device pool only (dev_n cells at pool_off, an NQ seed last): nothing on the host until somebody asks
+  // (frontier_fetch_cluster).  Copying every kept list out before each search was ~30 us of every streaming frame.
+  bool dev_only = false;
+  u32 dev_n = 0;
+  size_t size() const { return dev_only ? (size_t)dev_n : (lazy ? (size_t)lazy_n + (lazy_seed >= 0 ? 1u : 0u) : cells.size()); }
   void copy_to(int* out) const {  // ascending addresses
     if (!lazy) {
       if (!cells.empty()) memcpy(out, cells.data(), cells.size() * sizeof(int));
@@ -286,8 +291,10 @@ struct fuelmi_frontier {
   // retired buffer set (see F2), which nothing touches until the next reset -- a caller that works in cycles reads
   // cycle k - 1's cells while cycle k runs on the device (fuelmi_bench_cycles_delivered does).
   std::list<HCluster> prev;
+  hipEvent_t ev_planes_read = nullptr;  // behind the last kernel of the running search that reads the map's occupancy planes
   hipEvent_t ev_prev = nullptr;  // the retired search's tail (and the copy of its grouped cells to the host) have completed
   bool prev_pending = false;
+  unsigned long long fusion_at_begin = 0;  // map->fusion_count when the running search began
   bool keep_prev = false;  // fuelmi_frontier_keep_previous
   std::vector<int> removed_ids;
   hipStream_t stream = nullptr;  // frontier work runs beside the map's own stream
@@ -318,6 +325,7 @@ struct fuelmi_frontier {
   hipGraphNode_t fast_k1[4][2] = {};    // ... the node of the chain's first kernel (its FVar argument is rewritten per search)
   hipKernelNodeParams fast_k1_params[4][2] = {};
   int fast_menu = 0;  // menu entry of the running search
+  int ft_threads[3] = {512, 512, 512};  // workgroup sizes of k_tile_ccl / _cross / _out (FUELMI_FT_THREADS), per finder
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;

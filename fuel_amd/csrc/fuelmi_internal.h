@@ -162,6 +162,11 @@ struct fuelmi_map {
   double bench_host_us[7] = {0, 0, 0, 0, 0, 0, 0};  // fuelmi_bench_cycles: mean host microseconds per C-ABI call
   hipEvent_t t0 = nullptr, t1 = nullptr;
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
+  // ... and the other direction: the last kernel of a running frontier search that READS those planes (set by
+  // fuelmi_frontier_search_begin, owned by the finder).  A fusion queued while the search is in flight -- the next
+  // depth frame of a streaming pipeline -- waits for it on the device instead of being forbidden
+  hipEvent_t planes_read_ev = nullptr;
+  unsigned long long fusion_count = 0;  // fusions / uploads queued so far (a search notices one queued behind its back)
   unsigned profile_mask = 0;
   ProfileSlot prof[FUELMI_K_COUNT];
   // event pair of a single-kernel stage being profiled: the launch site attaches it to the kernel itself
@@ -221,6 +226,14 @@ static inline hipError_t stream_wait(hipStream_t s) {
     if (yld) std::this_thread::yield();
   }
   return hipStreamSynchronize(s);
+}
+
+// to be called by everything that rewrites the occupancy planes, before it queues its kernels
+static inline hipError_t map_wait_plane_readers(fuelmi_map* m) {
+  if (!m->planes_read_ev) return hipSuccess;
+  const hipError_t e = hipStreamWaitEvent(m->stream, m->planes_read_ev, 0);
+  m->planes_read_ev = nullptr;
+  return e;
 }
 
 // ---- device helpers ---------------------------------------------------------------------------

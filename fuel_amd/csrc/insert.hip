@@ -474,6 +474,8 @@ k_insert_update(Geo g, u64* __restrict__ hit, u64* __restrict__ miss, double* __
 // all empty leave the map untouched, like `if (point_num == 0) return;` (:260).
 static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stride, int n, const double cam[3],
                              const DepthArgs* depth, bool counted, int* n_valid) {
+  HIPCHK(map_wait_plane_readers(m));  // (a frontier search in flight still reads the planes this fusion rewrites)
+  ++m->fusion_count;
   const Geo& g = m->g;
   const fuelmi_map_info& I = m->info;
   const signed char num_before = m->raycast_num;

@@ -625,6 +625,8 @@ extern "C" int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ) {
   ARGCHK(m && occ);
   HIPCHK(hipSetDevice(m->device));
   const Geo& g = m->g;
+  HIPCHK(map_wait_plane_readers(m));
+  ++m->fusion_count;
   HIPCHK(hipMemcpyAsync(m->occ, occ, (size_t)g.N * sizeof(double), hipMemcpyHostToDevice, m->stream));
   k_state_planes<<<blocks_for((long)g.W * 64, 256, 65536), 256, 0, m->stream>>>(
       g, m->occ, m->occ_bits.p, m->unk_bits.p, m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3, 0,

@@ -253,8 +253,9 @@ int fuelmi_frontier_search(fuelmi_frontier* f, int* n_new);
  * the frontier's own HIP stream without waiting; _end waits, drops the changed clusters from
  * frontiers_ / dormant_frontiers_ (removed_ids_) and assembles the new ones.  Work queued on the map
  * between the two calls (inflation, ESDF, B-spline evaluation) overlaps the scan, which only reads the
- * occupancy state.  Do not fuse points between _begin and _end; _commit, _reset, _compute_to_visit,
- * _is_covered and a second _begin return FUELMI_EINVAL until _end has been called. */
+ * occupancy state.  The next frame MAY be fused between _begin and _end (a streaming pipeline: fuelmi_bench_stream):
+ * the search reads the occupancy planes only in its first kernels and the fusion waits for those on the device.
+ * _commit, _reset, _compute_to_visit, _is_covered and a second _begin return FUELMI_EINVAL until _end has been called. */
 int fuelmi_frontier_search_begin(fuelmi_frontier* f);
 int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new);
 /* Pipelined delivery for callers that work in cycles (fresh search every cycle): with keep_previous on,
