@@ -761,13 +761,13 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/), else null
         traffic, traffic_commit = None, None
         try:
-            pmc_file = {"G400": "r03_pmc_hbm_traffic_G400.json", "G800": "r03_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
+            pmc_file = {"G400": "r04_pmc_hbm_traffic_G400.json", "G800": "r04_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
             pmc_doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             pmc = pmc_doc["kernels"]
             traffic_commit = pmc_doc.get("commit")
-            key = {"esdf_zy": "k_esdf_zy4<", "esdf_x": "k_esdf_x4", "inflate": "k_inflate_yz",
-                   "bspline": "k_bspline_cost_grad"}[dominant]
-            hit = [v for k, v in pmc.items() if key in k or (dominant == "esdf_zy" and "k_esdf_zy_pk<" in k)]
+            keys = {"esdf_zy": ("k_esdf_zy_pk<", "k_esdf_zy4<"), "esdf_x": ("k_esdf_x_pk<", "k_esdf_x4"),
+                    "inflate": ("k_inflate_fused", "k_inflate_yz"), "bspline": ("k_bspline_cost_grad",)}[dominant]
+            hit = [v for key in keys for k, v in pmc.items() if key in k]
             traffic = hit[0]["hbm_bytes_per_launch"]
         except Exception:
             traffic, traffic_commit = None, None

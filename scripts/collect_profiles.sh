@@ -1,14 +1,17 @@
 #!/bin/bash
-# Round-3 evidence, one gpurun call (COMMIT=<git hash of the code> in the environment stamps every summary): bench lines (headline, big map, sparse regimes, streaming), rocprofv3
-# kernel stats of the same commands (overlapped cycle and serial stages), PMC passes (HBM bytes: FETCH_SIZE and
-# WRITE_SIZE in separate passes; SQ issue / wait cycles in a third), next-row timings, facade bench, fleet test.
-# Everything lands under gpurun_out/prof_r02; scripts/publish_profiles.sh copies the summaries into profiles/.
+# Round-4 evidence, one gpurun call (COMMIT=<git hash of the code> in the environment stamps every summary): bench lines
+# (headline, big map, sparse regimes, streaming, fleet of two on one device), rocprofv3 kernel stats of the same commands
+# (overlapped cycle and serial stages), PMC passes (HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes; SQ issue /
+# wait cycles in a third; SQ instruction counts of the ESDF families in a fourth), cycle timelines, in-kernel phase
+# stamps of the z/y pass, same-box A/B runs of this round's switches, next-row timings, facade bench, fleet / perf tests.
+# Everything lands under gpurun_out/prof_r04; scripts/publish_profiles.sh r04 copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${R:-r03}
+R=${R:-r04}
 export FUELMI_COMMIT=${COMMIT:-unknown}
 O=gpurun_out/prof_$R
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+SQI="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"
 for WL in G400 G800; do
   ST=6; [ $WL = G800 ] && ST=4
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$WL -o s -- python bench.py --workload $WL --no-cpu-baseline --steps $ST --warmup 2 > /dev/null 2>&1
@@ -18,27 +21,57 @@ for WL in G400 G800; do
   cp $O/pmc_hbm_traffic_$WL.json profiles/${R}_pmc_hbm_traffic_$WL.json   # bench.py reads roofline.traffic from here
   python scripts/pmc_sq_summary.py $O/pmc_sq_$WL/s_counter_collection.csv $O/pmc_sq_$WL.json > /dev/null 2>> $O/pmc_sq_$WL.err
 done
+# instruction counts of the z/y and x passes, packed family (0) and 32-bit family (2), ESDF updates only
+for FAM in 0 2; do
+  timeout 300 rocprofv3 --pmc $SQI --output-format csv -d $O/pmc_insts_fam$FAM -o s -- python scripts/esdf_only.py G400 $FAM 4 > /dev/null 2>&1
+done
+python - > $O/esdf_instruction_counts.txt <<'PY'
+import csv, glob, collections
+print("# SQ_INSTS_* per launch (wave instructions, whole dispatch) of the ESDF kernels on the 400x400x100 map, rocprofv3 --pmc, own pass;")
+print("# family 0 = packed 16-bit kernels (k_esdf_zy_pk, k_esdf_x_pk), family 2 = 32-bit kernels (k_esdf_zy4, k_esdf_x4h)")
+for fam in (0, 2):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob("gpurun_out/prof_r04/pmc_insts_fam%d/**/*counter_collection.csv" % fam, recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"].split("(")[0][:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, c in sorted(acc.items()):
+        if "esdf" in k:
+            print("family", fam, k, {n: round(sum(v) / len(v)) for n, v in sorted(c.items())})
+PY
 timeout 300 python bench.py > $O/bench_G400.json 2> $O/bench_G400.err
 timeout 300 python bench.py --workload G800 > $O/bench_G800.json 2> $O/bench_G800.err
 for WL in G400K G400E; do timeout 300 python bench.py --workload $WL --no-cpu-baseline > $O/bench_$WL.json 2>/dev/null; done
 timeout 300 python bench.py --workload G800S > $O/bench_G800S.json 2> $O/bench_G800S.err
+timeout 300 python bench.py --workload G800S --no-cpu-baseline --steps 100 --warmup 10 > $O/bench_G800S_100steps.json 2>/dev/null
 timeout 300 python bench.py --no-cpu-baseline --candidates 1 > $O/bench_G400_C1.json 2>/dev/null
 timeout 300 python bench.py --no-cpu-baseline --candidates 256 > $O/bench_G400_C256.json 2>/dev/null
+FUELMI_FLEET_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --cpu-budget 6 > $O/bench_G400_two_ranks_one_device.json 2> $O/bench_two.err
 for WL in G400 G800; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cycle_$WL -o s -- python bench.py --workload $WL --no-cpu-baseline > $O/bench_${WL}_under_rocprof.json 2>/dev/null
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_$WL -o s -- python bench.py --workload $WL --no-cpu-baseline --serial-stages > /dev/null 2>&1
 done
+{ echo "# two consecutive plan cycles from the middle of the timed region (rocprofv3 --kernel-trace of python bench.py --no-cpu-baseline, commit $FUELMI_COMMIT;"
+  echo "# the profiler slows the host that issues both streams: the period under it is longer than the unprofiled cycle): start [us], duration, queue, kernel"
+  python scripts/cycle_timeline.py $O/cycle_G400/s_kernel_trace.csv; } > $O/cycle_timeline_G400.txt 2>&1
 for WL in G400K G400E; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_$WL -o s -- python bench.py --workload $WL --no-cpu-baseline --serial-stages --steps 20 --warmup 3 > /dev/null 2>&1
 done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -o s -- python bench.py --workload G800S --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -o s -- python bench.py --workload G800S --no-cpu-baseline --steps 40 > /dev/null 2>&1
+{ echo "# two consecutive streaming frames (rocprofv3 --kernel-trace of python bench.py --workload G800S --no-cpu-baseline --steps 40, commit $FUELMI_COMMIT)"
+  python scripts/cycle_timeline.py $O/stream/s_kernel_trace.csv k_insert_classify; } > $O/stream_timeline_G800S.txt 2>&1
+# in-kernel phase stamps of the packed z/y pass, and the ESDF kernels per family (same box)
+{ for WL in G400 G800; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep zy-timing | tail -1 | sed "s/^/$WL /"; done
+  for WL in G400 G800 G400K G400E; do for FAM in 0 2 1; do echo -n "$WL family $FAM: "; python scripts/esdf_only.py $WL $FAM 8; done; done; } > $O/esdf_family_ab.txt 2>&1
+# this round's switches, same box, two repetitions each
+WLARGS="" bash scripts/r4_cycle_ab.sh FUELMI_FR_GRAPH=1 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 FUELMI_X_PK=0 "FUELMI_X_PK=0 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 FUELMI_FR_GRAPH=1" > $O/tuning_ab_cycle.txt 2>&1
 timeout 300 python scripts/bench_next.py > $O/next_rows.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/next -o s -- python scripts/bench_next.py > /dev/null 2>&1
 timeout 300 python scripts/facade_bench.py --map G800S --frames 30 > $O/facade_bench_G800S.json 2> $O/facade_bench.err
 timeout 300 python scripts/facade_bench.py --fullbox G400 > $O/facade_bench_G400_fullbox.json 2>> $O/facade_bench.err
 for RO in 1 2; do timeout 300 python bench.py --workload G800S --no-cpu-baseline --reference-order $RO > $O/bench_G800S_reforder$RO.json 2>/dev/null; done
 timeout 300 python bench.py --no-cpu-baseline --reference-order 1 --steps 20 --warmup 3 > $O/bench_G400_reforder1.json 2>/dev/null
-timeout 300 python -m pytest tests/test_fleet_gpu.py -q -s -m gpu 2>&1 | grep -E "fleet on one device|passed|failed" > $O/fleet_one_device.txt
-for f in bench_G400 bench_G800 bench_G400K bench_G400E bench_G800S; do tail -1 $O/$f.json | cut -c1-160; done
-cat $O/fleet_one_device.txt; tail -1 $O/facade_bench_G800S.json | cut -c1-300
+timeout 300 python -m pytest tests/test_fleet_gpu.py -q -s -m gpu 2>&1 | grep -E "fleet on one device|bench --gpus|passed|failed" > $O/fleet_one_device.txt
+timeout 300 python -m pytest tests/test_perf_gpu.py -q -s -m perf 2>&1 | grep -E "ESDF ms|z/y pass ms|passed|failed" > $O/perf_statements.txt
+for f in bench_G400 bench_G800 bench_G400K bench_G400E bench_G800S bench_G400_two_ranks_one_device; do tail -1 $O/$f.json | cut -c1-160; done
+cat $O/fleet_one_device.txt $O/perf_statements.txt; tail -1 $O/facade_bench_G800S.json | cut -c1-300
 find $O -name "*.csv" | wc -l
