@@ -1526,7 +1526,10 @@ static int launch_x_pk(fuelmi_map* m, const Box3& b) {
                                150 * 1024));  // (the kernel also holds a few bytes of static LDS)
   const int ncol = ylen * zlen_a;
   static const char* th_env = getenv("FUELMI_X_PK_THREADS");  // tuning hook
-  const int threads = th_env ? atoi(th_env) : 256;
+  // 256-thread workgroups while eight of them share a CU's LDS (tiles of up to ~20 KB: lines of up to 320 voxels... in
+  // practice the 400-voxel lines too: 24 waves per CU); longer lines hold fewer tiles per CU and need the bigger
+  // workgroup to keep the wave slots filled (800-voxel lines: 0.236 ms with 512 threads, 0.293 with 256)
+  const int threads = th_env ? atoi(th_env) : (lds > 32 * 1024 ? 512 : 256);
   STAGE_LAUNCH(m, (k_esdf_x_pk<OUT>), (ncol + 31) / 32, threads, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a,
                esdf_stat_dev<OUT>(m), esdf_stat_host(m));
   HIPCHK(hipGetLastError());
