@@ -1176,10 +1176,17 @@ extern "C" int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_
   L.x_out = b->opt_x, L.cost_out = b->opt_cost, L.evals_out = b->opt_evals;
   {
     StageScope sc(m, FUELMI_K_BSPLINE);
-    if (npl == 2)
+    // four waves per candidate shorten ONE solve (the objective's terms side by side); a batch that fills the device
+    // by itself (more candidates than CUs) is faster with one wave each: 1 024 solves 2.5 ms against 7.9
+    const bool wide = A.C <= 256;
+    if (npl == 2 && wide)
       k_bspline_optimize_r<2, 4><<<A.C, 256, lds_opt, m->stream>>>(m->g, m->dist, A, L);
-    else if (npl == 4)
+    else if (npl == 4 && wide)
       k_bspline_optimize_r<4, 4><<<A.C, 256, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+    else if (npl == 2)
+      k_bspline_optimize_r<2, 1><<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
+    else if (npl == 4)
+      k_bspline_optimize_r<4, 1><<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
     else
       k_bspline_optimize<<<A.C, 64, lds_opt, m->stream>>>(m->g, m->dist, A, L);
     HIPCHK(hipGetLastError());
@@ -1292,10 +1299,15 @@ static int bspline_oneshot(fuelmi_map* m, const fuelmi_bspline_cfg* cfg, const f
       L.box_hi[k] = m->cfg.box_max[k] - 0.1;
     }
     L.x_out = o_b, L.cost_out = o_a, L.evals_out = o_e;
-    if (npl == 2)
+    const bool wide = A.C <= 256;
+    if (npl == 2 && wide)
       k_bspline_optimize_r<2, 4><<<A.C, 256, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
-    else if (npl == 4)
+    else if (npl == 4 && wide)
       k_bspline_optimize_r<4, 4><<<A.C, 256, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
+    else if (npl == 2)
+      k_bspline_optimize_r<2, 1><<<A.C, 64, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
+    else if (npl == 4)
+      k_bspline_optimize_r<4, 1><<<A.C, 64, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
     else
       k_bspline_optimize<<<A.C, 64, lds_opt, q.s->st>>>(m->g, m->dist, A, L);
   }

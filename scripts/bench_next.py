@@ -218,6 +218,14 @@ out["full_front_end_cycle"] = {"gpu_ms": float(np.median(tg3[2:]) * 1e3),
 # the same 100 frames with frontier reference_order 0 (address order), 1 (always the BFS order) and 2 (BFS order
 # while every cluster fits the LDS sweep: the facade's default), each on a fresh map, issued by the C++ loop
 row = {}
+# (the maps and finders of the rows above are closed first: HIP multiplexes a process's streams onto a handful of
+# hardware queues, and with enough of them alive a map's stream and its finder's can land on the same queue -- the
+# frame then serialises, 0.11 -> 0.37 ms, scripts/r4_hwq_probe.py; this row is about the cell order, not about that)
+for _o in ("dev3", "gf3", "gm3", "gm2", "devs", "devb", "dev", "gf", "gm"):
+    try:
+        globals()[_o].close()
+    except Exception:
+        pass
 try:
     map_size_s, n_obs_s, _ = bench.WORKLOADS["G800S"]
     box_s = bench.exploration_box(map_size_s)
