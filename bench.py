@@ -222,11 +222,10 @@ class GpuStreamCycle:
         stack = np.ascontiguousarray(np.stack([f[0] for f in frames]).astype(np.uint16))
         self.rows, self.cols = stack.shape[1], stack.shape[2]
         self.dev_frames = fuel_amd.DeviceBuffer(stack, device)
-        self.pinned = stack.copy()
-        fuel_amd._lib.check(self.map.L.fuelmi_host_register(self.pinned.ctypes.data, self.pinned.nbytes))
+        self.pinned = fuel_amd.RegisteredHostBuffer(stack.copy())  # (unregisters itself before its memory is released)
         fb = self.rows * self.cols * 2
         self.ptr = {"device": [self.dev_frames.ptr + i * fb for i in range(len(frames))],
-                    "pinned": [self.pinned.ctypes.data + i * fb for i in range(len(frames))]}
+                    "pinned": [self.pinned.ptr + i * fb for i in range(len(frames))]}
         self.frame_source = "device"
         self.opt = fuel_amd.BsplineOptimizer()
         self.opt.setEnvironment(self.map)
@@ -317,7 +316,7 @@ class GpuStreamCycle:
         for o in (self.dev_problem, self.ff, self.map):
             o.close()
         if self.pinned is not None:
-            self.map.L.fuelmi_host_unregister(self.pinned.ctypes.data)
+            self.pinned.close()
             self.pinned = None
         self.dev_frames = None
 

@@ -24,8 +24,12 @@
 //                    k_bfs_nbr (a lane per cell, nine lower-bound searches side by side) and left as a 24-byte
 //                    record per cell.  k_bfs_sweep then runs the levels with the keys and the queue in LDS (and
 //                    the records too when they fit): a level is one record fetch, LDS atomics and three barriers.
-//   k_bfs_order      larger clusters: keys by voxel address in global memory, membership through the chain's own
-//                    per-voxel records; every step is a round trip to L2 (about 25 us per level).
+//   k_bfs_sweep_g + k_bfs_emit  larger clusters (round 4; the round-2 kernel walked the chain's per-voxel records and
+//                    paid ~25 us per level): the same neighbour records with 32-bit list indices (48 bytes per cell), the
+//                    keys in a dense array by list index (4 bytes per cell: 0.56 MB for the 139 k cells of a surface
+//                    that spans the 400 x 400 x 100 map -- L2-resident), the queue in global memory with its tail
+//                    mirrored in an LDS ring.  A level is one record fetch, atomics that do not return, one round of
+//                    key reads and three barriers: ~2-3 us.  The ordered addresses are written by a grid-wide kernel.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,9 +38,10 @@
 #include "frontier_internal.h"
 
 struct OrderScratch {
-  u32* key = nullptr;     // [N] discovery keys by voxel address (0xFFFFFFFF outside a running sweep); allocated by the
-                          // first search that holds a cluster too large for the LDS sweep
-  u32* ord = nullptr;     // [cap_q + cap_kept] addresses in BFS order (large clusters)
+  u32* key = nullptr;     // [big_cap] discovery keys by grouped position (large clusters; set to "unset" by k_bfs_nbr)
+  u32* ord = nullptr;     // [cap_q + cap_kept] list indices in BFS order (large clusters)
+  u32* nbr32 = nullptr;   // [big_cap][12] neighbour records with 32-bit list indices (large clusters)
+  size_t big_cap = 0;
   u32* h_err = nullptr;   // pinned [4], written by the kernels
   uint2* nbr = nullptr;   // [nbr_cap][3] neighbour records of k_bfs_nbr (grouped cells, then one per cluster for its seed)
   size_t nbr_cap = 0;
@@ -50,6 +55,7 @@ namespace {
 #define BFSL_T 256
 #define BFSL_CAP FR_REFORDER_AUTO  // cells of a cluster ordered inside LDS (6 bytes each: key, queue entry)
 #define BFSL_LDS_MAX (160u * 1024u - 64u)
+#define BFSG_RING 32768u  // queue entries mirrored in LDS (128 KB)
 
 struct BArgs {
   u32* key;
@@ -61,6 +67,7 @@ struct BArgs {
   u32 nq;
   u32 lcap;           // largest cluster of this search that k_bfs_sweep orders
   uint2* nbr;         // neighbour records
+  u32* nbr32;         // ... of the large clusters
   u32* first;
   u32 n_grouped;      // cells in the grouped array; record n_grouped + r belongs to the seed of cluster r
   u32 nkept;
@@ -83,145 +90,14 @@ __device__ __forceinline__ u32 cluster_base(const FArgs& F, u32 r, u32* s_red) {
   return tot;
 }
 
-__device__ __forceinline__ u32 ld_agent(const u32* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// workgroup scope: what one workgroup's waves exchange through global memory between its own barriers (k_bfs_sweep_g).
+// Agent scope would send every atomic and every load past the XCD's L2 to the memory side (multi-XCD coherence):
+// ~8 us per BFS level instead of ~3.
+__device__ __forceinline__ u32 ld_wg(const u32* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void st_agent(u32* p, u32 v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// is the Q0 cell at address a = (xx, yy, .) a member of the cluster?  (fast chain: component of the cell by
-// address -> code of the component; legacy chain: per-cell claimer slot behind the compact index)
-__device__ __forceinline__ bool is_member(const FArgs& F, long a, int xx, int yy, int slot, u32 rank) {
-  if (F.fast) {
-    const FVar& V = *F.var;
-    const int tile = ((xx - V.px0) / V.ftx) * V.nty_f + (yy - V.py0) / V.fty;
-    return F.rcode[F.t_base[tile] + (u32)F.vlab[a]] == rank;
-  }
-  const u32 cj = rank_q(F, a);
-  return cj < F.cap_q && F.cell_slot[cj] == slot;
-}
-
-// member neighbours of the cell at address a, in allNeighbors order: calls fn(idx27, address)
-template <typename Fn>
-__device__ __forceinline__ void for_member_neighbours(const Geo& g, const FArgs& F, long a, int slot, u32 rank, Fn fn) {
-  const int x = (int)(a / g.nyz);
-  const int r = (int)(a - (long)x * g.nyz);
-  const int y = r / g.nz, z = r - y * g.nz;
-  for (int dx = -1; dx <= 1; ++dx) {
-    const int xx = x + dx;
-    if (xx < 0 || xx >= g.nx) continue;
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int yy = y + dy;
-      if (yy < 0 || yy >= g.ny) continue;
-      const long nb0 = a + (long)dx * g.nyz + (long)dy * g.nz - 1;
-      // (fast chain: the Q0 bits live in the per-tile segment arrays; legacy chain: in the Q0 plane)
-      u32 bits = F.fast ? q_bits3(g, *F.var, F, xx, yy, z) : (u32)(plane_window(F.qb, nb0) & 7ull);
-      if (z == 0) bits &= ~1u;
-      if (z == g.nz - 1) bits &= ~4u;
-      if (dx == 0 && dy == 0) bits &= ~2u;
-      while (bits) {
-        const int b = __builtin_ctz(bits);
-        bits &= bits - 1u;
-        if (is_member(F, nb0 + b, xx, yy, slot, rank)) fn((dx + 1) * 9 + (dy + 1) * 3 + b, (u32)(nb0 + b));
-      }
-    }
-  }
-}
-
-__global__ void __launch_bounds__(BFS_T) k_bfs_order(Geo g, FArgs F, BArgs B) {
-  __shared__ u32 s_wave[BFS_T / 64];
-  __shared__ u32 s_run;
-  const u32 r = blockIdx.x;
-  const KeptRec kr = F.krec[r];
-  const int slot = (int)kr.slot;
-  const bool seedc = kr.slot >= B.nq;  // started by an NQ seed: the seed is cells_[0] but not a Q0 cell
-  const u32 want = kr.size;
-  if (want <= BFSL_CAP) return;  // (k_bfs_sweep's)
-  const u32 base0 = cluster_base<BFS_T>(F, r, s_wave);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) {
-    if (!seedc) st_agent(&B.key[kr.addr], 0u);
-    st_agent(&B.ord[base0], kr.addr);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  u32 lev_lo = 0u, lev_hi = 1u;  // positions of the current level inside the cluster (uniform)
-  while (true) {
-    const u32 nL = lev_hi - lev_lo;
-    // ---- A: proposals ----
-    for (u32 j = threadIdx.x; j < nL; j += BFS_T) {
-      const long a = (long)ld_agent(&B.ord[base0 + lev_lo + j]);
-      const u32 kbase = (lev_lo + j) * 27u + 1u;
-      for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 aj) {
-        (void)__hip_atomic_fetch_min(&B.key[aj], kbase + (u32)idx27, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      });
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- B: children of every cell of the level, placed in (parent, neighbour) order ----
-    if (threadIdx.x == 0) s_run = 0u;
-    __syncthreads();
-    for (u32 c0 = 0u; c0 < nL; c0 += BFS_T) {
-      const u32 j = c0 + threadIdx.x;
-      u32 wmask = 0u;
-      long a = 0;
-      if (j < nL) {
-        a = (long)ld_agent(&B.ord[base0 + lev_lo + j]);
-        const u32 kbase = (lev_lo + j) * 27u + 1u;
-        for_member_neighbours(g, F, a, slot, r, [&](int idx27, u32 aj) {
-          if (ld_agent(&B.key[aj]) == kbase + (u32)idx27) wmask |= 1u << idx27;
-        });
-      }
-      const u32 cnt = (u32)__popc(wmask);
-      u32 v = cnt;
-      for (int off = 1; off < 64; off <<= 1) {
-        const u32 t = (u32)__shfl_up((int)v, off, 64);
-        if (lane >= off) v += t;
-      }
-      if (lane == 63) s_wave[wave] = v;
-      __syncthreads();
-      u32 woff = 0u, total = 0u;
-      for (int w = 0; w < BFS_T / 64; ++w) {
-        if (w < wave) woff += s_wave[w];
-        total += s_wave[w];
-      }
-      const u32 run = s_run;
-      u32 pos = base0 + lev_hi + run + woff + (v - cnt);
-      if (wmask) {
-        u32 m = wmask;
-        while (m) {
-          const int idx27 = __builtin_ctz(m);
-          m &= m - 1u;
-          const int dx = idx27 / 9 - 1, dy = (idx27 / 3) % 3 - 1, dz = idx27 % 3 - 1;
-          if (pos < base0 + want)
-            st_agent(&B.ord[pos], (u32)(a + (long)dx * g.nyz + (long)dy * g.nz + dz));
-          else
-            B.err[0] = 1u;  // more cells reached than the cluster holds: cannot happen
-          ++pos;
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) s_run = run + total;
-      __syncthreads();
-    }
-    const u32 grown = s_run;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (grown == 0u) break;
-    lev_lo = lev_hi;
-    lev_hi += grown;
-    if (lev_hi > want) break;  // (error already flagged)
-  }
-  if (lev_hi != want && threadIdx.x == 0) B.err[1] = 1u + r;  // the sweep did not reach every cell of the cluster
-  // ordered addresses + cluster rank of every cell; the keys go back to "unset" for the next search
-  for (u32 k = threadIdx.x; k < want && k < lev_hi; k += BFS_T) {
-    const u32 a = ld_agent(&B.ord[base0 + k]);
-    B.out_adr[base0 + k] = a;
-    B.out_key[base0 + k] = r;
-    if (B.h_out) B.h_out[base0 + k] = a;
-    if (k > 0u || !seedc) B.key[a] = 0xFFFFFFFFu;
-  }
+__device__ __forceinline__ void st_wg(u32* p, u32 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ---- clusters that fit into LDS ----
@@ -252,8 +128,9 @@ __device__ __forceinline__ u32 nbr_index(const NbrSet& s, int idx27) {
   return first + (u32)__popc(below);
 }
 
-__device__ __forceinline__ NbrSet find_neighbours(const Geo& g, const u32* adr, u32 n, int a) {
-  NbrSet s;
+// the block of cell a in the sorted list adr[0..n): returns the 27 presence bits (+ the z-end flags), lo[li] = list
+// index of the first cell at or after the start of line li
+__device__ __forceinline__ u32 find_neighbours_raw(const Geo& g, const u32* adr, u32 n, int a, u32 (&lo)[9]) {
   const int x = a / g.nyz;
   const int rr = a - x * g.nyz;
   const int y = rr / g.nz, z = rr - y * g.nz;
@@ -261,7 +138,6 @@ __device__ __forceinline__ NbrSet find_neighbours(const Geo& g, const u32* adr, 
   while (top * 2u <= n) top *= 2u;
   if (n == 0u) top = 0u;
   int t[9];
-  u32 lo[9];
 #pragma unroll
   for (int li = 0; li < 9; ++li) {
     const int dx = li / 3 - 1, dy = li % 3 - 1;
@@ -288,7 +164,12 @@ __device__ __forceinline__ NbrSet find_neighbours(const Geo& g, const u32* adr, 
   }
   if (z == 0) raw |= 1u << 27;
   if (z == g.nz - 1) raw |= 1u << 28;
-  s.raw = raw;
+  return raw;
+}
+__device__ __forceinline__ NbrSet find_neighbours(const Geo& g, const u32* adr, u32 n, int a) {
+  NbrSet s;
+  u32 lo[9];
+  s.raw = find_neighbours_raw(g, adr, n, a, lo);
   s.lo03 = (unsigned long long)lo[0] | (unsigned long long)lo[1] << 16 | (unsigned long long)lo[2] << 32 |
            (unsigned long long)lo[3] << 48;
   s.lo47 = (unsigned long long)lo[4] | (unsigned long long)lo[5] << 16 | (unsigned long long)lo[6] << 32 |
@@ -297,6 +178,26 @@ __device__ __forceinline__ NbrSet find_neighbours(const Geo& g, const u32* adr, 
   return s;
 }
 
+// large clusters: the same record with 32-bit indices, 12 words (48 bytes, three 16-byte accesses; word 10, 11 unused)
+struct Nbr32 {
+  u32 raw;
+  u32 lo[9];  // (only ever indexed by compile-time constants: registers)
+};
+__device__ __forceinline__ u32 nbr32_valid(u32 raw) {
+  u32 ok = raw & 0x7FFFFFFu & ~(2u << 12);
+  if (raw & (1u << 27)) ok &= ~0x1249249u;
+  if (raw & (1u << 28)) ok &= ~(0x1249249u << 2);
+  return ok;
+}
+__device__ __forceinline__ Nbr32 nbr32_load(const u32* rec) {
+  const uint4 a = reinterpret_cast<const uint4*>(rec)[0], b = reinterpret_cast<const uint4*>(rec)[1],
+              c = reinterpret_cast<const uint4*>(rec)[2];
+  Nbr32 s;
+  s.raw = a.x, s.lo[0] = a.y, s.lo[1] = a.z, s.lo[2] = a.w;
+  s.lo[3] = b.x, s.lo[4] = b.y, s.lo[5] = b.z, s.lo[6] = b.w;
+  s.lo[7] = c.x, s.lo[8] = c.y;
+  return s;
+}
 __device__ __forceinline__ void nbr_store(uint2* rec, const NbrSet& s) {
   rec[0] = make_uint2(s.raw, s.lo8);
   rec[1] = make_uint2((u32)s.lo03, (u32)(s.lo03 >> 32));
@@ -328,13 +229,22 @@ __global__ void __launch_bounds__(256) k_bfs_nbr(Geo g, FArgs F, BArgs B) {
     is_seed = true;
   }
   const KeptRec kr = F.krec[r];
-  if (kr.size > BFSL_CAP) return;
   const bool seedc = kr.slot >= B.nq;
   const u32 n = kr.size - (seedc ? 1u : 0u);
   if (is_seed ? !seedc : p - kr.off >= n) return;
   const u32* list = B.in_adr + kr.off;
   const u32 a = is_seed ? kr.addr : list[p - kr.off];
-  nbr_store(B.nbr + 3 * (size_t)p, find_neighbours(g, list, n, (int)a));
+  if (kr.size > BFSL_CAP) {  // (k_bfs_sweep_g's)
+    u32 lo[9];
+    const u32 raw = find_neighbours_raw(g, list, n, (int)a, lo);
+    uint4* rec = reinterpret_cast<uint4*>(B.nbr32 + 12 * (size_t)p);
+    rec[0] = make_uint4(raw, lo[0], lo[1], lo[2]);
+    rec[1] = make_uint4(lo[3], lo[4], lo[5], lo[6]);
+    rec[2] = make_uint4(lo[7], lo[8], 0u, 0u);
+    B.key[p] = 0xFFFFFFFFu;
+  } else {
+    nbr_store(B.nbr + 3 * (size_t)p, find_neighbours(g, list, n, (int)a));
+  }
   if (is_seed)
     B.first[r] = n;
   else if (!seedc && a == kr.addr)
@@ -471,12 +381,177 @@ __global__ void __launch_bounds__(BFSL_T) k_bfs_sweep(Geo g, FArgs F, BArgs B) {
   }
 }
 
+// ---- larger clusters: keys and queue in global memory (L2), the records of k_bfs_nbr with 32-bit indices ----
+// one workgroup per cluster.  key[i]: discovery key of cell i of the cluster's list (the NQ seed has none: nobody
+// reaches it), ordg[k] = list index of the k-th cell of the queue (n = the seed), mirrored in the LDS ring.
+template <int BFSG_T>
+__global__ void __launch_bounds__(BFSG_T) k_bfs_sweep_g(Geo g, FArgs F, BArgs B) {
+  extern __shared__ __align__(16) u32 ring[];
+  __shared__ u32 s_wave[BFSG_T / 64];
+  const u32 r = blockIdx.x;
+  const KeptRec kr = F.krec[r];
+  const u32 want = kr.size;
+  if (want <= BFSL_CAP) return;  // (k_bfs_sweep's)
+  const bool seedc = kr.slot >= B.nq;
+  const u32 n = want - (seedc ? 1u : 0u);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32* key = B.key + kr.off;
+  const u32* grec = B.nbr32 + 12 * (size_t)kr.off;
+  const u32* srec = B.nbr32 + 12 * ((size_t)B.n_grouped + r);
+  const u32 base0 = cluster_base<BFSG_T>(F, r, s_wave);  // (barriers inside)
+  u32* ordg = B.ord + base0;
+  if (threadIdx.x == 0) {
+    u32 first = B.first[r];
+    if (first > n || (first == n) != seedc) B.err[2] = 1u + r, first = 0u;  // the claimer is a cell of its cluster
+    if (first < n) st_wg(&key[first], 0u);
+    ring[0] = first;
+  }
+  __syncthreads();
+  // The queue lives in the ring; positions [0, flushed) have been copied to ordg.  A level whose children might wrap onto
+  // positions not copied yet ("direct") first copies what is pending and writes its children to ordg as well.
+  u32 lev_lo = 0u, lev_hi = 1u;  // positions of the current level in the queue (uniform)
+  u32 flushed = 0u;
+  u32 n_lev = 0u;
+  bool bad = false;
+  auto flush_to = [&](u32 upto) {  // (every position in [flushed, upto) is intact in the ring: see `direct`)
+    for (u32 k = flushed + threadIdx.x; k < upto; k += BFSG_T) st_wg(&ordg[k], ring[k & (BFSG_RING - 1u)]);
+    flushed = upto;
+  };
+  while (true) {
+    const u32 nL = lev_hi - lev_lo;
+    ++n_lev;
+    const u32 maxrun = min(26u * nL, want - lev_hi);
+    const bool direct = lev_hi + maxrun - flushed > BFSG_RING;
+    // the level is read from the ring when nothing written during this level can wrap onto it
+    const bool in_ring = nL + maxrun <= BFSG_RING;
+    if (direct) {
+      flush_to(lev_hi);
+      if (!in_ring) __syncthreads();  // (the level is about to be read back from ordg)
+    }
+    auto cell_at = [&](u32 pos) { return in_ring ? ring[pos & (BFSG_RING - 1u)] : ld_wg(&ordg[pos]); };
+    Nbr32 keep;  // the record of this lane's first cell of the level, fetched once for both passes
+    keep.raw = 0u;
+#pragma unroll
+    for (int li = 0; li < 9; ++li) keep.lo[li] = 0u;
+    // ---- A: proposals ----
+    for (u32 j = threadIdx.x; j < nL; j += BFSG_T) {
+      const u32 ci = cell_at(lev_lo + j);
+      const Nbr32 s = nbr32_load(ci < n ? grec + 12 * (size_t)ci : srec);
+      if (j < BFSG_T) keep = s;
+      const u32 kbase = (lev_lo + j) * 27u + 1u;
+      const u32 ok = nbr32_valid(s.raw);
+#pragma unroll
+      for (int li = 0; li < 9; ++li) {
+        const u32 bits = (s.raw >> (3 * li)) & 7u;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          if ((ok >> (3 * li + b)) & 1u)
+            (void)__hip_atomic_fetch_min(&key[s.lo[li] + (u32)__popc(bits & ((1u << b) - 1u))], kbase + (u32)(3 * li + b),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+    // ---- B: children of every cell of the level, placed in (parent, neighbour) order ----
+    u32 run = 0u;
+    for (u32 c0 = 0u; c0 < nL; c0 += BFSG_T) {
+      const u32 j = c0 + threadIdx.x;
+      u32 wmask = 0u;
+      Nbr32 s = keep;
+      if (j < nL) {
+        if (c0) {
+          const u32 ci = cell_at(lev_lo + j);
+          s = nbr32_load(ci < n ? grec + 12 * (size_t)ci : srec);
+        }
+        const u32 kbase = (lev_lo + j) * 27u + 1u;
+        const u32 ok = nbr32_valid(s.raw);
+        u32 kv[27];  // the keys of the present neighbours, all requested before the first is looked at
+#pragma unroll
+        for (int li = 0; li < 9; ++li) {
+          const u32 bits = (s.raw >> (3 * li)) & 7u;
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const u32 idx = s.lo[li] + (u32)__popc(bits & ((1u << b) - 1u));
+            kv[3 * li + b] = 0u;
+            if ((ok >> (3 * li + b)) & 1u) kv[3 * li + b] = ld_wg(&key[idx]);
+          }
+        }
+#pragma unroll
+        for (int i27 = 0; i27 < 27; ++i27)
+          if (kv[i27] == kbase + (u32)i27) wmask |= ok & (1u << i27);
+      }
+      const u32 cnt = (u32)__popc(wmask);
+      u32 v = cnt;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const unsigned long long bal = __ballot((cnt >> b) & 1u);
+        v += (u32)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)) << b;
+      }
+      if (c0) __syncthreads();  // (the sums of the previous chunk have been read)
+      if (lane == 63) s_wave[wave] = v;
+      __syncthreads();
+      u32 woff = 0u, total = 0u;
+      for (int w = 0; w < BFSG_T / 64; ++w) {
+        if (w < wave) woff += s_wave[w];
+        total += s_wave[w];
+      }
+      u32 pos = lev_hi + run + woff + (v - cnt);
+      if (wmask) {
+#pragma unroll
+        for (int li = 0; li < 9; ++li) {
+          const u32 bits = (s.raw >> (3 * li)) & 7u;
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            if ((wmask >> (3 * li + b)) & 1u) {
+              const u32 idx = s.lo[li] + (u32)__popc(bits & ((1u << b) - 1u));
+              if (pos < want) {
+                ring[pos & (BFSG_RING - 1u)] = idx;
+                if (direct) st_wg(&ordg[pos], idx);
+              } else {
+                bad = true;  // more cells reached than the cluster holds: cannot happen
+              }
+              ++pos;
+            }
+        }
+      }
+      run += total;
+    }
+    __syncthreads();
+    if (direct) flushed = min(lev_hi + run, want);
+    if (run == 0u) break;
+    lev_lo = lev_hi;
+    lev_hi += run;
+    if (lev_hi > want) break;
+  }
+  if (lev_hi <= want) flush_to(lev_hi);
+  if (bad) B.err[0] = 1u;
+  if (lev_hi != want && threadIdx.x == 0) B.err[1] = 1u + r;  // the sweep did not reach every cell of the cluster
+  if (threadIdx.x == 0) B.err[3] = n_lev;  // (diagnostics: FUELMI_FR_TIMING)
+}
+
+// ordered addresses + cluster rank of every cell of the large clusters (grid: chunks x clusters)
+__global__ void __launch_bounds__(256) k_bfs_emit(Geo g, FArgs F, BArgs B) {
+  __shared__ u32 s_red[4];
+  const u32 r = blockIdx.y;
+  const KeptRec kr = F.krec[r];
+  const u32 want = kr.size;
+  if (want <= BFSL_CAP) return;
+  const u32 n = want - (kr.slot >= B.nq ? 1u : 0u);
+  const u32 base0 = cluster_base<256>(F, r, s_red);
+  for (u32 k = blockIdx.x * 256u + threadIdx.x; k < want; k += gridDim.x * 256u) {
+    const u32 ci = B.ord[base0 + k];
+    const u32 a = ci < n ? B.in_adr[kr.off + ci] : kr.addr;
+    B.out_adr[base0 + k] = a;
+    B.out_key[base0 + k] = r;
+    if (B.h_out) B.h_out[base0 + k] = a;
+  }
+}
+
 }  // namespace
 
 void frontier_order_free(fuelmi_frontier* f) {
   OrderScratch* o = f->order;
   if (!o) return;
-  void* dev[] = {o->key, o->ord, o->nbr, o->first};
+  void* dev[] = {o->key, o->ord, o->nbr, o->nbr32, o->first};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (o->h_err) (void)hipHostFree(o->h_err);
@@ -492,7 +567,7 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
   if (!f->order) {
     OrderScratch* o = new OrderScratch;
     f->order = o;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&o->h_err), 4 * sizeof(u32), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&o->h_err), 16 * sizeof(u32), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->first), (size_t)F.cap_kept * sizeof(u32)));
   }
   OrderScratch* o = f->order;
@@ -524,39 +599,62 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
   B.out_adr = F.ms_val[1 - fin], B.out_key = F.ms_key[1 - fin];
   B.h_out = fetch_cells ? F.h_cells : nullptr;  // (written by the kernels themselves: no copy engine, no second wait)
   B.nq = nq, B.lcap = lcap, B.err = o->h_err;
-  B.nbr = nullptr, B.first = nullptr, B.n_grouped = 0u, B.nkept = nkept, B.nbr_in_lds = 0;
+  B.nbr = nullptr, B.nbr32 = nullptr, B.first = o->first, B.n_grouped = n_grouped, B.nkept = nkept, B.nbr_in_lds = 0;
   for (int k = 0; k < 4; ++k) o->h_err[k] = 0u;  // (the kernels of the previous search are long done)
+  const size_t need = (size_t)n_grouped + nkept;
+  if (lcap && need > o->nbr_cap) {  // (grown by need: 24 bytes per cell of the largest search so far)
+    if (o->nbr) HIPCHK(hipFree(o->nbr));
+    o->nbr = nullptr, o->nbr_cap = 0;
+    const size_t cap = std::max<size_t>(need + need / 2, 1u << 16);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->nbr), cap * 3 * sizeof(uint2)));
+    o->nbr_cap = cap;
+  }
+  if (any_big && need > o->big_cap) {  // (52 bytes per cell: records and keys)
+    if (o->nbr32) HIPCHK(hipFree(o->nbr32));
+    if (o->key) HIPCHK(hipFree(o->key));
+    o->nbr32 = o->key = nullptr, o->big_cap = 0;
+    const size_t cap = std::max<size_t>(need + need / 2, 1u << 16);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->nbr32), cap * 12 * sizeof(u32)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->key), cap * sizeof(u32)));
+    o->big_cap = cap;
+  }
+  if (any_big && !o->ord) HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->ord), ((size_t)F.cap_q + F.cap_kept) * sizeof(u32)));
+  B.nbr = o->nbr, B.nbr32 = o->nbr32, B.key = o->key, B.ord = o->ord;
+  k_bfs_nbr<<<(u32)((need + 255) / 256), 256, 0, st>>>(m->g, F, B);
+  HIPCHK(hipGetLastError());
   if (lcap) {
-    const size_t need = (size_t)n_grouped + nkept;
-    if (need > o->nbr_cap) {  // (grown by need: 24 bytes per cell of the largest search so far)
-      if (o->nbr) HIPCHK(hipFree(o->nbr));
-      o->nbr = nullptr, o->nbr_cap = 0;
-      const size_t cap = std::max<size_t>(need + need / 2, 1u << 16);
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->nbr), cap * 3 * sizeof(uint2)));
-      o->nbr_cap = cap;
-    }
-    B.nbr = o->nbr, B.first = o->first, B.n_grouped = n_grouped, B.nkept = nkept;
     const size_t base = (((size_t)lcap + 2) & ~(size_t)1) * 4 + ((size_t)lcap + 1) * 2 + 16;
     B.nbr_in_lds = base + ((size_t)lcap + 1) * 24 <= BFSL_LDS_MAX ? 1 : 0;
     const size_t lds = base + (B.nbr_in_lds ? ((size_t)lcap + 1) * 24 : 0);
     if (!o->lds_attr) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bfs_sweep), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)BFSL_LDS_MAX));
+      for (const void* fn : {reinterpret_cast<const void*>(&k_bfs_sweep_g<256>), reinterpret_cast<const void*>(&k_bfs_sweep_g<512>),
+                             reinterpret_cast<const void*>(&k_bfs_sweep_g<1024>)})
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BFSG_RING * sizeof(u32))));
       o->lds_attr = true;
     }
-    k_bfs_nbr<<<(u32)((need + 255) / 256), 256, 0, st>>>(m->g, F, B);
-    HIPCHK(hipGetLastError());
     k_bfs_sweep<<<nkept, BFSL_T, lds, st>>>(m->g, F, B);
     HIPCHK(hipGetLastError());
   }
   if (any_big) {
-    if (!o->key) {
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->key), (size_t)m->g.N * sizeof(u32)));
-      HIPCHK(hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&o->ord), ((size_t)F.cap_q + F.cap_kept) * sizeof(u32)));
-      B.key = o->key, B.ord = o->ord;
+    if (!o->lds_attr) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bfs_sweep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)BFSL_LDS_MAX));
+      for (const void* fn : {reinterpret_cast<const void*>(&k_bfs_sweep_g<256>), reinterpret_cast<const void*>(&k_bfs_sweep_g<512>),
+                             reinterpret_cast<const void*>(&k_bfs_sweep_g<1024>)})
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BFSG_RING * sizeof(u32))));
+      o->lds_attr = true;
     }
-    k_bfs_order<<<nkept, BFS_T, 0, st>>>(m->g, F, B);
+    static const int bt = getenv("FUELMI_BFSG_T") ? atoi(getenv("FUELMI_BFSG_T")) : 512;  // tuning hook
+    if (bt == 1024)
+      k_bfs_sweep_g<1024><<<nkept, 1024, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
+    else if (bt == 512)
+      k_bfs_sweep_g<512><<<nkept, 512, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
+    else
+      k_bfs_sweep_g<256><<<nkept, 256, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
+    HIPCHK(hipGetLastError());
+    k_bfs_emit<<<dim3(64, nkept), 256, 0, st>>>(m->g, F, B);
     HIPCHK(hipGetLastError());
   }
   for (;;) {  // (poll: a blocking synchronisation adds ~15 us of wake-up to a sweep of a few hundred)
@@ -569,8 +667,6 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
                  nkept, total, lcap, o->h_err[3], any_big ? 1 : 0,
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   if (o->h_err[0] || o->h_err[1] || o->h_err[2]) {
-    if (o->key)
-      (void)hipMemsetAsync(o->key, 0xFF, (size_t)m->g.N * sizeof(u32), st);  // (a sweep that stopped half-way leaves keys behind)
     fuelmi_set_error("reference order: the level sweep of cluster %u did not match its cell set",
                      (o->h_err[1] ? o->h_err[1] : o->h_err[2]) - 1u);
     return FUELMI_EHIP;

@@ -277,6 +277,31 @@ class DeviceBuffer:
             pass
 
 
+class RegisteredHostBuffer:
+    """A numpy array registered with the device (fuelmi_host_register: a camera driver's frame ring, read in place by
+    the fusion kernels).  The registration is undone BEFORE the array's memory goes back to the allocator -- by close()
+    or, at the latest, when this object dies: a registration that outlives its memory stays in the HIP runtime's
+    address map, and a later pageable copy from whatever the allocator puts there fails with "invalid argument"."""
+
+    def __init__(self, array):
+        self.array = np.ascontiguousarray(array)
+        self.L = lib()
+        check(self.L.fuelmi_host_register(self.array.ctypes.data, self.array.nbytes))
+        self.ptr, self.nbytes = self.array.ctypes.data, self.array.nbytes
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.L.fuelmi_host_unregister(C.c_void_p(self.ptr))
+            self.ptr = None
+        self.array = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class EDTEnvironment:
     """fast_planner::EDTEnvironment: distance/gradient query facade over SDFMap."""
 

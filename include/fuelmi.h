@@ -100,7 +100,9 @@ typedef struct {
  * (read in place); in the last two cases the caller leaves it unchanged until its next call on this map.  Projects on the device and fuses the points without a host round
  * trip; a frame taken from outside the map is ignored like the reference does.  *n_points (may be
  * NULL) receives proj_points_cnt.  Follow with fuelmi_map_inflate_local (local_updated_ branch). */
-int fuelmi_host_register(void* ptr, size_t bytes); /* hipHostRegister(mapped) of a frame ring; undo with _unregister */
+int fuelmi_host_register(void* ptr, size_t bytes); /* hipHostRegister(mapped) of a frame ring; undo with _unregister
+                                                     * BEFORE the memory is freed (a registration that outlives its
+                                                     * memory makes later copies from that address range fail) */
 int fuelmi_host_unregister(void* ptr);
 /* plain device buffers for callers without a HIP runtime of their own (tests, bench.py) */
 int fuelmi_device_alloc(int device, size_t bytes, void** out);

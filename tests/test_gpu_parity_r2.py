@@ -487,8 +487,8 @@ def test_depth_frames_read_in_place_give_the_same_map(fa, where):
         dev = fa.DeviceBuffer(stack)
         base = dev.ptr
     else:
-        check(gm.L.fuelmi_host_register(stack.ctypes.data, stack.nbytes))
-        base = stack.ctypes.data
+        ring = fa.RegisteredHostBuffer(stack)
+        base = ring.ptr
     try:
         for k, (img, pos, q) in enumerate(frames):
             pts = fo.project_depth(img, pos, q, ocfg)
@@ -498,7 +498,7 @@ def test_depth_frames_read_in_place_give_the_same_map(fa, where):
         gm.synchronize()
     finally:
         if where == "registered":
-            check(gm.L.fuelmi_host_unregister(stack.ctypes.data))
+            ring.close()
     assert np.array_equal(gm.syncHost(occupancy=True)["occupancy"], om.occ)
     gm.close()
 
@@ -525,9 +525,9 @@ def test_cpp_streaming_loop_equals_the_call_sequence(fa):
         cost, _ = cyc.dev_problem.download()
         out.append((cyc.map.syncHost(occupancy=True, distance=True), [c.copy() for c in cyc.ff.clusters(1)], cost.copy(),
                     cyc.n_clusters))
-        cyc.dev_problem.close()
-        cyc.ff.close()
-        cyc.map.close()
+        cyc.close()  # (also undoes the registration of the host frame ring -- round 4: this test used to close the
+        #              objects one by one and left the ring registered; its freed memory then poisoned whichever later
+        #              test's numpy array the allocator placed there: "hipMemcpyAsync invalid argument", 1 run in 8)
     a, b = out
     assert np.array_equal(a[0]["occupancy"], b[0]["occupancy"])
     assert np.array_equal(a[0]["distance"], b[0]["distance"])

@@ -291,6 +291,19 @@ def test_reference_order_auto_reports_the_order_it_delivered(fa):
     last, n_ref, n_fallback, cells = gf.orderStats()
     assert (last, n_ref, n_fallback, cells) == (0, 0, 1, big)
     gf.close()
+    # (c) the same search with reference_order = 1: the cluster above the LDS limit is swept through global memory
+    # (k_bfs_sweep_g) and comes out in expandFrontier's order, sequential means included
+    gf = fa.FrontierFinder(gm, cluster_min=100, reference_order=1)
+    gm.setUpdatedBox(*box)
+    assert gf.searchFrontiers() == len(ca)
+    cb = gf.clusters(0)
+    for k, (a, b) in enumerate(zip(ca, cb)):
+        assert np.array_equal(a, b), "cluster %d (%d cells): order differs" % (k, len(a))
+    kbig = int(np.argmax([len(c) for c in ca]))
+    for x, y in zip(of.cluster_info(0, kbig), gf.clusterInfo(0, kbig)):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), "average_/box of the large cluster not bit-equal"
+    assert gf.orderStats()[:2] == (1, 1)
+    gf.close()
     # an invalid mode is refused, not treated as 0
     L = lib()
     cfg = fa._lib.FrontierCfg(100, 0.4, -1.0, -1, 0, 3)
