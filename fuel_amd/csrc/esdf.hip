@@ -1288,6 +1288,36 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   return FUELMI_OK;
 }
 
+// FUELMI_ZY_TIMING: a pass has left four 100 MHz stamps per workgroup (start, tile filled, barrier passed, done)
+static int pass_timing_report(fuelmi_map* m, unsigned long long* dbg, int grid, const char* what) {
+  HIPCHK(hipStreamSynchronize(m->stream));
+  std::vector<unsigned long long> d((size_t)grid * 8);
+  HIPCHK(hipMemcpy(d.data(), dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(dbg));
+  unsigned long long t0 = ~0ull, t1 = 0;
+  double ph[3] = {0, 0, 0}, life = 0;
+  int n = 0;
+  for (int w = 0; w < grid; ++w) {
+    const unsigned long long* r = &d[(size_t)w * 8];
+    if (!r[0] || !r[3]) continue;
+    t0 = std::min(t0, r[0]), t1 = std::max(t1, r[3]);
+    ph[0] += (double)(r[1] - r[0]), ph[1] += (double)(r[2] - r[1]), ph[2] += (double)(r[3] - r[2]), life += (double)(r[3] - r[0]);
+    ++n;
+  }
+  int alive = 0, early = 0;
+  const unsigned long long mid = t0 + (t1 - t0) / 2;
+  for (int w = 0; w < grid; ++w) {
+    const unsigned long long* r = &d[(size_t)w * 8];
+    if (!r[0] || !r[3]) continue;
+    if (r[0] <= mid && r[3] >= mid) ++alive;
+    if (r[0] - t0 < 100) ++early;
+  }
+  std::fprintf(stderr, "[%s: %d workgroups, span %.2f us; per workgroup: fill %.2f barrier %.2f scan %.2f life %.2f us; "
+               "alive at mid-span %d, started in the first us %d\n", what, n, (double)(t1 - t0) / 100.0, ph[0] / n / 100.0,
+               ph[1] / n / 100.0, ph[2] / n / 100.0, life / n / 100.0, alive, early);
+  return FUELMI_OK;
+}
+
 // packed plain z/y pass (k_esdf_zy_pk): ESDF_NO_FIT when the box is not its kind (z extents above 255 voxels,
 // nz % 4 != 0, y lines too long for the tile)
 template <int MODE, int G, int NW>
@@ -1307,31 +1337,9 @@ static int launch_zy_pk_g(fuelmi_map* m, const Box3& b, int nzc, int z0a, int th
                (const u64*)m->unk_bits.p, m->esdf_tmp, nzc, z0a, zy_fastrow() ? 1 : 0, MODE == 2 ? nullptr : esdf_stat_dev<0>(m), dbg);
   HIPCHK(hipGetLastError());
   if (timing) {
-    HIPCHK(hipStreamSynchronize(m->stream));
-    std::vector<unsigned long long> d((size_t)grid * 8);
-    HIPCHK(hipMemcpy(d.data(), dbg, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(dbg));
-    unsigned long long t0 = ~0ull, t1 = 0;
-    double ph[3] = {0, 0, 0}, life = 0;
-    int n = 0;
-    for (int w = 0; w < grid; ++w) {
-      const unsigned long long* r = &d[(size_t)w * 8];
-      if (!r[0] || !r[3]) continue;
-      t0 = std::min(t0, r[0]), t1 = std::max(t1, r[3]);
-      ph[0] += (double)(r[1] - r[0]), ph[1] += (double)(r[2] - r[1]), ph[2] += (double)(r[3] - r[2]), life += (double)(r[3] - r[0]);
-      ++n;
-    }
-    int alive = 0, early = 0;
-    const unsigned long long mid = t0 + (t1 - t0) / 2;
-    for (int w = 0; w < grid; ++w) {
-      const unsigned long long* r = &d[(size_t)w * 8];
-      if (!r[0] || !r[3]) continue;
-      if (r[0] <= mid && r[3] >= mid) ++alive;
-      if (r[0] - t0 < 100) ++early;
-    }
-    std::fprintf(stderr, "[zy-timing] G %d threads %d lds %zu: %d workgroups, span %.2f us; per workgroup: fill %.2f "
-                 "barrier %.2f scan %.2f life %.2f us; alive at mid-span %d, started in the first us %d\n", G, threads, lds, n,
-                 (double)(t1 - t0) / 100.0, ph[0] / n / 100.0, ph[1] / n / 100.0, ph[2] / n / 100.0, life / n / 100.0, alive, early);
+    char what[96];
+    std::snprintf(what, sizeof what, "zy-timing] G %d threads %d lds %zu", G, threads, lds);
+    { const int rc_ = pass_timing_report(m, dbg, grid, what); if (rc_ != FUELMI_OK) return rc_; }
   }
   return FUELMI_OK;
 }
@@ -1426,7 +1434,7 @@ __device__ __forceinline__ u32 pk_pack_sat(u32 lo, u32 hi) { return min(lo, PK_I
 template <int OUT>
 __global__ void __launch_bounds__(512)
 k_esdf_x_pk(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, u32* stat,
-            volatile u32* h_stat) {
+            volatile u32* h_stat, unsigned long long* __restrict__ dbg) {
   constexpr int SEGS = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   forward_stat(stat, h_stat);
@@ -1439,6 +1447,8 @@ k_esdf_x_pk(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist
   const int total = npx * SEGS;
   const float resf = (float)g.res;
   __shared__ u32 s_colfin;  // bit c: column c of the tile holds a finite value
+  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;  // (FUELMI_ZY_TIMING)
+  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
   if (threadIdx.x == 0) s_colfin = 0u;
   __syncthreads();
   u32 finbits = 0u;
@@ -1461,7 +1471,9 @@ k_esdf_x_pk(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist
     tile[o] = pk;
   }
   if (finbits) atomicOr(&s_colfin, finbits);
+  if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
   __syncthreads();
+  if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
   const u32 colfin = s_colfin;
   const int any_src = colfin != 0u;
   if (any_src && colfin != 0xFFFFFFFFu) {
@@ -1511,6 +1523,7 @@ k_esdf_x_pk(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist
     x_store4<OUT>(dst, z, b.lo[2], b.hi[2], ra, resf);
     if (2 * p + 1 < xlen) x_store4<OUT>(dst + g.nyz, z, b.lo[2], b.hi[2], rb, resf);
   }
+  if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
 }
 template <int OUT>
 static int launch_x_pk(fuelmi_map* m, const Box3& b) {
@@ -1530,9 +1543,21 @@ static int launch_x_pk(fuelmi_map* m, const Box3& b) {
   // practice the 400-voxel lines too: 24 waves per CU); longer lines hold fewer tiles per CU and need the bigger
   // workgroup to keep the wave slots filled (800-voxel lines: 0.236 ms with 512 threads, 0.293 with 256)
   const int threads = th_env ? atoi(th_env) : (lds > 32 * 1024 ? 512 : 256);
-  STAGE_LAUNCH(m, (k_esdf_x_pk<OUT>), (ncol + 31) / 32, threads, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a,
-               esdf_stat_dev<OUT>(m), esdf_stat_host(m));
+  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
+  const int grid = (ncol + 31) / 32;
+  unsigned long long* dbg = nullptr;
+  if (timing) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)grid * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
+  }
+  STAGE_LAUNCH(m, (k_esdf_x_pk<OUT>), grid, threads, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a,
+               esdf_stat_dev<OUT>(m), esdf_stat_host(m), dbg);
   HIPCHK(hipGetLastError());
+  if (timing) {
+    char what[96];
+    std::snprintf(what, sizeof what, "x-timing] threads %d lds %zu", threads, lds);
+    { const int rc_ = pass_timing_report(m, dbg, grid, what); if (rc_ != FUELMI_OK) return rc_; }
+  }
   return FUELMI_OK;
 }
 
