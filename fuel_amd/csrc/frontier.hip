@@ -180,6 +180,41 @@ k_rm_pool(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u64* 
     if (d_mark[k] == mark) atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
   }
 }
+// both modes in ONE workgroup for the searches of an exploration (a few thousand pooled cells in the clusters the updated
+// box touches: one launch instead of two dependent ones -- the first kernels of a streaming frame's critical path).
+// The marks live in LDS; h_changed[k] is written as by MODE 0.
+#define RM_ONE_T 1024
+#define RM_ONE_CELLS (16 * RM_ONE_T)
+__global__ void __launch_bounds__(RM_ONE_T)
+k_rm_pool_one(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u64* flag, const u32* __restrict__ pool,
+              const RmCand* __restrict__ cand, int ncand, u32 total, int* h_changed) {
+  __shared__ u32 s_start[RM_LDS];
+  __shared__ u64 s_off[RM_LDS];
+  __shared__ u32 s_mark[RM_LDS];
+  for (int k = threadIdx.x; k < ncand; k += RM_ONE_T) {
+    const RmCand c = cand[k];
+    s_start[k] = c.start;
+    s_off[k] = c.off;
+    s_mark[k] = 0u;
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < total; i += RM_ONE_T) {
+    const int k = rm_cluster_of(s_start, ncand, i);
+    const u32 a = pool[s_off[k] + (i - s_start[k])];
+    if (!f1_cell(g, occ, unk, a) && s_mark[k] == 0u) {
+      s_mark[k] = 1u;
+      h_changed[k] = 1;
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < total; i += RM_ONE_T) {
+    const int k = rm_cluster_of(s_start, ncand, i);
+    if (s_mark[k]) {
+      const u32 a = pool[s_off[k] + (i - s_start[k])];
+      atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
+    }
+  }
+}
 __global__ void k_pool_put(u32* __restrict__ pool, const u32* __restrict__ cells, const PoolPut* __restrict__ table) {
   const PoolPut e = table[blockIdx.x];  // one workgroup per cluster (the table sits in pinned host memory)
   u32* dst = pool + e.dst;
@@ -3066,6 +3101,13 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
     HIPCHK(hipMemcpyAsync(f->d_stage, hc, nc * sizeof(RmCand), hipMemcpyHostToDevice, f->stream));
     hc = reinterpret_cast<RmCand*>(f->d_stage);
   }
+  static const bool one_off = getenv("FUELMI_RM_TWO_PASS") != nullptr;  // A/B switch
+  if (nc <= RM_LDS && total <= RM_ONE_CELLS && !one_off) {
+    k_rm_pool_one<<<1, RM_ONE_T, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc, (int)nc, total,
+                                                 f->h_changed);
+    FDBG("k_rm_pool_one");
+    return FUELMI_OK;
+  }
   const int mark = ++f->rm_mark;  // (marks of earlier searches never match: no clearing pass)
   k_rm_pool<0><<<fblocks((long)total, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc,
                                                                (int)nc, total, f->d_mark, mark, f->h_changed);
@@ -3166,6 +3208,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   const int tiles = ((qx + ftx - 1) / ftx) * ((qy + fty - 1) / fty);
   // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
   const int* nt3 = f->ft_threads;  // (per finder, fixed at creation: ADVICE r3 -- a process-wide static took the first finder's)
+  if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[0], f->stream));
   if (nt3[0] == 256)
     k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   else
@@ -3177,6 +3220,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   if (!capturing) {
     HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
     f->map->planes_read_ev = f->ev_planes_read;
+    if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
   }
   if (nt3[1] == 256)
     k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F);
@@ -3185,11 +3229,13 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   FDBG("k_tile_cross");
   k_resolve<<<1, RS_T, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
+  if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[2], f->stream));
   if (nt3[2] == 256)
     k_tile_out<256><<<tiles, 256, f->out_lds[mk], f->stream>>>(g, F);
   else
     k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
   FDBG("k_tile_out");
+  if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[3], f->stream));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -4153,38 +4199,128 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   const auto t0 = std::chrono::steady_clock::now();
   // Frame k + 1 is fused while the search of frame k is still running: the search reads the occupancy planes only in
   // its first kernels, the fusion waits for those ON THE DEVICE (map_wait_plane_readers), and the host's wait for the
-  // fused frame's box (which the next search needs) falls beside the chain instead of in front of it.  Same calls,
-  // same arguments, same results as the frame-by-frame order (serial != 0 keeps that order for diagnostics).
+  // fused frame's box (which the next search needs) falls beside the chain instead of in front of it.  The map chain
+  // of a frame (inflation, ESDF, B-spline batch) is issued the moment its fusion has handed the box over, then the
+  // search bookkeeping of the previous frame (collect, commit) and the launch of this frame's search.  The frame is
+  // bound by the host's ~55 us of API calls plus the device's fusion -> plane-reading kernels -> fusion chain
+  // (FUELMI_STREAM_TIMING=1: host time per call group, =2: also a device timeline from events), and the order of the
+  // call groups does not matter to it (FUELMI_STREAM_OLD_ORDER=1: search first, as in round 3 -- same rate).  Same
+  // calls, same arguments, same results as the frame-by-frame order (serial != 0 keeps that order for diagnostics).
+  static const bool old_order = getenv("FUELMI_STREAM_OLD_ORDER") != nullptr;
   int npts = 0;
   if (n > 0)
     rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[0]), rows, cols, cfg, cam_pos3, cam_q4, &npts);
-  for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
-    if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
+  auto map_chain = [&]() -> int {
+    int r = FUELMI_OK;
     if (npts > 0) {
       int lo[3], hi[3];
-      if ((rc = fuelmi_map_get_local_bound(m, lo, hi))) break;
+      if ((r = fuelmi_map_get_local_bound(m, lo, hi))) return r;
       vox += (double)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
-      if ((rc = fuelmi_map_inflate_local(m))) break;
-      if ((rc = fuelmi_map_update_esdf(m))) break;
+      if ((r = fuelmi_map_inflate_local(m))) return r;
+      if ((r = fuelmi_map_update_esdf(m))) return r;
     }
-    if (batch && (rc = fuelmi_bspline_dev_eval(batch))) break;
-    int npts_next = 0;
-    if (serial) {
+    if (batch) r = fuelmi_bspline_dev_eval(batch);
+    return r;
+  };
+  auto fuse_next = [&](int k, int* np) -> int {
+    return fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k + 1]), rows, cols, cfg, cam_pos3 + 3 * (k + 1),
+                                  cam_q4 + 4 * (k + 1), np);
+  };
+  if (serial || old_order) {
+    for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
+      if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
+      if ((rc = map_chain())) break;
+      int npts_next = 0;
+      if (serial) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if ((rc = fuelmi_frontier_search_begin(f))) break;
+      } else if (k + 1 < n) {
+        if ((rc = fuse_next(k, &npts_next))) break;
+      }
+      if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
+      if ((rc = fuelmi_frontier_commit(f, 0))) break;
+      if (serial && k + 1 < n && (rc = fuse_next(k, &npts_next))) break;
+      npts = npts_next;
+    }
+  } else {
+    static const bool timing = getenv("FUELMI_STREAM_TIMING") != nullptr;  // host wall clock of every call of the loop
+    double acc[5] = {0, 0, 0, 0, 0};
+    auto tick = [&](int slot, std::chrono::steady_clock::time_point& t) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      acc[slot] += std::chrono::duration<double, std::micro>(now - t).count();
+      t = now;
+    };
+    static const bool timeline = timing && atoi(getenv("FUELMI_STREAM_TIMING")) >= 2;  // + device timeline (events)
+    std::vector<hipEvent_t> tl;  // per frame: chain start, planes read, resolved, tail done, fusion done, map chain done
+    if (timeline) {
+      tl.resize((size_t)n * 6);
+      for (auto& e : tl) HIPCHK(hipEventCreate(&e));
+    }
+    // (Round 4 also tried a second host thread for the search bookkeeping, like the reference's separate map and
+    // planning callbacks: launches from two threads serialise inside the HIP runtime and each gets slower -- 7.4 k
+    // frames/s against 8.1 k.  One thread issues everything.)
+    auto bookkeeping = [&](int k) -> int {
+      int r = FUELMI_OK;
+      if (k > 0) {
+        if ((r = fuelmi_frontier_search_end(f, &ncl))) return r;
+        if ((r = fuelmi_frontier_commit(f, 0))) return r;
+      }
+      return fuelmi_frontier_search_begin(f);
+    };
+    for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
+      auto t = std::chrono::steady_clock::now();
+      if (timeline) {
+        if (hipEventRecord(tl[(size_t)k * 6 + 4], m->stream) != hipSuccess) rc = FUELMI_EHIP;  // (the fusion of this frame is queued)
+        f->tl_ev = &tl[(size_t)k * 6];
+      }
+      if (rc == FUELMI_OK) rc = map_chain();
+      if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
+      tick(0, t);
+      if (rc == FUELMI_OK) rc = bookkeeping(k);
+      tick(3, t);
+      if (rc) break;
+      int npts_next = 0;
+      if (k + 1 < n && (rc = fuse_next(k, &npts_next))) break;
+      tick(4, t);
+      npts = npts_next;
+    }
+    if (timeline) {
+      f->tl_ev = nullptr;
       HIPCHK(hipStreamSynchronize(m->stream));
-      if ((rc = fuelmi_frontier_search_begin(f))) break;
-    } else if (k + 1 < n) {
-      if ((rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k + 1]), rows, cols, cfg, cam_pos3 + 3 * (k + 1),
-                                       cam_q4 + 4 * (k + 1), &npts_next)))
-        break;
+      HIPCHK(frontier_drain(f));
+      double off[6] = {0, 0, 0, 0, 0, 0}, period = 0;
+      int cnt = 0;
+      for (int k = 10; k + 1 < n; ++k) {
+        float ms = 0.f;
+        const hipEvent_t base = tl[(size_t)k * 6 + 4];  // fusion of frame k done
+        bool okf = true;
+        double o[6];
+        for (int j = 0; j < 6 && okf; ++j) {
+          okf = hipEventElapsedTime(&ms, base, tl[(size_t)k * 6 + j]) == hipSuccess;
+          o[j] = ms * 1e3;
+        }
+        if (okf) okf = hipEventElapsedTime(&ms, base, tl[(size_t)(k + 1) * 6 + 4]) == hipSuccess;
+        if (!okf) {
+          (void)hipGetLastError();
+          continue;
+        }
+        for (int j = 0; j < 6; ++j) off[j] += o[j];
+        period += ms * 1e3;
+        ++cnt;
+      }
+      if (cnt)
+        std::fprintf(stderr, "[stream-timing] device timeline, us after the frame's fusion finished: map chain done %.1f; search "
+                     "chain starts %.1f, planes read %.1f, resolved %.1f, tail done %.1f; next frame's fusion done %.1f (%d frames)\n",
+                     off[5] / cnt, off[0] / cnt, off[1] / cnt, off[2] / cnt, off[3] / cnt, period / cnt, cnt);
+      for (auto& e : tl) (void)hipEventDestroy(e);
     }
-    if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
-    if ((rc = fuelmi_frontier_commit(f, 0))) break;
-    if (serial && k + 1 < n) {
-      if ((rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k + 1]), rows, cols, cfg, cam_pos3 + 3 * (k + 1),
-                                       cam_q4 + 4 * (k + 1), &npts_next)))
-        break;
+    if (timing && n > 0)
+      std::fprintf(stderr, "[stream-timing] host us per frame: map chain %.1f, search bookkeeping (collect, commit, begin) %.1f, "
+                   "input_depth (blocked on the device) %.1f\n", acc[0] / n, acc[3] / n, acc[4] / n);
+    if (rc == FUELMI_OK && n > 0) {
+      if ((rc = fuelmi_frontier_search_end(f, &ncl)) == FUELMI_OK) rc = fuelmi_frontier_commit(f, 0);
     }
-    npts = npts_next;
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));

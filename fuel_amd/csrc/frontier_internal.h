@@ -292,6 +292,8 @@ struct fuelmi_frontier {
   // cycle k - 1's cells while cycle k runs on the device (fuelmi_bench_cycles_delivered does).
   std::list<HCluster> prev;
   hipEvent_t ev_planes_read = nullptr;  // behind the last kernel of the running search that reads the map's occupancy planes
+  hipEvent_t* tl_ev = nullptr;          // FUELMI_STREAM_TIMING=2: four timing events of the current frame's chain (start,
+                                        // planes read, resolved, tail done), recorded by frontier_enqueue_fast
   hipEvent_t ev_prev = nullptr;  // the retired search's tail (and the copy of its grouped cells to the host) have completed
   bool prev_pending = false;
   unsigned long long fusion_at_begin = 0;  // map->fusion_count when the running search began
