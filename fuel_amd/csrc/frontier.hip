@@ -4199,14 +4199,14 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   const auto t0 = std::chrono::steady_clock::now();
   // Frame k + 1 is fused while the search of frame k is still running: the search reads the occupancy planes only in
   // its first kernels, the fusion waits for those ON THE DEVICE (map_wait_plane_readers), and the host's wait for the
-  // fused frame's box (which the next search needs) falls beside the chain instead of in front of it.  The map chain
-  // of a frame (inflation, ESDF, B-spline batch) is issued the moment its fusion has handed the box over, then the
-  // search bookkeeping of the previous frame (collect, commit) and the launch of this frame's search.  The frame is
-  // bound by the host's ~55 us of API calls plus the device's fusion -> plane-reading kernels -> fusion chain
-  // (FUELMI_STREAM_TIMING=1: host time per call group, =2: also a device timeline from events), and the order of the
-  // call groups does not matter to it (FUELMI_STREAM_OLD_ORDER=1: search first, as in round 3 -- same rate).  Same
-  // calls, same arguments, same results as the frame-by-frame order (serial != 0 keeps that order for diagnostics).
-  static const bool old_order = getenv("FUELMI_STREAM_OLD_ORDER") != nullptr;
+  // fused frame's box (which the next search needs) falls beside the chain instead of in front of it.  Per frame: the
+  // search bookkeeping (collect + commit the previous search, begin this one), the map chain (inflation, ESDF, B-spline
+  // batch), the next fusion.  The frame is bound by the host's ~55 us of API calls plus the device's fusion ->
+  // plane-reading kernels -> fusion chain (FUELMI_STREAM_TIMING=1: host time per call group, =2: also a device timeline
+  // from events); issuing the map chain BEFORE the bookkeeping (FUELMI_STREAM_MAP_FIRST=1) starts the map stream ~25 us
+  // earlier and the search chain as much later: 1-2 % slower.  Same calls, same arguments, same results as the
+  // frame-by-frame order (serial != 0 keeps that order for diagnostics).
+  static const bool map_first = getenv("FUELMI_STREAM_MAP_FIRST") != nullptr;
   int npts = 0;
   if (n > 0)
     rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[0]), rows, cols, cfg, cam_pos3, cam_q4, &npts);
@@ -4226,20 +4226,15 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
     return fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[k + 1]), rows, cols, cfg, cam_pos3 + 3 * (k + 1),
                                   cam_q4 + 4 * (k + 1), np);
   };
-  if (serial || old_order) {
+  if (serial) {
     for (int k = 0; k < n && rc == FUELMI_OK; ++k) {
-      if (!serial && (rc = fuelmi_frontier_search_begin(f))) break;
       if ((rc = map_chain())) break;
       int npts_next = 0;
-      if (serial) {
-        HIPCHK(hipStreamSynchronize(m->stream));
-        if ((rc = fuelmi_frontier_search_begin(f))) break;
-      } else if (k + 1 < n) {
-        if ((rc = fuse_next(k, &npts_next))) break;
-      }
+      HIPCHK(hipStreamSynchronize(m->stream));
+      if ((rc = fuelmi_frontier_search_begin(f))) break;
       if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
       if ((rc = fuelmi_frontier_commit(f, 0))) break;
-      if (serial && k + 1 < n && (rc = fuse_next(k, &npts_next))) break;
+      if (k + 1 < n && (rc = fuse_next(k, &npts_next))) break;
       npts = npts_next;
     }
   } else {
@@ -4274,11 +4269,18 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
         if (hipEventRecord(tl[(size_t)k * 6 + 4], m->stream) != hipSuccess) rc = FUELMI_EHIP;  // (the fusion of this frame is queued)
         f->tl_ev = &tl[(size_t)k * 6];
       }
-      if (rc == FUELMI_OK) rc = map_chain();
-      if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
-      tick(0, t);
+      if (map_first) {
+        if (rc == FUELMI_OK) rc = map_chain();
+        if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
+        tick(0, t);
+      }
       if (rc == FUELMI_OK) rc = bookkeeping(k);
       tick(3, t);
+      if (!map_first) {
+        if (rc == FUELMI_OK) rc = map_chain();
+        if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
+        tick(0, t);
+      }
       if (rc) break;
       int npts_next = 0;
       if (k + 1 < n && (rc = fuse_next(k, &npts_next))) break;

@@ -70,6 +70,18 @@ timeout 300 python scripts/facade_bench.py --map G800S --frames 30 > $O/facade_b
 timeout 300 python scripts/facade_bench.py --fullbox G400 > $O/facade_bench_G400_fullbox.json 2>> $O/facade_bench.err
 for RO in 1 2; do timeout 300 python bench.py --workload G800S --no-cpu-baseline --reference-order $RO > $O/bench_G800S_reforder$RO.json 2>/dev/null; done
 timeout 300 python bench.py --no-cpu-baseline --reference-order 1 --steps 20 --warmup 3 > $O/bench_G400_reforder1.json 2>/dev/null
+# where a streaming frame goes (host wall clock per call group, device timeline from events) and what the reference's cell
+# order costs on the full box (the level sweeps' own clock; workgroup sizes of the large-cluster sweep; x pass phase stamps)
+{ echo "# FUELMI_STREAM_TIMING=2 python bench.py --workload G800S --no-cpu-baseline (one line pair per bench_stream call: warm-up, timed, frame sources), commit $FUELMI_COMMIT"
+  FUELMI_STREAM_TIMING=2 python bench.py --workload G800S --no-cpu-baseline 2>&1 >/dev/null | grep stream-timing
+  echo "# default order (search bookkeeping, then the map chain) against FUELMI_STREAM_MAP_FIRST=1, frames/s, alternating"
+  for V in 0 1 0 1; do if [ $V = 1 ]; then export FUELMI_STREAM_MAP_FIRST=1; else unset FUELMI_STREAM_MAP_FIRST; fi
+    python bench.py --workload G800S --no-cpu-baseline | V=$V python -c "import sys,json,os; print('map_first=%s: %d frames/s' % (os.environ['V'], round(json.loads(sys.stdin.readline())['value'])))"; done
+  unset FUELMI_STREAM_MAP_FIRST; } > $O/stream_frame_timing.txt 2>&1
+{ echo "# FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 (400x400x100, full box: one cluster of 139 k cells), commit $FUELMI_COMMIT"
+  for T in 512 256 1024; do echo "# k_bfs_sweep_g with $T threads"; FUELMI_BFSG_T=$T FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 2>&1 >/dev/null | grep "reference order" | tail -2; done
+  echo "# x pass phase stamps (FUELMI_ZY_TIMING=1, scripts/esdf_only.py)"
+  for WL in G400 G800; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep x-timing | tail -1 | sed "s/^/$WL /"; done; } > $O/reference_order_timing.txt 2>&1
 timeout 300 python -m pytest tests/test_fleet_gpu.py -q -s -m gpu 2>&1 | grep -E "fleet on one device|bench --gpus|passed|failed" > $O/fleet_one_device.txt
 timeout 300 python -m pytest tests/test_perf_gpu.py -q -s -m perf 2>&1 | grep -E "ESDF ms|z/y pass ms|passed|failed" > $O/perf_statements.txt
 for f in bench_G400 bench_G800 bench_G400K bench_G400E bench_G800S bench_G400_two_ranks_one_device; do tail -1 $O/$f.json | cut -c1-160; done

@@ -18,7 +18,7 @@ cp $O/next_rows.json $P/${R}_next_rows.json
 [ -s $O/facade_bench_G800S.json ] && tail -1 $O/facade_bench_G800S.json > $P/${R}_facade_bench_G800S.json
 [ -s $O/facade_bench_G400_fullbox.json ] && tail -1 $O/facade_bench_G400_fullbox.json > $P/${R}_facade_bench_G400_fullbox.json
 for f in bench_G800S_reforder1 bench_G800S_reforder2 bench_G400_reforder1; do [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${R}_$f.json; done
-for f in fleet_one_device perf_statements esdf_family_ab esdf_instruction_counts tuning_ab_cycle cycle_timeline_G400 stream_timeline_G800S; do
+for f in fleet_one_device perf_statements esdf_family_ab esdf_instruction_counts tuning_ab_cycle cycle_timeline_G400 stream_timeline_G800S stream_frame_timing reference_order_timing; do
   [ -s $O/$f.txt ] && cp $O/$f.txt $P/${R}_$f.txt
 done
 ls $P | grep ${R}_ | wc -l
