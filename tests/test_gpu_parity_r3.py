@@ -310,3 +310,37 @@ def test_reference_order_auto_reports_the_order_it_delivered(fa):
     h = C.c_void_p()
     assert L.fuelmi_frontier_create(gm.h, C.byref(cfg), C.byref(h)) != 0
     gm.close()
+
+
+def test_reference_order_of_a_sheet_whose_levels_outgrow_the_queue_ring(fa):
+    """k_bfs_sweep_g keeps the BFS queue in an LDS ring and copies it out in bulk; a level too long to be re-read from
+    the ring, or whose children might wrap onto entries not copied yet, goes through global memory instead (`direct`,
+    `!in_ring` in frontier_order.hip).  The searches of the other tests never get there (their levels hold a few
+    hundred cells).  A flat frontier sheet does: free space below an unknown ceiling over the whole 80 x 80 m box is
+    ONE cluster of ~608 k cells whose BFS levels are square rings of up to ~1 560 cells (27 x 1 560 > 32 768 ring
+    entries).  Cell order and sequential mean against the literal oracle (frontier_finder.cpp:123-164,374-390)."""
+    map_size = (80.0, 80.0, 3.0)
+    org = (-40.0, -40.0, -1.0)
+    box = ((org[0] + 1.0, org[1] + 1.0, 0.0), (-org[0] - 1.0, -org[1] - 1.0, 1.4))
+    om = fo.OracleMap(map_size, *box)
+    nv = om.nvox
+    assert nv == (800, 800, 30)
+    occ = np.full(om.N, om.l_min).reshape(nv)   # known free ...
+    occ[:, :, 15:] = om.l_min - 0.01            # ... below an unknown ceiling (world z >= 0.5)
+    om.occ[:] = occ.reshape(-1)
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100, reference_order=1)
+    om.set_updated_box(*box)
+    gm.setUpdatedBox(*box)
+    n_o, n_g = of.search(), gf.searchFrontiers()
+    assert n_o == n_g == 1
+    a, b = of.clusters(0)[0], gf.clusters(0)[0]
+    assert len(a) > 500000, len(a)
+    assert np.array_equal(a, b), "first difference at position %d" % int(np.argmax(a != b))
+    for x, y in zip(of.cluster_info(0, 0), gf.clusterInfo(0, 0)):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), "average_/box of the sheet not bit-equal"
+    assert np.array_equal(of.flags, gf.flags())
+    gf.close()
+    gm.close()
