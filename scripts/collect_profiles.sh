@@ -70,6 +70,7 @@ timeout 300 python scripts/facade_bench.py --map G800S --frames 30 > $O/facade_b
 timeout 300 python scripts/facade_bench.py --fullbox G400 > $O/facade_bench_G400_fullbox.json 2>> $O/facade_bench.err
 for RO in 1 2; do timeout 300 python bench.py --workload G800S --no-cpu-baseline --reference-order $RO > $O/bench_G800S_reforder$RO.json 2>/dev/null; done
 timeout 300 python bench.py --no-cpu-baseline --reference-order 1 --steps 20 --warmup 3 > $O/bench_G400_reforder1.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/reforder1_G400 -o s -- python bench.py --no-cpu-baseline --reference-order 1 --steps 20 --warmup 3 > /dev/null 2>&1
 # where a streaming frame goes (host wall clock per call group, device timeline from events) and what the reference's cell
 # order costs on the full box (the level sweeps' own clock; workgroup sizes of the large-cluster sweep; x pass phase stamps)
 { echo "# FUELMI_STREAM_TIMING=2 python bench.py --workload G800S --no-cpu-baseline (one line pair per bench_stream call: warm-up, timed, frame sources), commit $FUELMI_COMMIT"

@@ -15,6 +15,7 @@ for WL in G400K G400E; do cp $O/serial_$WL/s_kernel_stats.csv $P/${R}_bench_${WL
 cp $O/stream/s_kernel_stats.csv $P/${R}_bench_G800S_streaming_kernel_stats.csv
 cp $O/next/s_kernel_stats.csv $P/${R}_next_rows_kernel_stats.csv
 cp $O/next_rows.json $P/${R}_next_rows.json
+[ -s $O/reforder1_G400/s_kernel_stats.csv ] && cp $O/reforder1_G400/s_kernel_stats.csv $P/${R}_bench_G400_reforder1_kernel_stats.csv
 [ -s $O/facade_bench_G800S.json ] && tail -1 $O/facade_bench_G800S.json > $P/${R}_facade_bench_G800S.json
 [ -s $O/facade_bench_G400_fullbox.json ] && tail -1 $O/facade_bench_G400_fullbox.json > $P/${R}_facade_bench_G400_fullbox.json
 for f in bench_G800S_reforder1 bench_G800S_reforder2 bench_G400_reforder1; do [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${R}_$f.json; done
