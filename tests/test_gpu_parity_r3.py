@@ -344,3 +344,44 @@ def test_reference_order_of_a_sheet_whose_levels_outgrow_the_queue_ring(fa):
     assert np.array_equal(of.flags, gf.flags())
     gf.close()
     gm.close()
+
+
+@pytest.mark.parametrize("extra_row,cells", [(79, 26624), (80, 26625)])
+def test_reference_order_at_the_lds_limit_exactly(fa, extra_row, cells):
+    """The largest cluster the in-LDS level sweep takes (FR_REFORDER_AUTO = 26 624 cells: keys + queue fill the CU's
+    160 KB) and the smallest one that goes through k_bfs_sweep_g (26 625), built to the cell: known free space under a
+    140 x 152 patch of unknown ceiling plus `extra_row` columns of a 141st row -- floor cells and the patch's four
+    walls are one frontier cluster.  Mode 1 delivers expandFrontier's order (frontier_finder.cpp:123-164) either way;
+    mode 2 delivers it for the first and ascending addresses, reported, for the second."""
+    map_size = (30.0, 30.0, 3.0)
+    org = (-15.0, -15.0, -1.0)
+    box = ((org[0] + 1.0, org[1] + 1.0, 0.0), (-org[0] - 1.0, -org[1] - 1.0, 1.4))
+    om = fo.OracleMap(map_size, *box)
+    nv = om.nvox
+    occ = np.full(om.N, om.l_min).reshape(nv)
+    occ[40:180, 40:192, 15:] = om.l_min - 0.01
+    occ[180, 40:40 + extra_row, 15:] = om.l_min - 0.01
+    om.occ[:] = occ.reshape(-1)
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 100)
+    om.set_updated_box(*box)
+    assert of.search() == 1
+    ref = of.clusters(0)[0]
+    assert len(ref) == cells, "the fixture is built to hold exactly %d cells (%d)" % (cells, len(ref))
+    for mode in (1, 2):
+        gf = fa.FrontierFinder(gm, cluster_min=100, reference_order=mode)
+        gm.setUpdatedBox(*box)
+        assert gf.searchFrontiers() == 1
+        got = gf.clusters(0)[0]
+        in_lds = cells <= 26624
+        if mode == 1 or in_lds:
+            assert np.array_equal(ref, got), "mode %d: first difference at %d" % (mode, int(np.argmax(ref != got)))
+            for x, y in zip(of.cluster_info(0, 0), gf.clusterInfo(0, 0)):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
+            assert gf.orderStats() == (1, 1, 0, 0)
+        else:
+            assert np.array_equal(np.sort(ref), got)
+            assert gf.orderStats() == (0, 0, 1, cells)
+        gf.close()
+    gm.close()
