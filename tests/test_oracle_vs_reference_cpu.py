@@ -488,3 +488,45 @@ def test_reference_map_ros_compiles_against_the_facade_header():
            "-I", "/root/reference/fuel_planner/plan_env/include", src]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
+
+
+def _ceiling_world(m, x0, x1, y0, y1, extra_row=0):
+    """known free space under a patch of unknown ceiling (world z >= 0.5 m) -- the fixtures of
+    tests/test_gpu_parity_r3.py::test_reference_order_at_the_lds_limit_exactly / ..._of_a_sheet_..."""
+    nv = m.nvox
+    occ = np.full(m.N, m.l_min).reshape(nv)
+    occ[x0:x1, y0:y1, 15:] = m.l_min - 0.01
+    if extra_row:
+        occ[x1, y0:y0 + extra_row, 15:] = m.l_min - 0.01
+    m.occ[:] = occ.reshape(-1)
+
+
+@pytest.mark.parametrize("name", ["lds_limit", "lds_limit_plus_one", "sheet"])
+def test_large_cluster_fixtures_of_the_gpu_suite_match_the_real_reference(name):
+    """The GPU suite checks the device's cell order of its largest clusters (26 624 / 26 625 cells at the hand-over
+    between the two level sweeps, a 608 400-cell sheet) against the oracle; this is the other half of the chain: the
+    REAL FrontierFinder::searchFrontiers / expandFrontier (frontier_finder.cpp:54-164) on the same worlds yields the
+    oracle's cells in the oracle's order, the same average_ and boxes, the same flags."""
+    if name == "sheet":
+        map_size, org = (80.0, 80.0, 3.0), (-40.0, -40.0, -1.0)
+    else:
+        map_size, org = (30.0, 30.0, 3.0), (-15.0, -15.0, -1.0)
+    box = ((org[0] + 1.0, org[1] + 1.0, 0.0), (-org[0] - 1.0, -org[1] - 1.0, 1.4))
+    om, rm = twin(map_size, box)
+    if name == "sheet":
+        _ceiling_world(om, 0, om.nvox[0], 0, om.nvox[1])
+        cells = 608400
+    else:
+        _ceiling_world(om, 40, 180, 40, 192, 79 if name == "lds_limit" else 80)
+        cells = 26624 if name == "lds_limit" else 26625
+    rm.occ[:] = om.occ
+    of, rf = fo.OracleFrontier(om, 100), ref.RefFrontier(rm, 100)
+    for m in (om, rm):
+        m.set_updated_box(*box)
+    assert of.search() == rf.search() == 1
+    a, b = of.clusters(0)[0], rf.clusters(0)[0]
+    assert len(a) == cells
+    assert np.array_equal(a, b)
+    for u, v in zip(of.cluster_info(0, 0), rf.cluster_info(0, 0)):
+        assert np.array_equal(u, v)
+    assert np.array_equal(of.flags, rf.flags)
