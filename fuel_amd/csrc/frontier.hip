@@ -2683,7 +2683,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
   if (f->ev_prev) (void)hipEventDestroy(f->ev_prev);
   if (f->ev_planes_read) {
-    if (f->map && f->map->planes_read_ev == f->ev_planes_read) f->map->planes_read_ev = nullptr;
+    if (f->map) map_drop_plane_reader(f->map, f->ev_planes_read);
     (void)hipEventDestroy(f->ev_planes_read);
   }
   Plane* pl[] = {&f->flag, &f->flag2, &f->qb, &f->sb};
@@ -3152,7 +3152,8 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   FArgs& F = f->F;
   const int nb_max = (g.W + 255) / 256 + 1;  // surplus blocks exit on F.var->nblocks
   const int cgrid = 2048;
-  k_load_var<<<1, 64, 0, f->stream>>>(f->h_var, f->d_var);
+  // (the CURRENT buffer set's copy: a reset swaps F and F2, each with a device FVar of its own -- ADVICE r4)
+  k_load_var<<<1, 64, 0, f->stream>>>(f->h_var, F.var_w);
   FDBG("k_load_var");
   k_pred<<<nb_max, 256, 0, f->stream>>>(g, F);
   FDBG("k_pred");
@@ -3219,7 +3220,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   // the event is recorded behind the whole chain by the caller)
   if (!capturing) {
     HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
-    f->map->planes_read_ev = f->ev_planes_read;
+    map_add_plane_reader(f->map, f->ev_planes_read);
     if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
   }
   if (nt3[1] == 256)
@@ -3313,6 +3314,15 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->scope.reset(new StageScope(m, FUELMI_K_FRONTIER, f->stream));
   f->removed_ids.clear();
   for (int q = 0; q < 3; ++q) f->rm_lo[q] = 1, f->rm_hi[q] = 0;
+  // on EVERY exit path below (the changed-cluster test reads the occupancy planes too, and an empty search or an
+  // error returns before the chain): whatever was queued, the planes are free behind it
+  struct PlanesRead {
+    fuelmi_frontier* f;
+    bool done = false;
+    ~PlanesRead() {
+      if (!done && f->map && hipEventRecord(f->ev_planes_read, f->stream) == hipSuccess) map_add_plane_reader(f->map, f->ev_planes_read);
+    }
+  } planes_read{f};
   int rc = remove_changed_begin(f, umin, umax);
   if (rc) return rc;
 
@@ -3437,13 +3447,6 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   static const bool dbg_sync = getenv("FUELMI_DEBUG_SYNC") != nullptr;
   static const bool fast_graph = getenv("FUELMI_FR_GRAPH") != nullptr && atoi(getenv("FUELMI_FR_GRAPH")) != 0 && !dbg_sync;
   static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || dbg_sync;
-  struct PlanesRead {  // on every path below: whatever was queued, the planes are free behind it
-    fuelmi_frontier* f;
-    bool done = false;
-    ~PlanesRead() {
-      if (!done && f->map && hipEventRecord(f->ev_planes_read, f->stream) == hipSuccess) f->map->planes_read_ev = f->ev_planes_read;
-    }
-  } planes_read{f};
   if (fast) {
     f->fast_launched = true;
     if (!fast_graph) {
@@ -3668,6 +3671,10 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       fuelmi_set_error("frontier search: the fast chain overflowed AFTER the map was fused again (a frame queued between "
                        "_search_begin and _search_end): the occupancy this search was about is gone -- call _search_end before the next fusion "
                        "on inputs this noisy");
+      // the changed clusters' flags are already cleared on the device: take them off the lists too, and make the next
+      // search look at the whole box again (the lists and the flag plane must not part ways on this path)
+      remove_changed_end(f);
+      f->dirty_all = true;
       return FUELMI_ELIMIT;
     }
     if (counts[2] == 2u) {
@@ -3999,7 +4006,9 @@ extern "C" int fuelmi_frontier_cluster_centres(const fuelmi_frontier* f, int whi
     adr = merged.data();
   }
   const double res = g.res, ox = g.org[0], oy = g.org[1], oz = g.org[2];
-  unsigned lb = 0xFFFFFFFFu;  // address of z = 0 of the current z-line
+  // address of z = 0 of the current z-line; the start value makes the first cell decode whatever its address is
+  // (addresses are below 2^31; 0xFFFFFFFF made a - lb wrap to a + 1 < nz for cells of the column x = y = 0)
+  unsigned lb = 0x80000000u;
   double cx = 0.0, cy = 0.0;
   const unsigned nz = (unsigned)g.nz, nyz = (unsigned)g.nyz;
   for (size_t i = 0; i < n; ++i) {

@@ -148,7 +148,7 @@ struct fuelmi_map {
   // caller polls the slot's event.  A slot's stream is ordered behind what the map's stream held when the call began.
   struct QuerySlot {
     hipStream_t st = nullptr;
-    hipEvent_t ev_dep = nullptr, ev_done = nullptr;
+    hipEvent_t ev_dep = nullptr, ev_done = nullptr, ev_rd = nullptr;  // ev_rd: recorded by a WRITER of dist / infl (map_wait_query_readers)
     unsigned char* pin = nullptr;
     size_t pin_cap = 0;
     bool busy = false;
@@ -165,7 +165,8 @@ struct fuelmi_map {
   // ... and the other direction: the last kernel of a running frontier search that READS those planes (set by
   // fuelmi_frontier_search_begin, owned by the finder).  A fusion queued while the search is in flight -- the next
   // depth frame of a streaming pipeline -- waits for it on the device instead of being forbidden
-  hipEvent_t planes_read_ev = nullptr;
+  // (one entry per finder with a search in flight: two finders on one map must not overwrite each other's event)
+  std::vector<hipEvent_t> planes_read_evs;
   unsigned long long fusion_count = 0;  // fusions / uploads queued so far (a search notices one queued behind its back)
   unsigned profile_mask = 0;
   ProfileSlot prof[FUELMI_K_COUNT];
@@ -230,10 +231,30 @@ static inline hipError_t stream_wait(hipStream_t s) {
 
 // to be called by everything that rewrites the occupancy planes, before it queues its kernels
 static inline hipError_t map_wait_plane_readers(fuelmi_map* m) {
-  if (!m->planes_read_ev) return hipSuccess;
-  const hipError_t e = hipStreamWaitEvent(m->stream, m->planes_read_ev, 0);
-  m->planes_read_ev = nullptr;
+  hipError_t e = hipSuccess;
+  for (hipEvent_t ev : m->planes_read_evs) {
+    const hipError_t e1 = hipStreamWaitEvent(m->stream, ev, 0);
+    if (e1 != hipSuccess) e = e1;
+  }
+  m->planes_read_evs.clear();
   return e;
+}
+// Writers of the distance field / the inflated plane on the map's stream wait for the query kernels already LAUNCHED
+// on busy query slots (write-after-read).  A query whose slot is taken but whose kernel is not launched yet
+// when the writer looks is not ordered against that writer: fuelmi.h says so.
+int map_wait_query_readers(fuelmi_map* m);
+// a finder has recorded `ev` behind the last kernel of its search that reads the planes
+static inline void map_add_plane_reader(fuelmi_map* m, hipEvent_t ev) {
+  for (hipEvent_t e : m->planes_read_evs)
+    if (e == ev) return;
+  m->planes_read_evs.push_back(ev);
+}
+static inline void map_drop_plane_reader(fuelmi_map* m, hipEvent_t ev) {
+  for (size_t i = 0; i < m->planes_read_evs.size(); ++i)
+    if (m->planes_read_evs[i] == ev) {
+      m->planes_read_evs.erase(m->planes_read_evs.begin() + (long)i);
+      return;
+    }
 }
 
 // ---- device helpers ---------------------------------------------------------------------------

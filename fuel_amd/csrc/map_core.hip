@@ -87,6 +87,7 @@ int QuerySlotGuard::acquire(fuelmi_map* m_, size_t bytes) {
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_rd, hipEventDisableTiming));
   }
   if (bytes > s->pin_cap) {
     if (s->pin) HIPCHK(hipHostFree(s->pin));
@@ -107,8 +108,19 @@ hipError_t QuerySlotGuard::finish() {
   for (long spins = 0;; ++spins) {  // poll: a blocking wait costs ~15 us of wake-up for a 10-us kernel
     e = hipEventQuery(s->ev_done);
     if (e != hipErrorNotReady) return e;
-    if (yld || spins > 2000000) std::this_thread::yield();
+    if (yld) std::this_thread::yield();
+    // a solve of milliseconds: stop burning the core (ten optimiser threads would burn ten), block on the event
+    if (spins > 4000) return hipEventSynchronize(s->ev_done);
   }
+}
+int map_wait_query_readers(fuelmi_map* m) {
+  std::lock_guard<std::mutex> lk(m->qs_mu);
+  for (auto& q : m->qslots)
+    if (q->busy && q->st && q->ev_rd) {
+      HIPCHK(hipEventRecord(q->ev_rd, q->st));
+      HIPCHK(hipStreamWaitEvent(m->stream, q->ev_rd, 0));
+    }
+  return FUELMI_OK;
 }
 QuerySlotGuard::~QuerySlotGuard() {
   if (!s) return;
@@ -597,6 +609,7 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
     if (q->st) (void)hipStreamSynchronize(q->st), (void)hipStreamDestroy(q->st);
     if (q->ev_dep) (void)hipEventDestroy(q->ev_dep);
     if (q->ev_done) (void)hipEventDestroy(q->ev_done);
+    if (q->ev_rd) (void)hipEventDestroy(q->ev_rd);
     if (q->pin) (void)hipHostFree(q->pin);
   }
   m->qslots.clear();
@@ -682,6 +695,8 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
     int ceil_id = (int)std::floor((m->cfg.virtual_ceil_height - g.org[2]) * g.res_inv);
     if (ceil_id >= 0 && ceil_id < g.nz) {
       int n = (b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1);
+      // (the ceiling rewrites occupancy-plane words: a search in flight may still read them -- ADVICE r4)
+      HIPCHK(map_wait_plane_readers(m));
       k_virtual_ceil<<<blocks_for(n, 256), 256, 0, m->stream>>>(
           g, b, ceil_id, m->info.clamp_max_log, m->occ, m->occ_bits.p, m->unk_bits.p,
           m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3);
@@ -695,6 +710,10 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
 extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
   ARGCHK(m);
   HIPCHK(hipSetDevice(m->device));
+  {
+    const int rcq = map_wait_query_readers(m);  // (query kernels in flight still read the field this update rewrites)
+    if (rcq) return rcq;
+  }
   return esdf_update(m);
 }
 
