@@ -751,7 +751,7 @@ __device__ __forceinline__ u32 bit_fill(u32 v, int zi) {
 template <int G>
 __device__ __forceinline__ u32 zy_fill_pair(u32* prow, u32 bA, u32 bB, u32 d0, int aboveA, int aboveB, int ze, u32 inbox, bool fast) {
   constexpr int ZC = 4 * G;
-  const u32 full = ZC == 32 ? 0xffffffffu : ((1u << ZC) - 1u);
+  const u32 full = ZC == 32 ? 0xffffffffu : ((1u << (ZC & 31)) - 1u);
   if (fast) {
     // rows that need no sweep: every in-box voxel of the chunk a source (the inside of unknown space), or no source
     // anywhere on the z-line.  Taken by whole waves only: a mixed wave would pay for both paths
@@ -1561,6 +1561,521 @@ static int launch_x_pk(fuelmi_map* m, const Box3& b) {
   return FUELMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5: the hand-over between the two packed passes is 16-bit and tile-contiguous.
+// Rounds 2-4 stored the y-pass result as u32 at the voxel's own address (64 MB on the 400^2 x 100 map) and the x pass
+// fetched its 32-column tile as 400 pieces of 128 B at a 160 KB stride, saturating every value to 16 bits on the way
+// in: 58-75 % of an x-pass workgroup's life was that fill (profiles/r04_reference_order_timing.txt).  Now the z/y pass
+// writes exactly what the x pass keeps in LDS:
+//   tmp16[tile t][x-pair q][seg 0..7] : uint4 = 4 z-adjacent columns, each u32 = (x-row 2q | x-row 2q+1 << 16),
+//   columns enumerated as in the x pass (s = y * nseg + zseg, tile = s >> 3, seg = s & 7),
+// so an x-pass workgroup copies ONE contiguous block of npx * 128 B (25.6 KB for 400 rows) into LDS and scans.  A u32
+// of that layout holds two x-slabs, so a z/y workgroup owns a slab PAIR: two tiles in LDS (lanes of the lower half fill
+// slab 2q, the upper half slab 2q+1), one fused scan loop per lane over both tiles (two independent LDS chains in
+// flight), two 16-byte stores per lane and trip where the u32 form needed four.
+// Values: v < PK_INF exact; PK_INF = "finite, at least 65025" -- the exact u32 then sits in the WIDE plane (esdf_tmp, the
+// voxel's own address; written only for such outputs: further than 255 voxels from every source of their slab);
+// 0xFFFF = no source in the slab.  Columns of the aligned z range outside the box hold 0 (they only must not stretch a
+// lane's shared scan loop).  Whether ANY slab of the box holds a source crosses to the x pass as one word stamped with
+// the update's serial number (a slab pair with a source writes it; nobody clears it).
+// ------------------------------------------------------------------------------------------------
+#define PK_NOSRC 0xFFFFu
+extern "C" __device__ int __ockl_wgred_or_i32(int a);  // workgroup-wide OR of a full int (what __syncthreads_or wraps)
+
+// fused scan of item (p, gi) over the two tiles of a slab pair: the packed minima of rows 2p / 2p + 1 x 4 z of both
+// slabs; want = bit 0 / 1: slab A / B holds a source at all (the other's tile is all PK_INF and must not keep the
+// loop running)
+template <int G>
+__device__ __forceinline__ void pk_scan16(const unsigned char* tA, const unsigned char* tB, int p, int gi, int npair, int want,
+                                          u32 (&a)[4], u32 (&c)[4]) {
+  constexpr int stride = 16 * G;
+  const int col = 16 * gi, base = __mul24(p, stride) + col;
+  const uint4 vA = lds4(tA, base), vB = lds4(tB, base);
+  const u32 one = 0x00010001u;
+  a[0] = pk_min(vA.x, pk_adds(pk_swap(vA.x), one)), a[1] = pk_min(vA.y, pk_adds(pk_swap(vA.y), one));
+  a[2] = pk_min(vA.z, pk_adds(pk_swap(vA.z), one)), a[3] = pk_min(vA.w, pk_adds(pk_swap(vA.w), one));
+  c[0] = pk_min(vB.x, pk_adds(pk_swap(vB.x), one)), c[1] = pk_min(vB.y, pk_adds(pk_swap(vB.y), one));
+  c[2] = pk_min(vB.z, pk_adds(pk_swap(vB.z), one)), c[3] = pk_min(vB.w, pk_adds(pk_swap(vB.w), one));
+  const u32 mA = (want & 1) ? 0xffffffffu : 0u, mB = (want & 2) ? 0xffffffffu : 0u;
+  u32 mx = pk_hmax(pk_max(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])) & mA, pk_max(pk_max(c[0], c[1]), pk_max(c[2], c[3])) & mB));
+  const int hi_off = __mul24(npair - 1, stride) + col;
+  const int jmax = max(p, npair - 1 - p);
+  int od = base, ou = base;
+  u32 ro2 = 1u, j8 = 8u;
+  for (int j = 1; j <= jmax && ro2 < mx; ++j) {
+    od = max(od - stride, col);
+    ou = min(ou + stride, hi_off);
+    const uint4 dA = lds4(tA, od), uA = lds4(tA, ou), dB = lds4(tB, od), uB = lds4(tB, ou);
+    const u32 rn2 = ro2 + j8;               // (2j+1)^2
+    const u32 re2 = (ro2 + rn2 - 2u) >> 1;  // (2j)^2
+    const u32 ke = pk_both(pk_sat16(re2));
+    const u32 k1 = pk_sat16(ro2) | (pk_sat16(rn2) << 16), k2 = pk_sat16(rn2) | (pk_sat16(ro2) << 16);
+#define PK16_STEP(B, D, U) B = pk_min(B, pk_min(pk_adds(pk_min(D, U), ke), pk_min(pk_adds(pk_swap(D), k1), pk_adds(pk_swap(U), k2))))
+    PK16_STEP(a[0], dA.x, uA.x);
+    PK16_STEP(a[1], dA.y, uA.y);
+    PK16_STEP(a[2], dA.z, uA.z);
+    PK16_STEP(a[3], dA.w, uA.w);
+    PK16_STEP(c[0], dB.x, uB.x);
+    PK16_STEP(c[1], dB.y, uB.y);
+    PK16_STEP(c[2], dB.z, uB.z);
+    PK16_STEP(c[3], dB.w, uB.w);
+#undef PK16_STEP
+    mx = pk_hmax(pk_max(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])) & mA, pk_max(pk_max(c[0], c[1]), pk_max(c[2], c[3])) & mB));
+    ro2 = rn2;
+    j8 += 8u;
+  }
+}
+
+// one tile only (experiment: the two slabs in two loops, each with its own trip count)
+template <int G>
+__device__ __forceinline__ void pk_scan8p(const unsigned char* t, int p, int gi, int npair, u32 (&a)[4]) {
+  constexpr int stride = 16 * G;
+  const int col = 16 * gi, base = __mul24(p, stride) + col;
+  const uint4 v = lds4(t, base);
+  const u32 one = 0x00010001u;
+  a[0] = pk_min(v.x, pk_adds(pk_swap(v.x), one)), a[1] = pk_min(v.y, pk_adds(pk_swap(v.y), one));
+  a[2] = pk_min(v.z, pk_adds(pk_swap(v.z), one)), a[3] = pk_min(v.w, pk_adds(pk_swap(v.w), one));
+  u32 mx = pk_hmax(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])));
+  const int hi_off = __mul24(npair - 1, stride) + col;
+  const int jmax = max(p, npair - 1 - p);
+  int od = base, ou = base;
+  u32 ro2 = 1u, j8 = 8u;
+  for (int j = 1; j <= jmax && ro2 < mx; ++j) {
+    od = max(od - stride, col);
+    ou = min(ou + stride, hi_off);
+    const uint4 d = lds4(t, od), u = lds4(t, ou);
+    const u32 rn2 = ro2 + j8;
+    const u32 re2 = (ro2 + rn2 - 2u) >> 1;
+    const u32 ke = pk_both(pk_sat16(re2));
+    const u32 k1 = pk_sat16(ro2) | (pk_sat16(rn2) << 16), k2 = pk_sat16(rn2) | (pk_sat16(ro2) << 16);
+#define PK16_STEP(B, D, U) B = pk_min(B, pk_min(pk_adds(pk_min(D, U), ke), pk_min(pk_adds(pk_swap(D), k1), pk_adds(pk_swap(U), k2))))
+    PK16_STEP(a[0], d.x, u.x);
+    PK16_STEP(a[1], d.y, u.y);
+    PK16_STEP(a[2], d.z, u.z);
+    PK16_STEP(a[3], d.w, u.w);
+#undef PK16_STEP
+    mx = pk_hmax(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])));
+    ro2 = rn2;
+    j8 += 8u;
+  }
+}
+
+// uint4 index of (tile, x-pair q, segment) in tmp16.  qsh < 0: a tile's rows are contiguous ([tile][q][8]: the x pass copies
+// one block per tile); qsh >= 0 (experiment, FUELMI_PK2_QSH): rows of 2^qsh x-pairs adjacent, [q >> qsh][tile][q & mask][8]
+__device__ __forceinline__ size_t pk2_index(int tile, int q, int seg, int ntiles, int npx, int qsh) {
+  if (qsh < 0) return ((size_t)tile * npx + q) * 8 + seg;
+  return ((((size_t)(q >> qsh) * ntiles + tile) << qsh) + (q & ((1 << qsh) - 1))) * 8 + seg;
+}
+
+// 16-bit hand-over value of one exact y-pass result; the exact value goes to the wide plane when it does not fit
+__device__ __forceinline__ u32 pk2_encode(u32 exact, u32* wide_at, bool in_box) {
+  if (exact >= INF32) return PK_NOSRC;
+  if (exact < PK_INF) return exact;
+  if (in_box) *wide_at = exact;
+  return PK_INF;
+}
+
+// The z extent is cut into chunks of g = 8, 4, 2 or 1 z-segments (a segment = 4 voxels) that add up to it exactly
+// (100 voxels: 8 + 8 + 8 + 1 segments); a column tile of the x pass is 8 / g y-rows x the g segments of ONE chunk, so
+// that every 128-byte row of tmp16 -- (tile, x-pair) -- is written whole, by adjacent lanes of one wave of the chunk's
+// workgroup.  (First version of the round: tiles of 8 consecutive segments of the (y, z) enumeration, chunks of 5
+// segments.  Every tile row was then assembled from 80-byte pieces of two or three workgroups, and a wave's store
+// touched 13 lines 640 KB apart: the z/y pass of the 800^2 x 200 map went from 169 to 297 us.)
+// (struct Pk2Chunks: fuelmi_internal.h)
+
+template <int MODE, int G, int NW>
+__device__ __forceinline__ void zy_pk2_body(const Geo& g, const Box3& b, const u64* __restrict__ infl, const u64* __restrict__ unk,
+                                            uint4* __restrict__ tmp16, u32* __restrict__ wide, int z0a, int seg0, int tile0, int tstride, int gsh,
+                                            int off, int ntiles, int npx, int qsh, int q, int fastrow, u32* __restrict__ stat, u32* __restrict__ src_flag, u32 serial,
+                                            unsigned long long* stamp, unsigned char* smem_raw) {
+  constexpr int ZC = 4 * G;
+  const int xA = b.lo[0] + 2 * q, xB = min(xA + 1, b.hi[0]);  // (odd line: the last pair repeats its slab, like the x pass's tile)
+  const int zc0 = z0a + 4 * seg0;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int npair = (ylen + 1) >> 1;
+  const int T = blockDim.x, TH = T >> 1;
+  const int half = (int)threadIdx.x >= TH ? 1 : 0;
+  const int x = half ? xB : xA;
+  unsigned char* tA = smem_raw;                            // [npair][ZC] u32: low half y-row 2p, high half 2p + 1
+  unsigned char* tB = smem_raw + (size_t)npair * ZC * 4;
+  u32* tile = reinterpret_cast<u32*>(half ? tB : tA);
+  const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);
+  const u32 inbox = zs <= ze ? (u32)bit_range(zs - zc0, ze - zs + 1) : 0u;
+  bool has_src = false;
+  for (int p = (int)threadIdx.x - half * TH; p < npair; p += TH) {
+    const int yA = 2 * p, yB = min(2 * p + 1, ylen - 1);
+    const long lbA = (long)x * g.nyz + (long)(b.lo[1] + yA) * g.nz;
+    const long lbB = (long)x * g.nyz + (long)(b.lo[1] + yB) * g.nz;
+    RowSrc A, B;
+    A.bits = B.bits = 0ull;
+    A.below = A.above = B.below = B.above = -1;
+    if (zs <= ze) {
+      const LineBits<NW> LA = line_load<MODE, NW>(infl, unk, lbA, z0a, b.lo[2], b.hi[2]);
+      const LineBits<NW> LB = line_load<MODE, NW>(infl, unk, lbB, z0a, b.lo[2], b.hi[2]);
+      A = row_src_line<NW, true>(LA, z0a, zc0, ZC);
+      B = row_src_line<NW, true>(LB, z0a, zc0, ZC);
+    }
+    has_src |= (A.bits | B.bits) != 0ull || A.below >= 0 || A.above >= 0 || B.below >= 0 || B.above >= 0;
+    (void)zy_fill_pair<G>(tile + p * ZC, (u32)A.bits, (u32)B.bits, pk_below_d0(A, B, zs), A.above, B.above, ze, inbox, (fastrow & 1) != 0);
+  }
+  if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
+  const int want = __ockl_wgred_or_i32(has_src ? (1 << half) : 0);  // (a barrier: both tiles are complete behind it)
+  if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+  if (want && threadIdx.x == 0) *src_flag = serial;
+  const int total = npair * G;
+  const bool sampA = stat != nullptr && ((xA & 15) == 0 || q == 0);
+  const bool sampB = stat != nullptr && xB != xA && (xB & 15) == 0;
+  int n_farA = 0, n_farB = 0;
+  for (int o = threadIdx.x; o < total; o += T) {
+    const int p = o / G, gi = o - p * G;  // (G is a power of two)
+    u32 a[4], c[4];
+    if (want == 3 && (fastrow & 2)) {
+      pk_scan8p<G>(tA, p, gi, npair, a);
+      pk_scan8p<G>(tB, p, gi, npair, c);
+    } else if (want) {
+      pk_scan16<G>(tA, tB, p, gi, npair, want, a, c);
+    } else {
+      a[0] = a[1] = a[2] = a[3] = c[0] = c[1] = c[2] = c[3] = pk_both(PK_INF);
+    }
+    if (sampA) n_farA += __popcll(__ballot(!(want & 1) || pk_hmin(pk_min(pk_min(a[0], a[1]), pk_min(a[2], a[3]))) > ESDF_FAR_D * ESDF_FAR_D));
+    if (sampB) n_farB += __popcll(__ballot(!(want & 2) || pk_hmin(pk_min(pk_min(c[0], c[1]), pk_min(c[2], c[3]))) > ESDF_FAR_D * ESDF_FAR_D));
+    uint4 r0, r1;  // y-rows 2p, 2p + 1: (slab A | slab B << 16) x 4 z
+    const u32 mxa = pk_hmax(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3]))), mxc = pk_hmax(pk_max(pk_max(c[0], c[1]), pk_max(c[2], c[3])));
+    if (max(mxa, mxc) < PK_INF) {
+      r0 = make_uint4(__builtin_amdgcn_perm(c[0], a[0], 0x05040100u), __builtin_amdgcn_perm(c[1], a[1], 0x05040100u),
+                      __builtin_amdgcn_perm(c[2], a[2], 0x05040100u), __builtin_amdgcn_perm(c[3], a[3], 0x05040100u));
+      r1 = make_uint4(__builtin_amdgcn_perm(c[0], a[0], 0x07060302u), __builtin_amdgcn_perm(c[1], a[1], 0x07060302u),
+                      __builtin_amdgcn_perm(c[2], a[2], 0x07060302u), __builtin_amdgcn_perm(c[3], a[3], 0x07060302u));
+    } else {
+      // rare: outputs out of the 16-bit range (or slabs without a source): exact values from the tiles, 32 bits
+      const int zc = 4 * gi, rA = 2 * p, rB = min(2 * p + 1, ylen - 1);
+      u32 w0[4], w1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int z = zc0 + zc + k;
+        const bool in_box = z >= b.lo[2] && z <= b.hi[2];
+        u32 e[4];  // (slab A row 2p, slab A row 2p+1, slab B row 2p, slab B row 2p+1)
+        e[0] = a[k] & 0xffffu, e[1] = a[k] >> 16, e[2] = c[k] & 0xffffu, e[3] = c[k] >> 16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const bool slabB = v >= 2;
+          const int row = (v & 1) ? rB : rA;
+          if (!((want >> (slabB ? 1 : 0)) & 1))
+            e[v] = in_box ? PK_NOSRC : 0u;
+          else if (e[v] >= PK_INF) {
+            const u32 ex = pk_slow_col(reinterpret_cast<const u32*>(slabB ? tB : tA), ZC, ylen, row, zc + k);
+            u32* wat = wide + (long)(slabB ? xB : xA) * g.nyz + (long)(b.lo[1] + row) * g.nz + z;
+            e[v] = pk2_encode(ex, wat, in_box);
+          }
+        }
+        w0[k] = e[0] | (e[2] << 16), w1[k] = e[1] | (e[3] << 16);
+      }
+      r0 = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+      r1 = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+    }
+    // column tile of y-row y: tile0 + (y / RY) * tstride with RY = 8 >> gsh rows per tile (gsh: log2 of the tile's z width in
+    // segments); inside its 128-byte row the lane's segment is (y % RY) << gsh + off + gi
+    {
+      const int y = 2 * p, ry1 = (8 >> gsh) - 1;
+      store16(tmp16 + pk2_index(tile0 + (y >> (3 - gsh)) * tstride, q, ((y & ry1) << gsh) + off + gi, ntiles, npx, qsh), r0);
+    }
+    if (2 * p + 1 < ylen) {
+      const int y = 2 * p + 1, ry1 = (8 >> gsh) - 1;
+      store16(tmp16 + pk2_index(tile0 + (y >> (3 - gsh)) * tstride, q, ((y & ry1) << gsh) + off + gi, ntiles, npx, qsh), r1);
+    }
+  }
+  if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
+  if ((sampA | sampB) && (threadIdx.x & 63) == 0) {
+    if (sampA) {
+      u32* sg = stat + 2 * ((xA >> 4) & (ESDF_NG - 1));
+      atomicAdd(sg, (u32)n_farA);
+      if (threadIdx.x == 0) atomicAdd(sg + 1, (u32)total);
+    }
+    if (sampB) {
+      u32* sg = stat + 2 * ((xB >> 4) & (ESDF_NG - 1));
+      atomicAdd(sg, (u32)n_farB);
+      if (threadIdx.x == 0) atomicAdd(sg + 1, (u32)total);
+    }
+  }
+}
+
+// GMAX: widest chunk of the launch (the kernel's registers follow the widest body it contains: 110 VGPRs with the
+// 8-segment body, 67 without)
+template <int MODE, int GMAX, int NW>
+__global__ void __launch_bounds__(1024)
+k_esdf_zy_pk2(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, uint4* __restrict__ tmp16,
+              u32* __restrict__ wide, Pk2ZChunks ch, int ntiles, int z0a, int npx, int qsh, int fastrow, u32* __restrict__ stat,
+              u32* __restrict__ src_flag, u32 serial, unsigned long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nzc = ch.n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;  // slab pair q -> XCD q % 8 with all its chunk-blocks
+  const int q = xcd + 8 * (slot / nzc);
+  if (q >= npx) return;
+  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;  // (FUELMI_ZY_TIMING)
+  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
+  const int c = slot % nzc;
+  const int seg0 = ch.seg0[c], tile0 = ch.tile0[c], tstride = ch.tstride[c], gsh = ch.gsh[c], off = ch.off[c];
+#define PK2_BODY(GG) zy_pk2_body<MODE, GG, NW>(g, b, infl, unk, tmp16, wide, z0a, seg0, tile0, tstride, gsh, off, ntiles, npx, qsh, q, fastrow, stat, src_flag, serial, stamp, smem_raw)
+  switch (ch.g[c]) {  // (uniform)
+    case 8:
+      if constexpr (GMAX >= 8) PK2_BODY(8);
+      break;
+    case 4:
+      if constexpr (GMAX >= 4) PK2_BODY(4);
+      break;
+    case 2: PK2_BODY(2); break;
+    default: PK2_BODY(1); break;
+  }
+#undef PK2_BODY
+}
+
+// exact 32-bit minimum of one x column from the 16-bit tile (PK_INF entries: the wide plane holds the value)
+__device__ __noinline__ u32 x_slow_col16(const u32* tile, int c, const u32* __restrict__ wide_col, long row_stride, int xlen, int row) {
+  u32 best = INF32;
+  const int rmax = max(row, xlen - 1 - row);
+  for (int r = 0; r <= rmax && (u32)__mul24(r, r) < best; ++r) {
+    const u32 rr = (u32)__mul24(r, r);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int qrow = s ? row + r : row - r;
+      if (qrow < 0 || qrow >= xlen || (s && !r)) continue;
+      u32 v = (tile[(qrow >> 1) * 32 + c] >> (16 * (qrow & 1))) & 0xffffu;
+      if (v == PK_NOSRC) continue;
+      if (v >= PK_INF) v = wide_col[(long)qrow * row_stride];
+      best = min(best, v + rr);
+    }
+  }
+  return best;
+}
+
+template <int OUT>
+__global__ void __launch_bounds__(512)
+k_esdf_x_pk2(Geo g, Box3 b, const uint4* __restrict__ tmp16, const u32* __restrict__ wide, float* __restrict__ dist, Pk2Chunks ch,
+             int z0a, int qsh, int full8, u32* stat, volatile u32* h_stat, const u32* __restrict__ src_flag, u32 serial,
+             unsigned long long* __restrict__ dbg) {
+  constexpr int SEGS = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  forward_stat(stat, h_stat);
+  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [npx][SEGS] of uint4: halves = x-rows 2p, 2p + 1
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int npx = (xlen + 1) >> 1;
+  const int T = blockDim.x;
+  const int total = npx * SEGS;
+  const float resf = (float)g.res;
+  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;  // (FUELMI_ZY_TIMING)
+  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
+  // Which tile (uniform).  The full-width tiles of y-row y run on XCD y % 8, one after the other: their 128-byte pieces of
+  // the distance field are adjacent but not line-aligned (a y-row is nz * 4 bytes), so neighbours share lines -- on one
+  // XCD the shared lines merge in its L2 instead of leaving as two partial writes.  Behind them (blocks >= full8) the
+  // narrower pieces of the z range's remainder, 8 / w y-rows each.
+  int gw = 8, gsh = 3, y0, seg0, t;
+  if ((int)blockIdx.x < full8) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    y0 = xcd + 8 * (slot / ch.n8);
+    if (y0 >= ylen) return;  // (the grid is padded to a multiple of 8 rows)
+    const int c8 = slot % ch.n8;
+    seg0 = 8 * c8;
+    t = y0 * ch.n8 + c8;
+  } else {
+    t = (int)blockIdx.x - full8 + ylen * ch.n8;
+    int c = ch.n8;
+    while (c + 1 < ch.n && t >= ch.tile0[c + 1]) ++c;
+    gw = ch.g[c], gsh = gw == 4 ? 2 : (gw == 2 ? 1 : 0);
+    y0 = (t - ch.tile0[c]) * (8 >> gsh);
+    seg0 = ch.seg0[c];
+  }
+  const bool any_src = *src_flag == serial;  // (no slab of the box holds a source: "no source" everywhere, nothing to scan)
+  if (any_src) {
+    // this tile's rows: one contiguous block
+    const int ntiles = ch.tile0[ch.n];
+#pragma unroll 4
+    for (int o = threadIdx.x; o < total; o += T) tile[o] = tmp16[pk2_index(t, o >> 3, o & 7, ntiles, npx, qsh)];
+  }
+  if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
+  __syncthreads();
+  if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+  int n_far = 0;
+  for (int o = threadIdx.x; o < total; o += T) {
+    const int p = o >> 3, seg = o & 7;
+    const int yy = y0 + (seg >> gsh);
+    if (yy >= ylen) continue;
+    uint4 ra, rb;
+    pk_scan8<SEGS, false>(smem_raw, p, seg, npx, xlen, any_src, false, n_far, ra, rb);
+    const int z = z0a + 4 * (seg0 + (seg & (gw - 1)));
+    const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
+    if (any_src && max(max4(ra.x, ra.y, ra.z, ra.w), max4(rb.x, rb.y, rb.z, rb.w)) >= PK_INF) {
+      // rare: outputs out of the 16-bit range -- exact from the tile and the wide plane
+      u32* pa = &ra.x;
+      u32* pb = &rb.x;
+      const u32* wc = wide + (long)b.lo[0] * g.nyz + coloff;
+      for (int k = 0; k < 4; ++k) {
+        if (pa[k] >= PK_INF) pa[k] = x_slow_col16(reinterpret_cast<const u32*>(smem_raw), 4 * seg + k, wc + k, g.nyz, xlen, 2 * p);
+        if (2 * p + 1 < xlen && pb[k] >= PK_INF)
+          pb[k] = x_slow_col16(reinterpret_cast<const u32*>(smem_raw), 4 * seg + k, wc + k, g.nyz, xlen, 2 * p + 1);
+      }
+    }
+    float* dst = dist + (long)(b.lo[0] + 2 * p) * g.nyz + coloff;
+    x_store4<OUT>(dst, z, b.lo[2], b.hi[2], ra, resf);
+    if (2 * p + 1 < xlen) x_store4<OUT>(dst + g.nyz, z, b.lo[2], b.hi[2], rb, resf);
+  }
+  if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
+}
+
+// The column tiles of a box (x pass) and the chunks of its z/y pass.  Tiles: the aligned z range in pieces of 8, then 4,
+// 2, 1 segments that add up to it exactly (100 voxels: 8 + 8 + 8 + 1 segments); a tile of width w holds 8 / w y-rows.
+// Chunks: a tile piece wider than gz_max is cut into chunks of gz_max.  ESDF_NO_FIT beyond PK2_MAXCH pieces.
+static int pk2_chunks(int ylen, int nseg, int gz_max, Pk2Chunks* xs, Pk2ZChunks* zs) {
+  *xs = Pk2Chunks{};
+  *zs = Pk2ZChunks{};
+  const int n8 = nseg >> 3;  // full-width pieces: tile (y, c) = y * n8 + c
+  int n = 0, nz = 0, seg = 0, tile = ylen * n8;
+  auto add_z = [&](int seg_lo, int gw, int gsh, int tile0, int tstride) {
+    const int gz = std::min(gw, gz_max);
+    for (int o = 0; o < gw; o += gz) {
+      if (nz == PK2_MAXZCH) return false;
+      zs->seg0[nz] = (short)(seg_lo + o), zs->g[nz] = (signed char)gz, zs->gsh[nz] = (signed char)gsh, zs->off[nz] = (signed char)o;
+      zs->tile0[nz] = tile0, zs->tstride[nz] = tstride;
+      ++nz;
+    }
+    return true;
+  };
+  for (int c = 0; c < n8; ++c, ++n, seg += 8) {
+    if (n == PK2_MAXCH) return ESDF_NO_FIT;
+    xs->seg0[n] = (short)seg, xs->g[n] = 8, xs->tile0[n] = 0;  // (interleaved: see n8)
+    if (!add_z(seg, 8, 3, c, n8)) return ESDF_NO_FIT;
+  }
+  xs->n8 = n8;
+  while (seg < nseg) {  // the remainder in binary: pieces of 4, 2, 1 segments, tiles of 2, 4, 8 y-rows
+    int gw = 4;
+    while (gw > nseg - seg) gw >>= 1;
+    const int gsh = gw == 4 ? 2 : (gw == 2 ? 1 : 0);
+    if (n == PK2_MAXCH) return ESDF_NO_FIT;
+    xs->seg0[n] = (short)seg, xs->g[n] = (short)gw, xs->tile0[n] = tile;
+    if (!add_z(seg, gw, gsh, tile, 1)) return ESDF_NO_FIT;
+    tile += (ylen + 8 / gw - 1) / (8 / gw);
+    seg += gw;
+    ++n;
+  }
+  xs->n = n;
+  zs->n = nz;
+  for (int k = n; k <= PK2_MAXCH; ++k) xs->tile0[k] = tile;
+  for (int k = n; k < PK2_MAXCH; ++k) xs->g[k] = 1;
+  if (n8 == n) xs->tile0[n8] = tile;
+  return FUELMI_OK;
+}
+static int pk2_qsh() {  // layout experiment (see pk2_index); default: a tile's rows contiguous
+  static const char* e = getenv("FUELMI_PK2_QSH");
+  static const int v = e ? atoi(e) : -1;
+  return v;
+}
+static u32 pk2_next_serial(fuelmi_map* m) {
+  if (++m->esdf_serial == 0u) m->esdf_serial = 1u;
+  return m->esdf_serial;
+}
+static u32* pk2_src_flag(fuelmi_map* m) { return m->esdf_stat + 2 * ESDF_NG + 2; }
+
+template <int MODE, int GMAX, int NW>
+static int launch_zy_pk2_g(fuelmi_map* m, const Box3& b, int z0a, int threads, size_t lds) {
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int npx = (xlen + 1) >> 1;
+  const Pk2ZChunks& ch = m->pk2_zch;
+  const int ntiles = m->pk2_ch.tile0[m->pk2_ch.n];
+  if (lds > 64 * 1024 && !m->attr_set[0][MODE][GMAX][NW / 2 - 1]) {  // (once per kernel, not per update)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pk2<MODE, GMAX, NW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    m->attr_set[0][MODE][GMAX][NW / 2 - 1] = true;
+  }
+  const int grid = ((npx + 7) / 8) * 8 * ch.n;
+  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
+  unsigned long long* dbg = nullptr;
+  if (timing) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)grid * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
+  }
+  STAGE_LAUNCH(m, (k_esdf_zy_pk2<MODE, GMAX, NW>), grid, threads, lds, m->g, b, (const u64*)m->infl_bits.p,
+               (const u64*)m->unk_bits.p, reinterpret_cast<uint4*>(m->esdf_tmp16), m->esdf_tmp, ch, ntiles, z0a, npx, pk2_qsh(),
+               (zy_fastrow() ? 1 : 0) | (getenv("FUELMI_ZY_PK_SEP") ? 2 : 0), MODE == 2 ? nullptr : esdf_stat_dev<0>(m), pk2_src_flag(m), m->esdf_serial, dbg);
+  HIPCHK(hipGetLastError());
+  if (timing) {
+    char what[96];
+    std::snprintf(what, sizeof what, "zy2-timing] GMAX %d chunks %d threads %d lds %zu", GMAX, (int)ch.n, threads, lds);
+    { const int rc_ = pass_timing_report(m, dbg, grid, what); if (rc_ != FUELMI_OK) return rc_; }
+  }
+  return FUELMI_OK;
+}
+// the packed family's z/y pass: ESDF_NO_FIT when the box is not its kind (z extents above 255 voxels, nz % 4 != 0,
+// y lines too long for two tiles, x lines too long for the x pass's tile)
+template <int MODE>
+static int launch_zy_pk2(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
+  if ((g.nz % 4) != 0 || zlen > 255 || !m->esdf_tmp16) return ESDF_NO_FIT;
+  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
+  const int zlen_a = z1a - z0a + 1;
+  const int npair = (ylen + 1) >> 1;
+  if ((size_t)((xlen + 1) >> 1) * 128 > 150 * 1024) return ESDF_NO_FIT;  // (the x pass's tile)
+  // widest chunk: 4 segments (16 voxels; the 8-segment body needs 110 VGPRs and measured 46 against 34 us on the
+  // 400^2 x 100 map) while the two tiles of a slab pair stay within 52 KB (three workgroups per CU), else 2
+  static const char* g_env = getenv("FUELMI_ZY_PK_G");  // tuning hook: 8, 4 or 2
+  int g_max = 4;
+  while (g_max > 2 && (size_t)npair * g_max * 32 > 52 * 1024) g_max >>= 1;
+  if (g_env && (atoi(g_env) == 8 || atoi(g_env) == 4 || atoi(g_env) == 2)) g_max = atoi(g_env);
+  const size_t lds = (size_t)npair * g_max * 32;
+  if (lds > 160 * 1024 - 64) return ESDF_NO_FIT;
+  if (pk2_chunks(ylen, zlen_a >> 2, g_max, &m->pk2_ch, &m->pk2_zch) != FUELMI_OK) return ESDF_NO_FIT;
+  {
+    const int qsh = pk2_qsh();
+    const size_t rows = qsh < 0 ? (size_t)((xlen + 1) >> 1) : (((size_t)((xlen + 1) >> 1) + (1u << qsh) - 1) >> qsh) << qsh;
+    if ((size_t)m->pk2_ch.tile0[m->pk2_ch.n] * rows * 128 > m->esdf_tmp16_bytes) return ESDF_NO_FIT;
+  }
+  static const char* th_env = getenv("FUELMI_ZY_PK_THREADS");  // tuning hook (threads of ONE half)
+  // a half fills its npair rows in two trips: 128 / 256 lanes for 400- / 800-voxel y lines (measured: 33.5 against 35.5 us
+  // with one trip on the 400^2 x 100 map, 158 against 203 us on 800^2 x 200, whose 896-thread workgroups fit one per CU)
+  const int threads = 2 * (th_env ? atoi(th_env) : std::min(256, std::max(64, ((npair / 2 + 63) / 64) * 64)));
+  const bool wide = zlen_a > 128;  // aligned z-lines of up to 128 / 256 bits
+  (void)pk2_next_serial(m);
+  if (g_max == 8) return wide ? launch_zy_pk2_g<MODE, 8, 4>(m, b, z0a, threads, lds) : launch_zy_pk2_g<MODE, 8, 2>(m, b, z0a, threads, lds);
+  if (g_max == 4) return wide ? launch_zy_pk2_g<MODE, 4, 4>(m, b, z0a, threads, lds) : launch_zy_pk2_g<MODE, 4, 2>(m, b, z0a, threads, lds);
+  return wide ? launch_zy_pk2_g<MODE, 2, 4>(m, b, z0a, threads, lds) : launch_zy_pk2_g<MODE, 2, 2>(m, b, z0a, threads, lds);
+}
+
+// the x pass behind launch_zy_pk2 (same box, same serial, same chunks)
+template <int OUT>
+static int launch_x_pk2(fuelmi_map* m, const Box3& b) {
+  const Geo& g = m->g;
+  const int xlen = b.hi[0] - b.lo[0] + 1;
+  const int z0a = b.lo[2] & ~3;
+  const int npx = (xlen + 1) >> 1;
+  const size_t lds = (size_t)npx * 8 * 16;
+  if (lds > 64 * 1024 && !m->attr_set[1][OUT][0][0]) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x_pk2<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               150 * 1024));
+    m->attr_set[1][OUT][0][0] = true;
+  }
+  static const char* th_env = getenv("FUELMI_X_PK_THREADS");  // tuning hook
+  const int threads = th_env ? atoi(th_env) : (lds > 32 * 1024 ? 512 : 256);
+  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;
+  const int ylen = b.hi[1] - b.lo[1] + 1;
+  const int full8 = ((ylen + 7) / 8) * 8 * m->pk2_ch.n8;  // blocks of the full-width tiles, y-rows padded to a multiple of 8
+  const int grid = full8 + (m->pk2_ch.tile0[m->pk2_ch.n] - ylen * m->pk2_ch.n8);
+  unsigned long long* dbg = nullptr;
+  if (timing) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)grid * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
+  }
+  STAGE_LAUNCH(m, (k_esdf_x_pk2<OUT>), grid, threads, lds, g, b, reinterpret_cast<const uint4*>(m->esdf_tmp16),
+               (const u32*)m->esdf_tmp, m->dist, m->pk2_ch, z0a, pk2_qsh(), full8, esdf_stat_dev<OUT>(m), esdf_stat_host(m),
+               (const u32*)pk2_src_flag(m), m->esdf_serial, dbg);
+  HIPCHK(hipGetLastError());
+  if (timing) {
+    char what[96];
+    std::snprintf(what, sizeof what, "x2-timing] threads %d lds %zu", threads, lds);
+    { const int rc_ = pass_timing_report(m, dbg, grid, what); if (rc_ != FUELMI_OK) return rc_; }
+  }
+  return FUELMI_OK;
+}
+
 template <int OUT>
 static int launch_x4h(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
@@ -1702,7 +2217,14 @@ static bool esdf_use_far(fuelmi_map* m, const Box3& b) {
 template <int MODE>
 static int launch_zy_family(fuelmi_map* m, const Box3& b, int fam, int* ran) {
   if (fam == FUELMI_ESDF_PLAIN) {
-    const int rc = launch_zy_pk<MODE>(m, b);
+    static const bool pk2 = !(getenv("FUELMI_PK2") != nullptr && atoi(getenv("FUELMI_PK2")) == 0);  // A/B hook: the round-4 u32 hand-over
+    int rc = ESDF_NO_FIT;
+    m->esdf_pk2_last = false;
+    if (pk2) {
+      rc = launch_zy_pk2<MODE>(m, b);
+      m->esdf_pk2_last = rc != ESDF_NO_FIT;
+    }
+    if (rc == ESDF_NO_FIT) rc = launch_zy_pk<MODE>(m, b);
     if (rc != ESDF_NO_FIT) {
       *ran = FUELMI_ESDF_PLAIN;
       return rc;
@@ -1732,7 +2254,10 @@ int esdf_update(fuelmi_map* m) {
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
     static const bool x32 = getenv("FUELMI_X_PK") != nullptr && atoi(getenv("FUELMI_X_PK")) == 0;  // A/B hook
     rc = ESDF_NO_FIT;
-    if (ran == FUELMI_ESDF_PLAIN && !x32) rc = launch_x_pk<0>(m, b);  // the packed family: both passes on 16-bit lanes
+    if (ran == FUELMI_ESDF_PLAIN && m->esdf_pk2_last)
+      rc = launch_x_pk2<0>(m, b);  // the packed family: both passes on 16-bit lanes, 16-bit tile-contiguous hand-over
+    else if (ran == FUELMI_ESDF_PLAIN && !x32)
+      rc = launch_x_pk<0>(m, b);
     if (rc == ESDF_NO_FIT) rc = far ? launch_x<0, true>(m, b) : launch_x<0, false>(m, b);
   }
   if (rc) return rc;
@@ -1741,10 +2266,11 @@ int esdf_update(fuelmi_map* m) {
       StageScope sc(m, FUELMI_K_ESDF_ZY, nullptr, true);
       int ran2;
       rc = launch_zy_family<2>(m, b, far ? FUELMI_ESDF_PLAIN : fam, &ran2);
+      if (ran2 != FUELMI_ESDF_PLAIN) m->esdf_pk2_last = false;
     }
     if (rc) return rc;
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
-    rc = launch_x<1, false>(m, b);
+    rc = m->esdf_pk2_last ? launch_x_pk2<1>(m, b) : launch_x<1, false>(m, b);
   }
   return rc;
 }

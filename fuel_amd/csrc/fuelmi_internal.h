@@ -64,6 +64,27 @@ struct Plane {
 #define INF32 0x3FFFFFFFu
 #define INF16 0xFFFFu
 
+// chunks of the packed ESDF family's z/y pass and the column tiles of its x pass (esdf.hip, round 5)
+#define PK2_MAXCH 16
+struct Pk2Chunks {
+  int n;                     // pieces of the aligned z range
+  int n8;                    // ... of which the first n8 are 8 segments wide: their tiles are interleaved, tile (y, c) = y * n8 + c
+  short seg0[PK2_MAXCH];     // first z-segment (4 voxels) of the aligned z range
+  short g[PK2_MAXCH];        // segments (8, 4, 2, 1)
+  int tile0[PK2_MAXCH + 1];  // first column tile of the narrower pieces (c >= n8; tile0[n8] = ylen * n8); [n] = tiles in all
+};
+
+#define PK2_MAXZCH 32
+struct Pk2ZChunks {  // chunks of the z/y pass: pieces of the column tiles' z extent
+  int n;
+  short seg0[PK2_MAXZCH];       // first z-segment
+  signed char g[PK2_MAXZCH];    // segments (8, 4, 2, 1)
+  signed char gsh[PK2_MAXZCH];  // log2 of the width of the tile piece the chunk lies in
+  signed char off[PK2_MAXZCH];  // first segment inside that piece
+  int tile0[PK2_MAXZCH];        // column tile of y-row y: tile0 + (y / rows per tile) * tstride
+  int tstride[PK2_MAXZCH];
+};
+
 // ---- the map object ---------------------------------------------------------------------------
 struct ProfileSlot {
   std::vector<hipEvent_t> ev;  // pairs
@@ -86,7 +107,14 @@ struct fuelmi_map {
   Plane tmp_bits;               // scratch plane (occ & box)
   Plane tmp2_bits;              // scratch plane (y/z-dilated sources of the inflation)
   float* dist = nullptr;        // distance_buffer_ as f32                     4 B/voxel
-  u32* esdf_tmp = nullptr;      // y-pass result (squared voxel units)         4 B/voxel
+  u32* esdf_tmp = nullptr;      // y-pass result (squared voxel units)         4 B/voxel (packed family: only the values above 16 bits)
+  u32* esdf_tmp16 = nullptr;    // packed family: 16-bit y-pass result in the x pass's tile order   2 B/voxel (esdf.hip, round 5)
+  size_t esdf_tmp16_bytes = 0;
+  u32 esdf_serial = 0;          // stamps the "some slab holds a source" word of an update
+  bool esdf_pk2_last = false;   // the last z/y pass wrote the 16-bit hand-over
+  Pk2Chunks pk2_ch = {};        // ... in these column tiles
+  Pk2ZChunks pk2_zch = {};      // ... written by these chunks of the z/y pass
+  bool attr_set[2][3][9][2] = {};  // hipFuncSetAttribute done for (pass, MODE / OUT, G, NW) -- once, not per update
   unsigned char* flag_rayend = nullptr;  // flag_rayend_                      1 B/voxel
   u32* ray_owner = nullptr;     // per-frame end-voxel owner (point index)     4 B/voxel
   Plane hit_bits, miss_bits;    // per-frame touched voxels

@@ -556,6 +556,14 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
     fuelmi_set_error("hipMalloc of %zu-voxel grid failed", Npad);
     return fail(FUELMI_ENOMEM);
   }
+  if ((g.nz % 4) == 0) {  // the packed ESDF family's 16-bit hand-over (esdf.hip): column tiles of 32 x x-pairs x 128 B
+    const size_t ntiles = ((size_t)g.ny * (size_t)((g.nz + 7) / 4 + 1) + 7) / 8 + PK2_MAXCH + 1;  // (8 segments per tile, ragged chunks)
+    m->esdf_tmp16_bytes = ntiles * (size_t)(((g.nx + 1) / 2 + 63) / 64) * 64 * 128;  // (tile rows of 128 B per x-pair)
+    if (hipMalloc(reinterpret_cast<void**>(&m->esdf_tmp16), m->esdf_tmp16_bytes) != hipSuccess) {
+      fuelmi_set_error("hipMalloc of the %zu-byte ESDF hand-over buffer failed", m->esdf_tmp16_bytes);
+      return fail(FUELMI_ENOMEM);
+    }
+  }
   // initial state (sdf_map.cpp:61-72): all unknown, inflate 0, distance default, flag_rayend -1
   k_fill_f64<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(m->occ, I.clamp_min_log - 0.01, (long)Npad);
   k_fill_f32<<<blocks_for(Npad, 256, 65536), 256, 0, m->stream>>>(m->dist, (float)c->default_dist, (long)Npad);
@@ -603,7 +611,7 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
                      &m->tmp2_bits, &m->hit_bits, &m->miss_bits};
   for (Plane* p : planes)
     if (p->base) (void)hipFree(p->base);
-  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial, m->ins_head, m->ins_rec};
+  void* bufs[] = {m->occ, m->dist, m->esdf_tmp, m->esdf_tmp16, m->flag_rayend, m->ray_owner, m->d_stage, m->ins_partial, m->ins_head, m->ins_rec};
   if (m->h_ins) (void)hipHostFree(m->h_ins);
   for (auto& q : m->qslots) {
     if (q->st) (void)hipStreamSynchronize(q->st), (void)hipStreamDestroy(q->st);
