@@ -749,10 +749,12 @@ def main():
         if streaming:  # box-local stages: mean voxel count of the frames' local bounds
             nvox = float(np.mean(cyc.box_vox[-args.steps:])) if cyc.box_vox else 0.0
         # algorithmic HBM bytes per launch of each stage, box = nvox voxels
+        fam_now = cyc.map.lastEsdfFamily() if args.esdf_family < 0 else args.esdf_family
+        tmp_b = 2.0 if fam_now == 0 else 4.0  # y-pass result: 16-bit hand-over in the packed family (round 5), else u32
         alg_bytes = {
             "inflate": nvox * (3 / 8.0),          # occupied plane in, scratch plane out+in, inflated plane out
-            "esdf_zy": nvox * (2 / 8.0 + 4.0),    # inflated+unknown planes in, u32 y-pass result out
-            "esdf_x": nvox * (4.0 + 4.0),         # u32 in, f32 distance out
+            "esdf_zy": nvox * (2 / 8.0 + tmp_b),  # inflated+unknown planes in, y-pass result out
+            "esdf_x": nvox * (tmp_b + 4.0),       # y-pass result in, f32 distance out
             "bspline": ctrl.shape[0] * ctrl.shape[1] * 56.0,
         }
         achieved = alg_bytes[dominant] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -760,11 +762,11 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/), else null
         traffic, traffic_commit = None, None
         try:
-            pmc_file = {"G400": "r04_pmc_hbm_traffic_G400.json", "G800": "r04_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
+            pmc_file = {"G400": "r05_pmc_hbm_traffic_G400.json", "G800": "r05_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
             pmc_doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             pmc = pmc_doc["kernels"]
             traffic_commit = pmc_doc.get("commit")
-            keys = {"esdf_zy": ("k_esdf_zy_pk<", "k_esdf_zy4<"), "esdf_x": ("k_esdf_x_pk<", "k_esdf_x4"),
+            keys = {"esdf_zy": ("k_esdf_zy_pk2<", "k_esdf_zy_pk<", "k_esdf_zy4<"), "esdf_x": ("k_esdf_x_pk2<", "k_esdf_x_pk<", "k_esdf_x4"),
                     "inflate": ("k_inflate_fused", "k_inflate_yz"), "bspline": ("k_bspline_cost_grad",)}[dominant]
             hit = [v for key in keys for k, v in pmc.items() if key in k]
             traffic = hit[0]["hbm_bytes_per_launch"]
@@ -785,7 +787,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64 bit-planes / u32 squared distances / f32 ESDF / f64 log-odds and B-spline",
+            "dtype": "u64 bit-planes / u16 (u32 beyond 255 voxels) exact squared distances / f32 ESDF / f64 log-odds and B-spline",
             "data": "synthetic",
             "commit": os.environ.get("FUELMI_COMMIT"),  # git revision of the code (set by scripts/collect_profiles.sh)
             "config": {"workload": ("%s: %dx%dx%d @0.1m map per GPU, streaming 640x480 depth frames from an unknown "
@@ -805,6 +807,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes[dominant],
+                         # every single-kernel stage of the map chain, same accounting (isolated = chains serialised)
+                         "kernels": {k: {"algorithmic_bytes": alg_bytes[k], "isolated_ms": round(iso_ms_all[k], 5),
+                                         "isolated_frac": (alg_bytes[k] / (iso_ms_all[k] * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms_all[k] > 0 else None}
+                                     for k in ("inflate", "esdf_zy", "esdf_x", "bspline")},
                          # git revision the counter pass behind `traffic` was taken at (profiles/*.json carry it)
                          "traffic_commit": traffic_commit},
         }
@@ -822,7 +828,7 @@ def main():
             crit = {"stage": "frontier chain (predicate + tile CCL, cross-tile pairs, resolve, grouped output + flags)",
                     "kernels": 4, "algorithmic_bytes": fr_bytes, "ms": stage_ms["frontier"]}
         else:
-            crit = {"stage": "map chain (inflate y/z + x, ESDF z/y, ESDF x, B-spline batch)", "kernels": 5,
+            crit = {"stage": "map chain (inflate, ESDF z/y, ESDF x, B-spline batch)", "kernels": 4,
                     "algorithmic_bytes": map_chain_bytes, "ms": map_chain_ms}
         crit["achieved"] = crit["algorithmic_bytes"] / (crit["ms"] * 1e-3) / 1e9 if crit["ms"] > 0 else 0.0
         crit["frac"] = crit["achieved"] / HBM_PEAK_GBS

@@ -13,7 +13,9 @@
 //               fully parallel, no per-line sequential stack.  Source voxels cost nothing.
 // HBM traffic per box voxel: planes 2 x 1/8 B read, y-pass result u32 written + read, f32
 // distance written = 12.25 B.
+#include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "fuelmi_internal.h"
 
@@ -1312,9 +1314,48 @@ static int pass_timing_report(fuelmi_map* m, unsigned long long* dbg, int grid, 
     if (r[0] <= mid && r[3] >= mid) ++alive;
     if (r[0] - t0 < 100) ++early;
   }
+  std::vector<double> st, en;
+  for (int w = 0; w < grid; ++w) {
+    const unsigned long long* r = &d[(size_t)w * 8];
+    if (!r[0] || !r[3]) continue;
+    st.push_back((double)(r[0] - t0) / 100.0), en.push_back((double)(r[3] - t0) / 100.0);
+  }
+  std::sort(st.begin(), st.end());
+  std::sort(en.begin(), en.end());
+  int peak = 0;
+  {
+    size_t i = 0, j = 0;
+    int cur = 0;
+    while (i < st.size()) {
+      if (st[i] <= en[j]) ++cur, ++i, peak = std::max(peak, cur);
+      else --cur, ++j;
+    }
+  }
+  {  // the slowest tenth of the workgroups: where THEIR life goes, and which blocks they are
+    std::vector<std::pair<double, int>> lv;
+    for (int w = 0; w < grid; ++w) {
+      const unsigned long long* r = &d[(size_t)w * 8];
+      if (!r[0] || !r[3]) continue;
+      lv.push_back({(double)(r[3] - r[0]) / 100.0, w});
+    }
+    std::sort(lv.begin(), lv.end());
+    const size_t k0 = lv.size() - std::max<size_t>(1, lv.size() / 10);
+    double f = 0, bb = 0, sc = 0, lf = 0;
+    for (size_t k = k0; k < lv.size(); ++k) {
+      const unsigned long long* r = &d[(size_t)lv[k].second * 8];
+      f += (double)(r[1] - r[0]), bb += (double)(r[2] - r[1]), sc += (double)(r[3] - r[2]), lf += lv[k].first;
+    }
+    const double nn = (double)(lv.size() - k0) * 100.0;
+    std::fprintf(stderr, "[slowest tenth: fill %.2f barrier %.2f scan %.2f life %.2f us; slowest blocks:", f / nn, bb / nn, sc / nn, lf * 100.0 / nn);
+    for (size_t k = lv.size() - std::min<size_t>(8, lv.size()); k < lv.size(); ++k) std::fprintf(stderr, " %d(%.1f)", lv[k].second, lv[k].first);
+    std::fprintf(stderr, "]\n");
+  }
+  auto pct = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * (double)v.size()))]; };
   std::fprintf(stderr, "[%s: %d workgroups, span %.2f us; per workgroup: fill %.2f barrier %.2f scan %.2f life %.2f us; "
-               "alive at mid-span %d, started in the first us %d\n", what, n, (double)(t1 - t0) / 100.0, ph[0] / n / 100.0,
-               ph[1] / n / 100.0, ph[2] / n / 100.0, life / n / 100.0, alive, early);
+               "alive at mid-span %d (peak %d), started in the first us %d; starts 25/50/75/100 %%: %.1f %.1f %.1f %.1f us, ends 25/50/75: %.1f %.1f %.1f\n",
+               what, n, (double)(t1 - t0) / 100.0, ph[0] / n / 100.0,
+               ph[1] / n / 100.0, ph[2] / n / 100.0, life / n / 100.0, alive, peak, early, pct(st, 0.25), pct(st, 0.5), pct(st, 0.75),
+               pct(st, 1.0), pct(en, 0.25), pct(en, 0.5), pct(en, 0.75));
   return FUELMI_OK;
 }
 
@@ -1573,6 +1614,10 @@ static int launch_x_pk(fuelmi_map* m, const Box3& b) {
 // of that layout holds two x-slabs, so a z/y workgroup owns a slab PAIR: two tiles in LDS (lanes of the lower half fill
 // slab 2q, the upper half slab 2q+1), one fused scan loop per lane over both tiles (two independent LDS chains in
 // flight), two 16-byte stores per lane and trip where the u32 form needed four.
+// (Also tried this round: the z pass as a kernel of its own writing one byte per voxel, so that the fill of this
+// kernel becomes a 32-byte load and 16 squares per row pair and chunk.  Parity-green; the z/y kernel 30 -> 24 us on the
+// 400^2 x 100 map, the byte kernel 14 us: its floor is a 16 MB store, and the z/y pass is no shorter than 24 us
+// with a free fill -- the tail of the kernel is the SCAN of the workgroups in the explored half.  Removed.)
 // Values: v < PK_INF exact; PK_INF = "finite, at least 65025" -- the exact u32 then sits in the WIDE plane (esdf_tmp, the
 // voxel's own address; written only for such outputs: further than 255 voxels from every source of their slab);
 // 0xFFFF = no source in the slab.  Columns of the aligned z range outside the box hold 0 (they only must not stretch a
@@ -1621,40 +1666,6 @@ __device__ __forceinline__ void pk_scan16(const unsigned char* tA, const unsigne
     PK16_STEP(c[3], dB.w, uB.w);
 #undef PK16_STEP
     mx = pk_hmax(pk_max(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])) & mA, pk_max(pk_max(c[0], c[1]), pk_max(c[2], c[3])) & mB));
-    ro2 = rn2;
-    j8 += 8u;
-  }
-}
-
-// one tile only (experiment: the two slabs in two loops, each with its own trip count)
-template <int G>
-__device__ __forceinline__ void pk_scan8p(const unsigned char* t, int p, int gi, int npair, u32 (&a)[4]) {
-  constexpr int stride = 16 * G;
-  const int col = 16 * gi, base = __mul24(p, stride) + col;
-  const uint4 v = lds4(t, base);
-  const u32 one = 0x00010001u;
-  a[0] = pk_min(v.x, pk_adds(pk_swap(v.x), one)), a[1] = pk_min(v.y, pk_adds(pk_swap(v.y), one));
-  a[2] = pk_min(v.z, pk_adds(pk_swap(v.z), one)), a[3] = pk_min(v.w, pk_adds(pk_swap(v.w), one));
-  u32 mx = pk_hmax(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])));
-  const int hi_off = __mul24(npair - 1, stride) + col;
-  const int jmax = max(p, npair - 1 - p);
-  int od = base, ou = base;
-  u32 ro2 = 1u, j8 = 8u;
-  for (int j = 1; j <= jmax && ro2 < mx; ++j) {
-    od = max(od - stride, col);
-    ou = min(ou + stride, hi_off);
-    const uint4 d = lds4(t, od), u = lds4(t, ou);
-    const u32 rn2 = ro2 + j8;
-    const u32 re2 = (ro2 + rn2 - 2u) >> 1;
-    const u32 ke = pk_both(pk_sat16(re2));
-    const u32 k1 = pk_sat16(ro2) | (pk_sat16(rn2) << 16), k2 = pk_sat16(rn2) | (pk_sat16(ro2) << 16);
-#define PK16_STEP(B, D, U) B = pk_min(B, pk_min(pk_adds(pk_min(D, U), ke), pk_min(pk_adds(pk_swap(D), k1), pk_adds(pk_swap(U), k2))))
-    PK16_STEP(a[0], d.x, u.x);
-    PK16_STEP(a[1], d.y, u.y);
-    PK16_STEP(a[2], d.z, u.z);
-    PK16_STEP(a[3], d.w, u.w);
-#undef PK16_STEP
-    mx = pk_hmax(pk_max(pk_max(a[0], a[1]), pk_max(a[2], a[3])));
     ro2 = rn2;
     j8 += 8u;
   }
@@ -1729,10 +1740,7 @@ __device__ __forceinline__ void zy_pk2_body(const Geo& g, const Box3& b, const u
   for (int o = threadIdx.x; o < total; o += T) {
     const int p = o / G, gi = o - p * G;  // (G is a power of two)
     u32 a[4], c[4];
-    if (want == 3 && (fastrow & 2)) {
-      pk_scan8p<G>(tA, p, gi, npair, a);
-      pk_scan8p<G>(tB, p, gi, npair, c);
-    } else if (want) {
+    if (want) {
       pk_scan16<G>(tA, tB, p, gi, npair, want, a, c);
     } else {
       a[0] = a[1] = a[2] = a[3] = c[0] = c[1] = c[2] = c[3] = pk_both(PK_INF);
@@ -1995,7 +2003,7 @@ static int launch_zy_pk2_g(fuelmi_map* m, const Box3& b, int z0a, int threads, s
   }
   STAGE_LAUNCH(m, (k_esdf_zy_pk2<MODE, GMAX, NW>), grid, threads, lds, m->g, b, (const u64*)m->infl_bits.p,
                (const u64*)m->unk_bits.p, reinterpret_cast<uint4*>(m->esdf_tmp16), m->esdf_tmp, ch, ntiles, z0a, npx, pk2_qsh(),
-               (zy_fastrow() ? 1 : 0) | (getenv("FUELMI_ZY_PK_SEP") ? 2 : 0), MODE == 2 ? nullptr : esdf_stat_dev<0>(m), pk2_src_flag(m), m->esdf_serial, dbg);
+               (zy_fastrow() ? 1 : 0), MODE == 2 ? nullptr : esdf_stat_dev<0>(m), pk2_src_flag(m), m->esdf_serial, dbg);
   HIPCHK(hipGetLastError());
   if (timing) {
     char what[96];

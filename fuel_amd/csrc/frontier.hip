@@ -2768,7 +2768,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, frontier_stream_priority()));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
-  HIPCHK(hipStreamCreateWithFlags(&f->zstream, hipStreamNonBlocking));  // zeroes the retired flag plane (frontier_apply_reset)
+  // (zstream -- zeroes the retired flag plane in one-stream mode -- is created on first use, frontier_finish_reset)
   HIPCHK(hipEventCreateWithFlags(&f->ev_zero, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_prev, hipEventDisableTiming));
@@ -3198,6 +3198,35 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   return FUELMI_OK;
 }
 
+// FUELMI_HOST_TIMING: where the host's time inside _search_begin / _search_end goes (mean microseconds per call, printed
+// by fuelmi_bench_cycles)
+struct HostTiming {
+  bool on = getenv("FUELMI_HOST_TIMING") != nullptr;
+  double acc[16] = {0};
+  long n = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() {
+    if (on) t = std::chrono::steady_clock::now(), ++n;
+  }
+  void lap(int k) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    acc[k] += std::chrono::duration<double, std::micro>(now - t).count();
+    t = now;
+  }
+  void report() {
+    if (!on || !n) return;
+    static const char* names[16] = {"b:lists+reset", "b:box+wait+scope", "b:rm_begin", "b:region", "b:launch ccl", "b:events", "b:launch cross",
+                                    "b:launch resolve", "b:launch out", "b:finish_reset", "e:pre-poll", "e:poll", "e:post-poll", "", "", ""};
+    std::fprintf(stderr, "[host-timing] per search:");
+    for (int k = 0; k < 13; ++k) std::fprintf(stderr, " %s %.2f", names[k], acc[k] / (double)n);
+    std::fprintf(stderr, "\n");
+    for (double& a : acc) a = 0;
+    n = 0;
+  }
+};
+static HostTiming g_ht;
+
 // the fast chain (capturable); falls back to the legacy one through counts[2] == 2
 static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   const Geo& g = f->map->g;
@@ -3215,6 +3244,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   else
     k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   FDBG("k_tile_ccl");
+  g_ht.lap(4);
   // the tile CCL (and the changed-cluster test in front of it) is the last reader of the map's occupancy planes: a
   // fusion queued behind this point may start as soon as it is done (direct launches only -- inside a captured graph
   // the event is recorded behind the whole chain by the caller)
@@ -3223,19 +3253,23 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
     map_add_plane_reader(f->map, f->ev_planes_read);
     if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
   }
+  g_ht.lap(5);
   if (nt3[1] == 256)
     k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F);
   else
     k_tile_cross<512><<<tiles, 512, f->cross_lds[mk], f->stream>>>(g, F);
   FDBG("k_tile_cross");
+  g_ht.lap(6);
   k_resolve<<<1, RS_T, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
+  g_ht.lap(7);
   if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[2], f->stream));
   if (nt3[2] == 256)
     k_tile_out<256><<<tiles, 256, f->out_lds[mk], f->stream>>>(g, F);
   else
     k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
   FDBG("k_tile_out");
+  g_ht.lap(8);
   if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[3], f->stream));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
@@ -3250,8 +3284,18 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
 static int frontier_finish_reset(fuelmi_frontier* f) {
   if (!f->zero_deferred) return FUELMI_OK;
   f->zero_deferred = false;
-  HIPCHK(hipStreamWaitEvent(f->zstream, f->ev_tail, 0));
   const int W = f->map->g.W;
+  if (f->stream2) {
+    // Two buffer sets: the plane just retired belongs to the stream just retired (they swap together), so the zeroing
+    // goes onto that stream itself -- in order behind the tail that still sets flags in the plane and in front of the
+    // search after next that uses it again.  One launch instead of wait + launch + record on a side stream (10.7 -> ~4 us
+    // of host time per search, profiles/r05_host_timing.txt), and one stream fewer per finder (hardware queues).
+    k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->stream2>>>(f->flag2.p, W);
+    HIPCHK(hipGetLastError());
+    return FUELMI_OK;
+  }
+  if (!f->zstream) HIPCHK(hipStreamCreateWithFlags(&f->zstream, hipStreamNonBlocking));  // (one-stream mode only)
+  HIPCHK(hipStreamWaitEvent(f->zstream, f->ev_tail, 0));
   k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->zstream>>>(f->flag2.p, W);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev_zero, f->zstream));
@@ -3261,7 +3305,9 @@ static int frontier_finish_reset(fuelmi_frontier* f) {
 static int frontier_apply_reset(fuelmi_frontier* f, bool defer_zeroing = false) {
   if (!f->fresh_pending) return FUELMI_OK;
   f->fresh_pending = false;
-  HIPCHK(hipEventRecord(f->ev_tail, f->stream));  // (everything that still writes the retired plane is in front of this)
+  // (everything that still writes the retired plane / the shared cell pool is in front of this; with two buffer sets only
+  // a commit since the last swap makes anybody wait for it)
+  if (!f->stream2 || f->pool_dirty) HIPCHK(hipEventRecord(f->ev_tail, f->stream));
   if (f->stream2) {
     // the other plane's buffer set and stream: the retiring search's tail keeps running on its own stream.  (The cell
     // pool is the one device buffer both sets share: if it was written since the last swap -- a commit -- the new
@@ -3292,6 +3338,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   const Geo& g = m->g;
   FArgs& F = f->F;
   f->tmp.clear();
+  g_ht.start();
   {
     const int rcm = frontier_materialize_lists(f);  // (the result buffer is about to be reused)
     if (rcm) return rcm;
@@ -3302,8 +3349,12 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   }
   struct FinishReset {  // (on every exit path, behind whatever was launched)
     fuelmi_frontier* f;
-    ~FinishReset() { (void)frontier_finish_reset(f); }
+    ~FinishReset() {
+      (void)frontier_finish_reset(f);
+      g_ht.lap(9);
+    }
   } finish_reset{f};
+  g_ht.lap(0);
   double umin[3], umax[3];
   fuelmi_map_get_updated_box(m, umin, umax, 1);
 
@@ -3314,6 +3365,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->scope.reset(new StageScope(m, FUELMI_K_FRONTIER, f->stream));
   f->removed_ids.clear();
   for (int q = 0; q < 3; ++q) f->rm_lo[q] = 1, f->rm_hi[q] = 0;
+  g_ht.lap(1);
   // on EVERY exit path below (the changed-cluster test reads the occupancy planes too, and an empty search or an
   // error returns before the chain): whatever was queued, the planes are free behind it
   struct PlanesRead {
@@ -3325,6 +3377,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   } planes_read{f};
   int rc = remove_changed_begin(f, umin, umax);
   if (rc) return rc;
+  g_ht.lap(2);
 
   // scan box (:95-106): updated box +- (1,1,0.5) clipped to the exploration box, as indices
   const int nv[3] = {g.nx, g.ny, g.nz};
@@ -3447,6 +3500,7 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   static const bool dbg_sync = getenv("FUELMI_DEBUG_SYNC") != nullptr;
   static const bool fast_graph = getenv("FUELMI_FR_GRAPH") != nullptr && atoi(getenv("FUELMI_FR_GRAPH")) != 0 && !dbg_sync;
   static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || dbg_sync;
+  g_ht.lap(3);
   if (fast) {
     f->fast_launched = true;
     if (!fast_graph) {
@@ -3548,6 +3602,9 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   // poll instead of a blocking wait: the caller is about to consume the result and the chain is
   // ~100 us long, an interrupt-driven wake-up costs a noticeable fraction of that
   F.fast = 0;
+  g_ht.start();
+  if (g_ht.on) --g_ht.n;
+  g_ht.lap(10);
   if (f->fast_launched) {
     // the fast chain publishes counts + cluster records from k_resolve and stamps them with the search's epoch;
     // the two kernels behind it (flags, regrouping + copy-out of the cells) keep running -- whoever touches the
@@ -3577,6 +3634,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    g_ht.lap(11);
     f->tail_pending = true;
     F.fast = 1;
     if (F.dbg) {  // FUELMI_FR_TIMING: where the tile kernel and the resolve kernel spend their time (100 MHz ticks)
@@ -3855,6 +3913,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   *n_new = (int)f->tmp.size();
   f->dirty_all = false;
   f->seen_epoch = m->occ_epoch;
+  g_ht.lap(12);
   return FUELMI_OK;
 }
 
@@ -4118,6 +4177,7 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   for (int q = 0; q < 6; ++q) m->bench_host_us[q] = n ? hp[q] / n : 0.0;
   m->bench_host_us[6] = f->wait_us_acc / std::max(n, 1);
   f->wait_us_acc = 0.0;
+  g_ht.report();
   return FUELMI_OK;
 }
 extern "C" int fuelmi_bench_host_profile(const fuelmi_map* m, double out7[7]) {
