@@ -24,10 +24,14 @@ static void warn(const char* what, int rc) {
 // ------------------------------------------------------------------------------------------------
 // SDFMap
 // ------------------------------------------------------------------------------------------------
-SDFMap::SDFMap() : dev_(nullptr), mirror_occ_(true), mirror_infl_(true), mirror_dist_(true) {}
+SDFMap::SDFMap() : ext_(new Ext{nullptr, true, true, true}) {}
 SDFMap::~SDFMap() {
-  if (dev_) fuelmi_map_destroy(dev_);
+  if (ext_->dev) fuelmi_map_destroy(ext_->dev);
+  delete ext_;
 }
+// (never called: this library does not create either object -- see the data members in plan_env/sdf_map.h)
+void SDFMap::MapROSDelete::operator()(MapROS*) const {}
+void SDFMap::RayCasterDelete::operator()(RayCaster*) const {}
 
 void SDFMap::initMap(ros::NodeHandle& nh) {
   // parameter names and defaults of the reference (plan_env/src/sdf_map.cpp:19-47,78-82)
@@ -66,11 +70,11 @@ void SDFMap::initMap(ros::NodeHandle& nh) {
     nh.param(std::string("sdf_map/box_min_") + axis[i], c.box_min[i], org[i]);
     nh.param(std::string("sdf_map/box_max_") + axis[i], c.box_max[i], org[i] + c.map_size[i]);
   }
-  int rc = fuelmi_map_create(&c, &dev_);
+  int rc = fuelmi_map_create(&c, &ext_->dev);
   warn("fuelmi_map_create", rc);
   if (rc != FUELMI_OK) return;
   fuelmi_map_info I;
-  fuelmi_map_get_info(dev_, &I);
+  fuelmi_map_get_info(ext_->dev, &I);
   mp_->resolution_ = c.resolution;
   mp_->resolution_inv_ = I.resolution_inv;
   mp_->obstacles_inflation_ = c.obstacles_inflation;
@@ -109,19 +113,19 @@ void SDFMap::initMap(ros::NodeHandle& nh) {
   // the mirrors never move again: pin and map them once, every refresh is then one kernel storing the box
   // voxels straight into them (no staging copy, one synchronisation)
   warn("fuelmi_map_register_mirrors",
-       fuelmi_map_register_mirrors(dev_, md_->occupancy_buffer_.data(), md_->occupancy_buffer_inflate_.data(),
+       fuelmi_map_register_mirrors(ext_->dev, md_->occupancy_buffer_.data(), md_->occupancy_buffer_inflate_.data(),
                                    md_->distance_buffer_.data()));
 }
 
 void SDFMap::setHostMirror(bool occupancy, bool inflate, bool distance) {
-  mirror_occ_ = occupancy, mirror_infl_ = inflate, mirror_dist_ = distance;
+  ext_->mirror_occ = occupancy, ext_->mirror_infl = inflate, ext_->mirror_dist = distance;
 }
 
 void SDFMap::pullBounds() {
   int lo[3], hi[3];
   double a[3], b[3];
-  fuelmi_map_get_local_bound(dev_, lo, hi);
-  fuelmi_map_get_updated_box(dev_, a, b, 0);
+  fuelmi_map_get_local_bound(ext_->dev, lo, hi);
+  fuelmi_map_get_updated_box(ext_->dev, a, b, 0);
   for (int i = 0; i < 3; ++i) {
     md_->local_bound_min_(i) = lo[i], md_->local_bound_max_(i) = hi[i];
     md_->update_min_(i) = a[i], md_->update_max_(i) = b[i];
@@ -132,7 +136,7 @@ void SDFMap::syncMirrors(const Eigen::Vector3i& bmin, const Eigen::Vector3i& bma
   if (!(occ || infl || dist)) return;
   const int lo[3] = {bmin(0), bmin(1), bmin(2)}, hi[3] = {bmax(0), bmax(1), bmax(2)};
   warn("fuelmi_map_sync_host",
-       fuelmi_map_sync_host(dev_, lo, hi, occ ? md_->occupancy_buffer_.data() : nullptr,
+       fuelmi_map_sync_host(ext_->dev, lo, hi, occ ? md_->occupancy_buffer_.data() : nullptr,
                             infl ? md_->occupancy_buffer_inflate_.data() : nullptr,
                             dist ? md_->distance_buffer_.data() : nullptr));
 }
@@ -142,15 +146,15 @@ void SDFMap::inputPointCloud(const pcl::PointCloud<pcl::PointXYZ>& points, const
   if (point_num == 0) return;
   const double cam[3] = {camera_pos(0), camera_pos(1), camera_pos(2)};
   warn("fuelmi_map_input_points",
-       fuelmi_map_input_points(dev_, &points.points[0].x, (int)sizeof(pcl::PointXYZ), point_num, cam));
+       fuelmi_map_input_points(ext_->dev, &points.points[0].x, (int)sizeof(pcl::PointXYZ), point_num, cam));
   pullBounds();
   md_->reset_updated_box_ = false;
   // fused voxels lie in the index box of camera + end points, inside the inflated local bound
-  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, mirror_occ_, false, false);
+  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, ext_->mirror_occ, false, false);
 }
 
 void SDFMap::clearAndInflateLocalMap() {
-  warn("fuelmi_map_inflate_local", fuelmi_map_inflate_local(dev_));
+  warn("fuelmi_map_inflate_local", fuelmi_map_inflate_local(ext_->dev));
   // stamps spill up to inflate_step voxels outside the box; a stamp that leaves the map in z lands in the
   // neighbouring y row at the other end of z, one that leaves it in y in the neighbouring x slab (the
   // reference only tests the linear address, sdf_map.cpp:453-458): widen the refreshed box accordingly
@@ -164,10 +168,10 @@ void SDFMap::clearAndInflateLocalMap() {
     }
   boundIndex(lo);
   boundIndex(hi);
-  syncMirrors(lo, hi, false, mirror_infl_, false);
+  syncMirrors(lo, hi, false, ext_->mirror_infl, false);
   // the virtual ceiling (sdf_map.cpp:464-471) rewrites occupancy_buffer_ in one z row over the x,y extent of
   // the local bound: the callers' inline getOccupancy() must see it right away, as in the reference
-  if (mirror_occ_ && mp_->virtual_ceil_height_ > -0.5) {
+  if (ext_->mirror_occ && mp_->virtual_ceil_height_ > -0.5) {
     const int ceil_id = (int)floor((mp_->virtual_ceil_height_ - mp_->map_origin_(2)) * mp_->resolution_inv_);
     if (ceil_id >= 0 && ceil_id < mp_->map_voxel_num_(2)) {
       Eigen::Vector3i clo = md_->local_bound_min_, chi = md_->local_bound_max_;
@@ -178,31 +182,31 @@ void SDFMap::clearAndInflateLocalMap() {
 }
 
 void SDFMap::updateESDF3d() {
-  warn("fuelmi_map_update_esdf", fuelmi_map_update_esdf(dev_));
-  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, false, false, mirror_dist_);
+  warn("fuelmi_map_update_esdf", fuelmi_map_update_esdf(ext_->dev));
+  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, false, false, ext_->mirror_dist);
 }
 
 void SDFMap::resetBuffer() {
-  warn("fuelmi_map_reset_buffer_all", fuelmi_map_reset_buffer_all(dev_));
+  warn("fuelmi_map_reset_buffer_all", fuelmi_map_reset_buffer_all(ext_->dev));
   pullBounds();
-  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, false, mirror_infl_, mirror_dist_);
+  syncMirrors(md_->local_bound_min_, md_->local_bound_max_, false, ext_->mirror_infl, ext_->mirror_dist);
 }
 
 void SDFMap::resetBuffer(const Eigen::Vector3d& min_pos, const Eigen::Vector3d& max_pos) {
   const double a[3] = {min_pos(0), min_pos(1), min_pos(2)}, b[3] = {max_pos(0), max_pos(1), max_pos(2)};
-  warn("fuelmi_map_reset_buffer", fuelmi_map_reset_buffer(dev_, a, b));
+  warn("fuelmi_map_reset_buffer", fuelmi_map_reset_buffer(ext_->dev, a, b));
   Eigen::Vector3i lo, hi;
   posToIndex(min_pos, lo);
   posToIndex(max_pos, hi);
   boundIndex(lo);
   boundIndex(hi);
-  syncMirrors(lo, hi, false, mirror_infl_, mirror_dist_);
+  syncMirrors(lo, hi, false, ext_->mirror_infl, ext_->mirror_dist);
 }
 
 void SDFMap::setOccupied(const Eigen::Vector3d& pos, const int& occ) {
   if (!isInMap(pos)) return;
   const double p[3] = {pos(0), pos(1), pos(2)};
-  const int rc = fuelmi_map_set_occupied(dev_, p, 1, occ);
+  const int rc = fuelmi_map_set_occupied(ext_->dev, p, 1, occ);
   warn("fuelmi_map_set_occupied", rc);
   if (rc != FUELMI_OK) return;  // the device refused the value (only 0 / 1 exist there): the mirror must not diverge
   Eigen::Vector3i id;
@@ -215,7 +219,7 @@ void SDFMap::setOccupied(const Eigen::Vector3d& pos, const int& occ) {
 // the host copy -- eight loads like the reference, the device's own arithmetic on the same f64 values, hence
 // the same doubles -- instead of a GPU round trip per point.  Batches go to the device (getDistWithGradBatch).
 double SDFMap::getDistWithGrad(const Eigen::Vector3d& pos, Eigen::Vector3d& grad) {
-  if (mirror_dist_) {
+  if (ext_->mirror_dist) {
     if (!isInMap(pos)) {
       grad = Eigen::Vector3d(0, 0, 0);
       return 0;
@@ -251,19 +255,19 @@ double SDFMap::getDistWithGrad(const Eigen::Vector3d& pos, Eigen::Vector3d& grad
   }
   const double p[3] = {pos(0), pos(1), pos(2)};
   double d = 0.0, g[3] = {0, 0, 0};
-  warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(dev_, p, 1, &d, g));
+  warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(ext_->dev, p, 1, &d, g));
   for (int k = 0; k < 3; ++k) grad(k) = g[k];
   return d;
 }
 void SDFMap::getDistWithGradBatch(const double* pos_xyz, int n, double* dist, double* grad_xyz) {
-  warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(dev_, pos_xyz, n, dist, grad_xyz));
+  warn("fuelmi_map_dist_grad", fuelmi_map_dist_grad(ext_->dev, pos_xyz, n, dist, grad_xyz));
 }
 
 void SDFMap::getRegion(Eigen::Vector3d& ori, Eigen::Vector3d& size) { ori = mp_->map_origin_, size = mp_->map_size_; }
 void SDFMap::getBox(Eigen::Vector3d& bmin, Eigen::Vector3d& bmax) { bmin = mp_->box_mind_, bmax = mp_->box_maxd_; }
 void SDFMap::getUpdatedBox(Eigen::Vector3d& bmin, Eigen::Vector3d& bmax, bool reset) {
   double a[3], b[3];
-  fuelmi_map_get_updated_box(dev_, a, b, reset ? 1 : 0);
+  fuelmi_map_get_updated_box(ext_->dev, a, b, reset ? 1 : 0);
   for (int k = 0; k < 3; ++k) bmin(k) = a[k], bmax(k) = b[k];
   if (reset) md_->reset_updated_box_ = true;
 }

@@ -3,7 +3,9 @@
 // API and inline getters, but the grid lives on an MI355X behind libfuelmi (include/fuelmi.h).
 //
 // The reference's inline getters read host std::vectors (sdf_map.h:196-237) and are compiled into
-// the callers' objects (A*, kino-A*, ViewNode, FSM ...).  This header keeps that contract: MapData
+// the callers' objects (A*, kino-A*, ViewNode, FSM ...).  This header keeps that contract down to the
+// layout: SDFMap's data members, MapParam and MapData have the reference's fields in the reference's order
+// (round 5; tests/test_abi_cpu.py compares every offset with the reference's own header).  MapData
 // still owns occupancy_buffer_ / occupancy_buffer_inflate_ / distance_buffer_ as HOST MIRRORS that
 // every mutator refreshes from the device for the box it touched (fuelmi_map_sync_host).  Callers
 // that only use the GPU path (FrontierFinder / BsplineOptimizer facades) can switch the mirrors off
@@ -89,7 +91,7 @@ public:
 
   // -- additions of this implementation (not in the reference) --
   // device handle for the FrontierFinder / BsplineOptimizer facades
-  fuelmi_map* device() const { return dev_; }
+  fuelmi_map* device() const { return ext_ ? ext_->dev : nullptr; }
   // which host mirrors the mutators keep coherent (default: all, as the reference's getters need)
   void setHostMirror(bool occupancy, bool inflate, bool distance);
   // batched getDistWithGrad for n positions (xyz packed), one kernel launch
@@ -104,42 +106,73 @@ private:
   void pullBounds();
   void syncMirrors(const V3i& lo, const V3i& hi, bool occ, bool infl, bool dist);
 
-  fuelmi_map* dev_;
-  bool mirror_occ_, mirror_infl_, mirror_dist_;
-  unique_ptr<MapData> md_;
+  // Data members: the reference's four, in its order and of pointer size each (sdf_map.h:74-77) -- the inline getters
+  // below are compiled into the callers and reach mp_ / md_ at these offsets -- then ONE pointer to this
+  // implementation's state ("new state behind an opaque pointer appended at the end").  mr_ / caster_ are
+  // never set by this library (MapROS is the caller's, the ray caster lives on the device); their deleters are declared
+  // here and defined in the library so that the header needs neither class.
+  struct MapROSDelete {
+    void operator()(MapROS*) const;
+  };
+  struct RayCasterDelete {
+    void operator()(RayCaster*) const;
+  };
+  struct Ext {
+    fuelmi_map* dev;
+    bool mirror_occ, mirror_infl, mirror_dist;
+  };
   unique_ptr<MapParam> mp_;
+  unique_ptr<MapData> md_;
+  unique_ptr<MapROS, MapROSDelete> mr_;
+  unique_ptr<RayCaster, RayCasterDelete> caster_;
+  Ext* ext_;
 };
 
-// Host copies of what the callers' inline getters and MapROS read.  Field NAMES and element types are
-// the reference's (sdf_map.h:86-125); everything else of its MapData lives on the device.
-struct MapData {
-  std::vector<char> occupancy_buffer_inflate_;
-  std::vector<double> occupancy_buffer_;
-  std::vector<double> distance_buffer_;
-  bool reset_updated_box_;
-  V3d update_min_, update_max_;
-  V3i local_bound_min_, local_bound_max_;
-
-  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
-};
-
+// The reference's MapParam / MapData, field for field: order, names and types of plan_env/sdf_map.h:86-125
+// (tests/test_abi_cpu.py compiles one translation unit against the reference's header and one against this one and
+// compares sizeof / offsetof of every field).  What the callers' inline getters and MapROS read -- occupancy_buffer_,
+// occupancy_buffer_inflate_, distance_buffer_, the bounds, the updated box -- are HOST MIRRORS the mutators refresh
+// from the device; the buffers only the reference's CPU algorithms used (distance_buffer_neg_, tmp_buffer*, count_*,
+// flag_*, cache_voxel_) stay empty: that state lives on the device.
 struct MapParam {
-  // grid geometry
+  // map properties
+  Eigen::Vector3d map_origin_, map_size_;
+  Eigen::Vector3d map_min_boundary_, map_max_boundary_;
+  Eigen::Vector3i map_voxel_num_;
   double resolution_, resolution_inv_;
-  V3i map_voxel_num_;
-  V3d map_origin_, map_size_, map_min_boundary_, map_max_boundary_;
-  double ground_height_, virtual_ceil_height_;
-  // exploration box, as indices and as positions
-  V3i box_min_, box_max_;
-  V3d box_mind_, box_maxd_;
-  // fusion
+  double obstacles_inflation_;
+  double virtual_ceil_height_, ground_height_;
+  Eigen::Vector3i box_min_, box_max_;
+  Eigen::Vector3d box_mind_, box_maxd_;
+  double default_dist_;
+  bool optimistic_, signed_dist_;
+  // map fusion
   double p_hit_, p_miss_, p_min_, p_max_, p_occ_;
   double prob_hit_log_, prob_miss_log_, clamp_min_log_, clamp_max_log_, min_occupancy_log_;
-  double max_ray_length_, local_bound_inflate_, unknown_flag_;
+  double max_ray_length_;
+  double local_bound_inflate_;
   int local_map_margin_;
-  // inflation / distance field
-  double obstacles_inflation_, default_dist_;
-  bool optimistic_, signed_dist_;
+  double unknown_flag_;
+};
+
+struct MapData {
+  // main map data (host mirrors of the device planes)
+  std::vector<double> occupancy_buffer_;
+  std::vector<char> occupancy_buffer_inflate_;
+  std::vector<double> distance_buffer_neg_;  // (empty: signed distances are merged on the device)
+  std::vector<double> distance_buffer_;
+  std::vector<double> tmp_buffer1_;  // (empty)
+  std::vector<double> tmp_buffer2_;  // (empty)
+  // data for updating (empty: the fusion's bookkeeping lives on the device)
+  vector<short> count_hit_, count_miss_, count_hit_and_miss_;
+  vector<char> flag_rayend_, flag_visited_;
+  char raycast_num_;
+  queue<int> cache_voxel_;
+  Eigen::Vector3i local_bound_min_, local_bound_max_;
+  Eigen::Vector3d update_min_, update_max_;
+  bool reset_updated_box_;
+
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 };
 
 // ---- inline helpers.  The arithmetic is the reference's (sdf_map.h:127-237: floor((p - origin) *

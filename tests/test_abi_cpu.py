@@ -91,3 +91,41 @@ def test_product_does_not_touch_the_oracle():
                                     not s.startswith(("#", "//", "*", '"""')):
                                 bad.append((f, s))
     assert not bad, bad
+
+
+def _layout_probe(tmp_path, header_dirs, name):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-std=c++14", "-w", "-o", exe, os.path.join(root, "tests", "golden", "sdf_map_layout_probe.cpp")]
+    for d in header_dirs:
+        cmd += ["-I", d]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return subprocess.run([exe], capture_output=True, text=True, timeout=60, check=True).stdout.splitlines()
+
+
+def test_sdf_map_header_layout_is_the_references(tmp_path):
+    """SURVEY 8(b) "header-level ABI": MapParam, MapData and SDFMap's data members in the facade's plan_env/sdf_map.h
+    have the reference's fields at the reference's offsets (plan_env/include/plan_env/sdf_map.h:74-125) -- the inline
+    getters of that header are compiled into the callers.  One probe, compiled against each header with the same
+    Eigen / ROS / PCL stand-ins; the reference's output is also kept as a golden file so that the comparison runs where
+    the reference checkout is absent."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shims = [os.path.join(root, "oracle", "ref_build", "shim_ros"), os.path.join(root, "compat")]
+    golden = os.path.join(root, "tests", "golden", "sdf_map_layout.txt")
+    ref_inc = "/root/reference/fuel_planner/plan_env/include"
+    if os.path.exists(os.path.join(ref_inc, "plan_env", "sdf_map.h")):
+        ref = _layout_probe(tmp_path, [ref_inc] + shims, "probe_ref")
+        if not os.path.exists(golden) or open(golden).read().splitlines() != ref:
+            with open(golden, "w") as f:
+                f.write("\n".join(ref) + "\n")
+    assert os.path.exists(golden), "no golden layout and no reference checkout"
+    ref = open(golden).read().splitlines()
+    ours = _layout_probe(tmp_path, [os.path.join(root, "fuel_amd", "facade"), os.path.join(root, "include")] + shims, "probe_ours")
+    assert len(ref) == len(ours) and len(ref) > 50
+    for a, b in zip(ref, ours):
+        if a.startswith("SDFMap size"):
+            # the drop-in appends exactly one pointer behind the reference's last member
+            assert int(b.split()[-1]) == int(a.split()[-1]) + 8, (a, b)
+        else:
+            assert a == b, (a, b)
