@@ -110,6 +110,7 @@ _PP = C.POINTER(C.c_void_p)
 SYMBOLS = {
     "fuelmi_last_error": (C.c_char_p, []),
     "fuelmi_version": (C.c_char_p, []),
+    "fuelmi_hw_queues": (C.c_int, []),
     "fuelmi_device_count": (C.c_int, []),
     "fuelmi_map_create": (C.c_int, [C.POINTER(MapCfg), _PP]),
     "fuelmi_map_destroy": (None, [_P]),

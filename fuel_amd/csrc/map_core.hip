@@ -12,6 +12,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <chrono>
+
 #include "fuelmi_internal.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -24,6 +26,22 @@ void fuelmi_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+// Hardware queues.  A map owns one stream, a finder two, every busy query slot one; the HIP runtime multiplexes a process's
+// streams onto GPU_MAX_HW_QUEUES hardware queues -- FOUR by default -- and two streams that land on one queue time-slice:
+// the library's own fifth stream took the plan cycle from 10 800 to 4 400 cycles/s (round 4), four idle maps in the
+// process a streaming frame from 0.11 to 0.37 ms, ten optimiser threads ten solves from 1.8 to 4.5 ms.  The runtime reads
+// the variable when it initialises (the first HIP call of the process), so the library sets it when it is LOADED --
+// unless the environment already has a value, or FUELMI_KEEP_HW_QUEUES is set.  A process that has initialised HIP before
+// loading this library (fuelmi_hw_queues() then still reports what the environment says) sets it itself.
+__attribute__((constructor)) static void fuelmi_default_hw_queues() {
+  if (getenv("FUELMI_KEEP_HW_QUEUES")) return;
+  setenv("GPU_MAX_HW_QUEUES", "16", 0 /* keep an existing value */);
+}
+extern "C" int fuelmi_hw_queues(void) {
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  return e ? atoi(e) : 4;
+}
+
 extern "C" const char* fuelmi_last_error(void) { return g_err; }
 extern "C" const char* fuelmi_version(void) { return "fuelmi 0.1 (gfx950)"; }
 extern "C" int fuelmi_device_count(void) {
@@ -96,21 +114,29 @@ int QuerySlotGuard::acquire(fuelmi_map* m_, size_t bytes) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->pin), want, hipHostMallocDefault));
     s->pin_cap = want;
   }
-  // behind everything the map's stream holds now (an ESDF update the caller has just queued, say)
-  HIPCHK(hipEventRecord(s->ev_dep, m->stream));
-  HIPCHK(hipStreamWaitEvent(s->st, s->ev_dep, 0));
+  // behind everything the map's stream holds now (an ESDF update the caller has just queued, say).  An IDLE map stream
+  // holds nothing to wait for: skipping the record + wait then keeps the query off a cross-queue dependency -- with the
+  // slot's stream on a hardware queue of its own that dependency alone was 59 of a combineCost's 92 us
+  // (profiles/r05_facade_bisect.txt; in round 4 the slot happened to share the map stream's queue)
+  if (hipStreamQuery(m->stream) != hipSuccess) {
+    HIPCHK(hipEventRecord(s->ev_dep, m->stream));
+    HIPCHK(hipStreamWaitEvent(s->st, s->ev_dep, 0));
+  }
   return FUELMI_OK;
 }
 hipError_t QuerySlotGuard::finish() {
   hipError_t e = hipEventRecord(s->ev_done, s->st);
   if (e != hipSuccess) return e;
   const bool yld = poll_yields();
+  const auto t_begin = std::chrono::steady_clock::now();
   for (long spins = 0;; ++spins) {  // poll: a blocking wait costs ~15 us of wake-up for a 10-us kernel
     e = hipEventQuery(s->ev_done);
     if (e != hipErrorNotReady) return e;
     if (yld) std::this_thread::yield();
-    // a solve of milliseconds: stop burning the core (ten optimiser threads would burn ten), block on the event
-    if (spins > 4000) return hipEventSynchronize(s->ev_done);
+    // a query that is not back after ~3 ms of polling (a poll is ~10 ns: a spin COUNT of a few thousand turned a 33-us
+    // combineCost into 91 us of poll + blocking wake-up): stop burning the core, block on the event
+    if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(3))
+      return hipEventSynchronize(s->ev_done);
   }
 }
 int map_wait_query_readers(fuelmi_map* m) {

@@ -42,6 +42,11 @@ extern "C" {
 #define FUELMI_ENOMEM (-4)
 #define FUELMI_ELIMIT (-5)  /* problem exceeds a documented limit */
 
+/* GPU_MAX_HW_QUEUES as the process's HIP runtime will see it.  The library sets it to 16 when it is loaded unless the
+ * environment already holds a value (or FUELMI_KEEP_HW_QUEUES is set): with the runtime's default of 4 the streams of a
+ * map, its finder and a few query threads share hardware queues and time-slice (INTEGRATION.md "streams and queues").
+ * The runtime reads the variable at its first call: load this library before anything initialises HIP. */
+int fuelmi_hw_queues(void);
 const char* fuelmi_last_error(void);
 const char* fuelmi_version(void);
 /* number of visible HIP devices (0 if none / runtime unusable) */

@@ -129,3 +129,23 @@ def test_sdf_map_header_layout_is_the_references(tmp_path):
             assert int(b.split()[-1]) == int(a.split()[-1]) + 8, (a, b)
         else:
             assert a == b, (a, b)
+
+
+def test_library_sets_the_hardware_queue_default_at_load():
+    """include/fuelmi.h fuelmi_hw_queues: loading libfuelmi.so puts GPU_MAX_HW_QUEUES=16 into the environment the HIP
+    runtime will read at its first call -- unless the environment already has a value or FUELMI_KEEP_HW_QUEUES is set
+    (with the runtime's default of 4 a map, its finder and a few query threads time-slice)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import fuel_amd; print(fuel_amd.lib().fuelmi_hw_queues())"
+
+    def run(**extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FUELMI_KEEP_HW_QUEUES")}
+        env.update(extra)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return int(p.stdout.strip().splitlines()[-1])
+
+    assert run() == 16
+    assert run(GPU_MAX_HW_QUEUES="8") == 8
+    assert run(FUELMI_KEEP_HW_QUEUES="1") == 4

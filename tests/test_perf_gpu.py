@@ -76,3 +76,85 @@ def test_packed_plain_pass_is_not_slower_than_the_32_bit_one_on_a_half_explored_
     print("half-explored 200x200x50, z/y pass ms:", {k: "%.4f" % v for k, v in med.items()})
     assert med["plain"] <= 1.1 * med["plain32"], med
     gm.close()
+
+
+def test_other_maps_alive_in_the_process_do_not_slow_the_streaming_frame(fa):
+    """five maps + finders alive in one process, the streaming frame of map 0 within 1.3 x of its solo
+    time, at the default environment (the library's load-time GPU_MAX_HW_QUEUES; a finder owns two streams since the
+    flag plane is zeroed on the retiring search stream)."""
+    import bench
+    map_size_s, n_obs_s, _ = bench.WORKLOADS["G800S"]
+    box_s = bench.exploration_box(map_size_s)
+    frames = bench.streaming_frames(map_size_s, n_obs_s, 124, seed=42)
+    ctrl = bench.make_trajectories(np.random.default_rng(1042), 64, 32, np.array(box_s[0]) + 0.5, np.array(box_s[1]) - 0.5)
+
+    def frame_ms():
+        cyc = bench.GpuStreamCycle(map_size_s, box_s, frames, ctrl, device=0, reference_order=0)
+        cyc.run_native(20)
+        cyc.finish()
+        best = 1e9
+        for _ in range(3):
+            sec = cyc.run_native(30)
+            cyc.finish()
+            best = min(best, sec / 30 * 1e3)
+        cyc.close()
+        return best
+
+    solo = frame_ms()
+    keep = []
+    for _ in range(4):
+        m = fa.SDFMap((10.0, 10.0, 5.0))
+        f = fa.FrontierFinder(m, cluster_min=10)
+        for _ in range(2):
+            m.setUpdatedBox((-4, -4, 0), (4, 4, 2))
+            f.searchFrontiers()
+            f.reset()
+        keep.append((m, f))
+    crowd = frame_ms()
+    for m, f in keep:
+        f.close()
+        m.close()
+    assert crowd <= 1.3 * solo, (solo, crowd)
+
+
+def test_ten_optimiser_threads_do_not_queue_behind_each_other(fa):
+    """topoReplan's ten optimiser threads (plan_manage/src/planner_manager.cpp:446-453) on ONE map: ten concurrent
+    solves within 2.2 x one solve (Python threads; the C++ figure is facade_bench's ten_threads_ten_solves_ms: 1.74 ms
+    for 1.46 ms solves, 4.3 ms with the runtime's four hardware queues)."""
+    import threading
+    import time
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    lo, hi = helpers.full_box(om.nvox)
+    gm.setLocalBound(lo, hi)
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    gm.synchronize()
+    rng = np.random.default_rng(3)
+    probs, opts = [], []
+    for t in range(10):
+        c = helpers.make_trajectories(rng, 1, 24, np.array(box[0]) + 0.5, np.array(box[1]) - 0.5)
+        x, ptd, st, en = helpers.bspline_inputs(c, 0.175, True)
+        probs.append(fa.BsplineBatchProblem(x, 24, fa.NORMAL_PHASE | fa.MINTIME, ptd, st, en, 3, 3, 0.175))
+        o = fa.BsplineOptimizer()
+        o.setEnvironment(gm)
+        o.optimize(probs[-1])
+        opts.append(o)
+    one = 1e9
+    for t in range(10):
+        t0 = time.perf_counter()
+        opts[t].optimize(probs[t])
+        one = min(one, time.perf_counter() - t0)
+    slowest = max(0.0, one)
+    ten = 1e9
+    for _ in range(5):
+        th = [threading.Thread(target=lambda k=k: opts[k].optimize(probs[k])) for k in range(10)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        ten = min(ten, time.perf_counter() - t0)
+    gm.close()
+    assert ten <= 3.0 * slowest + 1e-3, (one, ten)
