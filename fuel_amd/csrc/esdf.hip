@@ -832,20 +832,6 @@ __device__ __noinline__ u32 pk_slow_col(const u32* tile, int ZC, int ylen, int r
   return best;
 }
 
-// the 4 z-adjacent outputs of one row: one 16-byte store when the box is z-aligned (uniform test, see k_esdf_zy4)
-__device__ __forceinline__ void zy_store4(u32* dst, int z, const Box3& b, uint4 v, bool z_aligned) {
-  if (z_aligned) {
-    if (z >= b.lo[2] && z <= b.hi[2]) store16(dst, v);
-  } else if (z >= b.lo[2] && z + 3 <= b.hi[2]) {
-    *reinterpret_cast<uint4*>(dst) = v;
-  } else {
-    if (z >= b.lo[2] && z <= b.hi[2]) dst[0] = v.x;
-    if (z + 1 >= b.lo[2] && z + 1 <= b.hi[2]) dst[1] = v.y;
-    if (z + 2 >= b.lo[2] && z + 2 <= b.hi[2]) dst[2] = v.z;
-    if (z + 3 >= b.lo[2] && z + 3 <= b.hi[2]) dst[3] = v.w;
-  }
-}
-
 // the 8 outputs (rows 2p, 2p + 1 x 4 z of group gi) of one lane from the packed tile at `tile_b`
 // TILE_SLOW: outputs at or above PK_INF are recomputed from the tile itself (z/y pass: the tile holds every finite value
 // exactly); false: they are left to the caller (x pass: PK_INF in its tile may stand for a larger finite value)
@@ -904,74 +890,6 @@ __device__ __forceinline__ void pk_scan8(const unsigned char* tile_b, int p, int
         }
       }
     }
-}
-
-template <int MODE, int G, int NW>
-__global__ void __launch_bounds__(512)
-k_esdf_zy_pk(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, u32* __restrict__ tmp, int nzc,
-             int z0a, int fastrow, u32* __restrict__ stat, unsigned long long* __restrict__ dbg) {
-  constexpr int ZC = 4 * G;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32* tile = reinterpret_cast<u32*>(smem_raw);  // [npair][ZC]: low half row 2p, high half row 2p + 1
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;  // slab x -> XCD x % 8 with all its chunk-blocks (see k_esdf_zy4)
-  const int xrel = xcd + 8 * (slot / nzc);
-  if (xrel > b.hi[0] - b.lo[0]) return;
-  // FUELMI_ZY_TIMING: 100 MHz stamps of this workgroup's phases (start, tile filled, barrier passed, scans done)
-  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;
-  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
-  const int x = b.lo[0] + xrel;
-  const int zc0 = z0a + (slot % nzc) * ZC;
-  const int ylen = b.hi[1] - b.lo[1] + 1;
-  const int npair = (ylen + 1) >> 1;
-  const int T = blockDim.x;
-  const int zs = max(zc0, b.lo[2]), ze = min(zc0 + ZC - 1, b.hi[2]);
-  const u32 inbox = zs <= ze ? (u32)bit_range(zs - zc0, ze - zs + 1) : 0u;
-  bool has_src = false;
-  for (int p = threadIdx.x; p < npair; p += T) {
-    const int yA = 2 * p, yB = min(2 * p + 1, ylen - 1);  // (odd line: the last pair repeats its row -- a copy one
-    const long lbA = (long)x * g.nyz + (long)(b.lo[1] + yA) * g.nz;  //  row further out is never a better candidate)
-    const long lbB = (long)x * g.nyz + (long)(b.lo[1] + yB) * g.nz;
-    RowSrc A, B;
-    A.bits = B.bits = 0ull;
-    A.below = A.above = B.below = B.above = -1;
-    if (zs <= ze) {
-      const LineBits<NW> LA = line_load<MODE, NW>(infl, unk, lbA, z0a, b.lo[2], b.hi[2]);
-      const LineBits<NW> LB = line_load<MODE, NW>(infl, unk, lbB, z0a, b.lo[2], b.hi[2]);
-      A = row_src_line<NW, true>(LA, z0a, zc0, ZC);
-      B = row_src_line<NW, true>(LB, z0a, zc0, ZC);
-    }
-    has_src |= (A.bits | B.bits) != 0ull || A.below >= 0 || A.above >= 0 || B.below >= 0 || B.above >= 0;
-    (void)zy_fill_pair<G>(tile + p * ZC, (u32)A.bits, (u32)B.bits, pk_below_d0(A, B, zs), A.above, B.above, ze, inbox, fastrow != 0);
-  }
-  if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
-  const int any_src = __syncthreads_or(has_src ? 1 : 0);
-  if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
-  const int total = npair * G;
-  const bool sampled = stat != nullptr && ((x & 15) == 0 || xrel == 0);
-  const bool z_aligned = (b.lo[2] & 3) == 0 && (b.hi[2] & 3) == 3;
-  int n_far = 0;
-  const int dpi = T / G, dgi = T - dpi * G;
-  int p = threadIdx.x / G, gi = threadIdx.x - p * G;
-  for (int o = threadIdx.x; o < total; o += T) {
-    uint4 ra, rb;  // rows 2p and 2p + 1
-    pk_scan8<G>(smem_raw, p, gi, npair, ylen, any_src != 0, sampled, n_far, ra, rb);
-    const int z = zc0 + 4 * gi;
-    u32* dst = tmp + (long)x * g.nyz + (long)(b.lo[1] + 2 * p) * g.nz + z;
-    zy_store4(dst, z, b, ra, z_aligned);
-    if (2 * p + 1 < ylen) zy_store4(dst + g.nz, z, b, rb, z_aligned);
-    p += dpi;
-    gi += dgi;
-    if (gi >= G) {
-      gi -= G;
-      ++p;
-    }
-  }
-  if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
-  if (sampled && (threadIdx.x & 63) == 0) {
-    u32* sg = stat + 2 * ((x >> 4) & (ESDF_NG - 1));
-    atomicAdd(sg, (u32)n_far);
-    if (threadIdx.x == 0) atomicAdd(sg + 1, (u32)total);
-  }
 }
 
 // The y pass of this update has counted its far outputs per group of 16 x-slabs (stat[2 g], stat[2 g + 1]: far
@@ -1065,75 +983,6 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   }
 }
 
-// Persistent, software-pipelined x pass: a workgroup walks over column tiles; while it scans tile k out of the
-// LDS, the global loads of tile k + 1 are already in flight into registers (P = ceil(xlen / rows) uint4 per lane),
-// so the HBM fetch runs BESIDE the scan instead of in front of it (k_esdf_x4 does load -> barrier -> scan per
-// tile, and with one or two resident workgroups per CU nothing overlaps the fetch).
-// (P <= 4: x lines of up to 512 voxels, two workgroups share a CU's LDS -- hold the kernel to 64 VGPRs so that
-// they also share its register file)
-template <int OUT, int P, bool FAR>
-__global__ void __launch_bounds__(1024, (P <= 4 ? 8 : 4))
-k_esdf_x4p(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, int ntiles, int near,
-           u32* stat, volatile u32* h_stat) {
-  constexpr int SEGS = 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  forward_stat(stat, h_stat);
-  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [xlen][SEGS] of uint4 (FAR: + block / line minima)
-  const int xlen = b.hi[0] - b.lo[0] + 1;
-  unsigned char* bm = smem_raw + (size_t)xlen * SEGS * 16;
-  u32* cm = reinterpret_cast<u32*>(bm + (size_t)((xlen + 7) >> 3) * SEGS * 16);
-  const int ylen = b.hi[1] - b.lo[1] + 1;
-  const int ncol = ylen * zlen_a;
-  const int seg = threadIdx.x & (SEGS - 1);
-  const int row0 = threadIdx.x / SEGS;  // 0..127
-  constexpr int rows = 1024 / SEGS;
-  const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
-  const float resf = (float)g.res;
-  uint4 nxt[P];
-  // (a macro, not a lambda: capturing the array by reference sent it to scratch memory)
-#define X4P_FETCH(T)                                                                                             \
-  {                                                                                                              \
-    const int t_ = (T);                                                                                          \
-    const int col_ = t_ * (4 * SEGS) + seg * 4;                                                                  \
-    const bool valid_ = t_ < ntiles && col_ < ncol;                                                              \
-    const int yy_ = valid_ ? col_ / zlen_a : 0;                                                                  \
-    const int z_ = z0a + (valid_ ? col_ - yy_ * zlen_a : 0);                                                     \
-    const u32* src_ = tmp + (long)b.lo[0] * g.nyz + (long)(b.lo[1] + yy_) * g.nz + z_;                          \
-    _Pragma("unroll") for (int p = 0; p < P; ++p) {                                                              \
-      const int xi_ = row0 + p * rows;                                                                           \
-      nxt[p] = inf4;                                                                                             \
-      if (valid_ && xi_ < xlen) nxt[p] = *reinterpret_cast<const uint4*>(src_ + (long)xi_ * g.nyz);             \
-    }                                                                                                            \
-  }
-  X4P_FETCH(blockIdx.x)
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int xi = row0 + p * rows;
-      if (xi < xlen) tile[xi * SEGS + seg] = nxt[p];
-    }
-    if (FAR && threadIdx.x < 4 * SEGS) cm[threadIdx.x] = INF32;
-    __syncthreads();
-    X4P_FETCH(t + (int)gridDim.x)  // in flight during the scan below
-    if (FAR) {
-      build_block_minima(smem_raw, bm, cm, SEGS * 16, SEGS, xlen);
-      __syncthreads();
-    }
-    const int col = t * (4 * SEGS) + seg * 4;
-    const bool valid = col < ncol;
-    const int yy = valid ? col / zlen_a : 0;
-    const int z = z0a + (valid ? col - yy * zlen_a : 0);
-    const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
-    if (valid)
-      for (int xi = row0; xi < xlen; xi += rows) {
-        const uint4 bb = scan_line4<FAR>(smem_raw, bm, reinterpret_cast<const unsigned char*>(cm), SEGS * 16, xlen, xi, 16 * seg, near);
-        x_store4<OUT>(dist + (long)(b.lo[0] + xi) * g.nyz + coloff, z, b.lo[2], b.hi[2], bb, resf);
-      }
-    __syncthreads();  // the tile is rewritten at the top of the next trip
-  }
-#undef X4P_FETCH
-}
-
 // x pass in x blocks: a workgroup owns XR output rows of a column tile and stages them plus HALO rows on either
 // side.  An output whose scan reaches the end of what is staged -- its running minimum still exceeds the squared
 // distance to the first row it could not see -- finishes from global memory, row by row.  Exact either way: every
@@ -1216,43 +1065,6 @@ static u32* esdf_stat_dev(fuelmi_map* m) {
   return OUT == 0 && !off ? m->esdf_stat : nullptr;
 }
 static volatile u32* esdf_stat_host(fuelmi_map* m) { return m->h_esdf_stat; }
-
-template <int OUT, int P, bool FAR>
-static int launch_x4p_n(fuelmi_map* m, const Box3& b) {
-  const Geo& g = m->g;
-  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
-  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
-  const int zlen_a = z1a - z0a + 1;
-  const size_t lds = (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * 8 * 4 * sizeof(u32);
-  if (lds > 160 * 1024) return ESDF_NO_FIT;
-  if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4p<OUT, P, FAR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int ncol = ylen * zlen_a;
-  const int ntiles = (ncol + 31) / 32;
-  static const char* xg = getenv("FUELMI_X_GRID");  // tuning hook: workgroups per CU
-  const int per_cu = xg ? atoi(xg) : std::max(1, std::min(2, (int)((150 * 1024) / std::max<size_t>(lds, 1))));
-  const int grid = std::min(ntiles, 256 * per_cu);
-  STAGE_LAUNCH(m, (k_esdf_x4p<OUT, P, FAR>), grid, 1024, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a, ntiles,
-               esdf_near(), esdf_stat_dev<OUT>(m), esdf_stat_host(m));
-  HIPCHK(hipGetLastError());
-  return FUELMI_OK;
-}
-template <int OUT, bool FAR>
-static int launch_x4p(fuelmi_map* m, const Box3& b) {
-  const int xlen = b.hi[0] - b.lo[0] + 1;
-  switch ((xlen + 127) / 128) {
-    case 1: return launch_x4p_n<OUT, 1, FAR>(m, b);
-    case 2: return launch_x4p_n<OUT, 2, FAR>(m, b);
-    case 3: return launch_x4p_n<OUT, 3, FAR>(m, b);
-    case 4: return launch_x4p_n<OUT, 4, FAR>(m, b);
-    case 5: return launch_x4p_n<OUT, 5, FAR>(m, b);
-    case 6: return launch_x4p_n<OUT, 6, FAR>(m, b);
-    case 7: return launch_x4p_n<OUT, 7, FAR>(m, b);
-    case 8: return launch_x4p_n<OUT, 8, FAR>(m, b);
-    default: return ESDF_NO_FIT;
-  }
-}
 
 static inline bool use_vec4(const Geo& g, int xlen) { return (g.nz % 4) == 0 && (size_t)xlen * 64 <= 150 * 1024; }
 
@@ -1359,74 +1171,6 @@ static int pass_timing_report(fuelmi_map* m, unsigned long long* dbg, int grid, 
   return FUELMI_OK;
 }
 
-// packed plain z/y pass (k_esdf_zy_pk): ESDF_NO_FIT when the box is not its kind (z extents above 255 voxels,
-// nz % 4 != 0, y lines too long for the tile)
-template <int MODE, int G, int NW>
-static int launch_zy_pk_g(fuelmi_map* m, const Box3& b, int nzc, int z0a, int threads, size_t lds) {
-  const int xlen = b.hi[0] - b.lo[0] + 1;
-  if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pk<MODE, G, NW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  const int grid = ((xlen + 7) / 8) * 8 * nzc;
-  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
-  unsigned long long* dbg = nullptr;
-  if (timing) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)grid * 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
-  }
-  STAGE_LAUNCH(m, (k_esdf_zy_pk<MODE, G, NW>), grid, threads, lds, m->g, b, (const u64*)m->infl_bits.p,
-               (const u64*)m->unk_bits.p, m->esdf_tmp, nzc, z0a, zy_fastrow() ? 1 : 0, MODE == 2 ? nullptr : esdf_stat_dev<0>(m), dbg);
-  HIPCHK(hipGetLastError());
-  if (timing) {
-    char what[96];
-    std::snprintf(what, sizeof what, "zy-timing] G %d threads %d lds %zu", G, threads, lds);
-    { const int rc_ = pass_timing_report(m, dbg, grid, what); if (rc_ != FUELMI_OK) return rc_; }
-  }
-  return FUELMI_OK;
-}
-template <int MODE>
-static int launch_zy_pk(fuelmi_map* m, const Box3& b) {
-  const Geo& g = m->g;
-  const int ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
-  if ((g.nz % 4) != 0 || zlen > 255) return ESDF_NO_FIT;
-  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
-  const int zlen_a = z1a - z0a + 1;
-  const int npair = (ylen + 1) >> 1;
-  // chunk of 4 G <= 32 voxels: the padded z extent plus a per-chunk row prologue worth ~6 voxels, tile <= 40 KB
-  // while that allows a chunk at all (four workgroups per CU)
-  static const char* zc_env = getenv("FUELMI_ZY_PK_ZC");  // tuning hook
-  int best_zc = 0;
-  long best_cost = 0;
-  for (int zc : {8, 16, 20, 24, 32}) {  // (the chunk sizes the kernels are compiled for)
-    if ((size_t)npair * zc * 4 > 40 * 1024 && zc > 8) break;
-    const int n = (zlen_a + zc - 1) / zc;
-    const long cost = (long)n * (zc + 6);
-    if (!best_zc || cost <= best_cost) best_zc = zc, best_cost = cost;
-  }
-  if (zc_env)
-    for (int zc : {8, 16, 20, 24, 32})
-      if (atoi(zc_env) == zc) best_zc = zc;
-  const int ZC = best_zc, nzc = (zlen_a + ZC - 1) / ZC;
-  const size_t lds = (size_t)npair * ZC * 4;
-  if (lds > 160 * 1024) return ESDF_NO_FIT;
-  static const char* th_env = getenv("FUELMI_ZY_PK_THREADS");  // tuning hook
-  const int threads = th_env ? atoi(th_env) : std::min(512, std::max(128, ((npair + 63) / 64) * 64));
-  const bool wide = zlen_a > 128;  // aligned z-lines of up to 128 / 256 bits
-#define ZY_PK_CASE(GG)                                                                     \
-  case GG:                                                                                 \
-    return wide ? launch_zy_pk_g<MODE, GG, 4>(m, b, nzc, z0a, threads, lds) : launch_zy_pk_g<MODE, GG, 2>(m, b, nzc, z0a, threads, lds);
-  switch (ZC / 4) {
-    ZY_PK_CASE(2)
-    ZY_PK_CASE(4)
-    ZY_PK_CASE(5)
-    ZY_PK_CASE(6)
-    ZY_PK_CASE(8)
-    default: return ESDF_NO_FIT;
-  }
-#undef ZY_PK_CASE
-
-}
-
 template <int OUT, int SEGS, bool FAR>
 static int launch_x4s(fuelmi_map* m, const Box3& b) {
   const Geo& g = m->g;
@@ -1446,162 +1190,6 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
-// ------------------------------------------------------------------------------------------------
-// Packed x pass (round 4): the same two-rows-per-lane 16-bit scan as k_esdf_zy_pk, over x.  The tile holds
-// min(tmp, PK_INF) of x-rows 2p / 2p + 1 in the halves of one u32 (half the LDS of the 32-bit tile: 25 KB for 400 rows
-// x 32 columns, so eight 256-thread workgroups share a CU and all 1250 column tiles of the 400^2 x 100 map are resident
-// at once), a lane owns 8 outputs.  An output the packed scan leaves at or above PK_INF -- further than ~255 voxels
-// from every source, or a column without any -- is recomputed in 32 bits from the y-pass result in global memory
-// (x_slow_col); a column tile without a finite value at all answers "no source" without scanning.
-// ------------------------------------------------------------------------------------------------
-__device__ __noinline__ u32 x_slow_col(const u32* __restrict__ col, long row_stride, int xlen, int row) {
-  u32 best = INF32;
-  const int rmax = max(row, xlen - 1 - row);
-  for (int r = 0; r <= rmax && (u32)__mul24(r, r) < best; ++r) {
-    const u32 rr = (u32)__mul24(r, r);
-    if (row - r >= 0) {
-      const u32 v = col[(long)(row - r) * row_stride];
-      if (v < INF32) best = min(best, v + rr);
-    }
-    if (r && row + r < xlen) {
-      const u32 v = col[(long)(row + r) * row_stride];
-      if (v < INF32) best = min(best, v + rr);
-    }
-  }
-  return best;
-}
-__device__ __forceinline__ u32 pk_pack_sat(u32 lo, u32 hi) { return min(lo, PK_INF) | (min(hi, PK_INF) << 16); }
-
-template <int OUT>
-__global__ void __launch_bounds__(512)
-k_esdf_x_pk(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, u32* stat,
-            volatile u32* h_stat, unsigned long long* __restrict__ dbg) {
-  constexpr int SEGS = 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  forward_stat(stat, h_stat);
-  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [npx][SEGS] of uint4: halves = x-rows 2p, 2p + 1
-  const int xlen = b.hi[0] - b.lo[0] + 1;
-  const int ylen = b.hi[1] - b.lo[1] + 1;
-  const int npx = (xlen + 1) >> 1;
-  const int ncol = ylen * zlen_a;
-  const int T = blockDim.x;
-  const int total = npx * SEGS;
-  const float resf = (float)g.res;
-  __shared__ u32 s_colfin;  // bit c: column c of the tile holds a finite value
-  unsigned long long* stamp = dbg ? dbg + 8 * (size_t)blockIdx.x : nullptr;  // (FUELMI_ZY_TIMING)
-  if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
-  if (threadIdx.x == 0) s_colfin = 0u;
-  __syncthreads();
-  u32 finbits = 0u;
-  for (int o = threadIdx.x; o < total; o += T) {
-    const int p = o >> 3, seg = o & 7;
-    const int col = blockIdx.x * (4 * SEGS) + seg * 4;
-    uint4 pk = make_uint4(pk_both(PK_INF), pk_both(PK_INF), pk_both(PK_INF), pk_both(PK_INF));
-    if (col < ncol) {
-      const int yy = col / zlen_a;
-      const long coloff = (long)(b.lo[1] + yy) * g.nz + z0a + (col - yy * zlen_a);
-      const u32* src = tmp + (long)(b.lo[0] + 2 * p) * g.nyz + coloff;
-      const uint4 va = *reinterpret_cast<const uint4*>(src);
-      // (odd line: the last pair repeats its row -- a copy one row further out is never a better candidate)
-      const uint4 vb = *reinterpret_cast<const uint4*>(2 * p + 1 < xlen ? src + g.nyz : src);
-      pk = make_uint4(pk_pack_sat(va.x, vb.x), pk_pack_sat(va.y, vb.y), pk_pack_sat(va.z, vb.z), pk_pack_sat(va.w, vb.w));
-      const u32 f4 = (min(va.x, vb.x) < INF32 ? 1u : 0u) | (min(va.y, vb.y) < INF32 ? 2u : 0u) | (min(va.z, vb.z) < INF32 ? 4u : 0u) |
-                     (min(va.w, vb.w) < INF32 ? 8u : 0u);
-      finbits |= f4 << (4 * seg);
-    }
-    tile[o] = pk;
-  }
-  if (finbits) atomicOr(&s_colfin, finbits);
-  if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
-  __syncthreads();
-  if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
-  const u32 colfin = s_colfin;
-  const int any_src = colfin != 0u;
-  if (any_src && colfin != 0xFFFFFFFFu) {
-    // columns without any finite value (no source on the whole x line): they answer "no source" below; in the tile they
-    // read 0 so that they do not stretch the shared scan loop of the lane's other columns
-    for (int o = threadIdx.x; o < total; o += T) {
-      const u32 f4 = (colfin >> (4 * (o & 7))) & 15u;
-      if (f4 != 15u) {
-        uint4 v = tile[o];
-        if (!(f4 & 1u)) v.x = 0u;
-        if (!(f4 & 2u)) v.y = 0u;
-        if (!(f4 & 4u)) v.z = 0u;
-        if (!(f4 & 8u)) v.w = 0u;
-        tile[o] = v;
-      }
-    }
-    __syncthreads();
-  }
-  int n_far = 0;
-  for (int o = threadIdx.x; o < total; o += T) {
-    const int p = o >> 3, seg = o & 7;
-    const int col = blockIdx.x * (4 * SEGS) + seg * 4;
-    if (col >= ncol) continue;
-    uint4 ra, rb;
-    pk_scan8<SEGS, false>(smem_raw, p, seg, npx, xlen, any_src != 0, false, n_far, ra, rb);
-    const int yy = col / zlen_a;
-    const int z = z0a + (col - yy * zlen_a);
-    const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
-    if (any_src) {
-      const u32 f4 = (colfin >> (4 * seg)) & 15u;
-      u32* pa = &ra.x;
-      u32* pb = &rb.x;
-      if (f4 != 15u) {
-        for (int k = 0; k < 4; ++k)
-          if (!((f4 >> k) & 1u)) pa[k] = pb[k] = INF32;
-      }
-      if (max(max4(ra.x, ra.y, ra.z, ra.w), max4(rb.x, rb.y, rb.z, rb.w)) >= PK_INF) {
-        // rare: recompute the outputs out of the 16-bit range from the y-pass result itself
-        const u32* cb = tmp + (long)b.lo[0] * g.nyz + coloff;
-        for (int k = 0; k < 4; ++k) {
-          if (pa[k] >= PK_INF && pa[k] < INF32) pa[k] = x_slow_col(cb + k, g.nyz, xlen, 2 * p);
-          if (2 * p + 1 < xlen && pb[k] >= PK_INF && pb[k] < INF32) pb[k] = x_slow_col(cb + k, g.nyz, xlen, 2 * p + 1);
-        }
-      }
-    }
-    float* dst = dist + (long)(b.lo[0] + 2 * p) * g.nyz + coloff;
-    x_store4<OUT>(dst, z, b.lo[2], b.hi[2], ra, resf);
-    if (2 * p + 1 < xlen) x_store4<OUT>(dst + g.nyz, z, b.lo[2], b.hi[2], rb, resf);
-  }
-  if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
-}
-template <int OUT>
-static int launch_x_pk(fuelmi_map* m, const Box3& b) {
-  const Geo& g = m->g;
-  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
-  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
-  const int zlen_a = z1a - z0a + 1;
-  const int npx = (xlen + 1) >> 1;
-  const size_t lds = (size_t)npx * 8 * 16;
-  if ((g.nz % 4) != 0 || lds > 150 * 1024) return ESDF_NO_FIT;  // (x lines of up to 2400 voxels; longer ones: the 32-bit kernels)
-  if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x_pk<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               150 * 1024));  // (the kernel also holds a few bytes of static LDS)
-  const int ncol = ylen * zlen_a;
-  static const char* th_env = getenv("FUELMI_X_PK_THREADS");  // tuning hook
-  // 256-thread workgroups while eight of them share a CU's LDS (tiles of up to ~20 KB: lines of up to 320 voxels... in
-  // practice the 400-voxel lines too: 24 waves per CU); longer lines hold fewer tiles per CU and need the bigger
-  // workgroup to keep the wave slots filled (800-voxel lines: 0.236 ms with 512 threads, 0.293 with 256)
-  const int threads = th_env ? atoi(th_env) : (lds > 32 * 1024 ? 512 : 256);
-  static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
-  const int grid = (ncol + 31) / 32;
-  unsigned long long* dbg = nullptr;
-  if (timing) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)grid * 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
-  }
-  STAGE_LAUNCH(m, (k_esdf_x_pk<OUT>), grid, threads, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a, zlen_a,
-               esdf_stat_dev<OUT>(m), esdf_stat_host(m), dbg);
-  HIPCHK(hipGetLastError());
-  if (timing) {
-    char what[96];
-    std::snprintf(what, sizeof what, "x-timing] threads %d lds %zu", threads, lds);
-    { const int rc_ = pass_timing_report(m, dbg, grid, what); if (rc_ != FUELMI_OK) return rc_; }
-  }
-  return FUELMI_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Round 5: the hand-over between the two packed passes is 16-bit and tile-contiguous.
 // Rounds 2-4 stored the y-pass result as u32 at the voxel's own address (64 MB on the 400^2 x 100 map) and the x pass
@@ -1671,12 +1259,10 @@ __device__ __forceinline__ void pk_scan16(const unsigned char* tA, const unsigne
   }
 }
 
-// uint4 index of (tile, x-pair q, segment) in tmp16.  qsh < 0: a tile's rows are contiguous ([tile][q][8]: the x pass copies
-// one block per tile); qsh >= 0 (experiment, FUELMI_PK2_QSH): rows of 2^qsh x-pairs adjacent, [q >> qsh][tile][q & mask][8]
-__device__ __forceinline__ size_t pk2_index(int tile, int q, int seg, int ntiles, int npx, int qsh) {
-  if (qsh < 0) return ((size_t)tile * npx + q) * 8 + seg;
-  return ((((size_t)(q >> qsh) * ntiles + tile) << qsh) + (q & ((1 << qsh) - 1))) * 8 + seg;
-}
+// uint4 index of (tile, x-pair q, segment) in tmp16: a tile's rows are contiguous ([tile][q][8]: the x pass copies one
+// block per tile).  (Rows of 8 or 64 x-pairs adjacent instead -- better locality for the z/y pass's stores -- left the z/y
+// pass where it was and cost the x pass a third on the 800^2 x 200 map: its fill wants ONE run per tile.)
+__device__ __forceinline__ size_t pk2_index(int tile, int q, int seg, int npx) { return ((size_t)tile * npx + q) * 8 + seg; }
 
 // 16-bit hand-over value of one exact y-pass result; the exact value goes to the wide plane when it does not fit
 __device__ __forceinline__ u32 pk2_encode(u32 exact, u32* wide_at, bool in_box) {
@@ -1697,7 +1283,7 @@ __device__ __forceinline__ u32 pk2_encode(u32 exact, u32* wide_at, bool in_box) 
 template <int MODE, int G, int NW>
 __device__ __forceinline__ void zy_pk2_body(const Geo& g, const Box3& b, const u64* __restrict__ infl, const u64* __restrict__ unk,
                                             uint4* __restrict__ tmp16, u32* __restrict__ wide, int z0a, int seg0, int tile0, int tstride, int gsh,
-                                            int off, int ntiles, int npx, int qsh, int q, int fastrow, u32* __restrict__ stat, u32* __restrict__ src_flag, u32 serial,
+                                            int off, int npx, int q, int fastrow, u32* __restrict__ stat, u32* __restrict__ src_flag, u32 serial,
                                             unsigned long long* stamp, unsigned char* smem_raw) {
   constexpr int ZC = 4 * G;
   const int xA = b.lo[0] + 2 * q, xB = min(xA + 1, b.hi[0]);  // (odd line: the last pair repeats its slab, like the x pass's tile)
@@ -1785,11 +1371,11 @@ __device__ __forceinline__ void zy_pk2_body(const Geo& g, const Box3& b, const u
     // segments); inside its 128-byte row the lane's segment is (y % RY) << gsh + off + gi
     {
       const int y = 2 * p, ry1 = (8 >> gsh) - 1;
-      store16(tmp16 + pk2_index(tile0 + (y >> (3 - gsh)) * tstride, q, ((y & ry1) << gsh) + off + gi, ntiles, npx, qsh), r0);
+      store16(tmp16 + pk2_index(tile0 + (y >> (3 - gsh)) * tstride, q, ((y & ry1) << gsh) + off + gi, npx), r0);
     }
     if (2 * p + 1 < ylen) {
       const int y = 2 * p + 1, ry1 = (8 >> gsh) - 1;
-      store16(tmp16 + pk2_index(tile0 + (y >> (3 - gsh)) * tstride, q, ((y & ry1) << gsh) + off + gi, ntiles, npx, qsh), r1);
+      store16(tmp16 + pk2_index(tile0 + (y >> (3 - gsh)) * tstride, q, ((y & ry1) << gsh) + off + gi, npx), r1);
     }
   }
   if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
@@ -1812,7 +1398,7 @@ __device__ __forceinline__ void zy_pk2_body(const Geo& g, const Box3& b, const u
 template <int MODE, int GMAX, int NW>
 __global__ void __launch_bounds__(1024)
 k_esdf_zy_pk2(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict__ unk, uint4* __restrict__ tmp16,
-              u32* __restrict__ wide, Pk2ZChunks ch, int ntiles, int z0a, int npx, int qsh, int fastrow, u32* __restrict__ stat,
+              u32* __restrict__ wide, Pk2ZChunks ch, int z0a, int npx, int fastrow, u32* __restrict__ stat,
               u32* __restrict__ src_flag, u32 serial, unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nzc = ch.n;
@@ -1823,7 +1409,7 @@ k_esdf_zy_pk2(Geo g, Box3 b, const u64* __restrict__ infl, const u64* __restrict
   if (stamp && threadIdx.x == 0) stamp[0] = wall_clock64();
   const int c = slot % nzc;
   const int seg0 = ch.seg0[c], tile0 = ch.tile0[c], tstride = ch.tstride[c], gsh = ch.gsh[c], off = ch.off[c];
-#define PK2_BODY(GG) zy_pk2_body<MODE, GG, NW>(g, b, infl, unk, tmp16, wide, z0a, seg0, tile0, tstride, gsh, off, ntiles, npx, qsh, q, fastrow, stat, src_flag, serial, stamp, smem_raw)
+#define PK2_BODY(GG) zy_pk2_body<MODE, GG, NW>(g, b, infl, unk, tmp16, wide, z0a, seg0, tile0, tstride, gsh, off, npx, q, fastrow, stat, src_flag, serial, stamp, smem_raw)
   switch (ch.g[c]) {  // (uniform)
     case 8:
       if constexpr (GMAX >= 8) PK2_BODY(8);
@@ -1859,7 +1445,7 @@ __device__ __noinline__ u32 x_slow_col16(const u32* tile, int c, const u32* __re
 template <int OUT>
 __global__ void __launch_bounds__(512)
 k_esdf_x_pk2(Geo g, Box3 b, const uint4* __restrict__ tmp16, const u32* __restrict__ wide, float* __restrict__ dist, Pk2Chunks ch,
-             int z0a, int qsh, int full8, u32* stat, volatile u32* h_stat, const u32* __restrict__ src_flag, u32 serial,
+             int z0a, int full8, u32* stat, volatile u32* h_stat, const u32* __restrict__ src_flag, u32 serial,
              unsigned long long* __restrict__ dbg) {
   constexpr int SEGS = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1896,9 +1482,9 @@ k_esdf_x_pk2(Geo g, Box3 b, const uint4* __restrict__ tmp16, const u32* __restri
   const bool any_src = *src_flag == serial;  // (no slab of the box holds a source: "no source" everywhere, nothing to scan)
   if (any_src) {
     // this tile's rows: one contiguous block
-    const int ntiles = ch.tile0[ch.n];
+    const uint4* src = tmp16 + pk2_index(t, 0, 0, npx);
 #pragma unroll 4
-    for (int o = threadIdx.x; o < total; o += T) tile[o] = tmp16[pk2_index(t, o >> 3, o & 7, ntiles, npx, qsh)];
+    for (int o = threadIdx.x; o < total; o += T) tile[o] = src[o];
   }
   if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
   __syncthreads();
@@ -1972,11 +1558,6 @@ static int pk2_chunks(int ylen, int nseg, int gz_max, Pk2Chunks* xs, Pk2ZChunks*
   if (n8 == n) xs->tile0[n8] = tile;
   return FUELMI_OK;
 }
-static int pk2_qsh() {  // layout experiment (see pk2_index); default: a tile's rows contiguous
-  static const char* e = getenv("FUELMI_PK2_QSH");
-  static const int v = e ? atoi(e) : -1;
-  return v;
-}
 static u32 pk2_next_serial(fuelmi_map* m) {
   if (++m->esdf_serial == 0u) m->esdf_serial = 1u;
   return m->esdf_serial;
@@ -1988,7 +1569,6 @@ static int launch_zy_pk2_g(fuelmi_map* m, const Box3& b, int z0a, int threads, s
   const int xlen = b.hi[0] - b.lo[0] + 1;
   const int npx = (xlen + 1) >> 1;
   const Pk2ZChunks& ch = m->pk2_zch;
-  const int ntiles = m->pk2_ch.tile0[m->pk2_ch.n];
   if (lds > 64 * 1024 && !m->attr_set[0][MODE][GMAX][NW / 2 - 1]) {  // (once per kernel, not per update)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pk2<MODE, GMAX, NW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2002,7 +1582,7 @@ static int launch_zy_pk2_g(fuelmi_map* m, const Box3& b, int z0a, int threads, s
     HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
   }
   STAGE_LAUNCH(m, (k_esdf_zy_pk2<MODE, GMAX, NW>), grid, threads, lds, m->g, b, (const u64*)m->infl_bits.p,
-               (const u64*)m->unk_bits.p, reinterpret_cast<uint4*>(m->esdf_tmp16), m->esdf_tmp, ch, ntiles, z0a, npx, pk2_qsh(),
+               (const u64*)m->unk_bits.p, reinterpret_cast<uint4*>(m->esdf_tmp16), m->esdf_tmp, ch, z0a, npx,
                (zy_fastrow() ? 1 : 0), MODE == 2 ? nullptr : esdf_stat_dev<0>(m), pk2_src_flag(m), m->esdf_serial, dbg);
   HIPCHK(hipGetLastError());
   if (timing) {
@@ -2032,11 +1612,7 @@ static int launch_zy_pk2(fuelmi_map* m, const Box3& b) {
   const size_t lds = (size_t)npair * g_max * 32;
   if (lds > 160 * 1024 - 64) return ESDF_NO_FIT;
   if (pk2_chunks(ylen, zlen_a >> 2, g_max, &m->pk2_ch, &m->pk2_zch) != FUELMI_OK) return ESDF_NO_FIT;
-  {
-    const int qsh = pk2_qsh();
-    const size_t rows = qsh < 0 ? (size_t)((xlen + 1) >> 1) : (((size_t)((xlen + 1) >> 1) + (1u << qsh) - 1) >> qsh) << qsh;
-    if ((size_t)m->pk2_ch.tile0[m->pk2_ch.n] * rows * 128 > m->esdf_tmp16_bytes) return ESDF_NO_FIT;
-  }
+  if ((size_t)m->pk2_ch.tile0[m->pk2_ch.n] * (size_t)((xlen + 1) >> 1) * 128 > m->esdf_tmp16_bytes) return ESDF_NO_FIT;
   static const char* th_env = getenv("FUELMI_ZY_PK_THREADS");  // tuning hook (threads of ONE half)
   // a half fills its npair rows in two trips: 128 / 256 lanes for 400- / 800-voxel y lines (measured: 33.5 against 35.5 us
   // with one trip on the 400^2 x 100 map, 158 against 203 us on 800^2 x 200, whose 896-thread workgroups fit one per CU)
@@ -2073,7 +1649,7 @@ static int launch_x_pk2(fuelmi_map* m, const Box3& b) {
     HIPCHK(hipMemsetAsync(dbg, 0, (size_t)grid * 8 * sizeof(unsigned long long), m->stream));
   }
   STAGE_LAUNCH(m, (k_esdf_x_pk2<OUT>), grid, threads, lds, g, b, reinterpret_cast<const uint4*>(m->esdf_tmp16),
-               (const u32*)m->esdf_tmp, m->dist, m->pk2_ch, z0a, pk2_qsh(), full8, esdf_stat_dev<OUT>(m), esdf_stat_host(m),
+               (const u32*)m->esdf_tmp, m->dist, m->pk2_ch, z0a, full8, esdf_stat_dev<OUT>(m), esdf_stat_host(m),
                (const u32*)pk2_src_flag(m), m->esdf_serial, dbg);
   HIPCHK(hipGetLastError());
   if (timing) {
@@ -2116,21 +1692,6 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
     static const char* he = getenv("FUELMI_X_HALO");
     const bool halo = he ? atoi(he) != 0 : xlen <= 512;
     if (halo && !FAR && xlen > 2 * XH_HALO + 64) return launch_x4h<OUT>(m, b);
-  }
-  // The persistent kernel is the faster x pass on its own (400^2 x 100: 26.5 us against 31) but not in a plan
-  // cycle: its two 1024-thread workgroups hold every wave slot of every CU for the whole pass, and the frontier
-  // finder's chain of short kernels (the cycle's critical path, on its own stream) waits behind them -- measured
-  // 7050 cycles/s with it, 7450 without.  FUELMI_X_PIPE=1 selects it (stand-alone ESDF updates).
-  static const bool piped = getenv("FUELMI_X_PIPE") != nullptr;
-  // the persistent kernel pays when two of its workgroups share a CU (x lines of up to ~560 voxels; measured on
-  // 800-voxel lines, one workgroup per CU: 0.275 ms against 0.250 ms for the one-tile-per-workgroup kernel)
-  if (piped && (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * 128 * 2 <= 160 * 1024) {
-    // big enough to keep every CU busy for several tiles? small boxes keep the one-tile-per-workgroup kernel
-    const int ylen = b.hi[1] - b.lo[1] + 1, zlen_a = (b.hi[2] | 3) - (b.lo[2] & ~3) + 1;
-    if ((long)ylen * zlen_a / 32 >= 512) {
-      const int rc = launch_x4p<OUT, FAR>(m, b);
-      if (rc != ESDF_NO_FIT) return rc;
-    }
   }
   static const char* force = getenv("FUELMI_X_SEGS");  // tuning hook: "4" or "8"
   // the 32-column tile is faster whenever it fits (measured on 800-voxel lines: 0.32 vs 0.37 ms), the
@@ -2225,14 +1786,8 @@ static bool esdf_use_far(fuelmi_map* m, const Box3& b) {
 template <int MODE>
 static int launch_zy_family(fuelmi_map* m, const Box3& b, int fam, int* ran) {
   if (fam == FUELMI_ESDF_PLAIN) {
-    static const bool pk2 = !(getenv("FUELMI_PK2") != nullptr && atoi(getenv("FUELMI_PK2")) == 0);  // A/B hook: the round-4 u32 hand-over
-    int rc = ESDF_NO_FIT;
-    m->esdf_pk2_last = false;
-    if (pk2) {
-      rc = launch_zy_pk2<MODE>(m, b);
-      m->esdf_pk2_last = rc != ESDF_NO_FIT;
-    }
-    if (rc == ESDF_NO_FIT) rc = launch_zy_pk<MODE>(m, b);
+    const int rc = launch_zy_pk2<MODE>(m, b);
+    m->esdf_pk2_last = rc != ESDF_NO_FIT;
     if (rc != ESDF_NO_FIT) {
       *ran = FUELMI_ESDF_PLAIN;
       return rc;
@@ -2260,12 +1815,9 @@ int esdf_update(fuelmi_map* m) {
   m->esdf_family_last = ran;
   {
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
-    static const bool x32 = getenv("FUELMI_X_PK") != nullptr && atoi(getenv("FUELMI_X_PK")) == 0;  // A/B hook
     rc = ESDF_NO_FIT;
     if (ran == FUELMI_ESDF_PLAIN && m->esdf_pk2_last)
       rc = launch_x_pk2<0>(m, b);  // the packed family: both passes on 16-bit lanes, 16-bit tile-contiguous hand-over
-    else if (ran == FUELMI_ESDF_PLAIN && !x32)
-      rc = launch_x_pk<0>(m, b);
     if (rc == ESDF_NO_FIT) rc = far ? launch_x<0, true>(m, b) : launch_x<0, false>(m, b);
   }
   if (rc) return rc;
