@@ -30,6 +30,10 @@
 #include <vector>
 
 #include "fuelmi_internal.h"
+#include <functional>
+#include <condition_variable>
+#include <thread>
+
 #include "frontier_internal.h"
 
 // FUELMI_DEBUG_SYNC=1: synchronise and name every frontier kernel (locates device faults)
@@ -4030,6 +4034,78 @@ extern "C" int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which
   c->copy_to(adr);
   return FUELMI_OK;
 }
+// A few helper threads for the host-side bulk steps of result delivery (decoding a large cluster's cells): created on
+// first use, parked on a condition variable, shared by every finder of the process.  FUELMI_HOST_HELPERS=0 switches them
+// off (everything then runs on the calling thread).
+namespace {
+struct HostHelpers {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  const std::function<void(size_t, size_t)>* job = nullptr;
+  size_t n = 0, piece = 0;
+  std::atomic<size_t> next{0};
+  int gen = 0, running = 0;
+  bool stop = false;
+  void worker() {
+    int seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+      }
+      take();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--running == 0) cv_done.notify_one();
+      }
+    }
+  }
+  void take() {
+    for (;;) {
+      const size_t i0 = next.fetch_add(piece);
+      if (i0 >= n) return;
+      (*job)(i0, std::min(n, i0 + piece));
+    }
+  }
+  void run(size_t total, const std::function<void(size_t, size_t)>& f) {
+    static const int want = getenv("FUELMI_HOST_HELPERS") ? atoi(getenv("FUELMI_HOST_HELPERS")) : 3;
+    if (want <= 0) {
+      f(0, total);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu);
+    if (th.empty())
+      for (int k = 0; k < want; ++k) th.emplace_back([this] { worker(); });
+    job = &f, n = total, piece = std::max<size_t>(8192, (total + 4 * (th.size() + 1) - 1) / (4 * (th.size() + 1)));
+    next = 0;
+    running = (int)th.size();
+    ++gen;
+    lk.unlock();
+    cv_go.notify_all();
+    take();  // the caller works too
+    lk.lock();
+    cv_done.wait(lk, [&] { return running == 0; });
+  }
+  ~HostHelpers() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+std::mutex g_helpers_once;
+}  // namespace
+static void host_parallel_for(size_t n, const std::function<void(size_t, size_t)>& f) {
+  static HostHelpers* H = new HostHelpers;  // (leaked on purpose: joining threads from a static destructor at exit can hang)
+  std::lock_guard<std::mutex> lk(g_helpers_once);  // one bulk step at a time
+  H->run(n, f);
+}
+
 // Frontier::cells_ as the reference's callers hold them: the voxel CENTRES of cluster k, three doubles per cell (the
 // layout of a vector<Eigen::Vector3d>), decoded by the library straight out of the pinned result block into the
 // caller's storage -- no intermediate address list, and no division per cell: consecutive cells of a list mostly share
@@ -4065,22 +4141,30 @@ extern "C" int fuelmi_frontier_cluster_centres(const fuelmi_frontier* f, int whi
     adr = merged.data();
   }
   const double res = g.res, ox = g.org[0], oy = g.org[1], oz = g.org[2];
-  // address of z = 0 of the current z-line; the start value makes the first cell decode whatever its address is
-  // (addresses are below 2^31; 0xFFFFFFFF made a - lb wrap to a + 1 < nz for cells of the column x = y = 0)
-  unsigned lb = 0x80000000u;
-  double cx = 0.0, cy = 0.0;
   const unsigned nz = (unsigned)g.nz, nyz = (unsigned)g.nyz;
-  for (size_t i = 0; i < n; ++i) {
-    const unsigned a = (unsigned)adr[i];
-    unsigned z = a - lb;
-    if (z >= nz) {  // another line
-      const unsigned x = a / nyz, r = a - x * nyz, y = r / nz;
-      z = r - y * nz;
-      lb = a - z;
-      cx = (x + 0.5) * res + ox, cy = (y + 0.5) * res + oy;
+  auto decode = [&](size_t i0, size_t i1) {
+    // address of z = 0 of the current z-line; the start value makes the first cell decode whatever its address is
+    // (addresses are below 2^31; 0xFFFFFFFF made a - lb wrap to a + 1 < nz for cells of the column x = y = 0)
+    unsigned lb = 0x80000000u;
+    double cx = 0.0, cy = 0.0;
+    for (size_t i = i0; i < i1; ++i) {
+      const unsigned a = (unsigned)adr[i];
+      unsigned z = a - lb;
+      if (z >= nz) {  // another line
+        const unsigned x = a / nyz, r = a - x * nyz, y = r / nz;
+        z = r - y * nz;
+        lb = a - z;
+        cx = (x + 0.5) * res + ox, cy = (y + 0.5) * res + oy;
+      }
+      xyz[3 * i] = cx, xyz[3 * i + 1] = cy, xyz[3 * i + 2] = (z + 0.5) * res + oz;
     }
-    xyz[3 * i] = cx, xyz[3 * i + 1] = cy, xyz[3 * i + 2] = (z + 0.5) * res + oz;
-  }
+  };
+  // a map-spanning cluster (140 k cells = 3.4 MB of doubles) is decoded by the caller and three helper threads of the
+  // library: one host thread writing it was the longest single step of a full-box cycle through the facade
+  if (n >= 32768)
+    host_parallel_for(n, decode);
+  else
+    decode(0, n);
   return FUELMI_OK;
 }
 extern "C" int fuelmi_frontier_cluster_filtered_size(const fuelmi_frontier* f, int which, int k) {

@@ -102,6 +102,9 @@ private:
   bool order_fallback_logged_ = false;  // the first address-order fallback of reference_order = 2 has been reported
   vector<int> removed_ids_;
   list<Frontier> frontiers_, dormant_frontiers_, tmp_frontiers_;
+  // storage of the large cells_ vectors a pull() replaces, kept for the next one: a fresh 3.4 MB vector<Vector3d> is a
+  // new mapping whose first touch faults 830 pages -- as long as decoding the cells into it
+  vector<vector<Vector3d>> cells_spare_;
   list<Frontier>::iterator first_new_ftr_;  // first cluster appended by the last computeFrontiersToVisit()
   Frontier next_frontier_;
 };

@@ -343,13 +343,26 @@ FrontierFinder::~FrontierFinder() {
 
 // host copies of the device list `which`, from position `from` on (from = 0 replaces `out`)
 void FrontierFinder::pull(int which, list<Frontier>& out, int from) {
-  if (from == 0) out.clear();
+  if (from == 0) {
+    for (Frontier& old : out)  // (large cell buffers stay mapped for the clusters about to be built)
+      if (old.cells_.capacity() >= 4096 && cells_spare_.size() < 8) cells_spare_.emplace_back(std::move(old.cells_));
+    out.clear();
+  }
   const int n = fuelmi_frontier_count(dev_, which);
   static_assert(sizeof(Vector3d) == 3 * sizeof(double), "cells_ is written as packed doubles");
   for (int k = from; k < n; ++k) {
     out.emplace_back();
     Frontier& f = out.back();  // (built in place: a 140 k-cell cluster is 3.4 MB, a copy of it a third of a plan cycle)
     const int sz = fuelmi_frontier_cluster_size(dev_, which, k);
+    if (sz >= 4096) {  // the smallest spare buffer that holds the cluster
+      int pick = -1;
+      for (int i = 0; i < (int)cells_spare_.size(); ++i)
+        if ((int)cells_spare_[i].capacity() >= sz && (pick < 0 || cells_spare_[i].capacity() < cells_spare_[pick].capacity())) pick = i;
+      if (pick >= 0) {
+        f.cells_.swap(cells_spare_[pick]);
+        cells_spare_.erase(cells_spare_.begin() + pick);
+      }
+    }
     f.cells_.resize(sz);
     // voxel centres straight into the vector's storage (the library decodes them from its pinned result block)
     if (sz > 0) warn("fuelmi_frontier_cluster_centres", fuelmi_frontier_cluster_centres(dev_, which, k, f.cells_[0].data()));

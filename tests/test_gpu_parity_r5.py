@@ -77,3 +77,79 @@ def test_centres_of_a_cluster_starting_in_the_corner_column(fa):
         assert np.array_equal(cen, (idx + 0.5) * om.res + np.array(om.origin))
     gf.close()
     gm.close()
+
+
+BIG = 1e6
+ESDF_TOL = 1e-4  # north_star: ESDF values within 1e-4 m
+
+
+def _esdf_equal(om, gm, lo, hi):
+    h = gm.syncHost(distance=True)
+    sl = tuple(slice(lo[i], hi[i] + 1) for i in range(3))
+    d_o = np.clip(om.dist, -BIG, BIG).reshape(om.nvox)[sl]
+    d_g = np.clip(h["distance"], -BIG, BIG).reshape(om.nvox)[sl]
+    assert np.abs(d_o - d_g).max() <= ESDF_TOL, (lo, hi, float(np.abs(d_o - d_g).max()))
+
+
+@pytest.mark.parametrize("map_size,optimistic,signed", [
+    ((6.4, 4.8, 4.0), 0, 0),   # nz = 40: z range in pieces of 8 + 2 segments
+    ((5.0, 4.4, 2.8), 1, 0),   # nz = 28: 4 + 2 + 1 segments (no full-width tile at all)
+    ((5.0, 4.4, 2.8), 0, 1),   # ... signed: the negative field through the same 16-bit hand-over, merged in place
+    ((4.2, 3.8, 10.0), 1, 1),  # nz = 100: 8 + 8 + 8 + 1 (the headline map's z extent)
+])
+def test_packed_esdf_hand_over_over_box_shapes(fa, map_size, optimistic, signed):
+    """The packed family's 16-bit, tile-contiguous hand-over (esdf.hip k_esdf_zy_pk2 / k_esdf_x_pk2, round 5) on boxes
+    that exercise its geometry: odd and even x / y extents (the last slab pair and the last row pair repeat their
+    partner), boxes starting at odd x, z ranges that are not 4-aligned at either end, y extents that do not fill the
+    remainder tiles, single-voxel and single-slab boxes.  Family pinned to the packed one and asserted to have run."""
+    om, _, _, box = helpers.explored_oracle_map(map_size, 10, 14, width=120, height=90, optimistic=optimistic,
+                                                signed_dist=signed)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1], optimistic=optimistic, signed_dist=signed)
+    gm.uploadOccupancy(om.occ)
+    gm.setEsdfFamily(0)
+    nv = om.nvox
+    rng = np.random.default_rng(nv[2])
+    boxes = [helpers.full_box(nv), ((1, 0, 0), (nv[0] - 1, nv[1] - 2, nv[2] - 1)), ((3, 2, 1), (nv[0] - 2, nv[1] - 1, nv[2] - 2)),
+             ((5, 5, 2), (5, 20, 13)), ((0, 7, 5), (30, 7, 6)), ((9, 9, 9), (9, 9, 9)), ((2, 1, 3), (17, 12, 3))]
+    for _ in range(6):
+        a = [int(rng.integers(0, nv[k] - 1)) for k in range(3)]
+        b = [int(rng.integers(a[k], nv[k])) for k in range(3)]
+        boxes.append((tuple(a), tuple(b)))
+    for lo, hi in boxes:
+        om.set_local_bound(lo, hi)
+        gm.setLocalBound(lo, hi)
+        om.inflate_local()
+        om.update_esdf()
+        gm.clearAndInflateLocalMap()
+        gm.updateESDF3d()
+        assert gm.lastEsdfFamily() == 0, "the packed family did not run on box %s %s" % (lo, hi)
+        _esdf_equal(om, gm, lo, hi)
+    gm.close()
+
+
+@pytest.mark.parametrize("map_size,src", [((32.0, 1.2, 0.8), (4, 5, 3)), ((1.2, 32.0, 0.8), (5, 4, 3)), ((2.0, 30.0, 0.8), (17, 290, 2))])
+def test_packed_esdf_far_from_every_source_uses_the_wide_plane(fa, map_size, src):
+    """Outputs further than 255 voxels from every source leave the 16-bit range.  Along x: the x pass recomputes them from
+    its tile.  Along y: the z/y pass marks them in the hand-over and keeps the exact value in the wide plane, the x pass
+    reads it back.  One occupied voxel in a 300-voxel-long known corridor, optimistic map (only the inflated voxel block
+    is a source)."""
+    om = fo.OracleMap(map_size, optimistic=1)
+    gm = fa.SDFMap(map_size, optimistic=1)
+    nv = om.nvox
+    occ = np.full(nv, om.l_min)
+    occ[src] = om.l_max
+    om.occ[:] = occ.reshape(-1)
+    gm.uploadOccupancy(om.occ)
+    gm.setEsdfFamily(0)
+    lo, hi = helpers.full_box(nv)
+    for o in (om,):
+        o.set_local_bound(lo, hi)
+        o.inflate_local()
+        o.update_esdf()
+    gm.setLocalBound(lo, hi)
+    gm.clearAndInflateLocalMap()
+    gm.updateESDF3d()
+    assert gm.lastEsdfFamily() == 0
+    assert np.nanmax(np.where(om.dist < BIG, om.dist, 0.0)) > 25.6  # (there ARE distances beyond 255 voxels)
+    _esdf_equal(om, gm, lo, hi)
+    gm.close()
