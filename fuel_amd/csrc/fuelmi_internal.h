@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -184,6 +185,11 @@ struct fuelmi_map {
   std::vector<std::unique_ptr<QuerySlot>> qslots;
   std::mutex qs_mu;
   std::condition_variable qs_cv;
+  // readers (query slots: from "is the map's stream idle?" to "my kernel is launched") share it, a writer of the distance
+  // field takes it alone while it makes its stream wait for the launched query kernels: no query can slip between a
+  // writer's look at the slots and the writer's kernels, so every query sees the field before or after an update, never
+  // a mix (with signed_dist: never the positive-only intermediate the negative pass merges into in place)
+  std::shared_timed_mutex rw_mu;
   std::mutex prof_mu;  // the stage-profile log (StageScope) is shared by every thread that launches on this map
 
   // measurement
@@ -210,6 +216,7 @@ int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
 struct QuerySlotGuard {
   fuelmi_map* m = nullptr;
   fuelmi_map::QuerySlot* s = nullptr;
+  bool reading = false;  // holds m->rw_mu shared (acquire() .. the launch; finish() lets go)
   int acquire(fuelmi_map* m_, size_t bytes);
   hipError_t finish();  // record + poll the slot's completion event
   ~QuerySlotGuard();
@@ -267,9 +274,8 @@ static inline hipError_t map_wait_plane_readers(fuelmi_map* m) {
   m->planes_read_evs.clear();
   return e;
 }
-// Writers of the distance field / the inflated plane on the map's stream wait for the query kernels already LAUNCHED
-// on busy query slots (write-after-read).  A query whose slot is taken but whose kernel is not launched yet
-// when the writer looks is not ordered against that writer: fuelmi.h says so.
+// Writers of the distance field on the map's stream wait for the query kernels already LAUNCHED on busy query slots
+// (write-after-read), under m->rw_mu so that no query is between its look at the stream and its launch.
 int map_wait_query_readers(fuelmi_map* m);
 // a finder has recorded `ev` behind the last kernel of its search that reads the planes
 static inline void map_add_plane_reader(fuelmi_map* m, hipEvent_t ev) {

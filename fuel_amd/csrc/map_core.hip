@@ -118,6 +118,8 @@ int QuerySlotGuard::acquire(fuelmi_map* m_, size_t bytes) {
   // holds nothing to wait for: skipping the record + wait then keeps the query off a cross-queue dependency -- with the
   // slot's stream on a hardware queue of its own that dependency alone was 59 of a combineCost's 92 us
   // (profiles/r05_facade_bisect.txt; in round 4 the slot happened to share the map stream's queue)
+  m->rw_mu.lock_shared();  // (until the caller's kernel is launched: finish(), or the destructor on an error path)
+  reading = true;
   if (hipStreamQuery(m->stream) != hipSuccess) {
     HIPCHK(hipEventRecord(s->ev_dep, m->stream));
     HIPCHK(hipStreamWaitEvent(s->st, s->ev_dep, 0));
@@ -126,6 +128,10 @@ int QuerySlotGuard::acquire(fuelmi_map* m_, size_t bytes) {
 }
 hipError_t QuerySlotGuard::finish() {
   hipError_t e = hipEventRecord(s->ev_done, s->st);
+  if (reading) {  // the query's kernel is on its stream: writers may look at the slots again
+    reading = false;
+    m->rw_mu.unlock_shared();
+  }
   if (e != hipSuccess) return e;
   const bool yld = poll_yields();
   const auto t_begin = std::chrono::steady_clock::now();
@@ -139,7 +145,7 @@ hipError_t QuerySlotGuard::finish() {
       return hipEventSynchronize(s->ev_done);
   }
 }
-int map_wait_query_readers(fuelmi_map* m) {
+int map_wait_query_readers(fuelmi_map* m) {  // (the caller holds m->rw_mu exclusively)
   std::lock_guard<std::mutex> lk(m->qs_mu);
   for (auto& q : m->qslots)
     if (q->busy && q->st && q->ev_rd) {
@@ -149,6 +155,10 @@ int map_wait_query_readers(fuelmi_map* m) {
   return FUELMI_OK;
 }
 QuerySlotGuard::~QuerySlotGuard() {
+  if (reading) {
+    reading = false;
+    m->rw_mu.unlock_shared();
+  }
   if (!s) return;
   (void)hipStreamSynchronize(s->st);  // (an error path may leave work behind: the pinned block is about to be reused)
   {
@@ -748,6 +758,10 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
 extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
   ARGCHK(m);
   HIPCHK(hipSetDevice(m->device));
+  // Alone on the map's reader / writer lock from the look at the query slots to the LAST launch of the update: a query
+  // that recorded its "behind the map's stream" event between two of the update's kernels would wait for the first ones
+  // only (signed maps: it would read the positive field while the negative pass merges into it)
+  std::unique_lock<std::shared_timed_mutex> wr(m->rw_mu);
   {
     const int rcq = map_wait_query_readers(m);  // (query kernels in flight still read the field this update rewrites)
     if (rcq) return rcq;

@@ -16,12 +16,11 @@
  *     (the reference runs them on the single ros::spin thread); different maps are independent.
  *     Host-staged queries (dist_grad, coarse_dist, query_state, sync_host) may run from other threads
  *     beside a mutator: they and the fusion entry points share the map's staging buffers under a per-map mutex.
- *     Ordering of such a query against the mutators: it sees every mutator queued BEFORE the call; an ESDF update
- *     queued after the query's kernel was launched waits for it on the device.  A query that is between taking its
- *     slot and launching when another thread queues an update is not ordered against that update (it may read a
- *     mix of the old and the new field -- with signed_dist including the positive-only intermediate, which the x pass
- *     of the negative field merges in place): callers that need one consistent field serialise the two calls
- *     themselves, as the reference's single spinner thread does.
+ *     Ordering of a distance query (dist_grad, coarse_dist, the one-shot B-spline calls) against ESDF updates of the
+ *     same map: it sees the field either before or after an update, never a mix -- a query issued while an update is
+ *     queued or running waits for it on the device, an update queued behind launched query kernels waits for them,
+ *     and a reader / writer lock keeps a query from slipping between the two (with signed_dist a reader can
+ *     therefore never see the positive-only intermediate the negative pass merges into in place).
  *   - all work is done by HIP kernels; there is no CPU fallback.  If no gfx950 device is
  *     usable fuelmi_map_create fails with FUELMI_ENODEV.
  */

@@ -24,9 +24,13 @@ def fa():
     return fuel_amd
 
 
-def test_ten_reader_threads_beside_the_mutating_owner(fa):
-    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40)
-    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+@pytest.mark.parametrize("signed", [0, 1])
+def test_ten_reader_threads_beside_the_mutating_owner(fa, signed):
+    """signed = 1: with signed_dist the x pass of the negative field merges into the distance buffer in
+    place -- a reader overlapping the update must never see the positive-only intermediate; every reader result below is
+    compared bit for bit with the serial run."""
+    om, _, _, box = helpers.explored_oracle_map((20.0, 20.0, 5.0), 60, 40, signed_dist=signed)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1], signed_dist=signed)
     gm.uploadOccupancy(om.occ)
     lo, hi = helpers.full_box(om.nvox)
     gm.setLocalBound(lo, hi)
