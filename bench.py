@@ -662,6 +662,13 @@ def main():
         triad_gbs = round(tri.value, 1)
     except Exception:
         triad_gbs = None
+    expand_gbs = None  # the x pass's read : write mix (1 : 2) as a plain streaming kernel
+    try:
+        ex = C.c_double()
+        _lib.check(cyc.map.L.fuelmi_hbm_expand(local_rank, 1 << 29, 5, C.byref(ex)))
+        expand_gbs = round(ex.value, 1)
+    except Exception:
+        expand_gbs = None
     for _ in range(min(args.warmup, 5)):  # (the state the profiling passes left behind: back to the steady cycle)
         cyc.step()
     cyc.finish()
@@ -859,6 +866,7 @@ def main():
         out["cycle_hbm"] = {"algorithmic_bytes_per_cycle": cyc_bytes, "achieved": cyc_bytes * cps_per_gpu / 1e9,
                             "unit": "GB/s", "frac": cyc_bytes * cps_per_gpu / 1e9 / HBM_PEAK_GBS}
         out["roofline"]["measured_triad_gbs"] = triad_gbs
+        out["roofline"]["measured_expand_gbs"] = expand_gbs  # u16 in, f32 out: the packed x pass's traffic mix
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms
             out["roofline"]["isolated_frac"] = alg_bytes[dominant] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

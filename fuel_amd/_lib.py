@@ -124,6 +124,7 @@ SYMBOLS = {
     "fuelmi_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "fuelmi_device_free": (C.c_int, [C.c_void_p]),
     "fuelmi_hbm_triad": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
+    "fuelmi_hbm_expand": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     "fuelmi_map_project_depth": (C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(DepthCfg), _dp, _dp,
                                            C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "fuelmi_map_inflate_local": (C.c_int, [_P]),

@@ -828,6 +828,51 @@ extern "C" int fuelmi_hbm_triad(int device, size_t bytes, int reps, double* gb_p
   }
   return FUELMI_OK;
 }
+/* The x pass's traffic mix as a plain streaming kernel: read n 16-bit values, write n floats (1 byte in : 2 bytes out).
+ * What the device reaches on THAT mix is the ceiling to hold k_esdf_x_pk2 against (writes cost more than reads: the
+ * triad's 2 : 1 read : write mix overstates it). */
+__global__ void __launch_bounds__(256) k_expand(float4* __restrict__ out, const uint2* __restrict__ in, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint2 v = in[i];
+    out[i] = make_float4((float)(v.x & 0xffffu), (float)(v.x >> 16), (float)(v.y & 0xffffu), (float)(v.y >> 16));
+  }
+}
+extern "C" int fuelmi_hbm_expand(int device, size_t bytes_in, int reps, double* gb_per_s) {
+  ARGCHK(gb_per_s && bytes_in >= 4096 && reps >= 1);
+  *gb_per_s = 0.0;
+  HIPCHK(hipSetDevice(device));
+  bytes_in &= ~(size_t)7;
+  struct Scratch {
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+    }
+  } S;
+  if (hipMalloc(&S.a, 2 * bytes_in) != hipSuccess || hipMalloc(&S.b, bytes_in) != hipSuccess) {
+    (void)hipGetLastError();
+    fuelmi_set_error("fuelmi_hbm_expand: cannot allocate 3 x %zu bytes", bytes_in);
+    return FUELMI_EHIP;
+  }
+  HIPCHK(hipMemset(S.b, 0, bytes_in));
+  HIPCHK(hipEventCreate(&S.e0));
+  HIPCHK(hipEventCreate(&S.e1));
+  const size_t n4 = bytes_in / 8;
+  for (int grid : {256 * 8, 256 * 16, 256 * 32, 256 * 64, 256 * 256}) {
+    k_expand<<<grid, 256>>>(static_cast<float4*>(S.a), static_cast<const uint2*>(S.b), n4);
+    HIPCHK(hipEventRecord(S.e0, nullptr));
+    for (int r = 0; r < reps; ++r) k_expand<<<grid, 256>>>(static_cast<float4*>(S.a), static_cast<const uint2*>(S.b), n4);
+    HIPCHK(hipEventRecord(S.e1, nullptr));
+    HIPCHK(hipEventSynchronize(S.e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, S.e0, S.e1));
+    *gb_per_s = std::max(*gb_per_s, 3.0 * (double)bytes_in * reps / (ms * 1e-3) / 1e9);
+  }
+  return FUELMI_OK;
+}
 extern "C" int fuelmi_device_free(void* ptr) {
   if (ptr) HIPCHK(hipFree(ptr));
   return FUELMI_OK;

@@ -121,6 +121,9 @@ int fuelmi_device_free(void* ptr);
 /* STREAM-triad over three device arrays of `bytes` each: the HBM bandwidth a plain kernel reaches on this device
  * (reported by bench.py beside the vendor peak the rooflines are quoted against). */
 int fuelmi_hbm_triad(int device, size_t bytes, int reps, double* gb_per_s);
+/* the same for the x pass's traffic mix: bytes_in of 16-bit values read, 2 * bytes_in of floats written; reports
+ * 3 * bytes_in / time */
+int fuelmi_hbm_expand(int device, size_t bytes_in, int reps, double* gb_per_s);
 int fuelmi_map_input_depth(fuelmi_map* m, const unsigned short* depth, int rows, int cols,
                            const fuelmi_depth_cfg* cfg, const double cam_pos[3], const double cam_q_wxyz[4],
                            int* n_points);
