@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-4 evidence, one gpurun call (COMMIT=<git hash of the code> in the environment stamps every summary): bench lines
+# Round-5 evidence (the round-4 script, brought forward), one gpurun call (COMMIT=<git hash of the code> in the environment stamps every summary): bench lines
 # (headline, big map, sparse regimes, streaming, fleet of two on one device), rocprofv3 kernel stats of the same commands
 # (overlapped cycle and serial stages), PMC passes (HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes; SQ issue /
 # wait cycles in a third; SQ instruction counts of the ESDF families in a fourth), cycle timelines, in-kernel phase
 # stamps of the z/y pass, same-box A/B runs of this round's switches, next-row timings, facade bench, fleet / perf tests.
-# Everything lands under gpurun_out/prof_r04; scripts/publish_profiles.sh r04 copies the summaries into profiles/.
+# Everything lands under gpurun_out/prof_$R; scripts/publish_profiles.sh $R copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${R:-r04}
+R=${R:-r05}
 export FUELMI_COMMIT=${COMMIT:-unknown}
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
@@ -25,13 +25,13 @@ done
 for FAM in 0 2; do
   timeout 300 rocprofv3 --pmc $SQI --output-format csv -d $O/pmc_insts_fam$FAM -o s -- python scripts/esdf_only.py G400 $FAM 4 > /dev/null 2>&1
 done
-python - > $O/esdf_instruction_counts.txt <<'PY'
-import csv, glob, collections
+O=$O python - > $O/esdf_instruction_counts.txt <<'PY'
+import csv, glob, collections, os
 print("# SQ_INSTS_* per launch (wave instructions, whole dispatch) of the ESDF kernels on the 400x400x100 map, rocprofv3 --pmc, own pass;")
-print("# family 0 = packed 16-bit kernels (k_esdf_zy_pk, k_esdf_x_pk), family 2 = 32-bit kernels (k_esdf_zy4, k_esdf_x4h)")
+print("# family 0 = packed 16-bit kernels with the 16-bit hand-over (k_esdf_zy_pk2, k_esdf_x_pk2), family 2 = 32-bit kernels (k_esdf_zy4, k_esdf_x4h)")
 for fam in (0, 2):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob("gpurun_out/prof_r04/pmc_insts_fam%d/**/*counter_collection.csv" % fam, recursive=True):
+    for f in glob.glob(os.environ["O"] + "/pmc_insts_fam%d/**/*counter_collection.csv" % fam, recursive=True):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"].split("(")[0][:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in sorted(acc.items()):
@@ -60,10 +60,24 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -o
 { echo "# two consecutive streaming frames (rocprofv3 --kernel-trace of python bench.py --workload G800S --no-cpu-baseline --steps 40, commit $FUELMI_COMMIT)"
   python scripts/cycle_timeline.py $O/stream/s_kernel_trace.csv k_insert_classify; } > $O/stream_timeline_G800S.txt 2>&1
 # in-kernel phase stamps of the packed z/y pass, and the ESDF kernels per family (same box)
-{ for WL in G400 G800; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep zy-timing | tail -1 | sed "s/^/$WL /"; done
+{ for WL in G400 G800 G400K; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep -E "zy2-timing|x2-timing|slowest" | tail -4 | sed "s/^/$WL /"; done
   for WL in G400 G800 G400K G400E; do for FAM in 0 2 1; do echo -n "$WL family $FAM: "; python scripts/esdf_only.py $WL $FAM 8; done; done; } > $O/esdf_family_ab.txt 2>&1
 # this round's switches, same box, two repetitions each
-WLARGS="" bash scripts/r4_cycle_ab.sh FUELMI_FR_GRAPH=1 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 FUELMI_X_PK=0 "FUELMI_X_PK=0 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 FUELMI_FR_GRAPH=1" > $O/tuning_ab_cycle.txt 2>&1
+WLARGS="" bash scripts/r4_cycle_ab.sh FUELMI_FR_GRAPH=1 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 FUELMI_KEEP_HW_QUEUES=1 > $O/tuning_ab_cycle.txt 2>&1
+# the round-4 build of the library on the same box (build/r4 is a worktree of 72541aa built by hand before the call)
+if [ -d build/r4/fuel_amd ]; then
+  { echo "# same box, same call: round-4 final (72541aa) against this tree; bench.py --no-cpu-baseline of each (value, stage_ms isolated)"
+    for WL in G400 G800 G400K G400E G800S; do
+      for T in build/r4 .; do (cd $T && python bench.py --workload $WL --no-cpu-baseline 2>/dev/null | T=$T WL=$WL python -c "
+import sys,json,os
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(os.environ['WL'], 'r4' if 'r4' in os.environ['T'] else 'r5', round(d['value'],1), d.get('stage_ms_isolated') or d['stage_ms'])"); done; done; } > $O/r4_vs_r5_same_box.txt 2>&1
+fi
+# the driver's own command line (short timed regions, repeated) and the host's time per call / inside the search calls
+timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_G400_driver_cmdline.json 2>/dev/null
+{ echo "# FUELMI_HOST_TIMING=1 python bench.py --no-cpu-baseline (host microseconds inside fuelmi_frontier_search_begin / _end per search), commit $FUELMI_COMMIT"
+  FUELMI_HOST_TIMING=1 python bench.py --no-cpu-baseline 2>&1 >/dev/null | grep host-timing | tail -2
+  echo "# hardware queues: scripts/r5_hwq.py at the library's load-time default, then with the runtime's (FUELMI_KEEP_HW_QUEUES=1)"
+  python scripts/r5_hwq.py 2>&1 | tail -5; FUELMI_KEEP_HW_QUEUES=1 python scripts/r5_hwq.py 2>&1 | tail -5; } > $O/host_timing.txt 2>&1
 timeout 300 python scripts/bench_next.py > $O/next_rows.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/next -o s -- python scripts/bench_next.py > /dev/null 2>&1
 timeout 300 python scripts/facade_bench.py --map G800S --frames 30 > $O/facade_bench_G800S.json 2> $O/facade_bench.err
@@ -82,7 +96,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/reforder1
 { echo "# FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 (400x400x100, full box: one cluster of 139 k cells), commit $FUELMI_COMMIT"
   for T in 512 256 1024; do echo "# k_bfs_sweep_g with $T threads"; FUELMI_BFSG_T=$T FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 2>&1 >/dev/null | grep "reference order" | tail -2; done
   echo "# x pass phase stamps (FUELMI_ZY_TIMING=1, scripts/esdf_only.py)"
-  for WL in G400 G800; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep x-timing | tail -1 | sed "s/^/$WL /"; done; } > $O/reference_order_timing.txt 2>&1
+  for WL in G400 G800; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep x2-timing | tail -1 | sed "s/^/$WL /"; done; } > $O/reference_order_timing.txt 2>&1
 timeout 300 python -m pytest tests/test_fleet_gpu.py -q -s -m gpu 2>&1 | grep -E "fleet on one device|bench --gpus|passed|failed" > $O/fleet_one_device.txt
 timeout 300 python -m pytest tests/test_perf_gpu.py -q -s -m perf 2>&1 | grep -E "ESDF ms|z/y pass ms|passed|failed" > $O/perf_statements.txt
 for f in bench_G400 bench_G800 bench_G400K bench_G400E bench_G800S bench_G400_two_ranks_one_device; do tail -1 $O/$f.json | cut -c1-160; done
