@@ -119,7 +119,7 @@ def test_other_maps_alive_in_the_process_do_not_slow_the_streaming_frame(fa):
 
 def test_ten_optimiser_threads_do_not_queue_behind_each_other(fa):
     """topoReplan's ten optimiser threads (plan_manage/src/planner_manager.cpp:446-453) on ONE map: ten concurrent
-    solves within 2.2 x one solve (Python threads; the C++ figure is facade_bench's ten_threads_ten_solves_ms: 1.74 ms
+    solves well below their serial sum (Python threads; the C++ figure is facade_bench's ten_threads_ten_solves_ms: 1.74 ms
     for 1.46 ms solves, 4.3 ms with the runtime's four hardware queues)."""
     import threading
     import time
@@ -141,12 +141,14 @@ def test_ten_optimiser_threads_do_not_queue_behind_each_other(fa):
         o.setEnvironment(gm)
         o.optimize(probs[-1])
         opts.append(o)
-    one = 1e9
+    singles = []
     for t in range(10):
-        t0 = time.perf_counter()
-        opts[t].optimize(probs[t])
-        one = min(one, time.perf_counter() - t0)
-    slowest = max(0.0, one)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            opts[t].optimize(probs[t])
+            best = min(best, time.perf_counter() - t0)
+        singles.append(best)
     ten = 1e9
     for _ in range(5):
         th = [threading.Thread(target=lambda k=k: opts[k].optimize(probs[k])) for k in range(10)]
@@ -157,4 +159,5 @@ def test_ten_optimiser_threads_do_not_queue_behind_each_other(fa):
             x.join()
         ten = min(ten, time.perf_counter() - t0)
     gm.close()
-    assert ten <= 3.0 * slowest + 1e-3, (one, ten)
+    # side by side: well below the serial sum, and not far above the slowest of them (Python threads add ~0.1 ms each)
+    assert ten <= 0.6 * sum(singles) and ten <= 2.0 * max(singles) + 1.5e-3, (singles, ten)
