@@ -714,11 +714,12 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
     // plane itself (zero margins included) is the source plane
     const bool whole = b.lo[0] == 0 && b.lo[1] == 0 && b.lo[2] == 0 && b.hi[0] == g.nx - 1 && b.hi[1] == g.ny - 1 &&
                        b.hi[2] == g.nz - 1;
-    // The fused kernel re-reads every source word five times: free while the planes sit in the caches (400^2 x 100: 9.8
-    // against 11.8 us and a launch saved), not on the HBM-resident 800^2 x 200 map (53.6 against 42 us): by size, like
-    // every other kernel choice.  FUELMI_INFLATE_2PASS=0 / 1 pins.
+    // The fused kernel re-reads every source word five times: free while the words it touches sit in the caches (400^2 x
+    // 100: 9.8 against 11.8 us and a launch saved; the local box of a streaming frame on any map), not for the full box of
+    // the HBM-resident 800^2 x 200 map (53.6 against 42 us): by the size of the BOX's address range, like every other
+    // kernel choice.  FUELMI_INFLATE_2PASS=0 / 1 pins.
     static const char* tp_env = getenv("FUELMI_INFLATE_2PASS");
-    const bool two_pass = tp_env ? atoi(tp_env) != 0 : (long)g.N > (48L << 20);
+    const bool two_pass = tp_env ? atoi(tp_env) != 0 : (long)(out_hi - out_lo + 1) * 64 > (48L << 20);
     const int ry = (step * (g.nz + 1) + 63) / 64 + 1;
     const size_t lds_f = (size_t)(2 * step + 1) * (2 * (size_t)(256 + 2 * ry + 2) + 2) * sizeof(u64);
     if (step == 2 && !two_pass && lds_f <= 64 * 1024) {
