@@ -1054,6 +1054,20 @@ k_esdf_x4h(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist,
   }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device, not once per launch
+static hipError_t lds_attr_once(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;  // (function, device)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.push_back({fn, dev});
+  return e;
+}
+
 // "this kernel variant does not fit this box" (LDS tables, line length): the caller takes the next variant.  Positive,
 // so that it can never be taken for one of the negative FUELMI_E* codes
 enum { ESDF_NO_FIT = 1 };
@@ -1093,8 +1107,7 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
     return FUELMI_ELIMIT;
   }
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy4<MODE, FAR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_zy4<MODE, FAR>), 160 * 1024));
   STAGE_LAUNCH(m, (k_esdf_zy4<MODE, FAR>), ((xlen + 7) / 8) * 8 * nzc, 512, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
                m->esdf_tmp, ZC, nzc, z0a, esdf_near() | (zy_fastrow() ? 256 : 0),
                MODE == 2 ? nullptr : esdf_stat_dev<0>(m));
@@ -1180,8 +1193,7 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
   const size_t lds = (size_t)(FAR ? xlen + ((xlen + 7) >> 3) + 1 : xlen) * SEGS * 4 * sizeof(u32);
   if (lds > 160 * 1024) return ESDF_NO_FIT;  // (FAR only: the longest lines, > 2270 voxels, scan without the far phase)
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS, FAR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS, FAR>), 160 * 1024));
   int ncol = ylen * zlen_a;
   static const char* xt = getenv("FUELMI_X_THREADS");  // tuning hook
   const int threads = xt ? atoi(xt) : 1024;
@@ -1569,11 +1581,7 @@ static int launch_zy_pk2_g(fuelmi_map* m, const Box3& b, int z0a, int threads, s
   const int xlen = b.hi[0] - b.lo[0] + 1;
   const int npx = (xlen + 1) >> 1;
   const Pk2ZChunks& ch = m->pk2_zch;
-  if (lds > 64 * 1024 && !m->attr_set[0][MODE][GMAX][NW / 2 - 1]) {  // (once per kernel, not per update)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy_pk2<MODE, GMAX, NW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    m->attr_set[0][MODE][GMAX][NW / 2 - 1] = true;
-  }
+  if (lds > 64 * 1024) HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_zy_pk2<MODE, GMAX, NW>), 160 * 1024));
   const int grid = ((npx + 7) / 8) * 8 * ch.n;
   static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;  // debug: where a workgroup's life goes
   unsigned long long* dbg = nullptr;
@@ -1632,11 +1640,7 @@ static int launch_x_pk2(fuelmi_map* m, const Box3& b) {
   const int z0a = b.lo[2] & ~3;
   const int npx = (xlen + 1) >> 1;
   const size_t lds = (size_t)npx * 8 * 16;
-  if (lds > 64 * 1024 && !m->attr_set[1][OUT][0][0]) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x_pk2<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               150 * 1024));
-    m->attr_set[1][OUT][0][0] = true;
-  }
+  if (lds > 64 * 1024) HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_x_pk2<OUT>), 150 * 1024));
   static const char* th_env = getenv("FUELMI_X_PK_THREADS");  // tuning hook
   const int threads = th_env ? atoi(th_env) : (lds > 32 * 1024 ? 512 : 256);
   static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;
@@ -1722,8 +1726,7 @@ static int launch_zy(fuelmi_map* m, const Box3& b) {
     return FUELMI_ELIMIT;
   }
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_zy<MODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_zy<MODE>), 160 * 1024));
   STAGE_LAUNCH(m, (k_esdf_zy<MODE>), xlen * nzc, 256, lds, g, b, (const u64*)m->infl_bits.p, (const u64*)m->unk_bits.p,
                m->esdf_tmp, ZC, nzc);
   HIPCHK(hipGetLastError());
@@ -1736,8 +1739,7 @@ static int launch_x_s(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1, zlen = b.hi[2] - b.lo[2] + 1;
   size_t lds = (size_t)xlen * S * sizeof(u32);
   if (lds > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_esdf_x<S, OUT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_x<S, OUT>), 160 * 1024));
   int ncol = ylen * zlen;
   STAGE_LAUNCH(m, (k_esdf_x<S, OUT>), (ncol + S - 1) / S, 256, lds, g, b, (const u32*)m->esdf_tmp, m->dist);
   HIPCHK(hipGetLastError());
@@ -1765,7 +1767,11 @@ static int launch_x(fuelmi_map* m, const Box3& b) {
 // families are exact; fuelmi_map_set_esdf_family pins one (tests, A/B runs).
 static bool esdf_use_far(fuelmi_map* m, const Box3& b) {
   const volatile unsigned long long* h = reinterpret_cast<const volatile unsigned long long*>(esdf_stat_host(m));
-  for (int g = 0; g < ESDF_NG; ++g) {  // entries are self-describing (forward_stat): take whatever is new
+  // entries are self-describing (forward_stat): take whatever is new -- of the groups THIS box covers (a full-width box
+  // of a 400-voxel map: 25 words, not all 256; the other places are looked at when a box reaches them)
+  const int g_lo = b.lo[0] >> 4, g_n = std::min((b.hi[0] >> 4) - g_lo + 1, ESDF_NG);
+  for (int gi = 0; gi < g_n; ++gi) {
+    const int g = (g_lo + gi) & (ESDF_NG - 1);
     const unsigned long long v = h[g];
     const unsigned short tag = (unsigned short)(v >> 48);
     if (tag != 0 && tag != m->far_tag[g]) {

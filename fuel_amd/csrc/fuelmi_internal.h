@@ -115,7 +115,6 @@ struct fuelmi_map {
   bool esdf_pk2_last = false;   // the last z/y pass wrote the 16-bit hand-over
   Pk2Chunks pk2_ch = {};        // ... in these column tiles
   Pk2ZChunks pk2_zch = {};      // ... written by these chunks of the z/y pass
-  bool attr_set[2][3][9][2] = {};  // hipFuncSetAttribute done for (pass, MODE / OUT, G, NW) -- once, not per update
   unsigned char* flag_rayend = nullptr;  // flag_rayend_                      1 B/voxel
   u32* ray_owner = nullptr;     // per-frame end-voxel owner (point index)     4 B/voxel
   Plane hit_bits, miss_bits;    // per-frame touched voxels
