@@ -988,7 +988,7 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
 // distance to the first row it could not see -- finishes from global memory, row by row.  Exact either way: every
 // candidate f(p) + r^2 is examined unless r^2 alone already reaches the minimum.  The x blocks of one column tile
 // are dealt to the same XCD (block b -> XCD b % 8).  Used with ONE block (XR = the whole line, no halo) for
-// lines of up to 512 voxels, see launch_x4; real halo tiling (FUELMI_X_HALO=1, FUELMI_XH_ROWS) was meant for
+// lines of up to 512 voxels, see launch_x4; real halo tiling (more than one x block) was meant for
 // the 800-voxel lines of the big maps (102 KB per whole-line tile, one workgroup per CU, parked on memory three
 // quarters of the time) and measured slower there: more workgroups per CU do not help a pass that waits for DRAM
 // bandwidth, and the halo adds a third to what it reads.
@@ -1090,17 +1090,14 @@ static int launch_zy4(fuelmi_map* m, const Box3& b) {
   const int zlen_a = z1a - z0a + 1;
   // ~20 z per chunk amortises the per-row bit fetches (measured: 400 rows x 20 z = 32 KB on G400,
   // 800 rows x 20 z = 64 KB on G800 are the optima; bigger tiles lose occupancy, smaller ones repeat the
-  // row prologue); FUELMI_ZY_TILE_KB overrides for tuning
-  static const char* zy_kb = getenv("FUELMI_ZY_TILE_KB");
-  const int budget = zy_kb ? atoi(zy_kb) * 1024 : std::min(std::max(32 * 1024, ylen * 4 * 20), 80 * 1024);
+  // row prologue)
+  const int budget = std::min(std::max(32 * 1024, ylen * 4 * 20), 80 * 1024);
   int zc_max = std::max(4, (budget / (4 * ylen)) & ~3);
   zc_max = std::min(zc_max, std::min(zlen_a, 64));
   int nzc = (zlen_a + zc_max - 1) / zc_max;
   int ZC = (((zlen_a + nzc - 1) / nzc) + 3) & ~3;
   nzc = (zlen_a + ZC - 1) / ZC;
   size_t lds = (size_t)(FAR ? ylen + ((ylen + 7) >> 3) + 1 : ylen) * ZC * sizeof(u32);  // tile (+ block and line minima)
-  static const char* pad = getenv("FUELMI_ZY_LDS_PAD_KB");  // tuning: fewer workgroups per CU
-  if (pad) lds += (size_t)atoi(pad) * 1024;
   if (lds > 160 * 1024) {
     if (FAR) return ESDF_NO_FIT;  // (the far-field tables do not fit beside the tile: the caller takes the plain kernel)
     fuelmi_set_error("ESDF y-line of %d voxels does not fit the LDS tile", ylen);
@@ -1195,8 +1192,7 @@ static int launch_x4s(fuelmi_map* m, const Box3& b) {
   if (lds > 64 * 1024)
     HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_x4<OUT, SEGS, FAR>), 160 * 1024));
   int ncol = ylen * zlen_a;
-  static const char* xt = getenv("FUELMI_X_THREADS");  // tuning hook
-  const int threads = xt ? atoi(xt) : 1024;
+  const int threads = 1024;
   STAGE_LAUNCH(m, (k_esdf_x4<OUT, SEGS, FAR>), (ncol + 4 * SEGS - 1) / (4 * SEGS), threads, lds, g, b, (const u32*)m->esdf_tmp,
                m->dist, z0a, zlen_a, esdf_near(), esdf_stat_dev<OUT>(m), esdf_stat_host(m));
   HIPCHK(hipGetLastError());
@@ -1670,8 +1666,7 @@ static int launch_x4h(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
   const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
   const int zlen_a = z1a - z0a + 1;
-  static const char* xr_env = getenv("FUELMI_XH_ROWS");  // tuning hook: output rows per workgroup
-  const int xr_target = xr_env ? std::max(32, atoi(xr_env)) : (xlen <= 512 ? xlen : 200);
+  const int xr_target = xlen <= 512 ? xlen : 200;  // output rows per workgroup
   const int nxb = (xlen + xr_target - 1) / xr_target;
   const int XR = (xlen + nxb - 1) / nxb;
   const size_t lds = (size_t)(XR + 2 * XH_HALO) * 8 * 4 * sizeof(u32);
@@ -1692,15 +1687,13 @@ static int launch_x4(fuelmi_map* m, const Box3& b) {
     // plan cycle gains 2-5 % (8 500 vs 8 350 / 7 730 cycles/s on one box): the frontier chain's kernels find wave
     // slots sooner beside 512-thread workgroups.  Longer lines: its halo tiling is SLOWER than whole lines
     // (800-voxel lines: 271 vs 243 us -- the x pass there is bound by DRAM, and the halo rows are read twice), so
-    // they keep k_esdf_x4.  FUELMI_X_HALO=0 / 1 pins the choice.
-    static const char* he = getenv("FUELMI_X_HALO");
-    const bool halo = he ? atoi(he) != 0 : xlen <= 512;
+    // they keep k_esdf_x4.
+    const bool halo = xlen <= 512;
     if (halo && !FAR && xlen > 2 * XH_HALO + 64) return launch_x4h<OUT>(m, b);
   }
-  static const char* force = getenv("FUELMI_X_SEGS");  // tuning hook: "4" or "8"
   // the 32-column tile is faster whenever it fits (measured on 800-voxel lines: 0.32 vs 0.37 ms), the
   // 16-column one extends the vector path to x lines of up to 2400 voxels
-  const bool narrow = force ? atoi(force) == 4 : (size_t)xlen * 128 > 150 * 1024;
+  const bool narrow = (size_t)xlen * 128 > 150 * 1024;
   const int rc = narrow ? launch_x4s<OUT, 4, FAR>(m, b) : launch_x4s<OUT, 8, FAR>(m, b);
   if (rc != ESDF_NO_FIT || !FAR) return rc;
   return narrow ? launch_x4s<OUT, 4, false>(m, b) : launch_x4s<OUT, 8, false>(m, b);
