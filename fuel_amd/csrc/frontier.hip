@@ -2687,7 +2687,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
   if (f->ev_prev) (void)hipEventDestroy(f->ev_prev);
   if (f->ev_planes_read) {
-    if (f->map) map_drop_plane_reader(f->map, f->ev_planes_read);
+    if (f->map) map_drop_plane_reader(f->map, f->ev_planes_read), map_drop_late_reader(f->map, f->ev_planes_read);
     (void)hipEventDestroy(f->ev_planes_read);
   }
   Plane* pl[] = {&f->flag, &f->flag2, &f->qb, &f->sb};
@@ -3253,8 +3253,15 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   // fusion queued behind this point may start as soon as it is done (direct launches only -- inside a captured graph
   // the event is recorded behind the whole chain by the caller)
   if (!capturing) {
-    HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
-    map_add_plane_reader(f->map, f->ev_planes_read);
+    if (f->mark_planes_read) {
+      HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
+      map_add_plane_reader(f->map, f->ev_planes_read);
+    } else {
+      // nobody has rewritten the planes beside a running search of this finder yet (a plan cycle on a given map does
+      // not; a streaming pipeline does from its first frame on): no barrier packet between the chain's kernels -- a
+      // mutator that does arrive records the event behind what is queued and switches the marking on (map_wait_plane_readers)
+      map_add_late_reader(f->map, f->stream, f->ev_planes_read, &f->mark_planes_read);
+    }
     if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
   }
   g_ht.lap(5);
@@ -3376,7 +3383,11 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
     fuelmi_frontier* f;
     bool done = false;
     ~PlanesRead() {
-      if (!done && f->map && hipEventRecord(f->ev_planes_read, f->stream) == hipSuccess) map_add_plane_reader(f->map, f->ev_planes_read);
+      if (done || !f->map) return;
+      if (!f->mark_planes_read)
+        map_add_late_reader(f->map, f->stream, f->ev_planes_read, &f->mark_planes_read);
+      else if (hipEventRecord(f->ev_planes_read, f->stream) == hipSuccess)
+        map_add_plane_reader(f->map, f->ev_planes_read);
     }
   } planes_read{f};
   int rc = remove_changed_begin(f, umin, umax);
@@ -3589,6 +3600,14 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
   } scope_end{f};
   fuelmi_map* m = f->map;
   HIPCHK(hipSetDevice(m->device));
+  // (a plane mutator issued from here on comes behind this call's wait for the chain's result: the plane-reading
+  // kernels are done by then -- nothing left for it to wait for)
+  struct DropLate {
+    fuelmi_frontier* f;
+    ~DropLate() {
+      if (f->map) map_drop_late_reader(f->map, f->ev_planes_read);
+    }
+  } drop_late{f};
   if (f->search_empty) {
     if (!f->pend_rm.empty()) {
       HIPCHK(hipStreamSynchronize(f->stream));

@@ -200,6 +200,17 @@ struct fuelmi_map {
   // depth frame of a streaming pipeline -- waits for it on the device instead of being forbidden
   // (one entry per finder with a search in flight: two finders on one map must not overwrite each other's event)
   std::vector<hipEvent_t> planes_read_evs;
+  // ... and finders whose running search has NOT marked that point (round 5: the event between the chain's first two
+  // kernels is a barrier packet on the search's critical path and three API calls' worth of host time -- a finder records
+  // it only once it has seen a plane mutator arrive while one of its searches was in flight).  A mutator that finds such
+  // an entry records the event NOW -- behind the whole chain queued so far: correct, just later -- and tells the finder
+  // (`*sticky = true`) to mark the point itself from its next search on.
+  struct LateReader {
+    hipStream_t st;
+    hipEvent_t ev;
+    bool* sticky;
+  };
+  std::vector<LateReader> late_readers;
   unsigned long long fusion_count = 0;  // fusions / uploads queued so far (a search notices one queued behind its back)
   unsigned profile_mask = 0;
   ProfileSlot prof[FUELMI_K_COUNT];
@@ -271,7 +282,29 @@ static inline hipError_t map_wait_plane_readers(fuelmi_map* m) {
     if (e1 != hipSuccess) e = e1;
   }
   m->planes_read_evs.clear();
+  for (const fuelmi_map::LateReader& r : m->late_readers) {
+    hipError_t e1 = hipEventRecord(r.ev, r.st);
+    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(m->stream, r.ev, 0);
+    if (e1 != hipSuccess) e = e1;
+    *r.sticky = true;
+  }
+  m->late_readers.clear();
   return e;
+}
+static inline void map_add_late_reader(fuelmi_map* m, hipStream_t st, hipEvent_t ev, bool* sticky) {
+  for (fuelmi_map::LateReader& r : m->late_readers)
+    if (r.ev == ev) {
+      r.st = st;
+      return;
+    }
+  m->late_readers.push_back({st, ev, sticky});
+}
+static inline void map_drop_late_reader(fuelmi_map* m, hipEvent_t ev) {
+  for (size_t i = 0; i < m->late_readers.size(); ++i)
+    if (m->late_readers[i].ev == ev) {
+      m->late_readers.erase(m->late_readers.begin() + (long)i);
+      return;
+    }
 }
 // Writers of the distance field on the map's stream wait for the query kernels already LAUNCHED on busy query slots
 // (write-after-read), under m->rw_mu so that no query is between its look at the stream and its launch.
