@@ -153,3 +153,43 @@ def test_packed_esdf_far_from_every_source_uses_the_wide_plane(fa, map_size, src
     assert np.nanmax(np.where(om.dist < BIG, om.dist, 0.0)) > 25.6  # (there ARE distances beyond 255 voxels)
     _esdf_equal(om, gm, lo, hi)
     gm.close()
+
+
+def test_fusion_beside_a_running_search_waits_for_its_plane_reads(fa):
+    """A finder marks the point behind which the occupancy planes may be rewritten (an event between the chain's first two
+    kernels) only once it has seen a mutator arrive beside one of its searches; the FIRST such mutator finds no mark and
+    waits for what is queued (fuelmi_map::late_readers), the later ones for the mark.  Either way the running search must
+    see the planes of ITS frame: every search below equals the oracle's on the state before the frame fused beside it."""
+    map_size = (12.0, 10.0, 4.0)
+    box = ((-5.0, -4.0, 0.0), (5.0, 4.0, 2.4))
+    om = fo.OracleMap(map_size, *box)
+    gm = fa.SDFMap(map_size, *box)
+    truth = om.fixture_world(11, 20)
+    of = fo.OracleFrontier(om, 20)
+    gf = fa.FrontierFinder(gm, cluster_min=20)
+    n = 7
+    frames = []
+    for k in range(n):
+        pose = om.fixture_camera(truth, 3, k, n, 0.7)
+        frames.append((om.fixture_render(truth, pose, 160, 120, 2, 2), pose[:3].copy()))
+    om.input_points(*frames[0])
+    gm.inputPointCloud(*frames[0])
+    for k in range(n):
+        gf.searchFrontiersBegin()            # search of frame k ...
+        if k + 1 < n:
+            gm.inputPointCloud(*frames[k + 1])  # ... and frame k + 1 fused beside it (k = 0: the finder has no mark yet)
+        n_o = of.search()                       # the oracle: frame k's state only
+        n_g = gf.searchFrontiersEnd()
+        assert n_o == n_g, "frame %d: %d vs %d new clusters" % (k, n_g, n_o)
+        for a, b in zip(sorted_clusters(of.clusters(0)), gf.clusters(0)):
+            assert np.array_equal(a, b), "frame %d" % k
+        assert np.array_equal(of.removed_ids(), gf.removedIds())
+        of.commit()
+        gf.commit()
+        if k + 1 < n:
+            om.input_points(*frames[k + 1])
+    assert np.array_equal(of.flags, gf.flags())
+    h = gm.syncHost(occupancy=True)
+    assert np.array_equal(h["occupancy"], om.occ)
+    gf.close()
+    gm.close()
