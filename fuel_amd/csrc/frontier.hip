@@ -3372,7 +3372,11 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   // the scan reads only the occupancy state planes: it runs on its own stream, ordered after the
   // last kernel that rewrote them (fusion / upload), and overlaps the inflation / ESDF / B-spline
   // kernels the caller has queued on the map's stream for the same cycle
-  HIPCHK(hipStreamWaitEvent(f->stream, m->ev_planes, 0));
+  // (once per record and search stream: a plan cycle on an unchanged map queues no wait packet in front of its chain)
+  if (f->planes_waited[f->flag_cur] != m->planes_ver + 1) {
+    HIPCHK(hipStreamWaitEvent(f->stream, m->ev_planes, 0));
+    f->planes_waited[f->flag_cur] = m->planes_ver + 1;
+  }
   f->scope.reset(new StageScope(m, FUELMI_K_FRONTIER, f->stream));
   f->removed_ids.clear();
   for (int q = 0; q < 3; ++q) f->rm_lo[q] = 1, f->rm_hi[q] = 0;

@@ -301,6 +301,7 @@ struct fuelmi_frontier {
   std::vector<int> removed_ids;
   hipStream_t stream = nullptr;  // frontier work runs beside the map's own stream
   hipEvent_t ev_dep = nullptr;
+  unsigned long long planes_waited[2] = {0, 0};  // fuelmi_map::planes_ver + 1 each search stream (by flag plane) has waited for
   bool mark_planes_read = false;  // record ev_planes_read between the chain's first two kernels (see fuelmi_map::late_readers)
   void* d_stage = nullptr;
   size_t d_stage_bytes = 0;

@@ -195,6 +195,7 @@ struct fuelmi_map {
   double bench_host_us[7] = {0, 0, 0, 0, 0, 0, 0};  // fuelmi_bench_cycles: mean host microseconds per C-ABI call
   hipEvent_t t0 = nullptr, t1 = nullptr;
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
+  unsigned long long planes_ver = 0;  // ... and counted: a search stream that has already waited for this record does not queue the wait again
   // ... and the other direction: the last kernel of a running frontier search that READS those planes (set by
   // fuelmi_frontier_search_begin, owned by the finder).  A fusion queued while the search is in flight -- the next
   // depth frame of a streaming pipeline -- waits for it on the device instead of being forbidden

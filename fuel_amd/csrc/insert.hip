@@ -594,6 +594,7 @@ static int insert_points_dev(fuelmi_map* m, const unsigned char* d_pts, int stri
       I.prob_miss_log, I.clamp_min_log, I.clamp_max_log, I.min_occupancy_log);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ev_planes, m->stream));
+  ++m->planes_ver;
   return FUELMI_OK;
 }
 

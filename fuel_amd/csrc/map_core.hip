@@ -690,6 +690,7 @@ extern "C" int fuelmi_map_upload_occupancy(fuelmi_map* m, const double* occ) {
       g.W - 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ev_planes, m->stream));
+  ++m->planes_ver;
   HIPCHK(hipStreamSynchronize(m->stream));
   return FUELMI_OK;
 }
@@ -750,6 +751,7 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
           g, b, ceil_id, m->info.clamp_max_log, m->occ, m->occ_bits.p, m->unk_bits.p,
           m->info.min_occupancy_log, m->info.clamp_min_log - 1e-3);
       HIPCHK(hipEventRecord(m->ev_planes, m->stream));
+      ++m->planes_ver;
     }
   }
   HIPCHK(hipGetLastError());
