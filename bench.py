@@ -643,6 +643,26 @@ def main():
     for name, sid in stages.items():
         n, tot = cyc.map.profileGet(sid)
         stage_ms[name] = tot / max(n, 1)
+    # the device's own timeline of the LAST of those cycles (events, no tracer on the host): begin / end of every stage
+    # bracket in microseconds after the first one of that cycle, and the map queue's idle time between its kernels
+    timeline = None
+    try:
+        tl = []
+        for name, sid in stages.items():
+            a, b = cyc.map.profileTimeline(sid)
+            if len(a):
+                tl.append((name, 1e3 * float(a[-1]), 1e3 * float(b[-1])))
+        if tl:
+            t_first = min(t[1] for t in tl)
+            tl = sorted((n_, round(a_ - t_first, 1), round(b_ - t_first, 1)) for n_, a_, b_ in tl)
+            tl.sort(key=lambda t: t[1])
+            mapq = [t for t in tl if t[0] in ("inflate", "esdf_zy", "esdf_x", "bspline", "insert")]
+            gaps = {"%s->%s" % (mapq[i][0], mapq[i + 1][0]): round(mapq[i + 1][1] - mapq[i][2], 1) for i in range(len(mapq) - 1)}
+            timeline = {"stage_begin_end_us": [list(t) for t in tl], "map_queue_idle_us": gaps,
+                        "note": "HIP events of one cycle of the untimed profiling pass (every stage bracketed: the brackets "
+                                "themselves add event packets); frontier = the whole chain incl. its tail, on its own stream"}
+    except Exception:
+        timeline = None
     # dominant kernel = longest single-kernel stage when the two chains do NOT overlap (stable from run
     # to run; inside the overlapped cycle the durations depend on what the other stream happens to run)
     cyc.map.profileEnable(sum(1 << v for v in stages.values()))  # (re-arming clears the event log)
@@ -852,6 +872,8 @@ def main():
         crit["frac"] = crit["achieved"] / HBM_PEAK_GBS
         crit["other_chain_ms"] = min(stage_ms["frontier"], map_chain_ms)
         out["roofline"]["critical"] = crit
+        if timeline is not None:
+            out["cycle_timeline"] = timeline
         if host_loop is not None:
             out["host_loop"] = host_loop
         if host_issue is not None:

@@ -197,6 +197,7 @@ SYMBOLS = {
     "fuelmi_profile_enable": (C.c_int, [_P, C.c_uint]),
     "fuelmi_profile_get": (C.c_int, [_P, C.c_int, _ip, _dp]),
     "fuelmi_profile_get_samples": (C.c_int, [_P, C.c_int, _dp, C.c_int, _ip]),
+    "fuelmi_profile_get_timeline": (C.c_int, [_P, C.c_int, _dp, _dp, C.c_int, _ip]),
 }
 
 

@@ -1049,6 +1049,28 @@ extern "C" int fuelmi_profile_enable(fuelmi_map* m, unsigned mask) {
   HIPCHK(hipStreamSynchronize(m->stream));
   m->profile_mask = mask;
   for (auto& s : m->prof) s.used = 0;
+  if (mask) HIPCHK(hipEventRecord(m->t0, m->stream));  // the origin of fuelmi_profile_get_timeline
+  return FUELMI_OK;
+}
+// Begin and end of every bracket of a stage in milliseconds after the fuelmi_profile_enable call that armed it: the
+// device's own timeline of a few cycles without a tracer attached to the host (a kernel trace slows the issuing thread
+// and stretches exactly the gaps one wants to see).  All events share the device's clock, whatever stream they were
+// recorded on.
+extern "C" int fuelmi_profile_get_timeline(fuelmi_map* m, int stage, double* begin_ms, double* end_ms, int cap, int* n) {
+  ARGCHK(m && stage >= 0 && stage < FUELMI_K_COUNT && begin_ms && end_ms && cap >= 0 && n);
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipEventSynchronize(m->t0));
+  ProfileSlot& s = m->prof[stage];
+  int k = 0;
+  for (size_t i = 0; i + 1 < s.used && k < cap; i += 2, ++k) {
+    float a = 0.f, b = 0.f;
+    HIPCHK(hipEventSynchronize(s.ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&a, m->t0, s.ev[i]));
+    HIPCHK(hipEventElapsedTime(&b, m->t0, s.ev[i + 1]));
+    begin_ms[k] = a, end_ms[k] = b;
+  }
+  *n = k;
   return FUELMI_OK;
 }
 extern "C" int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, double* total_ms) {

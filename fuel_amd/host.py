@@ -246,6 +246,14 @@ class SDFMap:
         check(self.L.fuelmi_profile_get(self.h, stage, C.byref(n), C.byref(t)))
         return n.value, t.value
 
+    def profileTimeline(self, stage, cap=4096):
+        """(begin, end) of every bracket of a stage in ms after the profileEnable call that armed it"""
+        a = np.empty(cap, dtype=np.float64)
+        b = np.empty(cap, dtype=np.float64)
+        n = C.c_int()
+        check(self.L.fuelmi_profile_get_timeline(self.h, stage, _dp(a), _dp(b), cap, C.byref(n)))
+        return a[:n.value].copy(), b[:n.value].copy()
+
     def profileSamples(self, stage, cap=4096):
         """Per-launch milliseconds of a stage since profileEnable."""
         ms = np.empty(cap)

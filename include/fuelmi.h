@@ -464,6 +464,9 @@ int fuelmi_profile_get(fuelmi_map* m, int stage, int* launches, double* total_ms
 /* the same brackets one by one (up to cap values, milliseconds; *n = how many were written): lets the
  * caller take a median, a single disturbed launch otherwise dominates a short sample */
 int fuelmi_profile_get_samples(fuelmi_map* m, int stage, double* ms, int cap, int* n);
+/* begin / end of every bracket of a stage, milliseconds after the fuelmi_profile_enable call that armed the stage: the
+ * device's timeline of a few cycles without a tracer on the host */
+int fuelmi_profile_get_timeline(fuelmi_map* m, int stage, double* begin_ms, double* end_ms, int cap, int* n);
 
 #ifdef __cplusplus
 }
