@@ -289,7 +289,10 @@ int fuelmi_frontier_cluster_size(const fuelmi_frontier* f, int which, int k);
  * the SET is identical) */
 int fuelmi_frontier_cluster_cells(const fuelmi_frontier* f, int which, int k, int* adr);
 /* the same cells as voxel CENTRES, xyz[3 * size] doubles (the storage of the reference's vector<Vector3d> cells_,
- * frontier_finder.h:27): indexToPos of every cell (sdf_map.h:137-140), same order as _cluster_cells */
+ * frontier_finder.h:27): indexToPos of every cell (sdf_map.h:137-140), same order as _cluster_cells.  Clusters of 32 768
+ * cells and more are decoded by the calling thread and three helper threads of the library (created on first use, parked
+ * on a condition variable between calls, shared by all finders of the process; FUELMI_HOST_HELPERS=0 keeps everything on
+ * the caller) */
 int fuelmi_frontier_cluster_centres(const fuelmi_frontier* f, int which, int k, double* xyz);
 /* average_[3], box_min_[3], box_max_[3] (computeFrontierInfo) */
 int fuelmi_frontier_cluster_info(const fuelmi_frontier* f, int which, int k, double out9[9]);
