@@ -983,77 +983,6 @@ k_esdf_x4(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, 
   }
 }
 
-// x pass in x blocks: a workgroup owns XR output rows of a column tile and stages them plus HALO rows on either
-// side.  An output whose scan reaches the end of what is staged -- its running minimum still exceeds the squared
-// distance to the first row it could not see -- finishes from global memory, row by row.  Exact either way: every
-// candidate f(p) + r^2 is examined unless r^2 alone already reaches the minimum.  The x blocks of one column tile
-// are dealt to the same XCD (block b -> XCD b % 8).  Used with ONE block (XR = the whole line, no halo) for
-// lines of up to 512 voxels, see launch_x4; real halo tiling (more than one x block) was meant for
-// the 800-voxel lines of the big maps (102 KB per whole-line tile, one workgroup per CU, parked on memory three
-// quarters of the time) and measured slower there: more workgroups per CU do not help a pass that waits for DRAM
-// bandwidth, and the halo adds a third to what it reads.
-#define XH_HALO 32
-template <int OUT>
-__global__ void __launch_bounds__(512)
-k_esdf_x4h(Geo g, Box3 b, const u32* __restrict__ tmp, float* __restrict__ dist, int z0a, int zlen_a, int XR, int nxb,
-           int ntiles, u32* stat, volatile u32* h_stat) {
-  constexpr int SEGS = 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* tile = reinterpret_cast<uint4*>(smem_raw);  // [rows][SEGS] of uint4
-  forward_stat(stat, h_stat);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int t = xcd + 8 * (slot / nxb), xb = slot % nxb;
-  if (t >= ntiles) return;  // (the grid is padded to a multiple of 8 tiles)
-  const int xlen = b.hi[0] - b.lo[0] + 1;
-  const int ylen = b.hi[1] - b.lo[1] + 1;
-  const int ncol = ylen * zlen_a;
-  const int x0 = xb * XR, x1 = min(x0 + XR, xlen);          // output rows (relative to b.lo[0])
-  const int r0 = max(x0 - XH_HALO, 0), r1 = min(x1 + XH_HALO, xlen);  // staged rows
-  const int rows = r1 - r0;
-  const int seg = threadIdx.x & (SEGS - 1);
-  const int row0 = threadIdx.x / SEGS;  // 0..63
-  constexpr int RL = 512 / SEGS;
-  const int col = t * (4 * SEGS) + seg * 4;
-  const bool valid = col < ncol;
-  const int yy = valid ? col / zlen_a : 0;
-  const int z = z0a + (valid ? col - yy * zlen_a : 0);
-  const long coloff = (long)(b.lo[1] + yy) * g.nz + z;
-  const u32* src = tmp + (long)b.lo[0] * g.nyz + coloff;
-  const uint4 inf4 = make_uint4(INF32, INF32, INF32, INF32);
-  const float resf = (float)g.res;
-#pragma unroll 4
-  for (int lr = row0; lr < rows; lr += RL)
-    tile[lr * SEGS + seg] = valid ? *reinterpret_cast<const uint4*>(src + (long)(r0 + lr) * g.nyz) : inf4;
-  __syncthreads();
-  if (!valid) return;
-  for (int xi = x0 + row0; xi < x1; xi += RL) {
-    const int li = xi - r0;
-    bool open;
-    uint4 bb = scan_near4(smem_raw, SEGS * 16, rows, li, 16 * seg, 0, open);
-    // rows the tile does not hold: below r0 (first at distance li + 1), above r1 - 1 (first at rows - li)
-    u32 mx = max4(bb.x, bb.y, bb.z, bb.w);
-    if (r0 > 0) {
-      int r = li + 1;
-      for (int row = r0 - 1; row >= 0 && (u32)__mul24(r, r) < mx; --row, ++r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(src + (long)row * g.nyz);
-        const u32 rr = (u32)__mul24(r, r);
-        bb.x = min(bb.x, q.x + rr), bb.y = min(bb.y, q.y + rr), bb.z = min(bb.z, q.z + rr), bb.w = min(bb.w, q.w + rr);
-        mx = max4(bb.x, bb.y, bb.z, bb.w);
-      }
-    }
-    if (r1 < xlen) {
-      int r = rows - li;
-      for (int row = r1; row < xlen && (u32)__mul24(r, r) < mx; ++row, ++r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(src + (long)row * g.nyz);
-        const u32 rr = (u32)__mul24(r, r);
-        bb.x = min(bb.x, q.x + rr), bb.y = min(bb.y, q.y + rr), bb.z = min(bb.z, q.z + rr), bb.w = min(bb.w, q.w + rr);
-        mx = max4(bb.x, bb.y, bb.z, bb.w);
-      }
-    }
-    x_store4<OUT>(dist + (long)(b.lo[0] + xi) * g.nyz + coloff, z, b.lo[2], b.hi[2], bb, resf);
-  }
-}
-
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device, not once per launch
 static hipError_t lds_attr_once(const void* fn, int bytes) {
   static std::mutex mu;
@@ -1660,37 +1589,9 @@ static int launch_x_pk2(fuelmi_map* m, const Box3& b) {
   return FUELMI_OK;
 }
 
-template <int OUT>
-static int launch_x4h(fuelmi_map* m, const Box3& b) {
-  const Geo& g = m->g;
-  const int xlen = b.hi[0] - b.lo[0] + 1, ylen = b.hi[1] - b.lo[1] + 1;
-  const int z0a = b.lo[2] & ~3, z1a = b.hi[2] | 3;
-  const int zlen_a = z1a - z0a + 1;
-  const int xr_target = xlen <= 512 ? xlen : 200;  // output rows per workgroup
-  const int nxb = (xlen + xr_target - 1) / xr_target;
-  const int XR = (xlen + nxb - 1) / nxb;
-  const size_t lds = (size_t)(XR + 2 * XH_HALO) * 8 * 4 * sizeof(u32);
-  const int ncol = ylen * zlen_a;
-  const int ntiles = (ncol + 31) / 32;
-  STAGE_LAUNCH(m, (k_esdf_x4h<OUT>), ((ntiles + 7) / 8) * 8 * nxb, 512, lds, g, b, (const u32*)m->esdf_tmp, m->dist, z0a,
-               zlen_a, XR, nxb, ntiles, esdf_stat_dev<OUT>(m), esdf_stat_host(m));
-  HIPCHK(hipGetLastError());
-  return FUELMI_OK;
-}
-
 template <int OUT, bool FAR>
 static int launch_x4(fuelmi_map* m, const Box3& b) {
   const int xlen = b.hi[0] - b.lo[0] + 1;
-  {
-    // Plain regime, lines of up to 512 voxels: k_esdf_x4h with ONE x block (no halo): 512-thread workgroups, three
-    // per CU, a column tile's work on one XCD.  Same speed as k_esdf_x4 on its own (31 us on 400^2 x 100) but the
-    // plan cycle gains 2-5 % (8 500 vs 8 350 / 7 730 cycles/s on one box): the frontier chain's kernels find wave
-    // slots sooner beside 512-thread workgroups.  Longer lines: its halo tiling is SLOWER than whole lines
-    // (800-voxel lines: 271 vs 243 us -- the x pass there is bound by DRAM, and the halo rows are read twice), so
-    // they keep k_esdf_x4.
-    const bool halo = xlen <= 512;
-    if (halo && !FAR && xlen > 2 * XH_HALO + 64) return launch_x4h<OUT>(m, b);
-  }
   // the 32-column tile is faster whenever it fits (measured on 800-voxel lines: 0.32 vs 0.37 ms), the
   // 16-column one extends the vector path to x lines of up to 2400 voxels
   const bool narrow = (size_t)xlen * 128 > 150 * 1024;
