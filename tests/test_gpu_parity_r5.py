@@ -193,3 +193,51 @@ def test_fusion_beside_a_running_search_waits_for_its_plane_reads(fa):
     assert np.array_equal(h["occupancy"], om.occ)
     gf.close()
     gm.close()
+
+
+def test_full_size_g800_esdf_properties(fa):
+    """BASELINE's largest map (800 x 800 x 200, bench.py --workload G800: the HBM-resident roofline run), full box, packed
+    kernels with the 16-bit hand-over: too large for the oracle in a test, so size-independent properties of an exact
+    Euclidean distance transform instead -- (a) bit-identical to the 32-bit kernel family (both claim exact integer squared
+    distances: any disagreement is a bug in one of them), (b) zero exactly on the sources, positive elsewhere, (c) squared
+    voxel distances are integers, (d) 1-Lipschitz along all three axes (|d(p) - d(q)| <= res for face neighbours),
+    (e) idempotent: a second update rewrites the same bits."""
+    import bench
+    map_size, box, occ, _, _ = bench.build_inputs("G800", seed=42, n_traj=1)
+    gm = fa.SDFMap(map_size, box[0], box[1])
+    gm.uploadOccupancy(occ)
+    nv = gm.nvox
+    assert nv == (800, 800, 200)
+    lo, hi = helpers.full_box(nv)
+    gm.setLocalBound(lo, hi)
+    gm.clearAndInflateLocalMap()
+    gm.setEsdfFamily(0)
+    gm.updateESDF3d()
+    assert gm.lastEsdfFamily() == 0
+    h = gm.syncHost(inflate=True, distance=True)
+    d0 = h["distance"].reshape(nv).astype(np.float32)
+    infl = h["inflate"].reshape(nv)
+    gm.updateESDF3d()                                   # (e)
+    assert np.array_equal(gm.syncHost(distance=True)["distance"].reshape(nv).astype(np.float32), d0)
+    gm.setEsdfFamily(2)                                 # (a)
+    gm.updateESDF3d()
+    assert gm.lastEsdfFamily() == 2
+    d2 = gm.syncHost(distance=True)["distance"].reshape(nv).astype(np.float32)
+    assert np.array_equal(d2, d0), "packed and 32-bit families disagree on %d voxels" % int((d2 != d0).sum())
+    del d2
+    o3 = np.asarray(occ).reshape(nv)
+    info = gm.info
+    unknown = o3 < info.clamp_min_log - 1e-3
+    src = (infl == 1) | unknown                          # (b) sources of a non-optimistic map: inflated or unknown
+    assert np.all(d0[src] == 0.0) and np.all(d0[~src] > 0.0)
+    res = np.float32(0.1)
+    for sl in (np.s_[::97, :, :], np.s_[:, ::89, :], np.s_[:, :, ::23]):   # (c) on a sample of slabs
+        sq = (d0[sl].astype(np.float64) / 0.1) ** 2
+        fin = np.isfinite(sq) & (sq < 1e9)
+        assert np.abs(sq[fin] - np.rint(sq[fin])).max() < 5e-2
+    for ax in range(3):                                  # (d)
+        a = np.take(d0, range(0, nv[ax] - 1), axis=ax)
+        b = np.take(d0, range(1, nv[ax]), axis=ax)
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.abs(a[fin] - b[fin]).max() <= res * (1 + 1e-5)
+    gm.close()
