@@ -110,7 +110,9 @@ _PP = C.POINTER(C.c_void_p)
 SYMBOLS = {
     "fuelmi_last_error": (C.c_char_p, []),
     "fuelmi_version": (C.c_char_p, []),
+    "fuelmi_init": (C.c_int, [C.c_int]),
     "fuelmi_hw_queues": (C.c_int, []),
+    "fuelmi_hw_queues_state": (C.c_int, []),
     "fuelmi_device_count": (C.c_int, []),
     "fuelmi_map_create": (C.c_int, [C.POINTER(MapCfg), _PP]),
     "fuelmi_map_destroy": (None, [_P]),
@@ -214,6 +216,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        # explicit process set-up (include/fuelmi.h fuelmi_init): GPU_MAX_HW_QUEUES=16 unless the environment decides --
+        # effective only if nothing in this process has initialised HIP yet (import fuel_amd before torch.cuda is used)
+        L.fuelmi_init(0)
         _LIB = L
     return _LIB
 

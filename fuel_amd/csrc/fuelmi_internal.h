@@ -193,7 +193,8 @@ struct fuelmi_map {
 
   // measurement
   double bench_host_us[7] = {0, 0, 0, 0, 0, 0, 0};  // fuelmi_bench_cycles: mean host microseconds per C-ABI call
-  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;  // fuelmi_timer_begin / _end
+  hipEvent_t t_prof0 = nullptr;           // origin of fuelmi_profile_get_timeline (recorded by fuelmi_profile_enable)
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
   unsigned long long planes_ver = 0;  // ... and counted: a search stream that has already waited for this record does not queue the wait again
   // ... and the other direction: the last kernel of a running frontier search that READS those planes (set by

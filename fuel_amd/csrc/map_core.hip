@@ -12,6 +12,9 @@
 #include <cstring>
 #include <mutex>
 
+#include <dirent.h>
+#include <unistd.h>
+
 #include <chrono>
 
 #include "fuelmi_internal.h"
@@ -27,19 +30,75 @@ void fuelmi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 // Hardware queues.  A map owns one stream, a finder two, every busy query slot one; the HIP runtime multiplexes a process's
-// streams onto GPU_MAX_HW_QUEUES hardware queues -- FOUR by default -- and two streams that land on one queue time-slice:
-// the library's own fifth stream took the plan cycle from 10 800 to 4 400 cycles/s (round 4), four idle maps in the
-// process a streaming frame from 0.11 to 0.37 ms, ten optimiser threads ten solves from 1.8 to 4.5 ms.  The runtime reads
-// the variable when it initialises (the first HIP call of the process), so the library sets it when it is LOADED --
-// unless the environment already has a value, or FUELMI_KEEP_HW_QUEUES is set.  A process that has initialised HIP before
-// loading this library (fuelmi_hw_queues() then still reports what the environment says) sets it itself.
+// streams onto GPU_MAX_HW_QUEUES hardware queues -- FOUR by default -- and two streams that land on one queue time-slice
+// (four idle maps in the process took a streaming frame from 0.11 to 0.37 ms; ten optimiser threads: ten solves 2.47 ms
+// with 16 queues, 2.65 ms with 4 -- profiles/r05_host_timing.txt).  The runtime latches the variable when it
+// initialises (the first HIP call of the process).  Rounds 4-5 set it from a load-time constructor; a dlopen constructor
+// that mutates the environment of a possibly multi-threaded host (glibc may move `environ` under a concurrent getenv)
+// and silently does nothing when HIP is already up was the wrong place.  Now it is EXPLICIT: fuelmi_init(), called by the
+// integrator (the facade's SDFMap::initMap, fuel_amd._lib.lib()) at a point of its choosing, reports whether it could
+// still take effect; the constructor only runs when the environment opts in (FUELMI_SET_HW_QUEUES=1).
+static int g_hwq_state = FUELMI_HWQ_UNINIT;
+static std::mutex g_init_mu;
+static bool hsa_runtime_is_up() {  // the ROCr runtime keeps /dev/kfd open from hsa_init() on: HIP initialised <=> it is there
+  DIR* d = opendir("/proc/self/fd");
+  if (!d) return false;
+  bool up = false;
+  char path[64], tgt[64];
+  while (struct dirent* e = readdir(d)) {
+    if (e->d_name[0] == '.') continue;
+    snprintf(path, sizeof(path), "/proc/self/fd/%s", e->d_name);
+    const ssize_t n = readlink(path, tgt, sizeof(tgt) - 1);
+    if (n <= 0) continue;
+    tgt[n] = 0;
+    if (!strcmp(tgt, "/dev/kfd")) {
+      up = true;
+      break;
+    }
+  }
+  closedir(d);
+  return up;
+}
+extern "C" int fuelmi_init(int hw_queues) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_hwq_state == FUELMI_HWQ_SET || g_hwq_state == FUELMI_HWQ_ENV) return FUELMI_OK;  // (decided earlier; idempotent)
+  if (getenv("GPU_MAX_HW_QUEUES")) {  // the environment decides (the robust way: export it in the launch file)
+    g_hwq_state = FUELMI_HWQ_ENV;
+    return FUELMI_OK;
+  }
+  if (hsa_runtime_is_up()) {  // too late: the runtime has latched its default of 4
+    if (g_hwq_state != FUELMI_HWQ_LATE && !getenv("FUELMI_QUIET"))
+      std::fprintf(stderr, "[fuelmi] fuelmi_init: the HIP runtime was initialised before this call and GPU_MAX_HW_QUEUES "
+                           "was not in the environment: its streams share the runtime's default of 4 hardware queues "
+                           "(export GPU_MAX_HW_QUEUES=16, or call fuelmi_init() before the first HIP call)\n");
+    g_hwq_state = FUELMI_HWQ_LATE;
+    return FUELMI_OK;
+  }
+  char buf[16];
+  snprintf(buf, sizeof(buf), "%d", hw_queues > 0 ? hw_queues : 16);
+  setenv("GPU_MAX_HW_QUEUES", buf, 0 /* keep an existing value */);
+  g_hwq_state = FUELMI_HWQ_SET;
+  return FUELMI_OK;
+}
 __attribute__((constructor)) static void fuelmi_default_hw_queues() {
-  if (getenv("FUELMI_KEEP_HW_QUEUES")) return;
-  setenv("GPU_MAX_HW_QUEUES", "16", 0 /* keep an existing value */);
+  const char* e = getenv("FUELMI_SET_HW_QUEUES");  // opt-in: hosts that cannot call fuelmi_init() early enough themselves
+  if (e && atoi(e) != 0) (void)fuelmi_init(atoi(e) > 1 ? atoi(e) : 16);
 }
 extern "C" int fuelmi_hw_queues(void) {
   const char* e = getenv("GPU_MAX_HW_QUEUES");
-  return e ? atoi(e) : 4;
+  const int env = e ? atoi(e) : 4;
+  return g_hwq_state == FUELMI_HWQ_LATE ? 4 : env;  // (LATE: no value was in the environment when the runtime came up)
+}
+extern "C" int fuelmi_hw_queues_state(void) { return g_hwq_state; }
+// fuelmi_map_create: say it once if the process ended up on the runtime's four queues without anybody having decided so
+static void warn_hw_queues_once() {
+  static bool said = false;
+  if (said || getenv("FUELMI_QUIET")) return;
+  if (g_hwq_state == FUELMI_HWQ_UNINIT && !getenv("GPU_MAX_HW_QUEUES")) {
+    said = true;
+    std::fprintf(stderr, "[fuelmi] GPU_MAX_HW_QUEUES is not set and fuelmi_init() was not called: a map's, its finder's and "
+                         "its query threads' streams share the HIP runtime's default of 4 hardware queues\n");
+  }
 }
 
 extern "C" const char* fuelmi_last_error(void) { return g_err; }
@@ -104,7 +163,9 @@ int QuerySlotGuard::acquire(fuelmi_map* m_, size_t bytes) {
   if (!s->st) {
     HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    // (blocking-sync: finish() polls it with hipEventQuery and, after 3 ms, really BLOCKS in hipEventSynchronize -- without
+    // the flag that call spins on ROCm and a long solve kept burning the core)
+    HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventCreateWithFlags(&s->ev_rd, hipEventDisableTiming));
   }
   if (bytes > s->pin_cap) {
@@ -515,6 +576,7 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
   }
   ARGCHK(c->device >= 0 && c->device < ndev);
   HIPCHK(hipSetDevice(c->device));
+  warn_hw_queues_once();
   fuelmi_map* m = new fuelmi_map;
   m->cfg = *c;
   m->device = c->device;
@@ -595,9 +657,12 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
   if ((g.nz % 4) == 0) {  // the packed ESDF family's 16-bit hand-over (esdf.hip): column tiles of 32 x x-pairs x 128 B
     const size_t ntiles = ((size_t)g.ny * (size_t)((g.nz + 7) / 4 + 1) + 7) / 8 + PK2_MAXCH + 1;  // (8 segments per tile, ragged chunks)
     m->esdf_tmp16_bytes = ntiles * (size_t)(((g.nx + 1) / 2 + 63) / 64) * 64 * 128;  // (tile rows of 128 B per x-pair)
+    // (+ ~2.3 B/voxel beside the 4 B/voxel of esdf_tmp: 300 MB on the 800^2 x 200 map.  Not fatal when it does not fit: the
+    // packed family then reports ESDF_NO_FIT and the 32-bit family runs -- ADVICE r5)
     if (hipMalloc(reinterpret_cast<void**>(&m->esdf_tmp16), m->esdf_tmp16_bytes) != hipSuccess) {
-      fuelmi_set_error("hipMalloc of the %zu-byte ESDF hand-over buffer failed", m->esdf_tmp16_bytes);
-      return fail(FUELMI_ENOMEM);
+      (void)hipGetLastError();
+      m->esdf_tmp16 = nullptr;
+      m->esdf_tmp16_bytes = 0;
     }
   }
   // initial state (sdf_map.cpp:61-72): all unknown, inflate 0, distance default, flag_rayend -1
@@ -622,7 +687,7 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
   (void)hipMemsetAsync(m->esdf_stat, 0, (2 * 256 + 4) * sizeof(u32), m->stream);
   memset(m->h_esdf_stat, 0, (2 * 256 + 4) * sizeof(u32));
   memset(m->h_ins, 0, 16 * sizeof(u64));
-  if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess ||
+  if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess || hipEventCreate(&m->t_prof0) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_planes, hipEventDisableTiming) != hipSuccess ||
       hipStreamSynchronize(m->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
     fuelmi_set_error("device initialisation failed (is this a gfx950 device?)");
@@ -665,6 +730,7 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   for (auto& s : m->prof)
     for (auto e : s.ev) (void)hipEventDestroy(e);
   if (m->t0) (void)hipEventDestroy(m->t0);
+  if (m->t_prof0) (void)hipEventDestroy(m->t_prof0);
   if (m->t1) (void)hipEventDestroy(m->t1);
   if (m->ev_planes) (void)hipEventDestroy(m->ev_planes);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -771,6 +837,15 @@ extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
   }
   return esdf_update(m);
 }
+// Every entry point that rewrites the distance field (or the inflated plane the slot kernels' callers pair it with) is a
+// WRITER in the sense of the contract in fuelmi.h: alone on rw_mu from the look at the query slots to its last launch,
+// behind the query kernels already launched (the resets below wrote dist without either).
+#define MAP_WRITER_PROLOGUE(m)                                  \
+  std::unique_lock<std::shared_timed_mutex> wr__((m)->rw_mu);   \
+  {                                                             \
+    const int rcq__ = map_wait_query_readers(m);                \
+    if (rcq__) return rcq__;                                    \
+  }
 
 extern "C" int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]) {
   if (m) ++m->occ_epoch;
@@ -785,6 +860,7 @@ extern "C" int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], c
   for (int i = 0; i < 3; ++i)
     if (b.lo[i] > b.hi[i]) return FUELMI_OK;
   int w_lo = (int)(adr_of(g, b.lo) >> 6), w_hi = (int)(adr_of(g, b.hi) >> 6);
+  MAP_WRITER_PROLOGUE(m);
   k_reset_bits<<<blocks_for(w_hi - w_lo + 1, 256), 256, 0, m->stream>>>(g, b, m->infl_bits.p, w_lo, w_hi);
   long n = (long)(b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1);
   k_reset_dist<<<blocks_for(n, 256, 65536), 256, 0, m->stream>>>(g, b, m->dist, (float)m->cfg.default_dist);
@@ -1049,7 +1125,8 @@ extern "C" int fuelmi_profile_enable(fuelmi_map* m, unsigned mask) {
   HIPCHK(hipStreamSynchronize(m->stream));
   m->profile_mask = mask;
   for (auto& s : m->prof) s.used = 0;
-  if (mask) HIPCHK(hipEventRecord(m->t0, m->stream));  // the origin of fuelmi_profile_get_timeline
+  if (mask) HIPCHK(hipEventRecord(m->t_prof0, m->stream));  // the origin of fuelmi_profile_get_timeline (its own event: the
+                                                          // timer's t0 moves with every fuelmi_timer_begin -- ADVICE r5)
   return FUELMI_OK;
 }
 // Begin and end of every bracket of a stage in milliseconds after the fuelmi_profile_enable call that armed it: the
@@ -1060,14 +1137,14 @@ extern "C" int fuelmi_profile_get_timeline(fuelmi_map* m, int stage, double* beg
   ARGCHK(m && stage >= 0 && stage < FUELMI_K_COUNT && begin_ms && end_ms && cap >= 0 && n);
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipStreamSynchronize(m->stream));
-  HIPCHK(hipEventSynchronize(m->t0));
+  HIPCHK(hipEventSynchronize(m->t_prof0));
   ProfileSlot& s = m->prof[stage];
   int k = 0;
   for (size_t i = 0; i + 1 < s.used && k < cap; i += 2, ++k) {
     float a = 0.f, b = 0.f;
     HIPCHK(hipEventSynchronize(s.ev[i + 1]));
-    HIPCHK(hipEventElapsedTime(&a, m->t0, s.ev[i]));
-    HIPCHK(hipEventElapsedTime(&b, m->t0, s.ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&a, m->t_prof0, s.ev[i]));
+    HIPCHK(hipEventElapsedTime(&b, m->t_prof0, s.ev[i + 1]));
     begin_ms[k] = a, end_ms[k] = b;
   }
   *n = k;

@@ -70,6 +70,10 @@ void SDFMap::initMap(ros::NodeHandle& nh) {
     nh.param(std::string("sdf_map/box_min_") + axis[i], c.box_min[i], org[i]);
     nh.param(std::string("sdf_map/box_max_") + axis[i], c.box_max[i], org[i] + c.map_size[i]);
   }
+  // process set-up (include/fuelmi.h): hardware queues for the streams of the map, its finder and the optimiser threads.
+  // In time only if nothing in the node has initialised HIP yet -- fuelmi_hw_queues_state() tells; exporting
+  // GPU_MAX_HW_QUEUES=16 in the launch file is the way that does not depend on the order
+  fuelmi_init(0);
   int rc = fuelmi_map_create(&c, &ext_->dev);
   warn("fuelmi_map_create", rc);
   if (rc != FUELMI_OK) return;

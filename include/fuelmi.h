@@ -41,11 +41,26 @@ extern "C" {
 #define FUELMI_ENOMEM (-4)
 #define FUELMI_ELIMIT (-5)  /* problem exceeds a documented limit */
 
-/* GPU_MAX_HW_QUEUES as the process's HIP runtime will see it.  The library sets it to 16 when it is loaded unless the
- * environment already holds a value (or FUELMI_KEEP_HW_QUEUES is set): with the runtime's default of 4 the streams of a
- * map, its finder and a few query threads share hardware queues and time-slice (INTEGRATION.md "streams and queues").
- * The runtime reads the variable at its first call: load this library before anything initialises HIP. */
+/* Process-level set-up: hardware queues.  A map owns one HIP stream, a finder two, every busy query thread one; the HIP
+ * runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share one
+ * time-slice (INTEGRATION.md "streams and queues").  The runtime latches the variable at its first call, so the robust
+ * way is to export GPU_MAX_HW_QUEUES=16 where the process is launched.  fuelmi_init() is the explicit in-process
+ * alternative (rounds 4-5 did this from a load-time constructor; that is now opt-in, FUELMI_SET_HW_QUEUES=1): called
+ * BEFORE the process's first HIP call and before threads that touch the environment exist, it puts
+ * GPU_MAX_HW_QUEUES=<hw_queues, 16 if <= 0> into the environment unless a value is already there.  Idempotent; always
+ * returns FUELMI_OK and reports through fuelmi_hw_queues_state() what happened -- including FUELMI_HWQ_LATE when the HIP
+ * runtime was already up (it is detected through the runtime's open /dev/kfd handle; one line on stderr unless
+ * FUELMI_QUIET is set): the streams then share the runtime's default of 4 queues.  fuelmi_map_create says so once on
+ * stderr when neither the environment nor fuelmi_init() decided. */
+#define FUELMI_HWQ_UNINIT 0 /* fuelmi_init() not called: the runtime sees the environment as it is */
+#define FUELMI_HWQ_SET 1    /* set by fuelmi_init() before the HIP runtime initialised: in effect */
+#define FUELMI_HWQ_ENV 2    /* the environment already held a value: kept */
+#define FUELMI_HWQ_LATE 3   /* the HIP runtime was initialised first without the variable: its default (4) is in effect */
+int fuelmi_init(int hw_queues);
+/* the number of hardware queues the process's HIP runtime uses, as far as the library can know it: the environment's
+ * value (4 if unset), or 4 in state FUELMI_HWQ_LATE */
 int fuelmi_hw_queues(void);
+int fuelmi_hw_queues_state(void);
 const char* fuelmi_last_error(void);
 const char* fuelmi_version(void);
 /* number of visible HIP devices (0 if none / runtime unusable) */

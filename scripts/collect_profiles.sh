@@ -63,7 +63,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -o
 { for WL in G400 G800 G400K; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep -E "zy2-timing|x2-timing|slowest" | tail -4 | sed "s/^/$WL /"; done
   for WL in G400 G800 G400K G400E; do for FAM in 0 2 1; do echo -n "$WL family $FAM: "; python scripts/esdf_only.py $WL $FAM 8; done; done; } > $O/esdf_family_ab.txt 2>&1
 # this round's switches, same box, two repetitions each
-WLARGS="" bash scripts/r4_cycle_ab.sh FUELMI_FR_GRAPH=1 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 FUELMI_KEEP_HW_QUEUES=1 > $O/tuning_ab_cycle.txt 2>&1
+WLARGS="" bash scripts/r4_cycle_ab.sh FUELMI_FR_GRAPH=1 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 GPU_MAX_HW_QUEUES=4 > $O/tuning_ab_cycle.txt 2>&1
 # the round-4 build of the library on the same box (build/r4 is a worktree of 72541aa built by hand before the call)
 if [ -d build/r4/fuel_amd ]; then
   { echo "# same box, same call: round-4 final (72541aa) against this tree; bench.py --no-cpu-baseline of each (value, stage_ms isolated)"
@@ -76,8 +76,8 @@ fi
 timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_G400_driver_cmdline.json 2>/dev/null
 { echo "# FUELMI_HOST_TIMING=1 python bench.py --no-cpu-baseline (host microseconds inside fuelmi_frontier_search_begin / _end per search), commit $FUELMI_COMMIT"
   FUELMI_HOST_TIMING=1 python bench.py --no-cpu-baseline 2>&1 >/dev/null | grep host-timing | tail -2
-  echo "# hardware queues: scripts/r5_hwq.py at the library's load-time default, then with the runtime's (FUELMI_KEEP_HW_QUEUES=1)"
-  python scripts/r5_hwq.py 2>&1 | tail -5; FUELMI_KEEP_HW_QUEUES=1 python scripts/r5_hwq.py 2>&1 | tail -5; } > $O/host_timing.txt 2>&1
+  echo "# hardware queues: scripts/r5_hwq.py at the library's fuelmi_init() default, then with the runtime's (GPU_MAX_HW_QUEUES=4)"
+  python scripts/r5_hwq.py 2>&1 | tail -5; GPU_MAX_HW_QUEUES=4 python scripts/r5_hwq.py 2>&1 | tail -5; } > $O/host_timing.txt 2>&1
 timeout 300 python scripts/bench_next.py > $O/next_rows.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/next -o s -- python scripts/bench_next.py > /dev/null 2>&1
 timeout 300 python scripts/facade_bench.py --map G800S --frames 30 > $O/facade_bench_G800S.json 2> $O/facade_bench.err

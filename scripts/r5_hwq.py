@@ -1,6 +1,6 @@
 """round 5: the library against the hardware-queue default.  (a) streaming frame of map 0 alone and with 4 idle maps +
 finders alive in the process; (b) ten optimiser threads, ten solves -- each at the environment the process was started
-with (GPU_MAX_HW_QUEUES unset: the library's load-time default applies; FUELMI_KEEP_HW_QUEUES=1: the runtime's 4)."""
+with (GPU_MAX_HW_QUEUES unset: the library's fuelmi_init() default applies; GPU_MAX_HW_QUEUES=4: the runtime's 4)."""
 import os, sys, threading, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -114,12 +114,13 @@ def test_sdf_map_header_layout_is_the_references(tmp_path):
     shims = [os.path.join(root, "oracle", "ref_build", "shim_ros"), os.path.join(root, "compat")]
     golden = os.path.join(root, "tests", "golden", "sdf_map_layout.txt")
     ref_inc = "/root/reference/fuel_planner/plan_env/include"
+    assert os.path.exists(golden), "tests/golden/sdf_map_layout.txt is missing (regenerate: tests/golden/make_layout_golden.py)"
     if os.path.exists(os.path.join(ref_inc, "plan_env", "sdf_map.h")):
-        ref = _layout_probe(tmp_path, [ref_inc] + shims, "probe_ref")
-        if not os.path.exists(golden) or open(golden).read().splitlines() != ref:
-            with open(golden, "w") as f:
-                f.write("\n".join(ref) + "\n")
-    assert os.path.exists(golden), "no golden layout and no reference checkout"
+        # read-only: the reference's probe must EQUAL the committed golden; a drift of the reference checkout,
+        # the probe or the shims fails here instead of silently rewriting a tracked file
+        ref_live = _layout_probe(tmp_path, [ref_inc] + shims, "probe_ref")
+        assert open(golden).read().splitlines() == ref_live, \
+            "the reference header's layout differs from tests/golden/sdf_map_layout.txt (tests/golden/make_layout_golden.py rewrites it)"
     ref = open(golden).read().splitlines()
     ours = _layout_probe(tmp_path, [os.path.join(root, "fuel_amd", "facade"), os.path.join(root, "include")] + shims, "probe_ours")
     assert len(ref) == len(ours) and len(ref) > 50
@@ -131,21 +132,29 @@ def test_sdf_map_header_layout_is_the_references(tmp_path):
             assert a == b, (a, b)
 
 
-def test_library_sets_the_hardware_queue_default_at_load():
-    """include/fuelmi.h fuelmi_hw_queues: loading libfuelmi.so puts GPU_MAX_HW_QUEUES=16 into the environment the HIP
-    runtime will read at its first call -- unless the environment already has a value or FUELMI_KEEP_HW_QUEUES is set
-    (with the runtime's default of 4 a map, its finder and a few query threads time-slice)."""
+def test_hardware_queue_default_is_explicit():
+    """include/fuelmi.h fuelmi_init / fuelmi_hw_queues / fuelmi_hw_queues_state: loading
+    libfuelmi.so no longer touches the environment; fuelmi_init() (which fuel_amd.lib() calls right after the dlopen, before
+    anything initialises HIP) puts GPU_MAX_HW_QUEUES=16 there unless the environment already decides, and says which of
+    the two happened; the load-time constructor is opt-in (FUELMI_SET_HW_QUEUES)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import fuel_amd; print(fuel_amd.lib().fuelmi_hw_queues())"
+    raw = ("import ctypes, os; L = ctypes.CDLL(os.path.join(%r, 'fuel_amd', 'libfuelmi.so')); "
+           "print(os.environ.get('GPU_MAX_HW_QUEUES', 'unset'), L.fuelmi_hw_queues(), L.fuelmi_hw_queues_state())" % root)
+    via = ("import os, fuel_amd; L = fuel_amd.lib(); "
+           "print(os.environ.get('GPU_MAX_HW_QUEUES', 'unset'), L.fuelmi_hw_queues(), L.fuelmi_hw_queues_state())")
 
-    def run(**extra):
-        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FUELMI_KEEP_HW_QUEUES")}
+    def run(code, **extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FUELMI_SET_HW_QUEUES")}
         env.update(extra)
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
-        return int(p.stdout.strip().splitlines()[-1])
+        return p.stdout.strip().splitlines()[-1].split()
 
-    assert run() == 16
-    assert run(GPU_MAX_HW_QUEUES="8") == 8
-    assert run(FUELMI_KEEP_HW_QUEUES="1") == 4
+    UNINIT, SET, ENV = 0, 1, 2
+    # (os.environ is Python's snapshot from start-up: a setenv made by the C library does not show there -- the C side's
+    # view is what fuelmi_hw_queues() returns)
+    assert run(raw)[1:] == ["4", str(UNINIT)]            # a bare dlopen changes nothing
+    assert run(raw, FUELMI_SET_HW_QUEUES="1")[1:] == ["16", str(SET)]   # opt-in constructor
+    assert run(via)[1:] == ["16", str(SET)]              # the Python binding calls fuelmi_init() itself
+    assert run(via, GPU_MAX_HW_QUEUES="8")[1:] == ["8", str(ENV)]       # the environment decides

@@ -80,7 +80,7 @@ def test_packed_plain_pass_is_not_slower_than_the_32_bit_one_on_a_half_explored_
 
 def test_other_maps_alive_in_the_process_do_not_slow_the_streaming_frame(fa):
     """five maps + finders alive in one process, the streaming frame of map 0 within 1.3 x of its solo
-    time, at the default environment (the library's load-time GPU_MAX_HW_QUEUES; a finder owns two streams since the
+    time, at the default environment (GPU_MAX_HW_QUEUES=16 from fuelmi_init(), which fuel_amd.lib() calls; a finder owns two streams since the
     flag plane is zeroed on the retiring search stream)."""
     import bench
     map_size_s, n_obs_s, _ = bench.WORKLOADS["G800S"]
