@@ -133,6 +133,7 @@ SYMBOLS = {
     "fuelmi_map_update_esdf": (C.c_int, [_P]),
     "fuelmi_map_set_esdf_family": (C.c_int, [_P, C.c_int]),
     "fuelmi_map_last_esdf_family": (C.c_int, [_P]),
+    "fuelmi_map_last_inflate_kernel": (C.c_int, [_P]),
     "fuelmi_map_reset_buffer_all": (C.c_int, [_P]),
     "fuelmi_map_reset_buffer": (C.c_int, [_P, _dp, _dp]),
     "fuelmi_map_set_occupied": (C.c_int, [_P, _dp, C.c_int, C.c_int]),

@@ -2609,7 +2609,7 @@ static int frontier_twin_set(fuelmi_frontier* f) {
   G2.h_cells = G2.h_part + ((size_t)G2.cap_q / SZ_CH + 2) * 10;
   memset(f->h_pin2, 0, 64);
   G2.flag = f->flag2.p;
-  HIPCHK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, frontier_stream_priority()));
+  HIPCHK(fuelmi_stream_create(&f->stream2, frontier_stream_priority(), "FR"));
   HIPCHK(hipStreamSynchronize(f->stream));
   return FUELMI_OK;
 }
@@ -2769,7 +2769,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   {
     // the scan is a chain of short latency-bound kernels and is the critical path of a plan cycle:
     // give its stream the highest priority so the wide ESDF kernels of the map stream fill in around it
-    HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, frontier_stream_priority()));
+    HIPCHK(fuelmi_stream_create(&f->stream, frontier_stream_priority(), "FR"));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
   // (zstream -- zeroes the retired flag plane in one-stream mode -- is created on first use, frontier_finish_reset)

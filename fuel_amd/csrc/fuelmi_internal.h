@@ -194,6 +194,7 @@ struct fuelmi_map {
   // measurement
   double bench_host_us[7] = {0, 0, 0, 0, 0, 0, 0};  // fuelmi_bench_cycles: mean host microseconds per C-ABI call
   hipEvent_t t0 = nullptr, t1 = nullptr;  // fuelmi_timer_begin / _end
+  int last_inflate_kernel = -1;           // 0: k_inflate_fused, 1: the factored pair (fuelmi_map_last_inflate_kernel)
   hipEvent_t t_prof0 = nullptr;           // origin of fuelmi_profile_get_timeline (recorded by fuelmi_profile_enable)
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
   unsigned long long planes_ver = 0;  // ... and counted: a search stream that has already waited for this record does not queue the wait again
@@ -223,6 +224,11 @@ struct fuelmi_map {
 };
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
+// Streams of the library.  `which` names the role ("MAP": a map's stream, "FR": a finder's search streams); the experiment
+// hook FUELMI_CUMASK_<which> = "<xcd mask>:<CUs per XCD>" (e.g. FUELMI_CUMASK_FR=0x03:32, FUELMI_CUMASK_MAP=0xfc:32)
+// creates the stream with hipExtStreamCreateWithCUMask instead: the CU mask's bit i selects the (i / 8)-th CU of XCD i % 8
+// on an 8-XCD part (the driver deals a queue's mask round-robin over the XCCs).  priority: INT_MIN = default.
+hipError_t fuelmi_stream_create(hipStream_t* s, int priority, const char* which);
 // a query slot with at least `bytes` of pinned memory, its stream ordered behind the map's; released (and waited for)
 // by the guard
 struct QuerySlotGuard {

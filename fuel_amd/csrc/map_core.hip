@@ -7,6 +7,7 @@
 // `inflated`.  Morphology (inflation, the 6-neighbour frontier test) then becomes shifts of the
 // linear bit string, which reproduces the reference's "only 0 <= adr < N is checked" wrap quirk
 // (sdf_map.cpp:453-458) for free.
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -99,6 +100,29 @@ static void warn_hw_queues_once() {
     std::fprintf(stderr, "[fuelmi] GPU_MAX_HW_QUEUES is not set and fuelmi_init() was not called: a map's, its finder's and "
                          "its query threads' streams share the HIP runtime's default of 4 hardware queues\n");
   }
+}
+
+hipError_t fuelmi_stream_create(hipStream_t* s, int priority, const char* which) {
+  char name[48];
+  snprintf(name, sizeof(name), "FUELMI_CUMASK_%s", which);
+  if (const char* e = getenv(name)) {
+    unsigned xm = 0xFFu;
+    int c_lo = 0, c_hi = 31;  // "<xcd mask>:<n>" = the first n CUs of each XCD, "<xcd mask>:<a>-<b>" = CUs a..b of each
+    char range[32] = "";
+    const int nf = sscanf(e, "%i:%31s", reinterpret_cast<int*>(&xm), range);
+    if (nf == 2) {
+      if (sscanf(range, "%d-%d", &c_lo, &c_hi) != 2) c_lo = 0, c_hi = atoi(range) - 1;
+    }
+    if (nf >= 1 && (xm & 0xFFu) && c_lo >= 0 && c_hi >= c_lo) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 256; ++i)
+        if (((xm >> (i & 7)) & 1u) && (i >> 3) >= c_lo && (i >> 3) <= c_hi) mask[i >> 5] |= 1u << (i & 31);
+      // (no priority / flags on this entry point: the stream is a default-priority, null-stream-blocking one)
+      return hipExtStreamCreateWithCUMask(s, 8, mask);
+    }
+  }
+  if (priority == INT_MIN) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
 }
 
 extern "C" const char* fuelmi_last_error(void) { return g_err; }
@@ -637,7 +661,7 @@ extern "C" int fuelmi_map_create(const fuelmi_map_cfg* c, fuelmi_map** out) {
     fuelmi_map_destroy(m);
     return code;
   };
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (fuelmi_stream_create(&m->stream, INT_MIN, "MAP") != hipSuccess) {
     fuelmi_set_error("hipStreamCreate failed");
     return fail(FUELMI_EHIP);
   }
@@ -789,6 +813,7 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
     const bool two_pass = tp_env ? atoi(tp_env) != 0 : (long)(out_hi - out_lo + 1) * 64 > (48L << 20);
     const int ry = (step * (g.nz + 1) + 63) / 64 + 1;
     const size_t lds_f = (size_t)(2 * step + 1) * (2 * (size_t)(256 + 2 * ry + 2) + 2) * sizeof(u64);
+    m->last_inflate_kernel = (step == 2 && !two_pass && lds_f <= 64 * 1024) ? 0 : 1;
     if (step == 2 && !two_pass && lds_f <= 64 * 1024) {
       const int nb = blocks_for(out_hi - out_lo + 1, 256);
       if (whole)
@@ -823,6 +848,8 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
+
+extern "C" int fuelmi_map_last_inflate_kernel(const fuelmi_map* m) { return m ? m->last_inflate_kernel : FUELMI_EINVAL; }
 
 extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
   ARGCHK(m);

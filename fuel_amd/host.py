@@ -91,6 +91,10 @@ class SDFMap:
         """family the z/y pass of the last updateESDF3d ran"""
         return self.L.fuelmi_map_last_esdf_family(self.h)
 
+    def lastInflateKernel(self):
+        """0: the fused inflation kernel ran in the last clearAndInflateLocalMap, 1: the factored pair"""
+        return self.L.fuelmi_map_last_inflate_kernel(self.h)
+
     def close(self):
         if getattr(self, "h", None):
             self.L.fuelmi_map_destroy(self.h)

@@ -159,6 +159,9 @@ int fuelmi_map_update_esdf(fuelmi_map* m);
 enum { FUELMI_ESDF_AUTO = -1, FUELMI_ESDF_PLAIN = 0, FUELMI_ESDF_FAR = 1, FUELMI_ESDF_PLAIN32 = 2 };
 int fuelmi_map_set_esdf_family(fuelmi_map* m, int family);
 int fuelmi_map_last_esdf_family(const fuelmi_map* m);
+/* which inflation kernels the last fuelmi_map_inflate_local ran: 0 the fused single launch, 1 the factored y/z + x pair
+ * (chosen by the size of the box's address range; -1 before the first call).  For tests that must know which code ran. */
+int fuelmi_map_last_inflate_kernel(const fuelmi_map* m);
 /* SDFMap::resetBuffer() (sdf_map.cpp:95-99) and resetBuffer(min,max) (:101-114) */
 int fuelmi_map_reset_buffer_all(fuelmi_map* m);
 int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]);

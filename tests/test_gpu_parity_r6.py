@@ -1,0 +1,67 @@
+"""Round-6 parity tests (GPU): what VERDICT r5 found missing -- the ORACLE at the largest size."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import fuel_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+ESDF_TOL = 1e-4   # north_star: ESDF values within 1e-4
+BIG = 1e6
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import fuel_amd
+    fuel_amd.lib()
+    return fuel_amd
+
+
+def test_full_size_g800_full_box_against_the_oracle(fa):
+    """BASELINE.json configs[3]'s map (800 x 800 x 200 @ 0.1 m, bench.py --workload G800), FULL box, against the oracle
+    itself (VERDICT r5 missing #5 / next #6; round 5 had properties and family-vs-family equality only): inflation
+    bit-exact (sdf_map.cpp:434-471) with the FACTORED inflation kernels asserted to have run (the box's address range is
+    above the fused kernel's limit -- this is the only size where they do), ESDF within 1e-4 over the whole box
+    (sdf_map.cpp:152-199) with the packed 16-bit family asserted to have run (its <0,4,4> z/y instantiation), and one
+    fresh full-box frontier search: sorted cell sets of every cluster, cluster order, flags
+    (frontier_finder.cpp:54-121).  The oracle needs ~6 GB of host memory and ~10 s of one core for this."""
+    import bench
+    map_size, box, occ, _, _ = bench.build_inputs("G800", seed=42, n_traj=1)
+    om = fo.OracleMap(map_size, *box)
+    assert om.nvox == (800, 800, 200)
+    om.occ[:] = occ
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(occ)
+    lo, hi = helpers.full_box(om.nvox)
+    om.set_local_bound(lo, hi)
+    gm.setLocalBound(lo, hi)
+    om.inflate_local()
+    gm.clearAndInflateLocalMap()
+    assert gm.lastInflateKernel() == 1, "the factored inflation pair was expected to run on the 128 M-voxel box"
+    gm.updateESDF3d()
+    assert gm.lastEsdfFamily() == 0, "the packed family was expected to run"
+    h = gm.syncHost(inflate=True, distance=True)
+    assert np.array_equal(h["inflate"], om.infl), "inflated occupancy not bit-exact"
+    del h["inflate"]
+    om.update_esdf()
+    worst = 0.0
+    d_g = h["distance"].reshape(om.nvox)
+    d_o = om.dist.reshape(om.nvox)
+    for x0 in range(0, om.nvox[0], 100):   # (slab by slab: the clipped copies of two 1-GB fields at once are not needed)
+        a = np.clip(d_o[x0:x0 + 100], -BIG, BIG)
+        b = np.clip(d_g[x0:x0 + 100], -BIG, BIG)
+        worst = max(worst, float(np.abs(a - b).max()))
+    assert worst <= ESDF_TOL, "ESDF differs from the oracle by %g" % worst
+    del h, d_g
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    om.set_updated_box(*box)
+    gm.setUpdatedBox(*box)
+    n_o, n_g = of.search(), gf.searchFrontiers()
+    assert n_o == n_g and n_o > 0
+    for a, b in zip(of.clusters(0), gf.clusters(0)):
+        assert np.array_equal(np.sort(a), b)
+    assert np.array_equal(of.flags, gf.flags())
+    gf.close()
+    gm.close()
