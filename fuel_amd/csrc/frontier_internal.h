@@ -54,8 +54,8 @@ struct FVar {
 // looked up by voxel address (vlab), and the grouped output positions come from per-(component, x-row) counts.
 #define FR_RCAP 8192            // tile-local components per search (8 per-XCD ranges of FR_RC8)
 #define FR_RC8 (FR_RCAP / 8)
-#define FR_TCELL 4096           // Q0 cells per tile
-#define FR_TPAIR 3072           // touching pairs of runs a tile lists (beyond: union-find on the spot)
+#define FR_TCELL 2048           // Q0 cells per tile
+#define FR_TPAIR 1536           // touching pairs of runs a tile lists (beyond: union-find on the spot)
 #define FR_TROOT 128            // components per tile (they are numbered in one byte; 0xFF is free)
 #define FR_TXS 16               // x-rows per tile at most (stride of the per-row counts)
 #define FR_KCAP 256             // kept clusters
@@ -129,6 +129,10 @@ struct FArgs {
   u32* fctr;              // [32] [0..7] roots per XCD range, [9] overflow -> legacy chain, [16..23] pairs per XCD
   int fast;               // the result of the last search came from the fast path
   unsigned long long* dbg;  // FUELMI_FR_TIMING: per-block phase time stamps of the fast chain's kernels (else null)
+  // k_tile_chain (tile CCL + cross-tile pairs + resolve in ONE launch): what a tile's higher-indexed neighbours need of it
+  u32* face;                   // [tiles][(ftx + fty) * nseg * 10] per face line and 32-voxel segment: Q0 bits, seed bits, 8 words of
+                               // component numbers (one byte per voxel) -- the tile's last x-row, then its last y-line per x-row
+  unsigned long long* tready;  // [tiles] epoch << 32 | "has NQ seeds" << 31 | id of the tile's component 0: the faces are published
 };
 // Result words in pinned host memory: the data stores of a workgroup, a barrier, then ONE lane stores the stamp
 // the polling host waits for with RELEASE semantics at system scope.  (A relaxed stamp was tried -- the release
@@ -142,6 +146,39 @@ struct FArgs {
   } while (0)
 
 #ifdef __HIPCC__
+// Relaxed accesses at AGENT scope: the store goes through the XCD's L2 to memory, the load comes from there -- how
+// workgroups of ONE launch (which may sit on different XCDs, each with its own write-back L2) hand data to each other
+// without a release fence (= an L2 write-back, which also flushes what the ESDF passes of the same cycle hold dirty).
+// Order: data stores, s_waitcnt vmcnt(0), workgroup barrier, then the flag / counter.
+__device__ __forceinline__ void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_vm_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// two tile-root records (48 bytes each, 16-byte aligned) with six 16-byte agent-scope loads and ONE wait
+__device__ __forceinline__ void ld_agent_trec2(const TRec* p0, const TRec* p1, TRec& A, TRec& B) {
+  static_assert(sizeof(TRec) == 48, "TRec is fetched as three 16-byte pieces");
+  uint4 a0, a1, a2, b0, b1, b2;
+  asm volatile(
+      "global_load_dwordx4 %0, %6, off sc1\n\t"
+      "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %6, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc1\n\t"
+      "global_load_dwordx4 %4, %7, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %5, %7, off offset:32 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(b0), "=&v"(b1), "=&v"(b2)
+      : "v"(p0), "v"(p1)
+      : "memory");
+  A.size = a0.x, A.sx = a0.y, A.sy = a0.z, A.sz = a0.w, A.lo[0] = a1.x, A.lo[1] = a1.y, A.lo[2] = a1.z, A.hi[0] = a1.w;
+  A.hi[1] = a2.x, A.hi[2] = a2.y, A.tx = a2.z, A.own = a2.w;
+  B.size = b0.x, B.sx = b0.y, B.sy = b0.z, B.sz = b0.w, B.lo[0] = b1.x, B.lo[1] = b1.y, B.lo[2] = b1.z, B.hi[0] = b1.w;
+  B.hi[1] = b2.x, B.hi[2] = b2.y, B.tx = b2.z, B.own = b2.w;
+}
 // compact index of the Q0 cell / NQ seed at voxel address a (valid after k_pred + k_scan_sums of this search)
 __device__ __forceinline__ u32 rank_q(const FArgs& F, long a) {
   int w = (int)(a >> 6);
