@@ -6,7 +6,6 @@
 // the stencils it belongs to) so no atomics are needed; cost and the knot-span gradient are
 // wave-reduced with DPP shuffles.  All arithmetic is f64 like the reference; the ESDF is read
 // as 8 f32 gathers per control point (trilinear, SDFMap::getDistWithGrad sdf_map.cpp:497-536).
-#include <climits>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -954,7 +953,6 @@ static int upload(fuelmi_bspline_dev* b, const void* src, size_t bytes, const vo
   void* d = nullptr;
   HIPCHK(hipMalloc(&d, bytes));
   b->allocs.push_back(d);
-  HIPCHK(map_batch_join(b->map));
   HIPCHK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, b->map->stream));
   *dst = d;
   return FUELMI_OK;
@@ -968,7 +966,6 @@ extern "C" void fuelmi_bspline_dev_destroy(fuelmi_bspline_dev* b) {
   (void)hipSetDevice(b->device);
   if (b->map) {
     (void)hipStreamSynchronize(b->map->stream);
-    if (b->map->batch_stream) (void)hipStreamSynchronize(b->map->batch_stream);
     std::lock_guard<std::mutex> lk(b->map->dep_mu);
     auto& deps = b->map->dependents;
     for (size_t k = 0; k < deps.size(); ++k)
@@ -1090,31 +1087,9 @@ extern "C" int fuelmi_bspline_dev_create(fuelmi_map* m, const fuelmi_bspline_cfg
 extern "C" int fuelmi_bspline_dev_eval(fuelmi_bspline_dev* b) {
   ARGCHK(b);
   HIPCHK(hipSetDevice(b->map->device));
-  fuelmi_map* m = b->map;
-  static const bool side = !(getenv("FUELMI_BATCH_STREAM") && atoi(getenv("FUELMI_BATCH_STREAM")) == 0);  // A/B hook
-  if (!side) {
-    StageScope sc(m, FUELMI_K_BSPLINE);
-    k_bspline_cost_grad<<<b->a.C, 256, b->lds_eval4, m->stream>>>(m->g, m->dist, b->a);
-    HIPCHK(hipGetLastError());
-    return FUELMI_OK;
-  }
-  // on the map's batch stream (see fuelmi_map::batch_stream): behind the ESDF update queued so far, beside the next
-  // cycle's inflation and z/y pass
-  if (!m->batch_stream) {
-    HIPCHK(fuelmi_stream_create(&m->batch_stream, INT_MIN, "BATCH"));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_batch_dep, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_batch_done, hipEventDisableTiming));
-  }
-  HIPCHK(map_batch_join(m));  // (the previous evaluation wrote the same cost / gradient buffers)
-  HIPCHK(hipEventRecord(m->ev_batch_dep, m->stream));
-  HIPCHK(hipStreamWaitEvent(m->batch_stream, m->ev_batch_dep, 0));
-  {
-    StageScope sc(m, FUELMI_K_BSPLINE, m->batch_stream);
-    k_bspline_cost_grad<<<b->a.C, 256, b->lds_eval4, m->batch_stream>>>(m->g, m->dist, b->a);
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipEventRecord(m->ev_batch_done, m->batch_stream));
-  m->batch_pending = true;
+  StageScope sc(b->map, FUELMI_K_BSPLINE);
+  k_bspline_cost_grad<<<b->a.C, 256, b->lds_eval4, b->map->stream>>>(b->map->g, b->map->dist, b->a);
+  HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
 
@@ -1228,7 +1203,6 @@ extern "C" int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_
 extern "C" int fuelmi_bspline_dev_download(fuelmi_bspline_dev* b, double* cost, double* grad) {
   ARGCHK(b && cost && grad);
   HIPCHK(hipSetDevice(b->map->device));
-  HIPCHK(map_batch_join(b->map));
   HIPCHK(hipMemcpyAsync(cost, b->a.cost, (size_t)b->a.C * sizeof(double), hipMemcpyDeviceToHost, b->map->stream));
   HIPCHK(hipMemcpyAsync(grad, b->a.grad, (size_t)b->a.C * b->a.nvar * sizeof(double), hipMemcpyDeviceToHost,
                         b->map->stream));

@@ -1713,7 +1713,6 @@ int esdf_update(fuelmi_map* m) {
   }
   if (rc) return rc;
   m->esdf_family_last = ran;
-  HIPCHK(map_batch_join(m));  // (a batch evaluation beside the z/y pass still reads the field the x pass rewrites)
   {
     StageScope sc(m, FUELMI_K_ESDF_X, nullptr, true);
     rc = ESDF_NO_FIT;

@@ -1446,21 +1446,16 @@ __device__ __forceinline__ void pop_run64(u64& m, int& s, int& len) {
 // per-segment popcounts), so a tile costs the same LDS whatever nz is.  The unit of work is the z-RUN: the cells
 // of a run share a label from the start, a run looks at each of the four lower z-lines through one 34-bit window
 // and joins every run it finds there -- a wall costs one union per line, not one per cell.
-// FUSED = false: the kernel k_tile_ccl (every result through plain stores, a kernel boundary in front of its readers).
-// FUSED = true: the first phase of k_tile_chain -- what OTHER workgroups of the same launch read (records, claims,
-// overflow codes) leaves through agent-scope stores, the component numbers by voxel address (vlab) are not written
-// (the chain's cross phase reads the neighbours' published faces instead).  Returns the tile's component count
-// (0: no cells, or a capacity was exceeded) and leaves in LDS: segb / segpre / segs / rcell.
-template <int NT, bool FUSED>
-__device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, const FVar& V, const TileGeo& T,
-                                               unsigned char* smem_raw, u32* gbase_out) {
-  auto set_code = [&](u32 code) {
-    if (FUSED)
-      st_agent(&F.fctr[9], code);
-    else
-      F.fctr[9] = code;
-  };
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
+  // the chain's first kernel: the per-search arguments arrive as a KERNEL ARGUMENT (the graph node's parameters are
+  // rewritten before every launch: no memory read -- least of all one over PCIe -- stands in front of the tile's
+  // loads); workgroup 0 leaves the device copy the later kernels read
+  if (blockIdx.x == 0 && threadIdx.x == 0) *F.var_w = V;
+  if ((int)blockIdx.x >= V.ntiles_f) return;
+  const TileGeo T = tile_geo(g, V, blockIdx.x);
   const Box3 sbox = V.sbox;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nz = g.nz, nseg = T.nseg, items = T.items, TY = T.TY;
   u32* lab = reinterpret_cast<u32*>(smem_raw);       // [FR_TCELL] union-find over the tile-local cell indices
   u32* segb = lab + FR_TCELL;                         // [items] Q0 bits of each 32-voxel segment
@@ -1487,14 +1482,13 @@ __device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, cons
     for (int it = threadIdx.x; it < items; it += NT) tq[it] = segb[it], ts[it] = segs[it];
   }
   FR_DBG_MARK(F, blockIdx.x, 1);
-  *gbase_out = 0u;
   if (total == 0u || total > FR_TCELL) {
     if (threadIdx.x == 0) {
       F.t_nroots[blockIdx.x] = 0u;
       F.t_base[blockIdx.x] = 0u;
-      if (total > FR_TCELL) set_code(11u);  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
+      if (total > FR_TCELL) F.fctr[9] = 11u;  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
     }
-    return 0u;
+    return;
   }
   FR_DBG_MARK(F, blockIdx.x, 2);
   // ---- components.  (1) One lane per CELL looks at the four lower z-lines around it through 3-bit windows of the LDS
@@ -1641,11 +1635,11 @@ __device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, cons
   const u32 nroots = s_nroots;
   if (nroots > FR_TROOT) {
     if (threadIdx.x == 0) {
-      set_code(12u);
+      F.fctr[9] = 12u;
       F.t_nroots[blockIdx.x] = 0u;
       F.t_base[blockIdx.x] = 0u;
     }
-    return 0u;
+    return;
   }
   // ---- ids of the components: one contiguous range per tile inside the XCD's part of the id space (the
   // returning atomic is issued here so that its latency hides behind the record loop) ----
@@ -1653,7 +1647,7 @@ __device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, cons
     const u32 xcd = blockIdx.x & 7u;
     const u32 b = atomicAdd(&F.fctr[xcd], nroots);
     if (b + nroots > FR_RC8) {
-      set_code(13u);
+      F.fctr[9] = 13u;
       s_flag = 1u;
     }
     s_base = xcd * FR_RC8 + b;
@@ -1729,8 +1723,7 @@ __device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, cons
     F.t_base[blockIdx.x] = gbase;
     F.t_nroots[blockIdx.x] = s_flag ? 0u : nroots;
   }
-  if (s_flag) return 0u;
-  *gbase_out = gbase;
+  if (s_flag) return;
   if (threadIdx.x < nroots) {
     const u32* r = acc + threadIdx.x * 8;
     const u32* rw = rrow + threadIdx.x * FR_TXS;
@@ -1748,36 +1741,26 @@ __device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, cons
     R.size = size, R.sx = sx, R.sy = r[0], R.sz = r[1];
     R.lo[0] = lox, R.lo[1] = r[3], R.lo[2] = r[4], R.hi[0] = hix, R.hi[1] = r[5], R.hi[2] = r[6];
     R.tx = (u32)T.tx, R.own = r[2];
-    if (FUSED) {  // (read by the LAST workgroup of this launch, claimed into by the neighbours: past the L2)
-      static_assert(sizeof(TRec) == 12 * sizeof(u32), "TRec is published word by word");
-      const u32* rw2 = reinterpret_cast<const u32*>(&R);
-      u32* dst = reinterpret_cast<u32*>(&F.trec[gbase + threadIdx.x]);
-#pragma unroll
-      for (int q = 0; q < 12; ++q) st_agent(dst + q, rw2[q]);
-      st_agent(&F.tclaim[gbase + threadIdx.x], r[2]);
-    } else {
-      F.trec[gbase + threadIdx.x] = R;
-      F.tclaim[gbase + threadIdx.x] = r[2];
-    }
+    F.trec[gbase + threadIdx.x] = R;
+    F.tclaim[gbase + threadIdx.x] = r[2];
   }
   // ---- component number of every cell, by tile-local index (k_tile_out) and by voxel address (k_tile_cross) ----
   {
     unsigned char* tl = F.tlab + (size_t)blockIdx.x * FR_TCELL;
     for (u32 l = threadIdx.x; l < total; l += NT) tl[l] = rcell[l];
   }
-  if (!FUSED)
-    for (int it = threadIdx.x; it < items; it += NT) {
-      u32 rem = segb[it];
-      if (!rem) continue;
-      const int line = it / nseg, c = it - line * nseg;
-      unsigned char* vl = F.vlab + tile_line_adr(g, T, line) + 32 * c;
-      u32 l = segpre[it];
-      while (rem) {
-        const int b = __builtin_ctz(rem);
-        rem &= rem - 1u;
-        vl[b] = rcell[l++];
-      }
+  for (int it = threadIdx.x; it < items; it += NT) {
+    u32 rem = segb[it];
+    if (!rem) continue;
+    const int line = it / nseg, c = it - line * nseg;
+    unsigned char* vl = F.vlab + tile_line_adr(g, T, line) + 32 * c;
+    u32 l = segpre[it];
+    while (rem) {
+      const int b = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      vl[b] = rcell[l++];
     }
+  }
   FR_DBG_MARK(F, blockIdx.x, 6);
   if (F.dbg && threadIdx.x == 0) {
     F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 8] = total;
@@ -1786,19 +1769,6 @@ __device__ __forceinline__ u32 tile_ccl_phase(const Geo& g, const FArgs& F, cons
     F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 11] = s_cnt[2];
     F.dbg[(size_t)blockIdx.x * FR_DBG_SLOTS + 12] = nroots;
   }
-  return nroots;
-}
-template <int NT>
-__global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
-  // the chain's first kernel: the per-search arguments arrive as a KERNEL ARGUMENT (the graph node's parameters are
-  // rewritten before every launch: no memory read -- least of all one over PCIe -- stands in front of the tile's
-  // loads); workgroup 0 leaves the device copy the later kernels read
-  if (blockIdx.x == 0 && threadIdx.x == 0) *F.var_w = V;
-  if ((int)blockIdx.x >= V.ntiles_f) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const TileGeo T = tile_geo(g, V, blockIdx.x);
-  u32 gbase;
-  (void)tile_ccl_phase<NT, false>(g, F, V, T, smem_raw, &gbase);
 }
 
 // Joins across tile faces + seed claims, one launch after k_tile_ccl (every cell's component number is in vlab by
@@ -1808,6 +1778,8 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
 // The tile's NQ seeds claim the tile roots touching their 26-neighbourhood (atomicMin on tclaim).
 #define XC_SET 256
 #define XC_WCAP 6144  // entries of a tile's work list (beyond: processed on the spot)
+template <int RS_T, bool IN_LAUNCH>
+__device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const FVar& V, unsigned char* smem_raw, const u32 rcap);
 __device__ __forceinline__ void xc_insert(u32* s_set, u32* s_list, u32* s_n, u32* fctr, u32 key) {
   u32 h = (key * 2654435761u) >> 24;
   bool done = false;
@@ -1820,10 +1792,15 @@ __device__ __forceinline__ void xc_insert(u32* s_set, u32* s_list, u32* s_n, u32
       done = true;
     h = (h + 1u) & (XC_SET - 1u);
   }
-  if (!done) fctr[9] = 15u;  // more than XC_SET distinct root pairs around one tile
+  if (!done) st_agent(&fctr[9], 15u);  // more than XC_SET distinct root pairs around one tile
 }
+// rcap != 0 (round 6): the workgroup that finishes LAST joins the tile roots itself (resolve_body, in the LDS its tile no
+// longer needs) -- k_resolve's launch and kernel boundary leave the search's critical path.  What it reads of the
+// other workgroups of this launch (pairs, claims, overflow codes) was written with agent-scope stores / memory-side
+// atomics and is counted in behind s_waitcnt vmcnt(0): no release fence, no L2 write-back.  rcap = tile roots that fit
+// the launch's LDS; searches with more leave the job to the kernel k_resolve behind (which returns at once otherwise).
 template <int NT>
-__global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
+__global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F, const u32 rcap) {
   FR_DBG_MARK(F, blockIdx.x, 13);  // (before the first load)
   __shared__ TilePro s_pro;
   stage_tile_pro(F, &s_pro);
@@ -1967,7 +1944,7 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
     if (slot < XC_WCAP)
       wl[slot] = (u32)fi;
     else
-      F.fctr[9] = 18u;  // work list full (a tile made of seeds): the legacy chain takes the search
+      st_agent(&F.fctr[9], 18u);  // work list full (a tile made of seeds): the legacy chain takes the search
   }
   // ---- NQ seeds of the tile (most tiles have none): nine items per seed segment, one per line around it (one
   // reservation for all nine) ----
@@ -1979,7 +1956,7 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
       if (slot0 + (u32)l < XC_WCAP)
         wl[slot0 + (u32)l] = e;
       else
-        F.fctr[9] = 18u;
+        st_agent(&F.fctr[9], 18u);
     }
   }
   __syncthreads();
@@ -2010,17 +1987,27 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F) {
   __syncthreads();
   FR_DBG_MARK(F, dblk, 3);
   const u32 n = s_n;
-  if (n == 0u) return;
-  const u32 xcd = blockIdx.x & 7u;
-  if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[16 + xcd], n);
-  __syncthreads();
-  const u32 base = s_base;
-  if (base + n > FR_PCAP / 8u) {
-    if (threadIdx.x == 0) F.fctr[9] = 14u;
-    return;
+  if (n != 0u) {  // (uniform)
+    const u32 xcd = blockIdx.x & 7u;
+    if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[16 + xcd], n);
+    __syncthreads();
+    const u32 base = s_base;
+    if (base + n > FR_PCAP / 8u) {
+      if (threadIdx.x == 0) st_agent(&F.fctr[9], 14u);
+    } else if (threadIdx.x < n)
+      st_agent(&F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x], s_list[threadIdx.x]);
   }
-  if (threadIdx.x < n) F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x] = s_list[threadIdx.x];
   FR_DBG_MARK(F, dblk, 4);
+  if constexpr (NT == 512) {
+    if (rcap == 0u) return;
+    // ---- last one out joins the roots ----
+    __shared__ u32 s_last;
+    wait_vm_stores();  // (every wave: its pairs and codes have left)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&F.fctr[24], 1u) == (u32)V.ntiles_f - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last) (void)resolve_body<NT, true>(g, F, V, smem_raw, rcap);
+  }
 }
 
 // one wave-level reduction step of the per-component accumulators (sum / min / max over the lanes that share
@@ -2041,16 +2028,17 @@ __device__ __forceinline__ void cacc_reduce(CAcc& a) {
 // array, per-cluster index sums / boxes, the (cluster x tile column) prefix matrix k_tile_out places the cells
 // with -- and the result records, written straight to pinned host memory.
 #define RS_TK 1024  // lanes of the kernel k_resolve
-#define RS_SH 512  // seed-claimed clusters (hash slots)
+#define RS_SH 512   // seed-claimed clusters (hash slots)
 // bytes of LDS resolve_body needs for `rcap` tile roots
 static inline size_t resolve_lds_bytes(size_t rcap) {
   return (4 * rcap + 6 * (size_t)FR_KCAP + 6 * (size_t)FR_KCAP + 3 * (size_t)RS_SH) * sizeof(u32) + 3 * (size_t)FR_KCAP * sizeof(unsigned long long);
 }
-// RS_T lanes of ONE workgroup; rcap = tile roots the LDS arrays hold (FR_RCAP in the kernel k_resolve, whatever the
-// tile's LDS leaves in the last workgroup of k_tile_chain).  IN_LAUNCH: the inputs were written by other workgroups of
-// the SAME launch (agent-scope stores): they are read with agent-scope loads, past this XCD's L2; the per-search block
-// is the kernel argument (the device copy is another workgroup's plain store).  Returns false when the search has more
-// tile roots than rcap (nothing written: the kernel k_resolve behind the chain does the work).
+// RS_T lanes of ONE workgroup; rcap = tile roots the LDS arrays hold (FR_RCAP in the kernel k_resolve; what the LDS of
+// k_tile_cross holds when its last workgroup does the job).  IN_LAUNCH: pairs, claims and overflow codes were written
+// by other workgroups of the SAME launch (agent-scope stores / memory-side atomics): they are read with agent-scope
+// loads, past this XCD's L2 (the records are the previous kernel's and would be visible anyway; they take the same
+// path).  Returns false when the search has more tile roots than rcap (nothing written: the kernel k_resolve, always
+// queued behind, does the work).
 template <int RS_T, bool IN_LAUNCH>
 __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const FVar& V, unsigned char* smem_raw, const u32 rcap) {
   auto ldw = [&](const u32* p) -> u32 { return IN_LAUNCH ? ld_agent(p) : *p; };
@@ -2374,7 +2362,7 @@ __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const
     F.counts[5] = bad ? 0u : s_nout;
   }
   if (threadIdx.x < 32) F.fctr[threadIdx.x] = 0u;  // the counters of the NEXT search (its first kernel adds to them at once)
-  if (threadIdx.x == 0) F.counts[8] = V.epoch;     // "resolved" (the kernel k_resolve behind a chain that did it returns at once)
+  if (threadIdx.x == 0) F.counts[8] = V.epoch;     // "resolved" (the kernel k_resolve behind a k_tile_cross that did it returns at once)
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
   // the barrier orders every thread's record stores before thread 0's system-scope release (cumulative): one
@@ -2389,6 +2377,7 @@ __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const
 __global__ void __launch_bounds__(RS_TK) k_resolve(Geo g, FArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ FVar s_v;
+  __shared__ u32 s_done;
   {
     constexpr int NV = (int)(sizeof(FVar) / 4);
     const int t = threadIdx.x;
@@ -2396,348 +2385,11 @@ __global__ void __launch_bounds__(RS_TK) k_resolve(Geo g, FArgs F) {
     if (t == NV) src = F.counts + 8;
     const u32 w = *src;  // (one load instruction for the block and the "resolved" word)
     if (t < NV) reinterpret_cast<u32*>(&s_v)[t] = w;
-    __shared__ u32 s_done;
     if (t == NV) s_done = w;
     __syncthreads();
-    if (s_done == s_v.epoch) return;  // the last workgroup of k_tile_chain has resolved this search
+    if (s_done == s_v.epoch) return;  // the last workgroup of k_tile_cross has resolved this search
   }
   (void)resolve_body<RS_TK, false>(g, F, s_v, smem_raw, FR_RCAP);
-}
-
-// =================================================================================================
-// The chain in ONE launch (round 6): tile CCL -> cross-tile pairs -> resolve, no kernel boundary between them.
-//   * A tile's relations with its neighbours are found by the HIGHER-indexed tile of every pair (tile index = tx * nty
-//     + ty = blockIdx.x): a workgroup waits only for tiles (tx-1, ty-1), (tx-1, ty), (tx-1, ty+1) and (tx, ty-1), which
-//     the dispatcher started before it (workgroups of a 1-D grid start in index order): no cycle, no deadlock however few
-//     workgroups are resident.  A spin that outlives 50 ms reports capacity code 19 (the legacy chain takes the search).
-//   * What a neighbour needs of a tile is its FACE: Q0 bits, NQ-seed bits and component numbers of its last x-row and of
-//     the last y-line of every x-row (FArgs::face), published with agent-scope stores, then the tile's ready word.
-//     Seeds claim across a face from whichever side is the higher tile (its own seeds against the lower tile's cells,
-//     the lower tile's seeds against its own cells).
-//   * The workgroup that finishes last (a counter behind every tile's pair stores) joins the tile roots (resolve_body) in
-//     the LDS its tile no longer needs, and publishes the result the host polls for.  Searches with more tile roots than
-//     that LDS holds leave the job to the kernel k_resolve, which is always queued behind and returns at once otherwise.
-// =================================================================================================
-#define XC_WCAP_F FR_TCELL  // work list of the cross phase (the CCL's label array, dead by then)
-template <int NT>
-__global__ void __launch_bounds__(NT) k_tile_chain(Geo g, FArgs F, const FVar V, const u32 rcap) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *F.var_w = V;  // (for the kernels behind this one)
-  if ((int)blockIdx.x >= V.ntiles_f) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const TileGeo T = tile_geo(g, V, blockIdx.x);
-  const int nz = g.nz, nseg = T.nseg, items = T.items, TX = T.TX, TY = T.TY;
-  const int lane = threadIdx.x & 63;
-  // (the CCL phase's layout: what stays alive behind it)
-  u32* wl = reinterpret_cast<u32*>(smem_raw);  // [FR_TCELL] labels of the CCL, then the work list
-  u32* segb = wl + FR_TCELL;                   // [items] Q0 bits
-  u32* segpre = segb + items;                  // [items + 1]
-  u32* acc_ = segpre + items + 1;
-  u32* rrow_ = acc_ + FR_TROOT * 8;
-  unsigned short* rootno_ = reinterpret_cast<unsigned short*>(rrow_ + FR_TROOT * FR_TXS);
-  const unsigned char* rcell = reinterpret_cast<const unsigned char*>(rootno_ + FR_TCELL);  // [FR_TCELL] component number per cell
-  const u32* segs = reinterpret_cast<const u32*>(rcell + FR_TCELL);                         // [items] NQ seed bits
-  u32 gbase = 0u;
-  const u32 nroots = tile_ccl_phase<NT, true>(g, F, V, T, smem_raw, &gbase);  // (uniform)
-  __syncthreads();  // (the record phase's last reads of the accumulators: their space is reused below)
-  // (the record accumulators of the CCL phase are dead: static LDS here would cost the third workgroup per CU)
-  u32* const s_set = acc_;            // [XC_SET] distinct (root, root) pairs of this tile: open addressing
-  u32* const s_list = acc_ + XC_SET;  // [XC_SET] ... in insertion order
-  static_assert(2 * XC_SET <= FR_TROOT * 8, "pair set does not fit the dead accumulators");
-  __shared__ u32 s_n, s_pbase, s_nw, s_seedface, s_last;
-  __shared__ u32 s_tb[5];         // ready words (id base | seeds << 31) of the four lower neighbours, own id base
-  // ---- publish the faces ----
-  const int NFL = TX + TY;
-  const size_t fstride = (size_t)NFL * nseg * 10;
-  u32* const face_q = F.face + (size_t)blockIdx.x * fstride;  // [NFL][nseg]
-  u32* const face_s = face_q + NFL * nseg;                    // [NFL][nseg]
-  u32* const face_l = face_s + NFL * nseg;                    // [NFL][nseg][8]
-  if (threadIdx.x < XC_SET) s_set[threadIdx.x] = 0xFFFFFFFFu;
-  if (threadIdx.x == 0) s_n = 0u, s_nw = 0u, s_seedface = 0u, s_last = 0u;
-  __syncthreads();
-  auto face_item = [&](int fl, int c) {  // face line fl -> segment index inside the tile
-    const int lx = fl < TY ? TX - 1 : fl - TY, ly = fl < TY ? fl : TY - 1;
-    return (lx * TY + ly) * nseg + c;
-  };
-  for (int i = threadIdx.x; i < NFL * nseg; i += NT) {
-    const int fl = i / nseg, c = i - fl * nseg;
-    const int it = face_item(fl, c);
-    const u32 sd = segs[it];
-    st_agent(face_q + i, nroots ? segb[it] : 0u);
-    st_agent(face_s + i, sd);
-    if (sd) s_seedface = 1u;
-  }
-  if (nroots)
-    for (int i = threadIdx.x; i < NFL * nseg * 8; i += NT) {
-      const int w = i & 7, fc = i >> 3, fl = fc / nseg, c = fc - fl * nseg;
-      const int it = face_item(fl, c);
-      const u32 q = segb[it];
-      const u32 nib = (q >> (4 * w)) & 0xFu;
-      if (!nib) continue;
-      u32 l = segpre[it] + (u32)__popc(q & ((1u << (4 * w)) - 1u));
-      u32 word = 0u;
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if ((nib >> b) & 1u) word |= (u32)rcell[l++] << (8 * b);
-      st_agent(face_l + i, word);
-    }
-  wait_vm_stores();  // (every wave: its face words, records and claims have left)
-  __syncthreads();
-  if (threadIdx.x == 0)
-    st_agent64(&F.tready[blockIdx.x], ((unsigned long long)V.epoch << 32) | (s_seedface ? 0x80000000ull : 0ull) | (unsigned long long)gbase);
-  const int dblk = V.ntiles_f + 1 + (int)blockIdx.x;
-  FR_DBG_MARK(F, dblk, 0);
-  // ---- the four lower neighbours ----
-  if (threadIdx.x < 4) {
-    const int k = (int)threadIdx.x;
-    const int ntx = T.tx + (k < 3 ? -1 : 0), nty = T.ty + (k < 3 ? k - 1 : -1);
-    u32 val = 0u;  // (no such tile: nothing to look at)
-    if (ntx >= 0 && nty >= 0 && nty < V.nty_f) {
-      const unsigned long long* p = &F.tready[ntx * V.nty_f + nty];
-      const unsigned long long t0 = wall_clock64();
-      for (;;) {
-        const unsigned long long v = ld_agent64(p);
-        if ((u32)(v >> 32) == V.epoch) {
-          val = (u32)v;
-          break;
-        }
-        if (wall_clock64() - t0 > 5000000ull) {  // 50 ms of the 100 MHz clock: give the search to the legacy chain
-          st_agent(&F.fctr[9], 19u);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    s_tb[k] = val;
-  }
-  if (threadIdx.x == 4) s_tb[4] = gbase;
-  __syncthreads();
-  FR_DBG_MARK(F, dblk, 1);
-  // ---- work list ----
-  // entry kinds: 0 (own Q0 face segment x lower neighbour's Q0 window -> root pairs), 0x40000000 (own Q0 face segment x
-  // lower neighbour's SEED window -> claims into own roots), 0x80000000 (own seed segment x Q0 window of one of the
-  // nine lines around it, own tile or lower neighbour -> claims into that line's roots)
-  auto put = [&](u32 e) {
-    const u32 slot = atomicAdd(&s_nw, 1u);
-    if (slot < XC_WCAP_F)
-      wl[slot] = e;
-    else
-      st_agent(&F.fctr[9], 18u);  // work list full (a tile made of seeds): the legacy chain takes the search
-  };
-  // own face lines: j < TY: (0, j); else (j - TY + 1, 0); offsets o: (-1,-1) (-1,0) (-1,+1) (0,-1) (+1,-1)
-  auto face_combo = [&](int j, int o, int& lx, int& ly, int& dx, int& dy, int& k) -> bool {
-    lx = j < TY ? 0 : j - TY + 1, ly = j < TY ? j : 0;
-    dx = o < 3 ? -1 : (o == 3 ? 0 : 1), dy = o < 3 ? o - 1 : -1;
-    if (lx >= T.nxl || ly >= T.nyl) return false;
-    const int xx = T.x0 + lx + dx, yy = T.y0 + ly + dy;
-    if (xx < V.px0 || xx > V.px1 || yy < V.py0 || yy > V.py1) return false;
-    if (dx == -1 && lx == 0) {  // column tx - 1
-      const int tdy = ly + dy < 0 ? -1 : (ly + dy >= TY ? 1 : 0);
-      k = tdy + 1;
-      return true;
-    }
-    if (dy == -1 && ly == 0 && lx + dx >= 0 && lx + dx < TX) {  // tile (tx, ty - 1)
-      k = 3;
-      return true;
-    }
-    return false;
-  };
-  if (nroots) {
-    const int nmy = TY + TX - 1;
-    for (int fi = threadIdx.x; fi < nmy * nseg * 5; fi += NT) {
-      const int o = fi % 5, js = fi / 5, j = js / nseg, c = js - j * nseg;
-      int lx, ly, dx, dy, k = 0;
-      if (!face_combo(j, o, lx, ly, dx, dy, k)) continue;
-      if (!segb[(lx * TY + ly) * nseg + c]) continue;
-      put((u32)fi);
-      if (s_tb[k] & 0x80000000u) put(0x40000000u | (u32)fi);
-    }
-  }
-  for (int it = threadIdx.x; it < items; it += NT) {
-    if (!segs[it]) continue;
-    for (int l = 0; l < 9; ++l) put(0x80000000u | (u32)(it * 9 + l));
-  }
-  __syncthreads();
-  FR_DBG_MARK(F, dblk, 2);
-  // ---- the list ----
-  auto own_window = [&](const u32* arr, int line, int c) -> u64 {  // bit j <-> z = 32 c - 1 + j
-    const u32* p = arr + line * nseg + c;
-    const u32 lo = c > 0 ? p[-1] >> 31 : 0u, hi = c + 1 < nseg ? p[1] & 1u : 0u;
-    return (u64)lo | ((u64)p[0] << 1) | ((u64)hi << 33);
-  };
-  auto face_window = [&](const u32* base, int fl, int c) -> u64 {  // (three loads, always legal: the first / last segment reads itself)
-    const u32* p = base + fl * nseg + c;
-    const u32 lo = ld_agent(p + (c > 0 ? -1 : 0)), mid = ld_agent(p), hi = ld_agent(p + (c + 1 < nseg ? 1 : 0));
-    return (u64)(c > 0 ? lo >> 31 : 0u) | ((u64)mid << 1) | ((u64)(c + 1 < nseg ? hi & 1u : 0u) << 33);
-  };
-  auto own_label = [&](int line, int z) -> u32 {
-    const int it = line * nseg + (z >> 5);
-    return (u32)rcell[segpre[it] + (u32)__popc(segb[it] & ((1u << (z & 31)) - 1u))];
-  };
-  auto face_label = [&](const u32* fbase, int fl, int z) -> u32 {
-    const u32 w = ld_agent(fbase + 2 * NFL * nseg + (fl * nseg + (z >> 5)) * 8 + ((z & 31) >> 2));
-    return (w >> (8 * (z & 3))) & 0xFFu;
-  };
-  struct Item {
-    u32 kind;     // 0, 1 (neighbour seeds -> own roots), 2 (own seeds -> roots of a line), 3: nothing
-    u32 bits;     // own segment (Q0 bits or seed bits)
-    int c;        // segment
-    int oline;    // own line the bits are from
-    int tline;    // kind 2, own tile: the line looked at
-    int fl;       // face line of the neighbour (-1: the line looked at is in the own tile)
-    u32 tb;       // id base of the tile the window is from
-    u32 adr;      // kind 1: address of the neighbour line's voxel z = 0; kind 2: address of the own line's voxel z = 0
-    const u32* fbase;
-  };
-  auto decode = [&](u32 e, Item& I) {
-    I.kind = 3u, I.bits = 0u, I.fl = -1, I.fbase = F.face, I.tb = 0u, I.c = 0, I.oline = 0, I.tline = 0, I.adr = 0u;
-    if (e >> 31) {
-      const int sj = (int)(e & 0x7FFFFFFFu), l = sj % 9, it = sj / 9;
-      const int line = it / nseg, lx = line / TY, ly = line - lx * TY;
-      const int dx = l / 3 - 1, dy = l % 3 - 1;
-      const int xx = T.x0 + lx + dx, yy = T.y0 + ly + dy;
-      if (xx < V.px0 || xx > V.px1 || yy < V.py0 || yy > V.py1) return;  // (no Q0 cells outside the tiles)
-      const int tdx = lx + dx < 0 ? -1 : (lx + dx >= TX ? 1 : 0), tdy = ly + dy < 0 ? -1 : (ly + dy >= TY ? 1 : 0);
-      I.c = it - line * nseg, I.oline = line, I.bits = segs[it];
-      I.adr = (u32)((long)(T.x0 + lx) * g.nyz + (long)(T.y0 + ly) * nz);
-      if (tdx == 0 && tdy == 0) {
-        if (!nroots) return;
-        I.kind = 2u, I.tline = (lx + dx) * TY + ly + dy, I.tb = s_tb[4];
-      } else if (tdx == -1 || (tdx == 0 && tdy == -1)) {
-        const int k = tdx == -1 ? tdy + 1 : 3;
-        I.kind = 2u, I.tb = s_tb[k] & 0x7FFFFFFFu;
-        I.fl = tdx == -1 ? ly + dy - tdy * TY : TY + lx + dx;
-        I.fbase = F.face + (size_t)((T.tx + tdx) * V.nty_f + T.ty + tdy) * fstride;
-      }  // (a higher tile looks at this tile's published seeds itself)
-      return;
-    }
-    const u32 fi = e & 0x3FFFFFFFu;
-    const int o = (int)(fi % 5u), js = (int)(fi / 5u), j = js / nseg;
-    int lx, ly, dx, dy, k = 0;
-    (void)face_combo(j, o, lx, ly, dx, dy, k);
-    I.c = js - j * nseg, I.oline = lx * TY + ly, I.bits = segb[I.oline * nseg + I.c];
-    I.kind = (e >> 30) & 1u;
-    I.tb = s_tb[k] & 0x7FFFFFFFu;
-    const int tdx = k < 3 ? -1 : 0, tdy = k < 3 ? k - 1 : -1;
-    I.fl = k < 3 ? ly + dy - tdy * TY : TY + lx + dx;
-    I.fbase = F.face + (size_t)((T.tx + tdx) * V.nty_f + T.ty + tdy) * fstride;
-    I.adr = (u32)((long)(T.x0 + lx + dx) * g.nyz + (long)(T.y0 + ly + dy) * nz);
-  };
-  auto xins = [&](u32 key) {
-    u32 h = (key * 2654435761u) >> 24;
-    bool done = false;
-    for (int probe = 0; probe < XC_SET && !done; ++probe) {
-      const u32 old = atomicCAS(&s_set[h], 0xFFFFFFFFu, key);
-      if (old == 0xFFFFFFFFu) {
-        s_list[atomicAdd(&s_n, 1u)] = key;
-        done = true;
-      } else if (old == key)
-        done = true;
-      h = (h + 1u) & (XC_SET - 1u);
-    }
-    if (!done) st_agent(&F.fctr[9], 15u);  // more than XC_SET distinct root pairs around one tile
-  };
-  u32 k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // up to two distinct pairs wait for the wave-level de-duplication
-  auto do_item = [&](const Item& I, u64 w3) {
-    const int c = I.c;
-    w3 &= (1ull << 34) - 1ull;
-    if (c == 0) w3 &= ~1ull;
-    const int jend = nz - 32 * c + 1;  // bit position of z = nz
-    if (jend < 34) w3 &= (1ull << jend) - 1ull;
-    if (I.kind == 2u) {  // own seeds: a component touching them is claimed by the lowest seed next to one of its cells
-      while (w3) {
-        int j, rl;
-        pop_run64(w3, j, rl);
-        const int b0 = max(j - 2, 0), b1 = min(j + rl - 1, 31);  // seeds at bits j - 2 .. j + rl - 1 touch the run
-        if (b0 > b1) continue;
-        const u32 m = I.bits & (((b1 - b0 + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (b1 - b0 + 1)) - 1u)) << b0);
-        if (!m) continue;
-        const int zr = 32 * c - 1 + j;  // first cell of the run
-        const u32 r = I.tb + (I.fl < 0 ? own_label(I.tline, zr) : face_label(I.fbase, I.fl, zr));
-        atomicMin(&F.tclaim[r], I.adr + (u32)(32 * c) + (u32)__builtin_ctz(m));
-      }
-      return;
-    }
-    u32 rem = I.bits;
-    while (rem && w3) {
-      int s, len;
-      pop_run32(rem, s, len);
-      u64 m = (w3 >> s) & ((1ull << (len + 2)) - 1ull);
-      if (!m) continue;
-      const u32 ga = s_tb[4] + own_label(I.oline, 32 * c + s);
-      if (I.kind == 1u) {  // the neighbour's seeds next to this run: the lowest one claims the run's component
-        atomicMin(&F.tclaim[ga], I.adr + (u32)(32 * c - 1 + s + __builtin_ctzll(m)));
-        continue;
-      }
-      while (m) {
-        int j, rl;
-        pop_run64(m, j, rl);
-        const u32 gb = I.tb + face_label(I.fbase, I.fl, 32 * c - 1 + s + j);
-        if (gb == ga) continue;
-        const u32 key = (min(ga, gb) << 16) | max(ga, gb);
-        if (key == k0 || key == k1) continue;
-        if (k0 == 0xFFFFFFFFu)
-          k0 = key;
-        else if (k1 == 0xFFFFFFFFu)
-          k1 = key;
-        else
-          xins(key);  // (a third distinct pair from one lane: rare)
-      }
-    }
-  };
-  auto flush_pairs = [&]() {  // (all lanes of the wave)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const u32 kq = q ? k1 : k0;
-      const bool on = kq != 0xFFFFFFFFu;
-      u64 todo = __ballot(on);
-      while (todo) {  // one insertion per distinct pair of the wave
-        const int leader = __builtin_ctzll(todo);
-        const u32 key = (u32)__shfl((int)kq, leader, 64);
-        todo &= ~__ballot(on && kq == key);
-        if (lane == leader) xins(key);
-      }
-    }
-    k0 = k1 = 0xFFFFFFFFu;
-  };
-  const u32 nw = min(s_nw, (u32)XC_WCAP_F);
-  for (u32 w0 = 0; w0 < nw; w0 += 2 * NT) {  // two items per lane and trip, their windows fetched together
-    Item A, B;
-    const u32 ja = w0 + threadIdx.x, jb = ja + NT;
-    A.kind = B.kind = 3u;
-    if (ja < nw) decode(wl[ja], A);
-    if (jb < nw) decode(wl[jb], B);
-    u64 wa = 0ull, wb = 0ull;
-    if (A.kind != 3u && A.bits)
-      wa = A.fl < 0 ? own_window(segb, A.tline, A.c) : face_window(A.fbase + (A.kind == 1u ? NFL * nseg : 0), A.fl, A.c);
-    if (B.kind != 3u && B.bits)
-      wb = B.fl < 0 ? own_window(segb, B.tline, B.c) : face_window(B.fbase + (B.kind == 1u ? NFL * nseg : 0), B.fl, B.c);
-    if (wa) do_item(A, wa);
-    flush_pairs();
-    if (wb) do_item(B, wb);
-    flush_pairs();
-  }
-  __syncthreads();
-  FR_DBG_MARK(F, dblk, 3);
-  // ---- the tile's distinct pairs, to the XCD's list ----
-  const u32 n = s_n;
-  if (n) {  // (uniform)
-    const u32 xcd = blockIdx.x & 7u;
-    if (threadIdx.x == 0) s_pbase = atomicAdd(&F.fctr[16 + xcd], n);
-    __syncthreads();
-    const u32 base = s_pbase;
-    if (base + n > FR_PCAP / 8u) {
-      if (threadIdx.x == 0) st_agent(&F.fctr[9], 14u);
-    } else if (threadIdx.x < n)
-      st_agent(&F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x], s_list[threadIdx.x]);
-  }
-  FR_DBG_MARK(F, dblk, 4);
-  // ---- last one out joins the roots ----
-  wait_vm_stores();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&F.fctr[24], 1u) == (u32)V.ntiles_f - 1u ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  if (rcap) (void)resolve_body<NT, true>(g, F, V, smem_raw, rcap);
 }
 
 // Flags (every claimed cell, every NQ seed) and the grouped result: the kept cells cluster by cluster in creation
@@ -3015,7 +2667,6 @@ static int frontier_twin_set(fuelmi_frontier* f) {
   G2.kept = G2.counts + 16;
   HIPCHK(hipMemsetAsync(G2.counts, 0, 16 * sizeof(u32), f->stream));
   HIPCHK(hipMemsetAsync(G2.fctr, 0, 32 * sizeof(u32), f->stream));
-  if (G2.tready) HIPCHK(hipMemsetAsync(G2.tready, 0, ((size_t)f->fast_tiles + 8) * sizeof(unsigned long long), f->stream));
   FVar* d_var2 = nullptr;
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_var2), sizeof(FVar)));
   f->allocs.push_back(d_var2);
@@ -3277,13 +2928,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       return rc;
     }
     size_t seg_words = 0;  // per-tile segment arrays: the largest (tiles x segments per tile) of the menu
-    size_t face_words = 0; // ... and the published faces of k_tile_chain
     for (int k = 0; k < 4; ++k) {
       const int ftx = f->FTX ? f->FTX : kFastMenu[k][0], fty = f->FTX ? f->FTY : kFastMenu[k][1];
       const size_t items = (size_t)(ftx * fty) * ((g.nz + 31) / 32);
       seg_words = std::max(seg_words, (size_t)((qx + 1 + ftx - 1) / ftx) * ((qy + 1 + fty - 1) / fty) * items);
-      face_words = std::max(face_words, (size_t)((qx + 1 + ftx - 1) / ftx) * ((qy + 1 + fty - 1) / fty) * (size_t)(ftx + fty) *
-                                            ((g.nz + 31) / 32) * 10);
       f->fast_items[k] = items;
       // k_tile_ccl: labels, bits + prefix, records, per-row counts, root numbers, component per cell
       f->tile_lds[k] = (FR_TCELL + 3 * items + 1 + (size_t)FR_TROOT * 8 + (size_t)FR_TROOT * FR_TXS) * sizeof(u32) +
@@ -3296,17 +2944,14 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       f->cross_lds[k] = (f->cross_lds[k] + 15) & ~(size_t)15;
       f->out_lds[k] = (f->out_lds[k] + 15) & ~(size_t)15;
     }
-    if ((rc = dmalloc(f, &F.tq, seg_words + 64)) || (rc = dmalloc(f, &F.ts, seg_words + 64)) ||
-        (rc = dmalloc(f, &F.face, face_words + 64)) || (rc = dmalloc(f, &F.tready, (size_t)f->fast_tiles + 8))) {
+    if ((rc = dmalloc(f, &F.tq, seg_words + 64)) || (rc = dmalloc(f, &F.ts, seg_words + 64))) {
       fuelmi_frontier_destroy(f);
       return rc;
     }
-    HIPCHK(hipMemsetAsync(F.tready, 0, ((size_t)f->fast_tiles + 8) * sizeof(unsigned long long), f->stream));  // (no search has epoch 0)
     const size_t lds_max = std::max(f->tile_lds[0], f->out_lds[0]);
     if (lds_max > 64 * 1024 && lds_max <= 150 * 1024) {
       // (the attribute belongs to the FUNCTION, not to this finder: always the kernels' ceiling, so that a second
       // finder with a shorter map cannot lower it under a taller finder's launches -- ADVICE r3)
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_chain<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -3667,16 +3312,7 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
   const int* nt3 = f->ft_threads;  // (per finder, fixed at creation: ADVICE r3 -- a process-wide static took the first finder's)
   if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[0], f->stream));
-  // round 6: tile CCL + cross-tile pairs + resolve in ONE launch (FUELMI_FR_CHAIN=0: the three kernels, for A/B runs)
-  static const bool chain_env = getenv("FUELMI_FR_CHAIN") && atoi(getenv("FUELMI_FR_CHAIN")) != 0;
-  const bool chain = chain_env && !capturing && nt3[0] == 512;
-  if (chain) {
-    // tile roots the last workgroup can join in the LDS its tile leaves it (more: the kernel k_resolve behind does it)
-    const size_t fixed = resolve_lds_bytes(0);
-    const u32 rcap = f->tile_lds[mk] > fixed ? (u32)std::min<size_t>((f->tile_lds[mk] - fixed) / 16, FR_RCAP) : 0u;
-    k_tile_chain<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var, rcap);
-    FDBG("k_tile_chain");
-  } else if (nt3[0] == 256)
+  if (nt3[0] == 256)
     k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   else
     k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
@@ -3698,11 +3334,15 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
     if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
   }
   g_ht.lap(5);
-  if (chain) {
-  } else if (nt3[1] == 256)
-    k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F);
-  else
-    k_tile_cross<512><<<tiles, 512, f->cross_lds[mk], f->stream>>>(g, F);
+  // round 6: the last workgroup of k_tile_cross resolves searches of up to 1 024 tile roots (FUELMI_FR_FUSE=0: never)
+  static const bool fuse = !(getenv("FUELMI_FR_FUSE") && atoi(getenv("FUELMI_FR_FUSE")) == 0);
+  if (nt3[1] == 256)
+    k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F, 0u);
+  else {
+    const size_t lds_x = fuse ? std::max(f->cross_lds[mk], resolve_lds_bytes(1024)) : f->cross_lds[mk];
+    const u32 rcap = fuse ? (u32)std::min<size_t>((lds_x - resolve_lds_bytes(0)) / 16, FR_RCAP) : 0u;
+    k_tile_cross<512><<<tiles, 512, lds_x, f->stream>>>(g, F, rcap);
+  }
   FDBG("k_tile_cross");
   g_ht.lap(6);
   k_resolve<<<1, RS_TK, f->resolve_lds, f->stream>>>(g, F);
@@ -4703,7 +4343,6 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
     const auto a5 = clk::now();
     if (serial) {
       HIPCHK(hipStreamSynchronize(m->stream));
-      if (m->batch_stream) HIPCHK(hipStreamSynchronize(m->batch_stream));
       if ((rc = fuelmi_frontier_search_begin(f))) break;
     }
     if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
@@ -4712,7 +4351,6 @@ extern "C" int fuelmi_bench_cycles(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
-  if (m->batch_stream) HIPCHK(stream_wait(m->batch_stream));
   HIPCHK(frontier_drain(f));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(clk::now() - t0).count();
@@ -4788,7 +4426,6 @@ extern "C" int fuelmi_bench_cycles_delivered(fuelmi_map* m, fuelmi_frontier* f, 
   (void)fuelmi_frontier_keep_previous(f, kept ? 1 : 0);
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
-  if (m->batch_stream) HIPCHK(stream_wait(m->batch_stream));
   HIPCHK(frontier_drain(f));
   f->tail_pending = false;
   seconds3[0] = std::chrono::duration<double>(clk::now() - t0).count();
@@ -4844,7 +4481,6 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
       if ((rc = map_chain())) break;
       int npts_next = 0;
       HIPCHK(hipStreamSynchronize(m->stream));
-      if (m->batch_stream) HIPCHK(hipStreamSynchronize(m->batch_stream));
       if ((rc = fuelmi_frontier_search_begin(f))) break;
       if ((rc = fuelmi_frontier_search_end(f, &ncl))) break;
       if ((rc = fuelmi_frontier_commit(f, 0))) break;
@@ -4940,7 +4576,6 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   }
   if (rc) return rc;
   HIPCHK(stream_wait(m->stream));
-  if (m->batch_stream) HIPCHK(stream_wait(m->batch_stream));
   HIPCHK(frontier_drain(f));
   f->tail_pending = false;
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

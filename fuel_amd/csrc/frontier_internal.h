@@ -129,10 +129,6 @@ struct FArgs {
   u32* fctr;              // [32] [0..7] roots per XCD range, [9] overflow -> legacy chain, [16..23] pairs per XCD
   int fast;               // the result of the last search came from the fast path
   unsigned long long* dbg;  // FUELMI_FR_TIMING: per-block phase time stamps of the fast chain's kernels (else null)
-  // k_tile_chain (tile CCL + cross-tile pairs + resolve in ONE launch): what a tile's higher-indexed neighbours need of it
-  u32* face;                   // [tiles][(ftx + fty) * nseg * 10] per face line and 32-voxel segment: Q0 bits, seed bits, 8 words of
-                               // component numbers (one byte per voxel) -- the tile's last x-row, then its last y-line per x-row
-  unsigned long long* tready;  // [tiles] epoch << 32 | "has NQ seeds" << 31 | id of the tile's component 0: the faces are published
 };
 // Result words in pinned host memory: the data stores of a workgroup, a barrier, then ONE lane stores the stamp
 // the polling host waits for with RELEASE semantics at system scope.  (A relaxed stamp was tried -- the release
@@ -149,15 +145,9 @@ struct FArgs {
 // Relaxed accesses at AGENT scope: the store goes through the XCD's L2 to memory, the load comes from there -- how
 // workgroups of ONE launch (which may sit on different XCDs, each with its own write-back L2) hand data to each other
 // without a release fence (= an L2 write-back, which also flushes what the ESDF passes of the same cycle hold dirty).
-// Order: data stores, s_waitcnt vmcnt(0), workgroup barrier, then the flag / counter.
+// Order: data stores, s_waitcnt vmcnt(0), workgroup barrier, then the counter.
 __device__ __forceinline__ void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void wait_vm_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // two tile-root records (48 bytes each, 16-byte aligned) with six 16-byte agent-scope loads and ONE wait
 __device__ __forceinline__ void ld_agent_trec2(const TRec* p0, const TRec* p1, TRec& A, TRec& B) {

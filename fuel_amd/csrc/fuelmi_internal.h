@@ -196,13 +196,6 @@ struct fuelmi_map {
   hipEvent_t t0 = nullptr, t1 = nullptr;  // fuelmi_timer_begin / _end
   int last_inflate_kernel = -1;           // 0: k_inflate_fused, 1: the factored pair (fuelmi_map_last_inflate_kernel)
   hipEvent_t t_prof0 = nullptr;           // origin of fuelmi_profile_get_timeline (recorded by fuelmi_profile_enable)
-  // The batched cost / gradient evaluation (fuelmi_bspline_dev_eval) reads the distance field only: it runs on a side
-  // stream behind everything queued on the map's stream so far, BESIDE what the map's stream does next (the next
-  // update's inflation and z/y pass -- neither touches the field); the next writer of the field waits for it
-  // (map_batch_join: the x pass of an ESDF update, a reset, and everything that touches the batch's buffers)
-  hipStream_t batch_stream = nullptr;
-  hipEvent_t ev_batch_dep = nullptr, ev_batch_done = nullptr;
-  bool batch_pending = false;
   hipEvent_t ev_planes = nullptr;  // recorded after every kernel that rewrites the occupancy state planes
   unsigned long long planes_ver = 0;  // ... and counted: a search stream that has already waited for this record does not queue the wait again
   // ... and the other direction: the last kernel of a running frontier search that READS those planes (set by
@@ -231,12 +224,7 @@ struct fuelmi_map {
 };
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
-// the map's stream waits for the batch evaluation launched last (no-op when none is in flight)
-static inline hipError_t map_batch_join(fuelmi_map* m) {
-  if (!m->batch_pending) return hipSuccess;
-  m->batch_pending = false;
-  return hipStreamWaitEvent(m->stream, m->ev_batch_done, 0);
-}
+
 // Streams of the library.  `which` names the role ("MAP": a map's stream, "FR": a finder's search streams); the experiment
 // hook FUELMI_CUMASK_<which> = "<xcd mask>:<CUs per XCD>" (e.g. FUELMI_CUMASK_FR=0x03:32, FUELMI_CUMASK_MAP=0xfc:32)
 // creates the stream with hipExtStreamCreateWithCUMask instead: the CU mask's bit i selects the (i / 8)-th CU of XCD i % 8

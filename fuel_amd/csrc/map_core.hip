@@ -757,9 +757,6 @@ extern "C" void fuelmi_map_destroy(fuelmi_map* m) {
   if (m->t_prof0) (void)hipEventDestroy(m->t_prof0);
   if (m->t1) (void)hipEventDestroy(m->t1);
   if (m->ev_planes) (void)hipEventDestroy(m->ev_planes);
-  if (m->batch_stream) (void)hipStreamSynchronize(m->batch_stream), (void)hipStreamDestroy(m->batch_stream);
-  if (m->ev_batch_dep) (void)hipEventDestroy(m->ev_batch_dep);
-  if (m->ev_batch_done) (void)hipEventDestroy(m->ev_batch_done);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -875,7 +872,6 @@ extern "C" int fuelmi_map_update_esdf(fuelmi_map* m) {
   {                                                             \
     const int rcq__ = map_wait_query_readers(m);                \
     if (rcq__) return rcq__;                                    \
-    HIPCHK(map_batch_join(m));                                  \
   }
 
 extern "C" int fuelmi_map_reset_buffer(fuelmi_map* m, const double min_pos[3], const double max_pos[3]) {
