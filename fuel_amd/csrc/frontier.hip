@@ -184,11 +184,71 @@ k_rm_pool(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u64* 
     if (d_mark[k] == mark) atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
   }
 }
+// Both modes in ONE launch of many workgroups (round 6; a streaming frame's changed-cluster test walks a 20 k-cell
+// surface: too long for one workgroup, and two dependent launches stood at the head of the frame's critical loop):
+// the marks leave with agent-scope stores, every workgroup counts itself in behind s_waitcnt vmcnt(0) and spins until
+// the count reaches `target` (the host keeps the running total: nobody resets the counter), then clears the flags of
+// the marked clusters, reading the marks past its L2.  The grid is capped at RM_BAR_BLOCKS workgroups of 256 lanes --
+// far below what the chip holds at once, so every workgroup is resident (or becomes so as other kernels drain) while
+// the others spin: no deadlock.  No fence anywhere.
+#define RM_BAR_BLOCKS 512
+__global__ void __launch_bounds__(256)
+k_rm_pool_bar(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u64* flag, const u32* __restrict__ pool,
+              const RmCand* __restrict__ cand, int ncand, u32 total, int* d_mark, int mark, int* h_changed, u32* bar, u32 target) {
+  __shared__ u32 s_start[RM_LDS];
+  __shared__ u64 s_off[RM_LDS];
+  for (int k = threadIdx.x; k < ncand; k += 256) {  // (ncand <= RM_LDS: checked by the host)
+    const RmCand c = cand[k];
+    s_start[k] = c.start;
+    s_off[k] = c.off;
+  }
+  __syncthreads();
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  int k = 0;
+  u32 a = 0u;
+  bool chg = false;
+  if (i < total) {
+    k = rm_cluster_of(s_start, ncand, i);
+    a = pool[s_off[k] + (i - s_start[k])];
+    chg = !f1_cell(g, occ, unk, a);
+  }
+  {  // one mark per wave and cluster (a wave's cells nearly always belong to one cluster: the verdict crosses PCIe)
+    const unsigned long long bm = __ballot(chg);
+    if (bm) {
+      const int leader = __builtin_ctzll(bm);
+      const int kl = __shfl(k, leader, 64);
+      if (chg && ((int)(threadIdx.x & 63) == leader || k != kl)) {
+        st_agent(reinterpret_cast<u32*>(d_mark) + k, (u32)mark);
+        h_changed[k] = 1;
+      }
+    }
+  }
+  wait_vm_stores();
+  __syncthreads();
+  // arrival: ONE returning atomic per workgroup; the last arriver releases everybody through per-workgroup words 64 bytes
+  // apart (pollers of one word serialise at the memory-side atomic unit and starve the arrivals: measured, 9 % of a frame)
+  __shared__ u32 s_lastw;
+  if (threadIdx.x == 0) s_lastw = atomicAdd(bar, 1u) + 1u == target ? 1u : 0u;
+  __syncthreads();
+  if (s_lastw) {
+    for (u32 w = threadIdx.x; w < gridDim.x; w += 256) st_agent(bar + 16u * (w + 1u), (u32)mark);
+  } else if (threadIdx.x == 0) {
+    const u32* mine = bar + 16u * (blockIdx.x + 1u);
+    const unsigned long long t0 = wall_clock64();
+    for (u32 spins = 0; ld_agent(mine) != (u32)mark; ++spins) {
+      if ((spins & 63u) == 63u && wall_clock64() - t0 > 5000000ull) break;  // (50 ms: unreachable with a resident grid; never hang the device)
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (i < total && ld_agent(reinterpret_cast<const u32*>(d_mark) + k) == (u32)mark) atomicAnd(&flag[a >> 6], ~(1ull << (a & 63)));
+}
 // both modes in ONE workgroup for the searches of an exploration (a few thousand pooled cells in the clusters the updated
 // box touches: one launch instead of two dependent ones -- the first kernels of a streaming frame's critical path).
 // The marks live in LDS; h_changed[k] is written as by MODE 0.
 #define RM_ONE_T 1024
-#define RM_ONE_CELLS (16 * RM_ONE_T)
+#define RM_ONE_CELLS (2 * RM_ONE_T)  // (round 6: was 16 per lane -- a streaming frame's 10-16 k-cell candidates kept ONE workgroup busy for 13-77 us,
+                                     // profiles/r06_rm_pool_variants.txt; beyond two cells per lane k_rm_pool_bar takes the test)
 __global__ void __launch_bounds__(RM_ONE_T)
 k_rm_pool_one(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u64* flag, const u32* __restrict__ pool,
               const RmCand* __restrict__ cand, int ncand, u32 total, int* h_changed) {
@@ -2737,6 +2797,7 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   if (f->h_cand) (void)hipHostFree(f->h_cand);
   if (f->h_put) (void)hipHostFree(f->h_put);
   if (f->d_mark) (void)hipFree(f->d_mark);
+  if (f->rm_bar) (void)hipFree(f->rm_bar);
   frontier_split_free(f);
   frontier_order_free(f);
   for (auto& row : f->graph_exec)
@@ -3182,6 +3243,19 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
     return FUELMI_OK;
   }
   const int mark = ++f->rm_mark;  // (marks of earlier searches never match: no clearing pass)
+  if (nc <= RM_LDS && fblocks((long)total, 256) <= RM_BAR_BLOCKS && !one_off) {
+    if (!f->rm_bar) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&f->rm_bar), 64 * (RM_BAR_BLOCKS + 1)));
+      HIPCHK(hipMemsetAsync(f->rm_bar, 0, 64 * (RM_BAR_BLOCKS + 1), f->stream));
+      f->rm_bar_total = 0u;
+    }
+    const int nb = fblocks((long)total, 256);
+    f->rm_bar_total += (u32)nb;
+    k_rm_pool_bar<<<nb, 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc, (int)nc, total, f->d_mark,
+                                             mark, f->h_changed, f->rm_bar, f->rm_bar_total);
+    FDBG("k_rm_pool_bar");
+    return FUELMI_OK;
+  }
   k_rm_pool<0><<<fblocks((long)total, 256), 256, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc,
                                                                (int)nc, total, f->d_mark, mark, f->h_changed);
   FDBG("k_rm_pool<0>");

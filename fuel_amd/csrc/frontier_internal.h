@@ -387,6 +387,8 @@ struct fuelmi_frontier {
   void* h_cand = nullptr;    // pinned (pool offset, first index) table of the candidates, read by the kernels
   int* d_mark = nullptr;     // device: search number in which candidate k was last found changed
   int rm_mark = 0;
+  u32* rm_bar = nullptr;     // device: arrival counter of k_rm_pool_bar's in-kernel barrier (never reset: rm_bar_total is its target)
+  u32 rm_bar_total = 0;
   void* h_put = nullptr;     // pinned table of k_pool_put
   size_t h_put_cap = 0;
   u32* pool = nullptr;  // device copies of the cells of frontiers_ / dormant_frontiers_
