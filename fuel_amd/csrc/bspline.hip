@@ -1143,8 +1143,7 @@ extern "C" int fuelmi_bspline_dev_optimize_timed(fuelmi_bspline_dev* b, int max_
   HIPCHK(hipSetDevice(m->device));
   const BsplineArgs& A = b->a;
   const size_t C = (size_t)A.C, n = (size_t)A.nvar;
-  static const bool lds_path = getenv("FUELMI_OPT_LDS") != nullptr;  // tuning hook: force the LDS-state kernel
-  const int npl = lds_path ? 0 : (n <= 128 ? 2 : (n <= 256 ? 4 : 0));  // register-state kernel up to 256 variables
+  const int npl = n <= 128 ? 2 : (n <= 256 ? 4 : 0);  // register-state kernel up to 256 variables
   const size_t lds_opt = npl ? b->lds_eval4 + 2 * n * sizeof(double)
                              : b->lds + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
   if (lds_opt > 160 * 1024) {
@@ -1280,8 +1279,7 @@ static int bspline_oneshot(fuelmi_map* m, const fuelmi_bspline_cfg* cfg, const f
     A.cost = o_a, A.grad = o_b;
     k_bspline_cost_grad<<<A.C, 256, lds4, q.s->st>>>(m->g, m->dist, A);
   } else {
-    static const bool lds_path = getenv("FUELMI_OPT_LDS") != nullptr;
-    const int npl = lds_path ? 0 : (n <= 128 ? 2 : (n <= 256 ? 4 : 0));
+    const int npl = n <= 128 ? 2 : (n <= 256 ? 4 : 0);
     const size_t lds_opt = npl ? lds_eval + ((size_t)A.N * 12 + 8) * sizeof(double) + 2 * n * sizeof(double)
                                : lds_eval + ((6 + 2 * LBFGS_MEM) * n + 2 * LBFGS_MEM) * sizeof(double);
     if (lds_opt > 160 * 1024) {

@@ -259,16 +259,10 @@ __device__ __forceinline__ int line_src_up(const u64* __restrict__ infl, const u
 // ------------------------------------------------------------------------------------------------
 #define ESDF_FAR_D 8u  // statistic: an output counts as "far from sources" beyond this many voxels
 #define ESDF_NG 256    // groups of 16 x-slabs the statistic is kept for (maps wider than 4096 voxels share groups)
-static bool zy_fastrow() {  // rows of the fused z/y pass that need no sweep (all sources / no source): measured
-  static const char* e = getenv("FUELMI_ZY_FASTROW");  // 400^2 x 100: 38.8 -> 37.2 us, 800^2 x 200: 188 -> 172 us
-  static const bool v = e ? atoi(e) != 0 : true;
-  return v;
-}
-static int esdf_near() {  // rows the FAR kernels scan one by one before the block walk (even: two rows per trip)
-  static const char* e = getenv("FUELMI_ESDF_NEAR");
-  static const int v = e ? std::max(2, atoi(e) & ~1) : 2;
-  return v;
-}
+// rows of the fused z/y pass that need no sweep (all sources / no source) take a short cut: measured 38.8 -> 37.2 us on
+// 400^2 x 100, 188 -> 172 us on 800^2 x 200
+static bool zy_fastrow() { return true; }
+static int esdf_near() { return 2; }  // rows the FAR kernels scan one by one before the block walk (even: two rows per trip)
 // one 16-byte global store that stays one instruction (a plain uint4 assignment next to the per-component edge
 // path came out as a 12-byte plus a 4-byte store)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -1004,8 +998,7 @@ enum { ESDF_NO_FIT = 1 };
 // the device and the pinned-host tables of the far-output statistic
 template <int OUT>
 static u32* esdf_stat_dev(fuelmi_map* m) {
-  static const bool off = getenv("FUELMI_ESDF_NOSTAT") != nullptr;
-  return OUT == 0 && !off ? m->esdf_stat : nullptr;
+  return OUT == 0 ? m->esdf_stat : nullptr;
 }
 static volatile u32* esdf_stat_host(fuelmi_map* m) { return m->h_esdf_stat; }
 
@@ -1538,18 +1531,15 @@ static int launch_zy_pk2(fuelmi_map* m, const Box3& b) {
   if ((size_t)((xlen + 1) >> 1) * 128 > 150 * 1024) return ESDF_NO_FIT;  // (the x pass's tile)
   // widest chunk: 4 segments (16 voxels; the 8-segment body needs 110 VGPRs and measured 46 against 34 us on the
   // 400^2 x 100 map) while the two tiles of a slab pair stay within 52 KB (three workgroups per CU), else 2
-  static const char* g_env = getenv("FUELMI_ZY_PK_G");  // tuning hook: 8, 4 or 2
   int g_max = 4;
   while (g_max > 2 && (size_t)npair * g_max * 32 > 52 * 1024) g_max >>= 1;
-  if (g_env && (atoi(g_env) == 8 || atoi(g_env) == 4 || atoi(g_env) == 2)) g_max = atoi(g_env);
   const size_t lds = (size_t)npair * g_max * 32;
   if (lds > 160 * 1024 - 64) return ESDF_NO_FIT;
   if (pk2_chunks(ylen, zlen_a >> 2, g_max, &m->pk2_ch, &m->pk2_zch) != FUELMI_OK) return ESDF_NO_FIT;
   if ((size_t)m->pk2_ch.tile0[m->pk2_ch.n] * (size_t)((xlen + 1) >> 1) * 128 > m->esdf_tmp16_bytes) return ESDF_NO_FIT;
-  static const char* th_env = getenv("FUELMI_ZY_PK_THREADS");  // tuning hook (threads of ONE half)
   // a half fills its npair rows in two trips: 128 / 256 lanes for 400- / 800-voxel y lines (measured: 33.5 against 35.5 us
   // with one trip on the 400^2 x 100 map, 158 against 203 us on 800^2 x 200, whose 896-thread workgroups fit one per CU)
-  const int threads = 2 * (th_env ? atoi(th_env) : std::min(256, std::max(64, ((npair / 2 + 63) / 64) * 64)));
+  const int threads = 2 * std::min(256, std::max(64, ((npair / 2 + 63) / 64) * 64));
   const bool wide = zlen_a > 128;  // aligned z-lines of up to 128 / 256 bits
   (void)pk2_next_serial(m);
   if (g_max == 8) return wide ? launch_zy_pk2_g<MODE, 8, 4>(m, b, z0a, threads, lds) : launch_zy_pk2_g<MODE, 8, 2>(m, b, z0a, threads, lds);
@@ -1566,8 +1556,7 @@ static int launch_x_pk2(fuelmi_map* m, const Box3& b) {
   const int npx = (xlen + 1) >> 1;
   const size_t lds = (size_t)npx * 8 * 16;
   if (lds > 64 * 1024) HIPCHK(lds_attr_once(reinterpret_cast<const void*>(&k_esdf_x_pk2<OUT>), 150 * 1024));
-  static const char* th_env = getenv("FUELMI_X_PK_THREADS");  // tuning hook
-  const int threads = th_env ? atoi(th_env) : (lds > 32 * 1024 ? 512 : 256);
+  const int threads = lds > 32 * 1024 ? 512 : 256;
   static const bool timing = getenv("FUELMI_ZY_TIMING") != nullptr;
   const int ylen = b.hi[1] - b.lo[1] + 1;
   const int full8 = ((ylen + 7) / 8) * 8 * m->pk2_ch.n8;  // blocks of the full-width tiles, y-rows padded to a multiple of 8

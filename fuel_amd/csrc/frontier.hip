@@ -2697,21 +2697,16 @@ static int dmalloc(fuelmi_frontier* f, T** p, size_t n) {
     f->f_scratch.push_back({(size_t)(fp - f0), std::max<size_t>(n, 1) * sizeof(T)});
   return FUELMI_OK;
 }
-// priority of the finder's streams: the highest by default (a chain of short latency-bound kernels beside the wide
-// ESDF passes); FUELMI_FR_PRIO = "high" | "normal" | "low" for A/B runs
+// priority of the finder's streams: the highest (a chain of short latency-bound kernels beside the wide ESDF passes;
+// normal / lowest measured in rounds 3, 4 and 6: within the run-to-run spread or worse, profiles/r06_frontier_prio_threads_sweep2.txt)
 static int frontier_stream_priority() {
   int lo_p = 0, hi_p = 0;
   if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) return 0;
-  static const char* e = getenv("FUELMI_FR_PRIO");
-  if (e && !strcmp(e, "normal")) return 0;
-  if (e && !strcmp(e, "low")) return lo_p;
   return hi_p;
 }
 // the second set of per-search buffers (see fuelmi_frontier::F2): a twin of every device buffer F points to, its own
 // per-search variables and its own pinned result block
 static int frontier_twin_set(fuelmi_frontier* f) {
-  static const bool one = getenv("FUELMI_FR_ONE_STREAM") != nullptr;  // A/B hook: the round-3 behaviour
-  if (one) return FUELMI_OK;
   FArgs& F = f->F;
   f->F2 = F;
   char* f2 = reinterpret_cast<char*>(&f->F2);
@@ -2803,17 +2798,6 @@ extern "C" void fuelmi_frontier_destroy(fuelmi_frontier* f) {
   for (auto& row : f->graph_exec)
     for (hipGraphExec_t e : row)
       if (e) (void)hipGraphExecDestroy(e);
-  for (auto& row : f->fast_exec)
-    for (hipGraphExec_t e : row)
-      if (e) (void)hipGraphExecDestroy(e);
-  for (auto& row : f->fast_graph)
-    for (hipGraph_t gph : row)
-      if (gph) (void)hipGraphDestroy(gph);
-  if (f->zstream) {
-    (void)hipStreamSynchronize(f->zstream);
-    (void)hipStreamDestroy(f->zstream);
-  }
-  if (f->ev_zero) (void)hipEventDestroy(f->ev_zero);
   if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
   if (f->ev_prev) (void)hipEventDestroy(f->ev_prev);
   if (f->ev_planes_read) {
@@ -2903,8 +2887,6 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     HIPCHK(fuelmi_stream_create(&f->stream, frontier_stream_priority(), "FR"));
   }
   HIPCHK(hipEventCreateWithFlags(&f->ev_dep, hipEventDisableTiming));
-  // (zstream -- zeroes the retired flag plane in one-stream mode -- is created on first use, frontier_finish_reset)
-  HIPCHK(hipEventCreateWithFlags(&f->ev_zero, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_prev, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&f->ev_planes_read, hipEventDisableTiming));
@@ -2939,17 +2921,10 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   F.h_rec = reinterpret_cast<KeptRec*>(F.h_counts + 16);
   F.h_part = reinterpret_cast<u32*>(F.h_rec + F.cap_kept);
   F.h_cells = F.h_part + ((size_t)F.cap_q / SZ_CH + 2) * 10;
-  {
-    static const char* e = getenv("FUELMI_HCELLS_DIRECT");  // tuning hook
-    F.hcells_direct_max = e ? (u32)atol(e) : FR_HCELLS_DIRECT;
-  }
+  F.hcells_direct_max = FR_HCELLS_DIRECT;
   // CCL tile = TX x TY z-lines with u32 labels in LDS (<= 48 KiB so three workgroups share a CU)
   f->TY = 16;
   f->TX = std::max(1, std::min(8, (48 * 1024) / (f->TY * g.nz * 4)));
-  if (const char* e = getenv("FUELMI_CCL_TILE")) {  // tuning hook: "TXxTY"
-    int a = 0, b = 0;
-    if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && b > 0 && (size_t)a * b * g.nz * 4 <= 150 * 1024) f->TX = a, f->TY = b;
-  }
   const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 1, qy = F.qbox.hi[1] - F.qbox.lo[1] + 1;
   f->ccl_tiles = 0;
   if (qx > 0 && qy > 0 && F.qbox.lo[2] <= F.qbox.hi[2]) {
@@ -2964,22 +2939,15 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     }
     if (f->ccl_lds > 64 * 1024)
     {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local<256>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->ccl_lds));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_local<512>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->ccl_lds));
     }
     // fast path: sparse labels -- the tile is not bound by nz.  32 z-lines deep, 8 wide, 16 wide once that
     // still leaves >= 512 tiles (measured on 400^2 x 100 and 800^2 x 200 maps: fewer tile roots and face pairs
-    // for k_tile_cross / k_resolve outweigh the longer tiles); FUELMI_FTILE = "TXxTY" overrides.
+    // for k_tile_cross / k_resolve outweigh the longer tiles).
     // The tile of a search is picked from a menu by the size of its region; the launch grid of a menu entry is
     // that tile over the largest rectangle a search can cover (the Q box plus the box_max face of the scan box).
-    f->FTX = f->FTY = 0;
-    if (const char* e = getenv("FUELMI_FTILE")) {
-      int a = 0, b = 0;
-      if (sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && a <= FR_TXS && b > 0 && b <= 32) f->FTX = a, f->FTY = b;
-    }
-    const int mtx = f->FTX ? f->FTX : 4, mty = f->FTX ? f->FTY : 8;  // smallest tile in use
+    const int mtx = 4, mty = 8;  // smallest tile of the menu
     f->fast_tiles = ((qx + 1 + mtx - 1) / mtx) * ((qy + 1 + mty - 1) / mty);
     F.pm_stride = (qx + 1 + mtx - 1) / mtx;
     if ((rc = dmalloc(f, &F.vlab, (size_t)g.N + 64)) || (rc = dmalloc(f, &F.tlab, (size_t)f->fast_tiles * FR_TCELL)) ||
@@ -2990,7 +2958,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
     }
     size_t seg_words = 0;  // per-tile segment arrays: the largest (tiles x segments per tile) of the menu
     for (int k = 0; k < 4; ++k) {
-      const int ftx = f->FTX ? f->FTX : kFastMenu[k][0], fty = f->FTX ? f->FTY : kFastMenu[k][1];
+      const int ftx = kFastMenu[k][0], fty = kFastMenu[k][1];
       const size_t items = (size_t)(ftx * fty) * ((g.nz + 31) / 32);
       seg_words = std::max(seg_words, (size_t)((qx + 1 + ftx - 1) / ftx) * ((qy + 1 + fty - 1) / fty) * items);
       f->fast_items[k] = items;
@@ -2999,7 +2967,7 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
                        FR_TCELL * sizeof(unsigned short) + FR_TCELL;
       f->cross_lds[k] = (2 * items + (size_t)XC_WCAP) * sizeof(u32);
       // k_tile_out: bits + prefix + seed bits, cell addresses, the two row tables, cluster map, codes, keys
-      f->out_lds[k] = (3 * items + 1 + FR_TCELL + 2 * (size_t)(f->FTX ? f->FTX : kFastMenu[k][0]) * FR_TROOT + FR_KCAP + FR_TROOT) * sizeof(u32) +
+      f->out_lds[k] = (3 * items + 1 + FR_TCELL + 2 * (size_t)kFastMenu[k][0] * FR_TROOT + FR_KCAP + FR_TROOT) * sizeof(u32) +
                       FR_TCELL * sizeof(unsigned short);
       f->tile_lds[k] = (f->tile_lds[k] + 15) & ~(size_t)15;
       f->cross_lds[k] = (f->cross_lds[k] + 15) & ~(size_t)15;
@@ -3015,8 +2983,6 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
       // finder with a shorter map cannot lower it under a taller finder's launches -- ADVICE r3)
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_ccl<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_out<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
   }
   f->resolve_lds = resolve_lds_bytes(FR_RCAP);
@@ -3025,15 +2991,6 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   // the fast path needs tiles, a cluster threshold that rules out one-seed clusters, and tile-local indices
   // that fit the 16-bit root numbers
   // (a thread of the tile kernels fetches at most FT_PER segments: z-lines of up to 256 voxels with the largest tile)
-  // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
-  f->ft_threads[0] = f->ft_threads[1] = f->ft_threads[2] = 512;
-  if (const char* e = getenv("FUELMI_FT_THREADS")) {
-    int a = 0, b2 = 0, c = 0;
-    if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3)
-      f->ft_threads[0] = a == 256 ? 256 : 512, f->ft_threads[1] = b2 == 256 ? 256 : 512, f->ft_threads[2] = c == 256 ? 256 : 512;
-  }
-  if (f->fast_items[0] > (size_t)FT_PER * 256)  // (a lane fetches at most FT_PER segments)
-    f->ft_threads[0] = f->ft_threads[1] = f->ft_threads[2] = 512;
   f->fast_ok = f->ccl_tiles > 0 && cfg->cluster_min >= 1 && std::max(f->tile_lds[0], f->out_lds[0]) <= 150 * 1024 &&
                f->fast_items[0] <= (size_t)FT_PER * 512 && getenv("FUELMI_FRONTIER_LEGACY") == nullptr;
   if ((rc = frontier_twin_set(f))) {
@@ -3235,15 +3192,14 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
     HIPCHK(hipMemcpyAsync(f->d_stage, hc, nc * sizeof(RmCand), hipMemcpyHostToDevice, f->stream));
     hc = reinterpret_cast<RmCand*>(f->d_stage);
   }
-  static const bool one_off = getenv("FUELMI_RM_TWO_PASS") != nullptr;  // A/B switch
-  if (nc <= RM_LDS && total <= RM_ONE_CELLS && !one_off) {
+  if (nc <= RM_LDS && total <= RM_ONE_CELLS) {
     k_rm_pool_one<<<1, RM_ONE_T, 0, f->stream>>>(m->g, m->occ_bits.p, m->unk_bits.p, f->flag.p, f->pool, hc, (int)nc, total,
                                                  f->h_changed);
     FDBG("k_rm_pool_one");
     return FUELMI_OK;
   }
   const int mark = ++f->rm_mark;  // (marks of earlier searches never match: no clearing pass)
-  if (nc <= RM_LDS && fblocks((long)total, 256) <= RM_BAR_BLOCKS && !one_off) {
+  if (nc <= RM_LDS && fblocks((long)total, 256) <= RM_BAR_BLOCKS) {
     if (!f->rm_bar) {
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&f->rm_bar), 64 * (RM_BAR_BLOCKS + 1)));
       HIPCHK(hipMemsetAsync(f->rm_bar, 0, 64 * (RM_BAR_BLOCKS + 1), f->stream));
@@ -3311,11 +3267,7 @@ static int frontier_enqueue_chain(fuelmi_frontier* f, int npass) {
   if (f->ccl_tiles > 0) {
     // 512 threads per tile: the busiest tiles (a wall of ~2000 cells) set the kernel's duration, and their
     // cells are independent chains of LDS unions (measured 29.5 -> 24.1 us on G400; 1024 loses occupancy)
-    static const int ccl_threads = getenv("FUELMI_CCL_THREADS") ? atoi(getenv("FUELMI_CCL_THREADS")) : 512;
-    if (ccl_threads == 512)
-      k_ccl_local<512><<<f->ccl_tiles, 512, f->ccl_lds, f->stream>>>(g, F, f->TX, f->TY);
-    else
-      k_ccl_local<256><<<f->ccl_tiles, 256, f->ccl_lds, f->stream>>>(g, F, f->TX, f->TY);
+    k_ccl_local<512><<<f->ccl_tiles, 512, f->ccl_lds, f->stream>>>(g, F, f->TX, f->TY);
     FDBG("k_ccl_local");
     k_union<<<cgrid, 256, 0, f->stream>>>(g, F, f->TX, f->TY);
     FDBG("k_union");
@@ -3374,45 +3326,37 @@ struct HostTiming {
 };
 static HostTiming g_ht;
 
-// the fast chain (capturable); falls back to the legacy one through counts[2] == 2
-static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
+// the fast chain: four direct launches (512-lane tile workgroups: 256 lanes measured 4-11 % slower in round 3 and again
+// in round 6, profiles/r06_frontier_threads_prio_sweep.txt); falls back to the legacy one through counts[2] == 2
+static int frontier_enqueue_fast(fuelmi_frontier* f) {
   const Geo& g = f->map->g;
   FArgs& F = f->F;
   // launch grid of the tile kernels: the chosen tile over the largest rectangle a search can cover
   const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 2, qy = F.qbox.hi[1] - F.qbox.lo[1] + 2;
-  const int mk = f->FTX ? 0 : f->fast_menu;
-  const int ftx = f->FTX ? f->FTX : kFastMenu[mk][0], fty = f->FTX ? f->FTY : kFastMenu[mk][1];
+  const int mk = f->fast_menu;
+  const int ftx = kFastMenu[mk][0], fty = kFastMenu[mk][1];
   const int tiles = ((qx + ftx - 1) / ftx) * ((qy + fty - 1) / fty);
-  // workgroup sizes of the three tile kernels (tuning hook: FUELMI_FT_THREADS="ccl,cross,out", each 256 or 512)
-  const int* nt3 = f->ft_threads;  // (per finder, fixed at creation: ADVICE r3 -- a process-wide static took the first finder's)
-  if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[0], f->stream));
-  if (nt3[0] == 256)
-    k_tile_ccl<256><<<tiles, 256, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
-  else
-    k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
+  if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[0], f->stream));
+  k_tile_ccl<512><<<tiles, 512, f->tile_lds[mk], f->stream>>>(g, F, *f->h_var);
   FDBG("k_tile_ccl");
   g_ht.lap(4);
   // the tile CCL (and the changed-cluster test in front of it) is the last reader of the map's occupancy planes: a
-  // fusion queued behind this point may start as soon as it is done (direct launches only -- inside a captured graph
-  // the event is recorded behind the whole chain by the caller)
-  if (!capturing) {
-    if (f->mark_planes_read) {
-      HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
-      map_add_plane_reader(f->map, f->ev_planes_read);
-    } else {
-      // nobody has rewritten the planes beside a running search of this finder yet (a plan cycle on a given map does
-      // not; a streaming pipeline does from its first frame on): no barrier packet between the chain's kernels -- a
-      // mutator that does arrive records the event behind what is queued and switches the marking on (map_wait_plane_readers)
-      map_add_late_reader(f->map, f->stream, f->ev_planes_read, &f->mark_planes_read);
-    }
-    if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
+  // fusion queued behind this point may start as soon as it is done
+  if (f->mark_planes_read) {
+    HIPCHK(hipEventRecord(f->ev_planes_read, f->stream));
+    map_add_plane_reader(f->map, f->ev_planes_read);
+  } else {
+    // nobody has rewritten the planes beside a running search of this finder yet (a plan cycle on a given map does
+    // not; a streaming pipeline does from its first frame on): no barrier packet between the chain's kernels -- a
+    // mutator that does arrive records the event behind what is queued and switches the marking on (map_wait_plane_readers)
+    map_add_late_reader(f->map, f->stream, f->ev_planes_read, &f->mark_planes_read);
   }
+  if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[1], f->stream));
   g_ht.lap(5);
-  // round 6: the last workgroup of k_tile_cross resolves searches of up to 1 024 tile roots (FUELMI_FR_FUSE=0: never)
+  // round 6: the last workgroup of k_tile_cross resolves searches of up to 1 024 tile roots (FUELMI_FR_FUSE=0: never --
+  // the A/B switch of profiles/r06_cross_resolve_fusion_ab.txt)
   static const bool fuse = !(getenv("FUELMI_FR_FUSE") && atoi(getenv("FUELMI_FR_FUSE")) == 0);
-  if (nt3[1] == 256)
-    k_tile_cross<256><<<tiles, 256, f->cross_lds[mk], f->stream>>>(g, F, 0u);
-  else {
+  {
     const size_t lds_x = fuse ? std::max(f->cross_lds[mk], resolve_lds_bytes(1024)) : f->cross_lds[mk];
     const u32 rcap = fuse ? (u32)std::min<size_t>((lds_x - resolve_lds_bytes(0)) / 16, FR_RCAP) : 0u;
     k_tile_cross<512><<<tiles, 512, lds_x, f->stream>>>(g, F, rcap);
@@ -3422,14 +3366,11 @@ static int frontier_enqueue_fast(fuelmi_frontier* f, bool capturing) {
   k_resolve<<<1, RS_TK, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
   g_ht.lap(7);
-  if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[2], f->stream));
-  if (nt3[2] == 256)
-    k_tile_out<256><<<tiles, 256, f->out_lds[mk], f->stream>>>(g, F);
-  else
-    k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
+  if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[2], f->stream));
+  k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
   FDBG("k_tile_out");
   g_ht.lap(8);
-  if (f->tl_ev && !capturing) HIPCHK(hipEventRecord(f->tl_ev[3], f->stream));
+  if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[3], f->stream));
   HIPCHK(hipGetLastError());
   return FUELMI_OK;
 }
@@ -3444,21 +3385,12 @@ static int frontier_finish_reset(fuelmi_frontier* f) {
   if (!f->zero_deferred) return FUELMI_OK;
   f->zero_deferred = false;
   const int W = f->map->g.W;
-  if (f->stream2) {
-    // Two buffer sets: the plane just retired belongs to the stream just retired (they swap together), so the zeroing
-    // goes onto that stream itself -- in order behind the tail that still sets flags in the plane and in front of the
-    // search after next that uses it again.  One launch instead of wait + launch + record on a side stream (10.7 -> ~4 us
-    // of host time per search, profiles/r05_host_timing.txt), and one stream fewer per finder (hardware queues).
-    k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->stream2>>>(f->flag2.p, W);
-    HIPCHK(hipGetLastError());
-    return FUELMI_OK;
-  }
-  if (!f->zstream) HIPCHK(hipStreamCreateWithFlags(&f->zstream, hipStreamNonBlocking));  // (one-stream mode only)
-  HIPCHK(hipStreamWaitEvent(f->zstream, f->ev_tail, 0));
-  k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->zstream>>>(f->flag2.p, W);
+  // The plane just retired belongs to the stream just retired (they swap together), so the zeroing goes onto that
+  // stream itself -- in order behind the tail that still sets flags in the plane and in front of the search after
+  // next that uses it again.  One launch instead of wait + launch + record on a side stream (10.7 -> ~4 us of host
+  // time per search, profiles/r05_host_timing.txt), and one stream fewer per finder (hardware queues).
+  k_zero_words<<<fblocks(W, 256, 1024), 256, 0, f->stream2>>>(f->flag2.p, W);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(f->ev_zero, f->zstream));
-  f->zero_pending = true;
   return FUELMI_OK;
 }
 static int frontier_apply_reset(fuelmi_frontier* f, bool defer_zeroing = false) {
@@ -3466,8 +3398,8 @@ static int frontier_apply_reset(fuelmi_frontier* f, bool defer_zeroing = false) 
   f->fresh_pending = false;
   // (everything that still writes the retired plane / the shared cell pool is in front of this; with two buffer sets only
   // a commit since the last swap makes anybody wait for it)
-  if (!f->stream2 || f->pool_dirty) HIPCHK(hipEventRecord(f->ev_tail, f->stream));
-  if (f->stream2) {
+  if (f->pool_dirty) HIPCHK(hipEventRecord(f->ev_tail, f->stream));
+  {
     // the other plane's buffer set and stream: the retiring search's tail keeps running on its own stream.  (The cell
     // pool is the one device buffer both sets share: if it was written since the last swap -- a commit -- the new
     // stream waits for the old one.)
@@ -3476,8 +3408,6 @@ static int frontier_apply_reset(fuelmi_frontier* f, bool defer_zeroing = false) 
     if (f->pool_dirty) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_tail, 0));
     f->pool_dirty = false;
   }
-  if (f->zero_pending) HIPCHK(hipStreamWaitEvent(f->stream, f->ev_zero, 0));
-  f->zero_pending = false;
   std::swap(f->flag, f->flag2);
   f->flag_cur ^= 1;
   f->F.flag = f->flag.p;
@@ -3621,7 +3551,6 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
       }
     f->fast_menu = pick;
     int ftx = kFastMenu[pick][0], fty = kFastMenu[pick][1];
-    if (f->FTX) ftx = f->FTX, fty = f->FTY;
     hv.ftx = ftx, hv.fty = fty;
     hv.px0 = p0[0], hv.py0 = p0[1], hv.px1 = p1[0], hv.py1 = p1[1];
     hv.ntx_f = std::max(0, (qx + ftx - 1) / ftx);
@@ -3656,69 +3585,17 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
   f->npass = f->last_nkept > 192 ? 2 : 1;
   f->nb_launch = 256;  // the multisplit kernels stride over however many 2048-cell chunks there are
 
-  // The chain is ~23 dependent launches whose arguments never change (everything per-search sits
-  // behind F.var): replay it as a hipGraph -- the host-side launch cost of the individual kernels
-  // (~6 us each) was longer than the kernels themselves.
-  // Round 4: the fast chain's four kernels are launched DIRECTLY by default.  Replaying them as a hipGraph cost the
-  // host less but reached the device ~10 us later; since a fresh search runs beside the previous one's tail that
-  // latency is on the cycle's critical path (same-box A/B, profiles/r04_tuning_*: direct >= graph on the full-box
-  // cycle and on the streaming one), and only direct launches can mark the point behind which the next depth frame
-  // may be fused.  FUELMI_FR_GRAPH=1 brings the graph back; the legacy chain (~23 launches) stays a graph.
-  static const bool dbg_sync = getenv("FUELMI_DEBUG_SYNC") != nullptr;
-  static const bool fast_graph = getenv("FUELMI_FR_GRAPH") != nullptr && atoi(getenv("FUELMI_FR_GRAPH")) != 0 && !dbg_sync;
-  static const bool no_graph = getenv("FUELMI_NO_GRAPH") != nullptr || dbg_sync;
+  // The fast chain's four kernels are launched DIRECTLY (rounds 2-3 replayed them as a hipGraph: cheaper for the host, but
+  // the graph reaches the device ~10 us later, which is on the cycle's critical path since a fresh search runs beside the
+  // previous one's tail -- same-box A/B in profiles/r04_tuning_ab_cycle.txt --, and only direct launches can mark the
+  // point behind which the next depth frame may be fused).  The legacy chain is ~23 dependent launches whose arguments
+  // never change (everything per-search sits behind F.var): it is replayed as a hipGraph.
+  static const bool no_graph = getenv("FUELMI_DEBUG_SYNC") != nullptr;
   g_ht.lap(3);
   if (fast) {
     f->fast_launched = true;
-    if (!fast_graph) {
-      planes_read.done = true;
-      return frontier_enqueue_fast(f, false);
-    }
-    const int gm = f->FTX ? 0 : f->fast_menu;
-    hipGraphExec_t& fexec = f->fast_exec[gm][f->flag_cur];
-    hipGraphNode_t& knode = f->fast_k1[gm][f->flag_cur];
-    if (!fexec) {
-      hipGraph_t graph = nullptr;
-      HIPCHK(hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal));
-      const int rc2 = frontier_enqueue_fast(f, true);
-      const hipError_t ec = hipStreamEndCapture(f->stream, &graph);
-      if (rc2) return rc2;
-      HIPCHK(ec);
-      // the node of the first kernel: its third argument (the per-search FVar) is rewritten before every launch
-      size_t nn = 0;
-      HIPCHK(hipGraphGetNodes(graph, nullptr, &nn));
-      std::vector<hipGraphNode_t> nodes(nn);
-      HIPCHK(hipGraphGetNodes(graph, nodes.data(), &nn));
-      knode = nullptr;
-      for (hipGraphNode_t nd : nodes) {
-        hipGraphNodeType ty;
-        hipKernelNodeParams kp;
-        if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
-        if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) continue;
-        if (kp.func == reinterpret_cast<void*>(&k_tile_ccl<512>) || kp.func == reinterpret_cast<void*>(&k_tile_ccl<256>)) {
-          knode = nd;
-          f->fast_k1_params[gm][f->flag_cur] = kp;
-        }
-      }
-      if (!knode) {
-        (void)hipGraphDestroy(graph);
-        fuelmi_set_error("frontier search: the captured chain has no tile kernel node");
-        return FUELMI_EHIP;
-      }
-      HIPCHK(hipGraphInstantiate(&fexec, graph, nullptr, nullptr, 0));
-      f->fast_graph[gm][f->flag_cur] = graph;  // (kept: the node handle belongs to it)
-    }
-    {
-      hipKernelNodeParams kp = f->fast_k1_params[gm][f->flag_cur];
-      Geo g_arg = g;
-      FArgs f_arg = F;
-      void* args[3] = {&g_arg, &f_arg, f->h_var};
-      kp.kernelParams = args;
-      kp.extra = nullptr;
-      HIPCHK(hipGraphExecKernelNodeSetParams(fexec, knode, &kp));
-    }
-    HIPCHK(hipGraphLaunch(fexec, f->stream));
-    return FUELMI_OK;
+    planes_read.done = true;
+    return frontier_enqueue_fast(f);
   }
   if (no_graph) return frontier_enqueue_chain(f, f->npass);
   hipGraphExec_t& exec = f->graph_exec[f->npass - 1][f->flag_cur];
@@ -4527,10 +4404,9 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
   // search bookkeeping (collect + commit the previous search, begin this one), the map chain (inflation, ESDF, B-spline
   // batch), the next fusion.  The frame is bound by the host's ~55 us of API calls plus the device's fusion ->
   // plane-reading kernels -> fusion chain (FUELMI_STREAM_TIMING=1: host time per call group, =2: also a device timeline
-  // from events); issuing the map chain BEFORE the bookkeeping (FUELMI_STREAM_MAP_FIRST=1) starts the map stream ~25 us
+  // from events); issuing the map chain BEFORE the bookkeeping (measured in round 4) starts the map stream ~25 us
   // earlier and the search chain as much later: 1-2 % slower.  Same calls, same arguments, same results as the
   // frame-by-frame order (serial != 0 keeps that order for diagnostics).
-  static const bool map_first = getenv("FUELMI_STREAM_MAP_FIRST") != nullptr;
   int npts = 0;
   if (n > 0)
     rc = fuelmi_map_input_depth(m, static_cast<const unsigned short*>(depth[0]), rows, cols, cfg, cam_pos3, cam_q4, &npts);
@@ -4593,18 +4469,11 @@ extern "C" int fuelmi_bench_stream(fuelmi_map* m, fuelmi_frontier* f, fuelmi_bsp
         if (hipEventRecord(tl[(size_t)k * 6 + 4], m->stream) != hipSuccess) rc = FUELMI_EHIP;  // (the fusion of this frame is queued)
         f->tl_ev = &tl[(size_t)k * 6];
       }
-      if (map_first) {
-        if (rc == FUELMI_OK) rc = map_chain();
-        if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
-        tick(0, t);
-      }
       if (rc == FUELMI_OK) rc = bookkeeping(k);
       tick(3, t);
-      if (!map_first) {
-        if (rc == FUELMI_OK) rc = map_chain();
-        if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
-        tick(0, t);
-      }
+      if (rc == FUELMI_OK) rc = map_chain();
+      if (timeline && rc == FUELMI_OK && hipEventRecord(tl[(size_t)k * 6 + 5], m->stream) != hipSuccess) rc = FUELMI_EHIP;
+      tick(0, t);
       if (rc) break;
       int npts_next = 0;
       if (k + 1 < n && (rc = fuse_next(k, &npts_next))) break;

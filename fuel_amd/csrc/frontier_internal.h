@@ -294,9 +294,7 @@ struct fuelmi_frontier {
   Plane flag, qb, sb;
   Plane flag2;  // the spare flag plane (all-zero or being zeroed): a reset swaps the two
   int flag_cur = 0;
-  hipStream_t zstream = nullptr;
-  hipEvent_t ev_zero = nullptr, ev_tail = nullptr;
-  bool zero_pending = false;
+  hipEvent_t ev_tail = nullptr;
   bool zero_deferred = false;  // the retired plane's zeroing is still to be queued (frontier_finish_reset)
   FArgs F;
   // A fresh search (fuelmi_frontier_reset) swaps to the OTHER flag plane -- and, with it, to the other set of every
@@ -338,7 +336,7 @@ struct fuelmi_frontier {
   FVar* h_var = nullptr;  // pinned per-search arguments
   FVar* d_var = nullptr;
   int TX = 1, TY = 16, ccl_tiles = 0;
-  int FTX = 8, FTY = 16, fast_tiles = 0;  // tiles of the fast chain (sparse labels: no LDS bound from nz)
+  int fast_tiles = 0;  // tiles of the fast chain at its smallest tile shape (sparse labels: no LDS bound from nz)
   size_t ccl_lds = 0;
   hipGraphExec_t graph_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // kernel chain with 1 / 2 radix passes, per flag plane
   bool pending = false, search_empty = false;
@@ -351,12 +349,7 @@ struct fuelmi_frontier {
   mutable bool tail_pending = false;
   bool fast_launched = false;  // the chain of the running search is the fast one
   u32 epoch = 0;
-  hipGraphExec_t fast_exec[4][2] = {};  // one per tile of the menu (launch grids differ) and flag plane
-  hipGraph_t fast_graph[4][2] = {};     // ... the graphs they were instantiated from (own the node handles)
-  hipGraphNode_t fast_k1[4][2] = {};    // ... the node of the chain's first kernel (its FVar argument is rewritten per search)
-  hipKernelNodeParams fast_k1_params[4][2] = {};
   int fast_menu = 0;  // menu entry of the running search
-  int ft_threads[3] = {512, 512, 512};  // workgroup sizes of k_tile_ccl / _cross / _out (FUELMI_FT_THREADS), per finder
   bool fast_ok = false;        // this finder may use the fast chain (decided at creation)
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;

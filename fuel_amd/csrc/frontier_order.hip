@@ -646,13 +646,8 @@ int frontier_reference_order(fuelmi_frontier* f, u32 nq, u32 nkept, u32 n_out, i
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BFSG_RING * sizeof(u32))));
       o->lds_attr = true;
     }
-    static const int bt = getenv("FUELMI_BFSG_T") ? atoi(getenv("FUELMI_BFSG_T")) : 512;  // tuning hook
-    if (bt == 1024)
-      k_bfs_sweep_g<1024><<<nkept, 1024, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
-    else if (bt == 512)
-      k_bfs_sweep_g<512><<<nkept, 512, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
-    else
-      k_bfs_sweep_g<256><<<nkept, 256, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
+    // (512 lanes: measured against 256 and 1 024, profiles/r04_reference_order_timing.txt)
+    k_bfs_sweep_g<512><<<nkept, 512, BFSG_RING * sizeof(u32), st>>>(m->g, F, B);
     HIPCHK(hipGetLastError());
     k_bfs_emit<<<dim3(64, nkept), 256, 0, st>>>(m->g, F, B);
     HIPCHK(hipGetLastError());

@@ -225,10 +225,8 @@ struct fuelmi_map {
 
 int map_ensure_stage(fuelmi_map* m, size_t dev_bytes, size_t host_bytes);
 
-// Streams of the library.  `which` names the role ("MAP": a map's stream, "FR": a finder's search streams); the experiment
-// hook FUELMI_CUMASK_<which> = "<xcd mask>:<CUs per XCD>" (e.g. FUELMI_CUMASK_FR=0x03:32, FUELMI_CUMASK_MAP=0xfc:32)
-// creates the stream with hipExtStreamCreateWithCUMask instead: the CU mask's bit i selects the (i / 8)-th CU of XCD i % 8
-// on an 8-XCD part (the driver deals a queue's mask round-robin over the XCCs).  priority: INT_MIN = default.
+// Streams of the library.  `which` names the role ("MAP": a map's stream, "FR": a finder's search streams);
+// priority: INT_MIN = default.
 hipError_t fuelmi_stream_create(hipStream_t* s, int priority, const char* which);
 // a query slot with at least `bytes` of pinned memory, its stream ordered behind the map's; released (and waited for)
 // by the guard

@@ -677,7 +677,6 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
     } else
       (void)hipGetLastError();  // ordinary pageable memory (a cv::Mat): not an error
   }
-  static const bool zero_copy = getenv("FUELMI_DEPTH_H2D") == nullptr;
   if (foreign) {
     HIPCHK(hipMemcpyAsync(d_img, depth, (size_t)rows * cols * 2, hipMemcpyDefault, m->stream));
   } else if (!direct) {
@@ -685,11 +684,11 @@ static int project_depth_dev(fuelmi_map* m, const unsigned short* depth, int row
     memcpy(m->h_stage, depth, (size_t)rows * cols * 2);
     // the fusion kernels read the (pinned) staged image over PCIe themselves -- ~0.6 MB per 640 x 480 frame, read
     // by two kernels -- instead of waiting for a DMA copy in front of them; the stand-alone projection keeps the copy
-    if (!zero_copy || launch)
+    if (launch)
       HIPCHK(hipMemcpyAsync(d_img, m->h_stage, (size_t)rows * cols * 2, hipMemcpyHostToDevice, m->stream));
   }
   DepthArgs D;
-  D.img = direct ? direct : ((zero_copy && !launch && !foreign) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img);
+  D.img = direct ? direct : ((!launch && !foreign) ? reinterpret_cast<const unsigned short*>(m->h_stage) : d_img);
   D.rows = rows, D.cols = cols, D.margin = margin, D.skip = skip, D.nu = nu, D.nslots = nslots;
   D.fx = c->fx, D.fy = c->fy, D.cx = c->cx, D.cy = c->cy;
   D.maxdist = c->depth_filter_maxdist, D.mindist = c->depth_filter_mindist;

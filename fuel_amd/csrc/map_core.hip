@@ -102,25 +102,10 @@ static void warn_hw_queues_once() {
   }
 }
 
-hipError_t fuelmi_stream_create(hipStream_t* s, int priority, const char* which) {
-  char name[48];
-  snprintf(name, sizeof(name), "FUELMI_CUMASK_%s", which);
-  if (const char* e = getenv(name)) {
-    unsigned xm = 0xFFu;
-    int c_lo = 0, c_hi = 31;  // "<xcd mask>:<n>" = the first n CUs of each XCD, "<xcd mask>:<a>-<b>" = CUs a..b of each
-    char range[32] = "";
-    const int nf = sscanf(e, "%i:%31s", reinterpret_cast<int*>(&xm), range);
-    if (nf == 2) {
-      if (sscanf(range, "%d-%d", &c_lo, &c_hi) != 2) c_lo = 0, c_hi = atoi(range) - 1;
-    }
-    if (nf >= 1 && (xm & 0xFFu) && c_lo >= 0 && c_hi >= c_lo) {
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < 256; ++i)
-        if (((xm >> (i & 7)) & 1u) && (i >> 3) >= c_lo && (i >> 3) <= c_hi) mask[i >> 5] |= 1u << (i & 31);
-      // (no priority / flags on this entry point: the stream is a default-priority, null-stream-blocking one)
-      return hipExtStreamCreateWithCUMask(s, 8, mask);
-    }
-  }
+// (Round 6 created these streams with hipExtStreamCreateWithCUMask behind an experiment hook -- the finder's streams on
+// one, two or four XCDs or on the first 8 / 16 CUs of every XCD, the map's on the rest: no split beat the shared chip
+// on any workload, profiles/r06_cu_mask_sweep_*.txt; the hook is gone, the call site stays in one place.)
+hipError_t fuelmi_stream_create(hipStream_t* s, int priority, const char* /*which*/) {
   if (priority == INT_MIN) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
 }
@@ -808,9 +793,8 @@ extern "C" int fuelmi_map_inflate_local(fuelmi_map* m) {
     // The fused kernel re-reads every source word five times: free while the words it touches sit in the caches (400^2 x
     // 100: 9.8 against 11.8 us and a launch saved; the local box of a streaming frame on any map), not for the full box of
     // the HBM-resident 800^2 x 200 map (53.6 against 42 us): by the size of the BOX's address range, like every other
-    // kernel choice.  FUELMI_INFLATE_2PASS=0 / 1 pins.
-    static const char* tp_env = getenv("FUELMI_INFLATE_2PASS");
-    const bool two_pass = tp_env ? atoi(tp_env) != 0 : (long)(out_hi - out_lo + 1) * 64 > (48L << 20);
+    // kernel choice.
+    const bool two_pass = (long)(out_hi - out_lo + 1) * 64 > (48L << 20);
     const int ry = (step * (g.nz + 1) + 63) / 64 + 1;
     const size_t lds_f = (size_t)(2 * step + 1) * (2 * (size_t)(256 + 2 * ry + 2) + 2) * sizeof(u64);
     m->last_inflate_kernel = (step == 2 && !two_pass && lds_f <= 64 * 1024) ? 0 : 1;
