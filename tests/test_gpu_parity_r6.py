@@ -65,3 +65,33 @@ def test_full_size_g800_full_box_against_the_oracle(fa):
     assert np.array_equal(of.flags, gf.flags())
     gf.close()
     gm.close()
+
+
+def test_legacy_chain_on_the_headline_map(fa):
+    """The round-1 frontier chain (global lock-free union-find + multisplit: what a search falls back to when a table
+    of the tile chain overflows, and what every finder with cluster_min < 1 runs) on the 400 x 400 x 100 headline map,
+    full exploration box, against the oracle (its only G400-size coverage was through the fast
+    chain).  cluster_min = 0 keeps every component, and two fresh searches in a row run on the finder's two buffer sets.  Cell sets per cluster, cluster order, flags
+    (frontier_finder.cpp:54-164)."""
+    import bench
+    map_size, box, occ, _, _ = bench.build_inputs("G400", seed=42, n_traj=1)
+    om = fo.OracleMap(map_size, *box)
+    om.occ[:] = occ
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(occ)
+    of = fo.OracleFrontier(om, 0)
+    gf = fa.FrontierFinder(gm, cluster_min=0)
+    for rnd in range(2):
+        if rnd:
+            of = fo.OracleFrontier(om, 0)
+            gf.reset()
+        om.set_updated_box(*box)
+        gm.setUpdatedBox(*box)
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g and n_o > 0, (n_o, n_g)
+        for a, b in zip(of.clusters(0), gf.clusters(0)):
+            assert np.array_equal(np.sort(a), b)
+        assert np.array_equal(of.flags, gf.flags())
+    assert gf.stats()[0] == 0 and gf.stats()[1] >= 2, gf.stats()  # (fast, legacy, fallbacks)
+    gf.close()
+    gm.close()
