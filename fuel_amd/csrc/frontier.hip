@@ -236,7 +236,10 @@ k_rm_pool_bar(Geo g, const u64* __restrict__ occ, const u64* __restrict__ unk, u
     const u32* mine = bar + 16u * (blockIdx.x + 1u);
     const unsigned long long t0 = wall_clock64();
     for (u32 spins = 0; ld_agent(mine) != (u32)mark; ++spins) {
-      if ((spins & 63u) == 63u && wall_clock64() - t0 > 5000000ull) break;  // (50 ms: unreachable with a resident grid; never hang the device)
+      if ((spins & 63u) == 63u && wall_clock64() - t0 > 5000000ull) {  // 50 ms: unreachable with a resident grid -- never
+        h_changed[ncand] = -1;                                          // hang the device, and never finish silently:
+        break;                                                          // _search_end reports the search as failed
+      }
       __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -3186,6 +3189,7 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
     hc[k].off = off[k], hc[k].start = start[k], hc[k].pad = 0u;
     f->h_changed[k] = 0;
   }
+  f->h_changed[nc] = 0;  // (time-out word of k_rm_pool_bar's barrier: h_changed holds nc + nc / 2 + 64 entries)
   if (nc > RM_LDS) {  // too many candidates for the LDS table: the kernels search a device copy
     int rcs = frontier_ensure_stage(f, nc * sizeof(RmCand));
     if (rcs) return rcs;
@@ -3224,6 +3228,7 @@ static int remove_changed_begin(fuelmi_frontier* f, const double* umin, const do
 // frontiers_ as the list shrinks; dormant clusters are dropped silently.
 static void remove_changed_end(fuelmi_frontier* f) {
   int erased_active = 0;
+  if (!f->pend_rm.empty() && f->h_changed[f->pend_rm.size()] == -1) f->rm_failed = true;  // (k_rm_pool_bar's time-out)
   for (size_t k = 0; k < f->pend_rm.size(); ++k) {
     if (!f->h_changed[k]) continue;
     const fuelmi_frontier::PendingRm& p = f->pend_rm[k];
@@ -3807,6 +3812,12 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
     HIPCHK(q);
   }
   remove_changed_end(f);
+  if (f->rm_failed) {
+    f->rm_failed = false;
+    f->dirty_all = true;
+    fuelmi_set_error("frontier search: the changed-cluster test's in-kernel barrier timed out (device oversubscribed for 50 ms?)");
+    return FUELMI_EHIP;
+  }
   if (counts[2] || counts[3] > F.cap_kept) {
     fuelmi_set_error("frontier capacity exceeded (cells %u/%u seeds %u/%u clusters %u/%u)", counts[0], F.cap_q,
                      counts[1], F.cap_s, counts[3], F.cap_kept);

@@ -382,6 +382,7 @@ struct fuelmi_frontier {
   int rm_mark = 0;
   u32* rm_bar = nullptr;     // device: arrival counter of k_rm_pool_bar's in-kernel barrier (never reset: rm_bar_total is its target)
   u32 rm_bar_total = 0;
+  bool rm_failed = false;    // the barrier of k_rm_pool_bar timed out in the search being collected (fuelmi_frontier_search_end fails)
   void* h_put = nullptr;     // pinned table of k_pool_put
   size_t h_put_cap = 0;
   u32* pool = nullptr;  // device copies of the cells of frontiers_ / dormant_frontiers_
