@@ -160,6 +160,7 @@ SYMBOLS = {
     "fuelmi_frontier_destroy": (None, [_P]),
     "fuelmi_frontier_reset": (C.c_int, [_P]),
     "fuelmi_frontier_stats": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "fuelmi_frontier_resolved_in_launch": (C.c_int, [_P]),
     "fuelmi_frontier_order_stats": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fuelmi_frontier_synchronize": (C.c_int, [_P]),
     "fuelmi_bench_cycles": (C.c_int, [_P, _P, _P, _dp, _dp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),

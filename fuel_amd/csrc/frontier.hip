@@ -2425,7 +2425,10 @@ __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const
     F.counts[5] = bad ? 0u : s_nout;
   }
   if (threadIdx.x < 32) F.fctr[threadIdx.x] = 0u;  // the counters of the NEXT search (its first kernel adds to them at once)
-  if (threadIdx.x == 0) F.counts[8] = V.epoch;     // "resolved" (the kernel k_resolve behind a k_tile_cross that did it returns at once)
+  if (threadIdx.x == 0) {
+    F.counts[8] = V.epoch;              // "resolved" (the kernel k_resolve behind a k_tile_cross that did it returns at once)
+    F.counts[9] = IN_LAUNCH ? 1u : 0u;  // ... by whom (fuelmi_frontier_resolved_in_launch)
+  }
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
   // the barrier orders every thread's record stores before thread 0's system-scope release (cumulative): one
@@ -3782,6 +3785,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
                    (rr[6] - rr[5]) / 100.0, (rr[7] - rr[6]) / 100.0, (rr[8] - rr[7]) / 100.0, rr[9], rr[10], rr[11]);
     }
     ++f->n_fast;
+    if (counts[9] == 1u) ++f->n_in_launch;
     if (counts[2] == 2u && m->fusion_count != f->fusion_at_begin) {
       fuelmi_set_error("frontier search: the fast chain overflowed AFTER the map was fused again (a frame queued between "
                        "_search_begin and _search_end): the occupancy this search was about is gone -- call _search_end before the next fusion "
@@ -3996,6 +4000,7 @@ extern "C" int fuelmi_frontier_synchronize(fuelmi_frontier* f) {
   HIPCHK(frontier_drain(f));
   return FUELMI_OK;
 }
+extern "C" int fuelmi_frontier_resolved_in_launch(const fuelmi_frontier* f) { return f ? f->n_in_launch : FUELMI_EINVAL; }
 extern "C" int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]) {
   ARGCHK(f && out3);
   out3[0] = f->n_fast, out3[1] = f->n_legacy, out3[2] = f->n_fallback;

@@ -387,6 +387,10 @@ class FrontierFinder:
         check(self.L.fuelmi_frontier_stats(self.h, o))
         return tuple(o)
 
+    def resolvedInLaunch(self):
+        """fast-chain searches resolved by the last workgroup of k_tile_cross itself (the others: by k_resolve)"""
+        return self.L.fuelmi_frontier_resolved_in_launch(self.h)
+
     def orderStats(self):
         """(order of the last search: 0 address / 1 reference BFS, searches in the reference's order, mode-2 searches
         that fell back to the address order, cells of the cluster that forced the last fallback)"""

@@ -241,6 +241,10 @@ int fuelmi_frontier_reset(fuelmi_frontier* f);
 /* diagnostics: searches answered by the fast clustering chain [0], by the legacy chain [1], and searches that
  * started on the fast chain and fell back because an input exceeded one of its capacities [2] */
 int fuelmi_frontier_stats(const fuelmi_frontier* f, int out3[3]);
+/* of the searches the fast chain answered: how many were resolved (cross-tile unions, cluster records, the result the
+ * caller polls for) by the last workgroup of the chain's second kernel itself rather than by a launch of their own --
+ * searches of up to 1 024 tile-local components; for tests that must know which code ran */
+int fuelmi_frontier_resolved_in_launch(const fuelmi_frontier* f);
 /* the cell order the searches delivered (cfg.reference_order is a request; mode 2 answers per search): [0] the last
  * search's order -- 0 ascending address, 1 the reference's BFS order --, [1] searches that delivered the reference's
  * order, [2] searches of a mode-2 finder that fell back to the address order because a cluster was too large for the

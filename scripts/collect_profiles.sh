@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-5 evidence (the round-4 script, brought forward), one gpurun call (COMMIT=<git hash of the code> in the environment stamps every summary): bench lines
+# Round-6 evidence (the round-5 script, brought forward), one gpurun call (COMMIT=<git hash of the code> in the environment stamps every summary): bench lines
 # (headline, big map, sparse regimes, streaming, fleet of two on one device), rocprofv3 kernel stats of the same commands
 # (overlapped cycle and serial stages), PMC passes (HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes; SQ issue /
 # wait cycles in a third; SQ instruction counts of the ESDF families in a fourth), cycle timelines, in-kernel phase
 # stamps of the z/y pass, same-box A/B runs of this round's switches, next-row timings, facade bench, fleet / perf tests.
 # Everything lands under gpurun_out/prof_$R; scripts/publish_profiles.sh $R copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${R:-r05}
+R=${R:-r06}
 export FUELMI_COMMIT=${COMMIT:-unknown}
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
@@ -62,15 +62,16 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -o
 # in-kernel phase stamps of the packed z/y pass, and the ESDF kernels per family (same box)
 { for WL in G400 G800 G400K; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep -E "zy2-timing|x2-timing|slowest" | tail -4 | sed "s/^/$WL /"; done
   for WL in G400 G800 G400K G400E; do for FAM in 0 2 1; do echo -n "$WL family $FAM: "; python scripts/esdf_only.py $WL $FAM 8; done; done; } > $O/esdf_family_ab.txt 2>&1
-# this round's switches, same box, two repetitions each
-WLARGS="" bash scripts/r4_cycle_ab.sh FUELMI_FR_GRAPH=1 FUELMI_FR_ONE_STREAM=1 FUELMI_INFLATE_2PASS=1 GPU_MAX_HW_QUEUES=4 > $O/tuning_ab_cycle.txt 2>&1
-# the round-4 build of the library on the same box (build/r4 is a worktree of 72541aa built by hand before the call)
-if [ -d build/r4/fuel_amd ]; then
-  { echo "# same box, same call: round-4 final (72541aa) against this tree; bench.py --no-cpu-baseline of each (value, stage_ms isolated)"
-    for WL in G400 G800 G400K G400E G800S; do
-      for T in build/r4 .; do (cd $T && python bench.py --workload $WL --no-cpu-baseline 2>/dev/null | T=$T WL=$WL python -c "
+# this round's one remaining switch, same box, interleaved: the last workgroup of k_tile_cross resolving the search (default)
+# against k_resolve as a launch of its own (FUELMI_FR_FUSE=0)
+NOTEST=1 bash scripts/r6_fuse_ab.sh > $O/cross_resolve_fusion_ab_final.txt 2>&1
+# the round-5 build of the library on the same box (build/r5 is a worktree of 5605e15 built by hand before the call)
+if [ -d build/r5/fuel_amd ]; then
+  { echo "# same box, same call: round-5 final (5605e15) against this tree, twice, interleaved; bench.py --no-cpu-baseline of each (value, stage_ms in the cycle, isolated)"
+    for REP in 1 2; do for WL in G400 G800 G400K G400E G800S; do
+      for T in build/r5 .; do (cd $T && python bench.py --workload $WL --no-cpu-baseline 2>/dev/null | T=$T WL=$WL python -c "
 import sys,json,os
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(os.environ['WL'], 'r4' if 'r4' in os.environ['T'] else 'r5', round(d['value'],1), d.get('stage_ms_isolated') or d['stage_ms'])"); done; done; } > $O/r4_vs_r5_same_box.txt 2>&1
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(os.environ['WL'], 'r5' if 'r5' in os.environ['T'] else 'r6', round(d['value'],1), d['stage_ms'], d.get('stage_ms_isolated'))"); done; done; done; } > $O/r5_vs_r6_same_box.txt 2>&1
 fi
 # the driver's own command line (short timed regions, repeated) and the host's time per call / inside the search calls
 timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_G400_driver_cmdline.json 2>/dev/null
@@ -78,6 +79,8 @@ timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_G400_driver_cmdline
   FUELMI_HOST_TIMING=1 python bench.py --no-cpu-baseline 2>&1 >/dev/null | grep host-timing | tail -2
   echo "# hardware queues: scripts/r5_hwq.py at the library's fuelmi_init() default, then with the runtime's (GPU_MAX_HW_QUEUES=4)"
   python scripts/r5_hwq.py 2>&1 | tail -5; GPU_MAX_HW_QUEUES=4 python scripts/r5_hwq.py 2>&1 | tail -5; } > $O/host_timing.txt 2>&1
+{ echo "# FUELMI_FR_TIMING=1 python bench.py --workload W --no-cpu-baseline --steps 5 --warmup 2 --serial-stages: in-kernel phase stamps of the frontier chain (last search), commit $FUELMI_COMMIT"
+  for WL in G400 G800 G800S; do FUELMI_FR_TIMING=1 python bench.py --workload $WL --no-cpu-baseline --steps 5 --warmup 2 --serial-stages 2>&1 | grep "fr-timing" | tail -6 | grep -v "entry avg" | cut -c1-330 | sed "s/^/$WL /"; done; } > $O/frontier_phase_stamps.txt 2>&1
 timeout 300 python scripts/bench_next.py > $O/next_rows.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/next -o s -- python scripts/bench_next.py > /dev/null 2>&1
 timeout 300 python scripts/facade_bench.py --map G800S --frames 30 > $O/facade_bench_G800S.json 2> $O/facade_bench.err
@@ -89,12 +92,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/reforder1
 # order costs on the full box (the level sweeps' own clock; workgroup sizes of the large-cluster sweep; x pass phase stamps)
 { echo "# FUELMI_STREAM_TIMING=2 python bench.py --workload G800S --no-cpu-baseline (one line pair per bench_stream call: warm-up, timed, frame sources), commit $FUELMI_COMMIT"
   FUELMI_STREAM_TIMING=2 python bench.py --workload G800S --no-cpu-baseline 2>&1 >/dev/null | grep stream-timing
-  echo "# default order (search bookkeeping, then the map chain) against FUELMI_STREAM_MAP_FIRST=1, frames/s, alternating"
-  for V in 0 1 0 1; do if [ $V = 1 ]; then export FUELMI_STREAM_MAP_FIRST=1; else unset FUELMI_STREAM_MAP_FIRST; fi
-    python bench.py --workload G800S --no-cpu-baseline | V=$V python -c "import sys,json,os; print('map_first=%s: %d frames/s' % (os.environ['V'], round(json.loads(sys.stdin.readline())['value'])))"; done
-  unset FUELMI_STREAM_MAP_FIRST; } > $O/stream_frame_timing.txt 2>&1
+  } > $O/stream_frame_timing.txt 2>&1
 { echo "# FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 (400x400x100, full box: one cluster of 139 k cells), commit $FUELMI_COMMIT"
-  for T in 512 256 1024; do echo "# k_bfs_sweep_g with $T threads"; FUELMI_BFSG_T=$T FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 2>&1 >/dev/null | grep "reference order" | tail -2; done
+  FUELMI_FR_TIMING=1 python bench.py --no-cpu-baseline --reference-order 1 --steps 10 --warmup 3 2>&1 >/dev/null | grep "reference order" | tail -2
   echo "# x pass phase stamps (FUELMI_ZY_TIMING=1, scripts/esdf_only.py)"
   for WL in G400 G800; do FUELMI_ZY_TIMING=1 python scripts/esdf_only.py $WL 0 3 2>&1 | grep x2-timing | tail -1 | sed "s/^/$WL /"; done; } > $O/reference_order_timing.txt 2>&1
 timeout 300 python -m pytest tests/test_fleet_gpu.py -q -s -m gpu 2>&1 | grep -E "fleet on one device|bench --gpus|passed|failed" > $O/fleet_one_device.txt

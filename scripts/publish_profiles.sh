@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the summaries scripts/collect_profiles.sh left under gpurun_out/prof_<round> into profiles/ (tracked)
-R=${1:-r05}; O=gpurun_out/prof_$R; P=profiles
+R=${1:-r06}; O=gpurun_out/prof_$R; P=profiles
 for f in bench_G400 bench_G800 bench_G400K bench_G400E bench_G400_C1 bench_G400_C256 bench_G400_under_rocprof bench_G800_under_rocprof bench_G400_two_ranks_one_device bench_G800S_100steps; do
   [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${R}_$f.json
 done
@@ -20,7 +20,7 @@ cp $O/next_rows.json $P/${R}_next_rows.json
 [ -s $O/facade_bench_G400_fullbox.json ] && tail -1 $O/facade_bench_G400_fullbox.json > $P/${R}_facade_bench_G400_fullbox.json
 for f in bench_G800S_reforder1 bench_G800S_reforder2 bench_G400_reforder1; do [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${R}_$f.json; done
 [ -s $O/bench_G400_driver_cmdline.json ] && tail -1 $O/bench_G400_driver_cmdline.json > $P/${R}_bench_G400_driver_cmdline.json
-for f in fleet_one_device perf_statements esdf_family_ab esdf_instruction_counts tuning_ab_cycle cycle_timeline_G400 stream_timeline_G800S stream_frame_timing reference_order_timing r4_vs_r5_same_box host_timing; do
+for f in fleet_one_device perf_statements esdf_family_ab esdf_instruction_counts cross_resolve_fusion_ab_final frontier_phase_stamps cycle_timeline_G400 stream_timeline_G800S stream_frame_timing reference_order_timing r5_vs_r6_same_box host_timing; do
   [ -s $O/$f.txt ] && cp $O/$f.txt $P/${R}_$f.txt
 done
 ls $P | grep ${R}_ | wc -l

@@ -95,3 +95,33 @@ def test_legacy_chain_on_the_headline_map(fa):
     assert gf.stats()[0] == 0 and gf.stats()[1] >= 2, gf.stats()  # (fast, legacy, fallbacks)
     gf.close()
     gm.close()
+
+
+def test_headline_search_is_resolved_by_the_cross_kernels_last_workgroup(fa):
+    """Round 6: the last workgroup of k_tile_cross joins the tile roots itself (agent-scope pair stores, a
+    last-workgroup-done counter, no fence) when the search has at most 1 024 of them -- the headline map's full-box search
+    has 779.  The CHOICE is asserted (a silent fall-through to the k_resolve launch would pass every parity test), then
+    the result against the oracle as everywhere: cell sets, cluster order, flags, and the same again on the finder's
+    other buffer set (frontier_finder.cpp:54-164)."""
+    import bench
+    map_size, box, occ, _, _ = bench.build_inputs("G400", seed=42, n_traj=1)
+    om = fo.OracleMap(map_size, *box)
+    om.occ[:] = occ
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(occ)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    for rnd in range(2):
+        of = fo.OracleFrontier(om, 100)
+        if rnd:
+            gf.reset()
+        om.set_updated_box(*box)
+        gm.setUpdatedBox(*box)
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g and n_o > 0
+        for a, b in zip(of.clusters(0), gf.clusters(0)):
+            assert np.array_equal(np.sort(a), b)
+        assert np.array_equal(of.flags, gf.flags())
+    assert gf.stats() == (2, 0, 0), gf.stats()
+    assert gf.resolvedInLaunch() == 2, "the searches were resolved by k_resolve, not inside k_tile_cross"
+    gf.close()
+    gm.close()
