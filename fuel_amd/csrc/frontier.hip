@@ -1549,7 +1549,7 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
     if (threadIdx.x == 0) {
       F.t_nroots[blockIdx.x] = 0u;
       F.t_base[blockIdx.x] = 0u;
-      if (total > FR_TCELL) F.fctr[9] = 11u;  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
+      if (total > FR_TCELL) F.fctr[FCTR(9)] = 11u;  // (codes 11..17 name the capacity for FUELMI_FR_TIMING / debugging)
     }
     return;
   }
@@ -1698,7 +1698,7 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
   const u32 nroots = s_nroots;
   if (nroots > FR_TROOT) {
     if (threadIdx.x == 0) {
-      F.fctr[9] = 12u;
+      F.fctr[FCTR(9)] = 12u;
       F.t_nroots[blockIdx.x] = 0u;
       F.t_base[blockIdx.x] = 0u;
     }
@@ -1708,9 +1708,9 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
   // returning atomic is issued here so that its latency hides behind the record loop) ----
   if (threadIdx.x == 0) {
     const u32 xcd = blockIdx.x & 7u;
-    const u32 b = atomicAdd(&F.fctr[xcd], nroots);
+    const u32 b = atomicAdd(&F.fctr[FCTR(xcd)], nroots);
     if (b + nroots > FR_RC8) {
-      F.fctr[9] = 13u;
+      F.fctr[FCTR(9)] = 13u;
       s_flag = 1u;
     }
     s_base = xcd * FR_RC8 + b;
@@ -1843,6 +1843,7 @@ __global__ void __launch_bounds__(NT) k_tile_ccl(Geo g, FArgs F, const FVar V) {
 #define XC_WCAP 6144  // entries of a tile's work list (beyond: processed on the spot)
 template <int RS_T, bool IN_LAUNCH>
 __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const FVar& V, unsigned char* smem_raw, const u32 rcap);
+
 __device__ __forceinline__ void xc_insert(u32* s_set, u32* s_list, u32* s_n, u32* fctr, u32 key) {
   u32 h = (key * 2654435761u) >> 24;
   bool done = false;
@@ -1855,7 +1856,7 @@ __device__ __forceinline__ void xc_insert(u32* s_set, u32* s_list, u32* s_n, u32
       done = true;
     h = (h + 1u) & (XC_SET - 1u);
   }
-  if (!done) st_agent(&fctr[9], 15u);  // more than XC_SET distinct root pairs around one tile
+  if (!done) st_agent(&fctr[FCTR(9)], 15u);  // more than XC_SET distinct root pairs around one tile
 }
 // rcap != 0 (round 6): the workgroup that finishes LAST joins the tile roots itself (resolve_body, in the LDS its tile no
 // longer needs) -- k_resolve's launch and kernel boundary leave the search's critical path.  What it reads of the
@@ -2007,7 +2008,7 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F, const u32 rca
     if (slot < XC_WCAP)
       wl[slot] = (u32)fi;
     else
-      st_agent(&F.fctr[9], 18u);  // work list full (a tile made of seeds): the legacy chain takes the search
+      st_agent(&F.fctr[FCTR(9)], 18u);  // work list full (a tile made of seeds): the legacy chain takes the search
   }
   // ---- NQ seeds of the tile (most tiles have none): nine items per seed segment, one per line around it (one
   // reservation for all nine) ----
@@ -2019,7 +2020,7 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F, const u32 rca
       if (slot0 + (u32)l < XC_WCAP)
         wl[slot0 + (u32)l] = e;
       else
-        st_agent(&F.fctr[9], 18u);
+        st_agent(&F.fctr[FCTR(9)], 18u);
     }
   }
   __syncthreads();
@@ -2052,11 +2053,11 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F, const u32 rca
   const u32 n = s_n;
   if (n != 0u) {  // (uniform)
     const u32 xcd = blockIdx.x & 7u;
-    if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[16 + xcd], n);
+    if (threadIdx.x == 0) s_base = atomicAdd(&F.fctr[FCTR(16 + xcd)], n);
     __syncthreads();
     const u32 base = s_base;
     if (base + n > FR_PCAP / 8u) {
-      if (threadIdx.x == 0) st_agent(&F.fctr[9], 14u);
+      if (threadIdx.x == 0) st_agent(&F.fctr[FCTR(9)], 14u);
     } else if (threadIdx.x < n)
       st_agent(&F.pairs[(size_t)xcd * (FR_PCAP / 8u) + base + threadIdx.x], s_list[threadIdx.x]);
   }
@@ -2067,7 +2068,19 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F, const u32 rca
     __shared__ u32 s_last;
     wait_vm_stores();  // (every wave: its pairs and codes have left)
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&F.fctr[24], 1u) == (u32)V.ntiles_f - 1u ? 1u : 0u;
+    // (the counter has a cache line of its own: on the line of the pair-list counters its 576 returning atomics stood in
+    // front of every tile's list reservation -- the busiest tile's cross phase 13 -> 19 us)
+    // two levels: the workgroups of an XCD (blockIdx & 7) count into that XCD's word, the last of each into the global one:
+    // 72 + 8 returning atomics per line instead of 576 on one
+    if (threadIdx.x == 0) {
+      const u32 xcd = blockIdx.x & 7u, n_x = ((u32)V.ntiles_f + 7u - xcd) >> 3;  // workgroups b < ntiles_f with b & 7 == xcd
+      u32 last = 0u;
+      if (atomicAdd(&F.fctr[FR_DONE_CTR + FCTR(1 + xcd)], 1u) == n_x - 1u) {
+        const u32 n_groups = min((u32)V.ntiles_f, 8u);
+        last = atomicAdd(&F.fctr[FR_DONE_CTR], 1u) == n_groups - 1u ? 1u : 0u;
+      }
+      s_last = last;
+    }
     __syncthreads();
     if (s_last) (void)resolve_body<NT, true>(g, F, V, smem_raw, rcap);
   }
@@ -2126,7 +2139,7 @@ __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const
   __shared__ u32 s_pre[9];  // dense number of the first tile root of every XCD range
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntx = V.ntx_f;
-  if (threadIdx.x < 32) s_fc[threadIdx.x] = ldw(&F.fctr[threadIdx.x]);
+  if (threadIdx.x < 32) s_fc[threadIdx.x] = ldw(&F.fctr[FCTR(threadIdx.x)]);
   const int dblk = V.ntiles_f;  // time stamps of this kernel go behind those of the tiles
   FR_DBG_MARK(F, dblk, 0);
   __syncthreads();
@@ -2424,7 +2437,8 @@ __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const
     F.counts[3] = bad ? 0u : nk;
     F.counts[5] = bad ? 0u : s_nout;
   }
-  if (threadIdx.x < 32) F.fctr[threadIdx.x] = 0u;  // the counters of the NEXT search (its first kernel adds to them at once)
+  if (threadIdx.x < 32) F.fctr[FCTR(threadIdx.x)] = 0u;  // the counters of the NEXT search (its first kernel adds to them at once)
+  if (threadIdx.x >= 32 && threadIdx.x < 41) F.fctr[FR_DONE_CTR + FCTR(threadIdx.x - 32)] = 0u;
   if (threadIdx.x == 0) {
     F.counts[8] = V.epoch;              // "resolved" (the kernel k_resolve behind a k_tile_cross that did it returns at once)
     F.counts[9] = IN_LAUNCH ? 1u : 0u;  // ... by whom (fuelmi_frontier_resolved_in_launch)
@@ -2727,7 +2741,7 @@ static int frontier_twin_set(fuelmi_frontier* f) {
   FArgs& G2 = f->F2;
   G2.kept = G2.counts + 16;
   HIPCHK(hipMemsetAsync(G2.counts, 0, 16 * sizeof(u32), f->stream));
-  HIPCHK(hipMemsetAsync(G2.fctr, 0, 32 * sizeof(u32), f->stream));
+  HIPCHK(hipMemsetAsync(G2.fctr, 0, FR_NCTR * sizeof(u32), f->stream));
   FVar* d_var2 = nullptr;
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_var2), sizeof(FVar)));
   f->allocs.push_back(d_var2);
@@ -2867,11 +2881,11 @@ extern "C" int fuelmi_frontier_create(fuelmi_map* m, const fuelmi_frontier_cfg* 
   F.keys_from_slots = 1;
   if ((rc = dmalloc(f, &F.trec, FR_RCAP + 256)) || (rc = dmalloc(f, &F.tclaim, FR_RCAP + 256)) || (rc = dmalloc(f, &F.rcode, FR_RCAP + 256)) ||
       (rc = dmalloc(f, &F.rrow, (size_t)FR_RCAP * FR_TXS)) || (rc = dmalloc(f, &F.pairs, (size_t)FR_PCAP)) ||
-      (rc = dmalloc(f, &F.fctr, 32))) {
+      (rc = dmalloc(f, &F.fctr, FR_NCTR))) {
     fuelmi_frontier_destroy(f);
     return rc;
   }
-  HIPCHK(hipMemsetAsync(F.fctr, 0, 32 * sizeof(u32), m->stream));
+  HIPCHK(hipMemsetAsync(F.fctr, 0, FR_NCTR * sizeof(u32), m->stream));
   F.dbg = nullptr;
   if (getenv("FUELMI_FR_TIMING")) {  // dev aid: phase time stamps of the fast chain (one row per tile + one for k_resolve)
     const size_t nrow = (size_t)(3 * ((g.nx + 4) / 4) * ((g.ny + 8) / 8) + 64);

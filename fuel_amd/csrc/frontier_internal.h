@@ -60,6 +60,13 @@ struct FVar {
 #define FR_TXS 16               // x-rows per tile at most (stride of the per-row counts)
 #define FR_KCAP 256             // kept clusters
 #define FR_PCAP (1u << 18)      // cross-tile adjacency records
+// The chain's counters (fctr): 32 logical words -- [0..7] roots per XCD range, [9] capacity code, [16..23] pairs per XCD --
+// each on a 128-byte line of its own, and the last-workgroup-done counter of k_tile_cross on a 33rd.  They are hit by
+// returning memory-side atomics of hundreds of workgroups: atomics to ONE line queue up behind each other whatever word
+// they address (round 6: with the done counter on the pair counters' line the busiest tile's cross phase went 13 -> 19 us).
+#define FCTR(k) ((k) * 32)
+#define FR_DONE_CTR FCTR(32)
+#define FR_NCTR (41 * 32)  // (FR_DONE_CTR: the global count, FR_DONE_CTR + FCTR(1 + xcd): per XCD)
 #define FR_PMCAP 16384          // entries of the (kept cluster x tile column) matrix k_resolve scans in its LDS
 #define FR_REFORDER_AUTO 26624u   // cfg.reference_order == 2: searches whose clusters all hold at most this many cells use the
                                   // reference's order (what frontier_order.hip sweeps inside LDS)
@@ -126,7 +133,7 @@ struct FArgs {
   u32* pm;                // [FR_KCAP][pm_stride] cells of kept cluster (by rank) in the tile columns in front of column tx
   int pm_stride;
   u32* pairs;             // [8][FR_PCAP / 8] distinct pairs of tile roots that touch across a tile face (lo << 16 | hi)
-  u32* fctr;              // [32] [0..7] roots per XCD range, [9] overflow -> legacy chain, [16..23] pairs per XCD
+  u32* fctr;              // [FR_NCTR] the chain's counters, one per cache line: FCTR(k), FR_DONE_CTR (above)
   int fast;               // the result of the last search came from the fast path
   unsigned long long* dbg;  // FUELMI_FR_TIMING: per-block phase time stamps of the fast chain's kernels (else null)
 };
