@@ -798,8 +798,12 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/), else null
         traffic, traffic_commit = None, None
         try:
-            pmc_file = {"G400": "r05_pmc_hbm_traffic_G400.json", "G800": "r05_pmc_hbm_traffic_G800.json"}.get(args.workload, "none")
-            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            pmc_doc = None
+            for rnd in ("r06", "r05"):  # the newest committed counter pass of this workload
+                pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%s.json" % (rnd, args.workload))
+                if os.path.exists(pmc_path):
+                    pmc_doc = json.load(open(pmc_path))
+                    break
             pmc = pmc_doc["kernels"]
             traffic_commit = pmc_doc.get("commit")
             keys = {"esdf_zy": ("k_esdf_zy_pk2<", "k_esdf_zy_pk<", "k_esdf_zy4<"), "esdf_x": ("k_esdf_x_pk2<", "k_esdf_x_pk<", "k_esdf_x4"),
