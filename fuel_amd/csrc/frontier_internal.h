@@ -361,6 +361,8 @@ struct fuelmi_frontier {
   bool fresh_pending = false;  // fuelmi_frontier_reset not yet executed on the flag plane
   int n_fast = 0, n_legacy = 0, n_fallback = 0;
   int n_in_launch = 0;  // fast-chain searches resolved by the last workgroup of k_tile_cross (the others: by k_resolve)
+  int fuse_skip = 0;    // searches left for which k_tile_cross is launched without the in-launch resolve
+  bool fuse_tried = false;
   // cell order of the searches (fuelmi_frontier_order_stats): what the last one delivered (0 address order, 1 the
   // reference's BFS order), how many delivered the reference's, how many wanted it (cfg.reference_order == 2) and fell
   // back to the address order because a cluster exceeded FR_REFORDER_AUTO cells, and that cluster's size
