@@ -2082,7 +2082,17 @@ __global__ void __launch_bounds__(NT) k_tile_cross(Geo g, FArgs F, const u32 rca
       s_last = last;
     }
     __syncthreads();
-    if (s_last) (void)resolve_body<NT, true>(g, F, V, smem_raw, rcap);
+    if (!s_last) return;
+    const bool no_kr = (rcap >> 31) != 0u;  // no k_resolve is queued behind this launch (the host expected this search to fit)
+    if (resolve_body<NT, true>(g, F, V, smem_raw, rcap & 0x7FFFFFFFu) || !no_kr) return;
+    // more tile roots than this launch's LDS holds and nobody behind to do the job: tell the host (it queues k_resolve and
+    // k_tile_out again and waits for the stamp a second time) and make the k_tile_out already queued return at once
+    if (threadIdx.x == 0) {
+      F.counts[2] = 3u;
+      F.h_counts[2] = 3u;
+      F.h_counts[6] = 20u;
+      __hip_atomic_store(&F.h_counts[15], V.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -2442,6 +2452,7 @@ __device__ __forceinline__ bool resolve_body(const Geo& g, const FArgs& F, const
   if (threadIdx.x == 0) {
     F.counts[8] = V.epoch;              // "resolved" (the kernel k_resolve behind a k_tile_cross that did it returns at once)
     F.counts[9] = IN_LAUNCH ? 1u : 0u;  // ... by whom (fuelmi_frontier_resolved_in_launch)
+    F.counts[10] = R;                   // ... and how many tile roots it had (the host's guess for the next search)
   }
   __syncthreads();
   if (threadIdx.x < 15) F.h_counts[threadIdx.x] = F.counts[threadIdx.x];
@@ -3386,11 +3397,16 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
     f->fuse_tried = fuse_now;
     const size_t lds_x = fuse_now ? std::max(f->cross_lds[mk], resolve_lds_bytes(1024)) : f->cross_lds[mk];
     const u32 rcap = fuse_now ? (u32)std::min<size_t>((lds_x - resolve_lds_bytes(0)) / 16, FR_RCAP) : 0u;
-    k_tile_cross<512><<<tiles, 512, lds_x, f->stream>>>(g, F, rcap);
+    // k_resolve is not even queued when this finder's last search was resolved in the launch with at most half the tile
+    // roots the launch holds (a launch and a kernel boundary of the tail per search); a search that outgrows the guess
+    // says so in its result (counts[2] == 3) and _search_end queues the two kernels then
+    f->kr_queued = !(fuse_now && f->kr_skip_ok);
+    k_tile_cross<512><<<tiles, 512, lds_x, f->stream>>>(g, F, rcap | (f->kr_queued ? 0u : 0x80000000u));
+    f->rcap_used = rcap;
   }
   FDBG("k_tile_cross");
   g_ht.lap(6);
-  k_resolve<<<1, RS_TK, f->resolve_lds, f->stream>>>(g, F);
+  if (f->kr_queued) k_resolve<<<1, RS_TK, f->resolve_lds, f->stream>>>(g, F);
   FDBG("k_resolve");
   g_ht.lap(7);
   if (f->tl_ev) HIPCHK(hipEventRecord(f->tl_ev[2], f->stream));
@@ -3803,6 +3819,29 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
                    (rr[2] - rr[1]) / 100.0, (rr[3] - rr[2]) / 100.0, (rr[4] - rr[3]) / 100.0, (rr[5] - rr[4]) / 100.0, 0.0,
                    (rr[6] - rr[5]) / 100.0, (rr[7] - rr[6]) / 100.0, (rr[8] - rr[7]) / 100.0, rr[9], rr[10], rr[11]);
     }
+    if (counts[2] == 3u) {  // the search outgrew the launch that was to resolve it and no k_resolve was queued: do it now
+      const int mk = f->fast_menu;
+      const int qx = F.qbox.hi[0] - F.qbox.lo[0] + 2, qy = F.qbox.hi[1] - F.qbox.lo[1] + 2;
+      const int tiles = ((qx + kFastMenu[mk][0] - 1) / kFastMenu[mk][0]) * ((qy + kFastMenu[mk][1] - 1) / kFastMenu[mk][1]);
+      *stamp = 0u;
+      k_resolve<<<1, RS_TK, f->resolve_lds, f->stream>>>(g, F);
+      k_tile_out<512><<<tiles, 512, f->out_lds[mk], f->stream>>>(g, F);
+      HIPCHK(hipGetLastError());
+      unsigned spins2 = 0;
+      while (*stamp != want) {
+        if ((++spins2 & 0x3FFFu) == 0u) {
+          const hipError_t q = hipStreamQuery(f->stream);
+          if (q != hipErrorNotReady && q != hipSuccess) HIPCHK(q);
+          if (q == hipSuccess && *stamp != want) {
+            fuelmi_set_error("frontier search: k_resolve finished without publishing its result");
+            return FUELMI_EHIP;
+          }
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      ++f->n_late_resolve;
+    }
+    f->kr_skip_ok = counts[2] == 0u && counts[9] == 1u && 2u * counts[10] <= f->rcap_used;
     ++f->n_fast;
     if (counts[9] == 1u)
       ++f->n_in_launch;

@@ -363,6 +363,10 @@ struct fuelmi_frontier {
   int n_in_launch = 0;  // fast-chain searches resolved by the last workgroup of k_tile_cross (the others: by k_resolve)
   int fuse_skip = 0;    // searches left for which k_tile_cross is launched without the in-launch resolve
   bool fuse_tried = false;
+  bool kr_skip_ok = false;  // the last search was resolved in the launch with room to spare: k_resolve is not queued for the next one
+  bool kr_queued = true;    // ... whether it was for the running search
+  u32 rcap_used = 0;        // tile roots the running search's k_tile_cross launch holds
+  int n_late_resolve = 0;   // searches that outgrew that guess (k_resolve + k_tile_out queued by _search_end)
   // cell order of the searches (fuelmi_frontier_order_stats): what the last one delivered (0 address order, 1 the
   // reference's BFS order), how many delivered the reference's, how many wanted it (cfg.reference_order == 2) and fell
   // back to the address order because a cluster exceeded FR_REFORDER_AUTO cells, and that cluster's size

@@ -125,3 +125,46 @@ def test_headline_search_is_resolved_by_the_cross_kernels_last_workgroup(fa):
     assert gf.resolvedInLaunch() == 2, "the searches were resolved by k_resolve, not inside k_tile_cross"
     gf.close()
     gm.close()
+
+
+def test_search_that_outgrows_the_in_launch_resolve(fa):
+    """A finder whose last search was resolved inside k_tile_cross with room to spare does not queue k_resolve for the next
+    one.  Here the next one has thousands of tile-local components (a lattice of isolated unknown voxels appears in free
+    space: each a little shell of frontier cells, none of them a kept cluster) -- more than the launch holds: the chain
+    reports that, _search_end queues k_resolve + k_tile_out itself and collects the result.  Three searches against the
+    oracle -- fresh full box, a small updated box, the full box after the change: cell sets, cluster order, flags
+    (frontier_finder.cpp:54-164)."""
+    import bench
+    map_size, box, occ, _, _ = bench.build_inputs("G400", seed=42, n_traj=1)
+    om = fo.OracleMap(map_size, *box)
+    om.occ[:] = occ
+    nv = om.nvox
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    lo = np.array(box[0]) + np.array([6.0, 6.0, 0.0])
+    small = (tuple(lo), tuple(lo + np.array([3.0, 3.0, 2.0])))
+    for rnd, ub in enumerate((box, small, box)):
+        if rnd == 2:
+            o3 = om.occ.reshape(nv)
+            free = (o3 >= om.l_min - 1e-3) & (o3 <= om.l_occ)
+            lat = np.zeros(nv, dtype=bool)
+            lat[10::20, 10::20, 5::10] = True
+            o3[free & lat] = om.l_min - 0.01  # unknown
+            gm.uploadOccupancy(om.occ)
+        om.set_updated_box(*ub)
+        gm.setUpdatedBox(*ub)
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g, (rnd, n_o, n_g)
+        for a, b in zip(of.clusters(0), gf.clusters(0)):
+            assert np.array_equal(np.sort(a), b)
+        assert np.array_equal(of.flags, gf.flags())
+        of.commit()
+        gf.commit()
+        if rnd == 1:
+            assert gf.resolvedInLaunch() == 2, "the first two searches were expected to be resolved inside k_tile_cross"
+    assert gf.stats() == (3, 0, 0), gf.stats()
+    assert gf.resolvedInLaunch() == 2, "the last search was expected to outgrow the launch (k_resolve queued by _search_end)"
+    gf.close()
+    gm.close()
