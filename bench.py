@@ -572,8 +572,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # the library first: it sets its hardware-queue default (GPU_MAX_HW_QUEUES, unless the environment decides) when it is
-    # LOADED, and the HIP runtime reads the variable at its first call -- which torch.cuda below would otherwise make
+    # the library first: fuel_amd.lib() calls fuelmi_init(), which sets the hardware-queue default (GPU_MAX_HW_QUEUES,
+    # unless the environment decides) -- and the HIP runtime reads the variable at its first call, which torch.cuda
+    # below would otherwise make
     import fuel_amd as _fa_first
     _fa_first.lib()
     if not torch.cuda.is_available():
