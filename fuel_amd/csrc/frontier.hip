@@ -3857,6 +3857,41 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       f->dirty_all = true;
       return FUELMI_ELIMIT;
     }
+    // A capacity of ONE TILE was exceeded (codes 11 cells, 12 components, 15 root pairs, 18 work-list entries -- a
+    // full-height frontier wall along a y-line puts 32 x nz cells into one 8 x 32 tile): nothing was modified, and
+    // the menu's next, smaller tile holds half as much per tile -- run the chain again on it before giving the search to
+    // the legacy chain (round 6, with FR_TCELL = 2 048).
+    while (counts[2] == 2u && f->fast_menu < 3 && (counts[6] == 11u || counts[6] == 12u || counts[6] == 15u || counts[6] == 18u)) {
+      HIPCHK(frontier_tail_sync(f) == FUELMI_OK ? hipSuccess : hipErrorUnknown);
+      ++f->fast_menu;
+      FVar hv = *f->h_var;
+      const int qx = hv.px1 - hv.px0 + 1, qy = hv.py1 - hv.py0 + 1;
+      hv.ftx = kFastMenu[f->fast_menu][0], hv.fty = kFastMenu[f->fast_menu][1];
+      hv.ntx_f = std::max(0, (qx + hv.ftx - 1) / hv.ftx);
+      hv.nty_f = std::max(0, (qy + hv.fty - 1) / hv.fty);
+      hv.ntiles_f = hv.ntx_f * hv.nty_f;
+      hv.epoch = ++f->epoch;
+      if (hv.epoch == 0u) hv.epoch = f->epoch = 1u;
+      *f->h_var = hv;
+      f->kr_skip_ok = false;  // (k_resolve queued: no second round trip whatever the root count)
+      if (getenv("FUELMI_FR_TIMING")) std::fprintf(stderr, "[fr-timing] capacity code %u: again with %d x %d tiles\n", counts[6], hv.ftx, hv.fty);
+      const int rcr = frontier_enqueue_fast(f);
+      if (rcr) return rcr;
+      unsigned spins3 = 0;
+      while (*stamp != hv.epoch) {
+        if ((++spins3 & 0x3FFFu) == 0u) {
+          const hipError_t q = hipStreamQuery(f->stream);
+          if (q != hipErrorNotReady && q != hipSuccess) HIPCHK(q);
+          if (q == hipSuccess && *stamp != hv.epoch) {
+            fuelmi_set_error("frontier search: the re-tiled chain finished without publishing its result");
+            return FUELMI_EHIP;
+          }
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      f->tail_pending = true;
+      ++f->n_retiled;
+    }
     if (counts[2] == 2u) {
       // a capacity of the fast path was exceeded (noise-like input): nothing was modified; run the legacy chain
       --f->n_fast;

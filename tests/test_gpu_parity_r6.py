@@ -168,3 +168,32 @@ def test_search_that_outgrows_the_in_launch_resolve(fa):
     assert gf.resolvedInLaunch() == 2, "the last search was expected to outgrow the launch (k_resolve queued by _search_end)"
     gf.close()
     gm.close()
+
+
+def test_full_height_frontier_wall_retiles_instead_of_falling_back(fa):
+    """A frontier WALL: everything with x < 20 m known free, everything beyond unknown -- the plane x = 199 is one
+    frontier surface of 400 x 100 cells, 3 200 of them in every 8 x 32 tile it crosses, more than a tile holds (2 048).
+    The chain reports the capacity, runs again on the menu's next tile (8 x 16: 1 600 cells) and answers -- the legacy
+    chain (ten times slower) is not needed.  Cells, cluster order, flags against the oracle (frontier_finder.cpp:54-164);
+    stats say (1 fast, 0 legacy, 0 fallbacks)."""
+    import bench
+    map_size, box, occ, _, _ = bench.build_inputs("G400", seed=42, n_traj=1)
+    om = fo.OracleMap(map_size, *box)
+    nv = om.nvox
+    o3 = np.full(nv, om.l_min - 0.01)   # unknown
+    o3[:200, :, :] = om.l_min            # known free
+    om.occ[:] = o3.reshape(-1)
+    gm = fa.SDFMap(map_size, *box)
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 100)
+    gf = fa.FrontierFinder(gm, cluster_min=100)
+    om.set_updated_box(*box)
+    gm.setUpdatedBox(*box)
+    n_o, n_g = of.search(), gf.searchFrontiers()
+    assert n_o == n_g and n_o >= 1, (n_o, n_g)
+    for a, b in zip(of.clusters(0), gf.clusters(0)):
+        assert np.array_equal(np.sort(a), b)
+    assert np.array_equal(of.flags, gf.flags())
+    assert gf.stats() == (1, 0, 0), gf.stats()
+    gf.close()
+    gm.close()
