@@ -3592,6 +3592,9 @@ extern "C" int fuelmi_frontier_search_begin(fuelmi_frontier* f) {
         pick = k;
         break;
       }
+    // (a finder whose tiles were too full lately starts on the smaller tile it ended on: the overflow costs a whole
+    // chain run; forgotten after 64 searches)
+    if (f->menu_min_ttl > 0) --f->menu_min_ttl, pick = std::max(pick, f->menu_min);
     f->fast_menu = pick;
     int ftx = kFastMenu[pick][0], fty = kFastMenu[pick][1];
     hv.ftx = ftx, hv.fty = fty;
@@ -3891,6 +3894,7 @@ extern "C" int fuelmi_frontier_search_end(fuelmi_frontier* f, int* n_new) {
       std::atomic_thread_fence(std::memory_order_acquire);
       f->tail_pending = true;
       ++f->n_retiled;
+      f->menu_min = f->fast_menu, f->menu_min_ttl = 64;
     }
     if (counts[2] == 2u) {
       // a capacity of the fast path was exceeded (noise-like input): nothing was modified; run the legacy chain

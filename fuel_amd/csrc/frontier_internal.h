@@ -366,6 +366,7 @@ struct fuelmi_frontier {
   bool kr_skip_ok = false;  // the last search was resolved in the launch with room to spare: k_resolve is not queued for the next one
   bool kr_queued = true;    // ... whether it was for the running search
   u32 rcap_used = 0;        // tile roots the running search's k_tile_cross launch holds
+  int menu_min = 0, menu_min_ttl = 0;  // smallest menu entry the next searches start on (after a re-tiled search), and for how long
   int n_retiled = 0;        // searches that ran the chain again on a smaller tile after a per-tile capacity overflow
   int n_late_resolve = 0;   // searches that outgrew that guess (k_resolve + k_tile_out queued by _search_end)
   // cell order of the searches (fuelmi_frontier_order_stats): what the last one delivered (0 address order, 1 the

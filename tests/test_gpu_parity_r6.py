@@ -185,15 +185,18 @@ def test_full_height_frontier_wall_retiles_instead_of_falling_back(fa):
     om.occ[:] = o3.reshape(-1)
     gm = fa.SDFMap(map_size, *box)
     gm.uploadOccupancy(om.occ)
-    of = fo.OracleFrontier(om, 100)
     gf = fa.FrontierFinder(gm, cluster_min=100)
-    om.set_updated_box(*box)
-    gm.setUpdatedBox(*box)
-    n_o, n_g = of.search(), gf.searchFrontiers()
-    assert n_o == n_g and n_o >= 1, (n_o, n_g)
-    for a, b in zip(of.clusters(0), gf.clusters(0)):
-        assert np.array_equal(np.sort(a), b)
-    assert np.array_equal(of.flags, gf.flags())
-    assert gf.stats() == (1, 0, 0), gf.stats()
+    for rnd in range(2):  # (the second fresh search starts on the smaller tile the first one ended on)
+        of = fo.OracleFrontier(om, 100)
+        if rnd:
+            gf.reset()
+        om.set_updated_box(*box)
+        gm.setUpdatedBox(*box)
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g and n_o >= 1, (n_o, n_g)
+        for a, b in zip(of.clusters(0), gf.clusters(0)):
+            assert np.array_equal(np.sort(a), b)
+        assert np.array_equal(of.flags, gf.flags())
+    assert gf.stats() == (2, 0, 0), gf.stats()
     gf.close()
     gm.close()
