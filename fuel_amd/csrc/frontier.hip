@@ -3392,8 +3392,8 @@ static int frontier_enqueue_fast(fuelmi_frontier* f) {
   {
     // (a finder whose last search had more tile roots than the launch's LDS holds -- the 800^2 x 200 map's full box: 2 465 --
     // does not try again for the next 16 searches: the attempt costs every workgroup a barrier and two atomics, -5 % there)
-    bool fuse_now = fuse;
-    if (f->fuse_skip > 0) --f->fuse_skip, fuse_now = false;
+    bool fuse_now = fuse && f->h_var->ntiles_f > 0;  // (no tile, no last workgroup: k_resolve publishes the empty result)
+    if (fuse_now && f->fuse_skip > 0) --f->fuse_skip, fuse_now = false;
     f->fuse_tried = fuse_now;
     const size_t lds_x = fuse_now ? std::max(f->cross_lds[mk], resolve_lds_bytes(1024)) : f->cross_lds[mk];
     const u32 rcap = fuse_now ? (u32)std::min<size_t>((lds_x - resolve_lds_bytes(0)) / 16, FR_RCAP) : 0u;

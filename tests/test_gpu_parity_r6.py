@@ -200,3 +200,30 @@ def test_full_height_frontier_wall_retiles_instead_of_falling_back(fa):
     assert gf.stats() == (2, 0, 0), gf.stats()
     gf.close()
     gm.close()
+
+
+def test_small_empty_and_full_searches_behind_each_other(fa):
+    """Searches of every size behind each other on one finder: the full box, a small updated box (resolved inside
+    k_tile_cross, after which k_resolve is no longer queued), an updated box outside the exploration box (an empty search:
+    no kernel at all), the small box again -- each against the oracle (cells, flags), none left waiting for a result
+    nobody publishes."""
+    map_size = (12.0, 10.0, 4.0)
+    om, _, _, box = helpers.explored_oracle_map(map_size, 25, 20, width=120, height=90)
+    gm = fa.SDFMap(tuple(om.cfg.map_size), box[0], box[1])
+    gm.uploadOccupancy(om.occ)
+    of = fo.OracleFrontier(om, 10)
+    gf = fa.FrontierFinder(gm, cluster_min=10)
+    lo = np.array(box[0])
+    boxes = [box, (tuple(lo + 1.0), tuple(lo + 2.5)), (tuple(lo - 30.0), tuple(lo - 20.0)), (tuple(lo + 1.0), tuple(lo + 2.5))]
+    for ub in boxes:
+        om.set_updated_box(*ub)
+        gm.setUpdatedBox(*ub)
+        n_o, n_g = of.search(), gf.searchFrontiers()
+        assert n_o == n_g, (ub, n_o, n_g)
+        for a, b in zip(of.clusters(0), gf.clusters(0)):
+            assert np.array_equal(np.sort(a), b)
+        assert np.array_equal(of.flags, gf.flags())
+        of.commit()
+        gf.commit()
+    gf.close()
+    gm.close()
